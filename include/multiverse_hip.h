@@ -1,0 +1,160 @@
+/*
+ * multiverse_hip.h -- C ABI of the MI355X-native Multiverse engine
+ * (libmultiverse_hip.so, built from multiverse_amd/csrc/).
+ *
+ * The reference (JunweiLiang/Multiverse) has no plugin / operator / FFI
+ * interface: its device boundary is `sess.run(fetches, feed_dict)` inside
+ *   Tester.step   code/pred_models.py:1761-1790   (greedy forward)
+ *   Trainer.step  code/pred_models.py:1719-1742   (training step)
+ *   multifuture_inference.py:460-472              (beam-search forward)
+ * over the TF-1 graph built by Model.build_forward (code/pred_models.py:123-308).
+ * The entry points below are what a binding for that boundary binds: one call
+ * per `sess.run`, numpy buffers in, numpy buffers out, weights addressed by
+ * their TF-1 variable names (HWIO layout, exactly what tf.train.Saver stores).
+ * No torch / TF types appear in any signature.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     available from mv_last_error(handle) (or mv_last_error(NULL) for
+ *     create-time failures).
+ *   - all tensors are dense, row-major, NHWC; float = IEEE binary32,
+ *     integers = int32.
+ *   - input buffers are caller-owned and only read during the call; output
+ *     buffers are caller-allocated and fully written on success.
+ *   - calls on one handle are not re-entrant (the reference is a single
+ *     synchronous Python thread).  Each handle owns one
+ *     HIP stream; calls return after their results are on the host unless the
+ *     *_async / *_resident variants are used.
+ */
+#ifndef MULTIVERSE_HIP_H_
+#define MULTIVERSE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MV_MAX_SCALES 2
+#define MV_ABI_VERSION 1
+
+typedef struct mv_engine* mv_handle;
+
+/* Mirrors the config fields Model reads; authoritative list:
+ * reference code/multifuture_inference.py:419-452. */
+typedef struct mv_config {
+  int32_t abi_version;       /* MV_ABI_VERSION */
+  int32_t batch_size;        /* N, fixed per model instance (pred_models.py:47) */
+  int32_t obs_len;           /* T_o */
+  int32_t max_pred_len;      /* upper bound of the run-time T_pred */
+  int32_t scene_h, scene_w, scene_class;        /* 36, 64, 11 */
+  int32_t scene_conv_dim, scene_conv_kernel;    /* 64, 3 */
+  int32_t emb_size;          /* 32 */
+  int32_t hidden_size;       /* enc_hidden_size == dec_hidden_size, 256 */
+  int32_t convlstm_kernel;   /* 3 */
+  int32_t num_scales;        /* len(scene_grid_strides), <= MV_MAX_SCALES */
+  int32_t grid_h[MV_MAX_SCALES];
+  int32_t grid_w[MV_MAX_SCALES];
+  int32_t use_grid[MV_MAX_SCALES];
+  int32_t use_gnn;           /* --use_gnn */
+  int32_t beam_size;         /* 1 = greedy (pred_models.py:260-285) */
+  int32_t diverse_beam;      /* --diverse_beam */
+  float   diverse_gamma;     /* --diverse_gamma */
+  int32_t fix_num_timestep;  /* --fix_num_timestep */
+} mv_config;
+
+/* The feed_dict of Model.get_feed_dict (pred_models.py:1042-1194), minus the
+ * placeholders the forward graph never consumes. */
+typedef struct mv_inputs {
+  const int32_t* obs_scene;        /* [N, T_o] row index into scene_feat */
+  const float*   scene_feat;       /* [U, SH, SW, SC] 0/1 masks */
+  int32_t        num_scene_frames; /* U */
+  int32_t        pred_len;         /* run-time T_pred (<= max_pred_len) */
+  const int32_t* grid_obs_labels[MV_MAX_SCALES];   /* [N, T_o] */
+  const float*   grid_obs_regress[MV_MAX_SCALES];  /* [N, T_o, H, W, 2] */
+} mv_inputs;
+
+/* Fetches of Tester.step (pred_models.py:1774-1790).  Pointers for unused
+ * scales may be NULL. */
+typedef struct mv_outputs {
+  float* grid_pred_class[MV_MAX_SCALES]; /* [N, T_p, H, W, 1] logits */
+  float* grid_pred_reg[MV_MAX_SCALES];   /* [N, T_p, H, W, 2] */
+} mv_outputs;
+
+/* model.beam_outputs (pred_models.py:276, 805-806) + the two greedy fetches
+ * of multifuture_inference.py:468-472 for the single active scale. */
+typedef struct mv_beam_outputs {
+  float*   best_beam;   /* [N, T, H, W, 1]  == logits[:, 0] */
+  float*   grid_reg;    /* [N, T, H, W, 2]  (regression decoder, un-beamed) */
+  float*   logits;      /* [N, B, T, H*W] */
+  int32_t* ids;         /* [N, B, T] */
+  float*   logprobs;    /* [N, B] */
+} mv_beam_outputs;
+
+/* -- lifetime ------------------------------------------------------------ */
+int  mv_create(const mv_config* cfg, int device, mv_handle* out);
+int  mv_destroy(mv_handle h);
+const char* mv_last_error(mv_handle h);
+int  mv_abi_version(void);
+
+/* -- weights: tf.train.Saver role (pred_utils.py:149-205) ---------------- */
+/* tf_name e.g. "person_pred/decoder_grid_class_0/decoder_rnn/dec_grid_0/kernel" */
+int  mv_set_param(mv_handle h, const char* tf_name, const float* data,
+                  const int64_t* shape, int32_t rank);
+int  mv_get_param(mv_handle h, const char* tf_name, float* out,
+                  int64_t capacity_elems);
+int  mv_num_params(mv_handle h);
+/* name/shape of the i-th parameter the engine expects; rank is returned */
+int  mv_param_info(mv_handle h, int32_t i, char* name_out, int32_t name_cap,
+                   int64_t* shape_out /* [4] */);
+
+/* -- forward: one call == one sess.run ------------------------------------ */
+int  mv_forward_greedy(mv_handle h, const mv_inputs* in, mv_outputs* out);
+int  mv_forward_beam(mv_handle h, const mv_inputs* in, mv_beam_outputs* out);
+
+/* -- resident-input variants (bench: inputs already in HBM) -------------- */
+int  mv_upload_inputs(mv_handle h, const mv_inputs* in);   /* H2D + sync */
+int  mv_run_greedy_resident(mv_handle h);   /* enqueue on the handle's stream */
+int  mv_run_beam_resident(mv_handle h);
+int  mv_synchronize(mv_handle h);
+int  mv_download_outputs(mv_handle h, mv_outputs* out);
+int  mv_download_beam_outputs(mv_handle h, mv_beam_outputs* out);
+
+/* -- measurement --------------------------------------------------------- */
+/* When enabled every kernel launch is bracketed by hipEvents on the handle's
+ * stream; totals are read back per kernel name. */
+int  mv_set_profiling(mv_handle h, int32_t enabled);
+int  mv_reset_kernel_stats(mv_handle h);
+int  mv_num_kernel_stats(mv_handle h);
+int  mv_kernel_stat(mv_handle h, int32_t i, char* name_out, int32_t name_cap,
+                    int64_t* launches, double* total_ms, double* flops,
+                    double* bytes);
+/* elapsed ms between two events recorded around fn on the engine's stream */
+int  mv_time_greedy_resident(mv_handle h, int32_t iters, float* ms_out);
+int  mv_time_beam_resident(mv_handle h, int32_t iters, float* ms_out);
+
+/* -- single-kernel entry points (parity tests go through these) ----------- */
+/* One tf.contrib.rnn.ConvLSTMCell step on host buffers:
+ * x [M,H,W,Cx], c,h [M,H,W,C], kernel [3,3,Cx+C,4C] HWIO, biases [4C]. */
+int  mv_op_convlstm_step(int device, const float* x, const float* c,
+                         const float* h, const float* kernel,
+                         const float* biases, int32_t M, int32_t H, int32_t W,
+                         int32_t Cx, int32_t C, float* c_out, float* h_out);
+/* h + GNN(h): gnn_edge/gnn_mask_edge/gnn_node (pred_models.py:808-909);
+ * h [M,H,W,C], scene_mean [M,H,W,D]. */
+int  mv_op_gnn(int device, const float* h, const float* scene_mean, int32_t M,
+               int32_t H, int32_t W, int32_t C, int32_t D, float* out);
+/* hidden2grid (pred_models.py:925-959): h [M,H,W,C], w [3,3,C,P] -> [M,H,W,P] */
+int  mv_op_hidden2grid(int device, const float* h, const float* w, int32_t M,
+                       int32_t H, int32_t W, int32_t C, int32_t P, float* out);
+/* One beam expansion (pred_models.py:557-591 + add_div_penalty :1197-1223):
+ * logits [N,B,K], prev_logprob [N,B] -> new_logprob, ids, parents [N,B]. */
+int  mv_op_beam_step(int device, const float* logits, const float* prev_logprob,
+                     int32_t N, int32_t B, int32_t K, int32_t time,
+                     int32_t diverse, float gamma, int32_t fix_num_timestep,
+                     float* new_logprob, int32_t* ids, int32_t* parents);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* MULTIVERSE_HIP_H_ */

@@ -1,0 +1,427 @@
+# coding=utf-8
+"""ctypes binding of libmultiverse_hip.so (C ABI: include/multiverse_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or a call fails this
+module raises.  The library is built in-tree by `__graft_entry__.build()`
+(`hipcc --offload-arch=gfx950`), so it travels with the source snapshot.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+MV_MAX_SCALES = 2
+MV_ABI_VERSION = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmultiverse_hip.so")
+
+# every symbol include/multiverse_hip.h declares
+EXPORTED_SYMBOLS = [
+    "mv_create", "mv_destroy", "mv_last_error", "mv_abi_version",
+    "mv_set_param", "mv_get_param", "mv_num_params", "mv_param_info",
+    "mv_forward_greedy", "mv_forward_beam",
+    "mv_upload_inputs", "mv_run_greedy_resident", "mv_run_beam_resident",
+    "mv_synchronize", "mv_download_outputs", "mv_download_beam_outputs",
+    "mv_set_profiling", "mv_reset_kernel_stats", "mv_num_kernel_stats",
+    "mv_kernel_stat", "mv_time_greedy_resident", "mv_time_beam_resident",
+    "mv_op_convlstm_step", "mv_op_gnn", "mv_op_hidden2grid", "mv_op_beam_step",
+]
+
+
+class MvError(RuntimeError):
+  pass
+
+
+class mv_config(C.Structure):
+  _fields_ = [
+      ("abi_version", C.c_int32),
+      ("batch_size", C.c_int32),
+      ("obs_len", C.c_int32),
+      ("max_pred_len", C.c_int32),
+      ("scene_h", C.c_int32), ("scene_w", C.c_int32), ("scene_class", C.c_int32),
+      ("scene_conv_dim", C.c_int32), ("scene_conv_kernel", C.c_int32),
+      ("emb_size", C.c_int32),
+      ("hidden_size", C.c_int32),
+      ("convlstm_kernel", C.c_int32),
+      ("num_scales", C.c_int32),
+      ("grid_h", C.c_int32 * MV_MAX_SCALES),
+      ("grid_w", C.c_int32 * MV_MAX_SCALES),
+      ("use_grid", C.c_int32 * MV_MAX_SCALES),
+      ("use_gnn", C.c_int32),
+      ("beam_size", C.c_int32),
+      ("diverse_beam", C.c_int32),
+      ("diverse_gamma", C.c_float),
+      ("fix_num_timestep", C.c_int32),
+  ]
+
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+class mv_inputs(C.Structure):
+  _fields_ = [
+      ("obs_scene", _ip),
+      ("scene_feat", _fp),
+      ("num_scene_frames", C.c_int32),
+      ("pred_len", C.c_int32),
+      ("grid_obs_labels", _ip * MV_MAX_SCALES),
+      ("grid_obs_regress", _fp * MV_MAX_SCALES),
+  ]
+
+
+class mv_outputs(C.Structure):
+  _fields_ = [
+      ("grid_pred_class", _fp * MV_MAX_SCALES),
+      ("grid_pred_reg", _fp * MV_MAX_SCALES),
+  ]
+
+
+class mv_beam_outputs(C.Structure):
+  _fields_ = [
+      ("best_beam", _fp), ("grid_reg", _fp), ("logits", _fp), ("ids", _ip),
+      ("logprobs", _fp),
+  ]
+
+
+_lib = None
+
+
+def load():
+  """dlopen the in-tree library; raises MvError if it has not been built."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise MvError(
+        "%s not found: the HIP extension has not been built "
+        "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+        "There is no CPU fallback." % LIB_PATH)
+  lib = C.CDLL(LIB_PATH)
+  h = C.c_void_p
+  lib.mv_last_error.restype = C.c_char_p
+  lib.mv_last_error.argtypes = [h]
+  lib.mv_create.argtypes = [C.POINTER(mv_config), C.c_int, C.POINTER(h)]
+  lib.mv_destroy.argtypes = [h]
+  lib.mv_set_param.argtypes = [h, C.c_char_p, _fp, C.POINTER(C.c_int64), C.c_int32]
+  lib.mv_get_param.argtypes = [h, C.c_char_p, _fp, C.c_int64]
+  lib.mv_num_params.argtypes = [h]
+  lib.mv_param_info.argtypes = [h, C.c_int32, C.c_char_p, C.c_int32,
+                                C.POINTER(C.c_int64)]
+  lib.mv_forward_greedy.argtypes = [h, C.POINTER(mv_inputs), C.POINTER(mv_outputs)]
+  lib.mv_forward_beam.argtypes = [h, C.POINTER(mv_inputs),
+                                  C.POINTER(mv_beam_outputs)]
+  lib.mv_upload_inputs.argtypes = [h, C.POINTER(mv_inputs)]
+  lib.mv_run_greedy_resident.argtypes = [h]
+  lib.mv_run_beam_resident.argtypes = [h]
+  lib.mv_synchronize.argtypes = [h]
+  lib.mv_download_outputs.argtypes = [h, C.POINTER(mv_outputs)]
+  lib.mv_download_beam_outputs.argtypes = [h, C.POINTER(mv_beam_outputs)]
+  lib.mv_set_profiling.argtypes = [h, C.c_int32]
+  lib.mv_reset_kernel_stats.argtypes = [h]
+  lib.mv_num_kernel_stats.argtypes = [h]
+  lib.mv_kernel_stat.argtypes = [h, C.c_int32, C.c_char_p, C.c_int32,
+                                 C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]
+  lib.mv_time_greedy_resident.argtypes = [h, C.c_int32, _fp]
+  lib.mv_time_beam_resident.argtypes = [h, C.c_int32, _fp]
+  lib.mv_op_convlstm_step.argtypes = [C.c_int, _fp, _fp, _fp, _fp, _fp] + \
+      [C.c_int32] * 5 + [_fp, _fp]
+  lib.mv_op_gnn.argtypes = [C.c_int, _fp, _fp] + [C.c_int32] * 5 + [_fp]
+  lib.mv_op_hidden2grid.argtypes = [C.c_int, _fp, _fp] + [C.c_int32] * 5 + [_fp]
+  lib.mv_op_beam_step.argtypes = [C.c_int, _fp, _fp, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                  C.c_int32, _fp, _ip, _ip]
+  if lib.mv_abi_version() != MV_ABI_VERSION:
+    raise MvError("ABI version mismatch: library %d, binding %d"
+                  % (lib.mv_abi_version(), MV_ABI_VERSION))
+  _lib = lib
+  return lib
+
+
+def f32(a):
+  return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def i32(a):
+  return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def fptr(a):
+  return a.ctypes.data_as(_fp) if a is not None else _fp()
+
+
+def iptr(a):
+  return a.ctypes.data_as(_ip) if a is not None else _ip()
+
+
+def check(rc, handle=None):
+  if rc != 0:
+    msg = load().mv_last_error(handle)
+    raise MvError(msg.decode("utf-8", "replace") if msg else "error %d" % rc)
+
+
+def make_config(cfg):
+  """argparse.Namespace (after process_args) -> mv_config."""
+  c = mv_config()
+  c.abi_version = MV_ABI_VERSION
+  c.batch_size = int(cfg.batch_size)
+  c.obs_len = int(cfg.obs_len)
+  c.max_pred_len = int(getattr(cfg, "max_pred_len", None) or cfg.pred_len)
+  c.scene_h, c.scene_w, c.scene_class = int(cfg.scene_h), int(cfg.scene_w), \
+      int(cfg.scene_class)
+  c.scene_conv_dim = int(cfg.scene_conv_dim)
+  c.scene_conv_kernel = int(cfg.scene_conv_kernel)
+  c.emb_size = int(cfg.emb_size)
+  if int(cfg.enc_hidden_size) != int(cfg.dec_hidden_size):
+    raise MvError("enc_hidden_size != dec_hidden_size is not supported")
+  c.hidden_size = int(cfg.enc_hidden_size)
+  c.convlstm_kernel = int(cfg.convlstm_kernel)
+  if len(cfg.scene_grids) > MV_MAX_SCALES:
+    raise MvError("at most %d scales" % MV_MAX_SCALES)
+  c.num_scales = len(cfg.scene_grids)
+  for s, (h, w) in enumerate(cfg.scene_grids):
+    c.grid_h[s], c.grid_w[s] = int(h), int(w)
+    c.use_grid[s] = 1 if cfg.use_grids[s] else 0
+  c.use_gnn = 1 if cfg.use_gnn else 0
+  c.beam_size = int(cfg.beam_size) if getattr(cfg, "use_beam_search", False) else 1
+  c.diverse_beam = 1 if getattr(cfg, "diverse_beam", False) else 0
+  c.diverse_gamma = float(getattr(cfg, "diverse_gamma", 1.0))
+  c.fix_num_timestep = int(getattr(cfg, "fix_num_timestep", 0))
+  return c
+
+
+class Engine(object):
+  """Owns one mv_handle."""
+
+  def __init__(self, cfg, device=0):
+    self.lib = load()
+    self.cfg = cfg
+    self.c_cfg = make_config(cfg)
+    self.handle = C.c_void_p()
+    rc = self.lib.mv_create(C.byref(self.c_cfg), int(device), C.byref(self.handle))
+    if rc != 0:
+      msg = self.lib.mv_last_error(None)
+      self.handle = None
+      raise MvError(msg.decode("utf-8", "replace"))
+    self._keep = []
+
+  def close(self):
+    if getattr(self, "handle", None):
+      self.lib.mv_destroy(self.handle)
+      self.handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  # ---- weights
+  def param_specs(self):
+    out = []
+    name = C.create_string_buffer(512)
+    shape = (C.c_int64 * 4)()
+    for i in range(self.lib.mv_num_params(self.handle)):
+      rank = self.lib.mv_param_info(self.handle, i, name, 512, shape)
+      out.append((name.value.decode(), tuple(int(shape[d]) for d in range(rank))))
+    return out
+
+  def set_param(self, name, value):
+    a = f32(value)
+    shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+    check(self.lib.mv_set_param(self.handle, name.encode(), fptr(a), shape, a.ndim),
+          self.handle)
+
+  def set_params(self, params):
+    for name, _ in self.param_specs():
+      if name not in params:
+        raise MvError("missing parameter %s" % name)
+      self.set_param(name, params[name])
+
+  def get_param(self, name):
+    shape = dict(self.param_specs())[name]
+    out = np.empty(shape, dtype=np.float32)
+    check(self.lib.mv_get_param(self.handle, name.encode(), fptr(out), out.size),
+          self.handle)
+    return out
+
+  # ---- inputs / outputs
+  def _inputs(self, feed):
+    cfg = self.cfg
+    N, T = cfg.batch_size, cfg.obs_len
+    inp = mv_inputs()
+    keep = []
+    obs_scene = i32(feed["obs_scene"]).reshape(N, T)
+    scene_feat = f32(feed["scene_feat"])
+    keep += [obs_scene, scene_feat]
+    inp.obs_scene = iptr(obs_scene)
+    inp.scene_feat = fptr(scene_feat)
+    inp.num_scene_frames = int(scene_feat.shape[0])
+    inp.pred_len = int(feed.get("pred_length", cfg.pred_len))
+    for s, (h, w) in enumerate(cfg.scene_grids):
+      if not cfg.use_grids[s]:
+        continue
+      lab = i32(feed["grid_obs_labels"][s]).reshape(N, T)
+      reg = f32(feed["grid_obs_regress"][s]).reshape(N, T, h, w, 2)
+      keep += [lab, reg]
+      inp.grid_obs_labels[s] = iptr(lab)
+      inp.grid_obs_regress[s] = fptr(reg)
+    self._keep = keep
+    return inp
+
+  def _alloc_outputs(self, Tp):
+    cfg = self.cfg
+    N = cfg.batch_size
+    out = mv_outputs()
+    cls, reg = [], []
+    for s, (h, w) in enumerate(cfg.scene_grids):
+      if not cfg.use_grids[s]:
+        cls.append([])
+        reg.append([])
+        continue
+      a = np.empty((N, Tp, h, w, 1), dtype=np.float32)
+      b = np.empty((N, Tp, h, w, 2), dtype=np.float32)
+      out.grid_pred_class[s] = fptr(a)
+      out.grid_pred_reg[s] = fptr(b)
+      cls.append(a)
+      reg.append(b)
+    return out, cls, reg
+
+  def _alloc_beam(self, Tp):
+    cfg = self.cfg
+    N, B = cfg.batch_size, cfg.beam_size
+    s = [i for i, u in enumerate(cfg.use_grids) if u][0]
+    h, w = cfg.scene_grids[s]
+    out = mv_beam_outputs()
+    arrs = {
+        "best_beam": np.empty((N, Tp, h, w, 1), dtype=np.float32),
+        "grid_reg": np.empty((N, Tp, h, w, 2), dtype=np.float32),
+        "logits": np.empty((N, B, Tp, h * w), dtype=np.float32),
+        "ids": np.empty((N, B, Tp), dtype=np.int32),
+        "logprobs": np.empty((N, B), dtype=np.float32),
+    }
+    out.best_beam = fptr(arrs["best_beam"])
+    out.grid_reg = fptr(arrs["grid_reg"])
+    out.logits = fptr(arrs["logits"])
+    out.ids = iptr(arrs["ids"])
+    out.logprobs = fptr(arrs["logprobs"])
+    return out, arrs, s
+
+  def forward_greedy(self, feed):
+    inp = self._inputs(feed)
+    out, cls, reg = self._alloc_outputs(inp.pred_len)
+    check(self.lib.mv_forward_greedy(self.handle, C.byref(inp), C.byref(out)),
+          self.handle)
+    return cls, reg
+
+  def forward_beam(self, feed):
+    inp = self._inputs(feed)
+    out, arrs, s = self._alloc_beam(inp.pred_len)
+    check(self.lib.mv_forward_beam(self.handle, C.byref(inp), C.byref(out)),
+          self.handle)
+    return arrs, s
+
+  # ---- resident-input path (bench)
+  def upload(self, feed):
+    inp = self._inputs(feed)
+    self._pred_len = inp.pred_len
+    check(self.lib.mv_upload_inputs(self.handle, C.byref(inp)), self.handle)
+
+  def run_resident(self, beam=False):
+    fn = self.lib.mv_run_beam_resident if beam else self.lib.mv_run_greedy_resident
+    check(fn(self.handle), self.handle)
+
+  def synchronize(self):
+    check(self.lib.mv_synchronize(self.handle), self.handle)
+
+  def time_resident(self, iters, beam=False):
+    ms = C.c_float()
+    fn = self.lib.mv_time_beam_resident if beam else self.lib.mv_time_greedy_resident
+    check(fn(self.handle, int(iters), C.byref(ms)), self.handle)
+    return float(ms.value)
+
+  def download(self):
+    out, cls, reg = self._alloc_outputs(self._pred_len)
+    check(self.lib.mv_download_outputs(self.handle, C.byref(out)), self.handle)
+    return cls, reg
+
+  def download_beam(self):
+    out, arrs, s = self._alloc_beam(self._pred_len)
+    check(self.lib.mv_download_beam_outputs(self.handle, C.byref(out)), self.handle)
+    return arrs, s
+
+  # ---- measurement
+  def set_profiling(self, on):
+    check(self.lib.mv_set_profiling(self.handle, 1 if on else 0), self.handle)
+
+  def reset_kernel_stats(self):
+    check(self.lib.mv_reset_kernel_stats(self.handle), self.handle)
+
+  def kernel_stats(self):
+    out = {}
+    name = C.create_string_buffer(256)
+    n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+    for i in range(self.lib.mv_num_kernel_stats(self.handle)):
+      self.lib.mv_kernel_stat(self.handle, i, name, 256, C.byref(n), C.byref(ms),
+                              C.byref(fl), C.byref(by))
+      out[name.value.decode()] = {"launches": int(n.value), "total_ms": ms.value,
+                                  "flops": fl.value, "bytes": by.value}
+    return out
+
+
+# ------------------------------------------------ single-kernel entry points
+
+def op_convlstm_step(x, c, h, kernel, biases, device=0):
+  lib = load()
+  x = f32(x)
+  M, H, W, Cx = x.shape
+  Cc = int(kernel.shape[3]) // 4
+  kernel, biases = f32(kernel), f32(biases)
+  c_out = np.empty((M, H, W, Cc), dtype=np.float32)
+  h_out = np.empty((M, H, W, Cc), dtype=np.float32)
+  if c is None:
+    cp, hp = _fp(), _fp()
+  else:
+    c, h = f32(c), f32(h)
+    cp, hp = fptr(c), fptr(h)
+  check(lib.mv_op_convlstm_step(device, fptr(x), cp, hp, fptr(kernel), fptr(biases),
+                                M, H, W, Cx, Cc, fptr(c_out), fptr(h_out)))
+  return c_out, h_out
+
+
+def op_gnn(h, scene_mean, device=0):
+  lib = load()
+  h, scene_mean = f32(h), f32(scene_mean)
+  M, H, W, Cc = h.shape
+  out = np.empty_like(h)
+  check(lib.mv_op_gnn(device, fptr(h), fptr(scene_mean), M, H, W, Cc,
+                      scene_mean.shape[-1], fptr(out)))
+  return out
+
+
+def op_hidden2grid(h, w, device=0):
+  lib = load()
+  h, w = f32(h), f32(w)
+  M, H, W, Cc = h.shape
+  P = w.shape[-1]
+  out = np.empty((M, H, W, P), dtype=np.float32)
+  check(lib.mv_op_hidden2grid(device, fptr(h), fptr(w), M, H, W, Cc, P, fptr(out)))
+  return out
+
+
+def op_beam_step(logits, prev_lp, time, diverse, gamma, fix_num_timestep, device=0):
+  lib = load()
+  logits, prev_lp = f32(logits), f32(prev_lp)
+  N, B, K = logits.shape
+  new_lp = np.empty((N, B), dtype=np.float32)
+  ids = np.empty((N, B), dtype=np.int32)
+  parents = np.empty((N, B), dtype=np.int32)
+  check(lib.mv_op_beam_step(device, fptr(logits), fptr(prev_lp), N, B, K, int(time),
+                            1 if diverse else 0, float(gamma), int(fix_num_timestep),
+                            fptr(new_lp), iptr(ids), iptr(parents)))
+  return new_lp, ids, parents

@@ -1,0 +1,1144 @@
+// libmultiverse_hip.so -- engine behind include/multiverse_hip.h.
+//
+// One mv_engine == one Model instance of the reference
+// (code/pred_models.py:32-121): fixed batch size N, weights addressed by TF-1
+// variable name, one HIP stream.  mv_forward_greedy / mv_forward_beam play the
+// role of `sess.run` at code/pred_models.py:1779 and
+// code/multifuture_inference.py:468-472.
+#include "../../include/multiverse_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "convlstm_mfma.h"
+#include "kernels_misc.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HipError { std::string msg; };
+
+#define HIP_CHECK(expr)                                                       \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      char _b[512];                                                           \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr,                \
+               hipGetErrorString(_e), __FILE__, __LINE__);                    \
+      throw HipError{_b};                                                     \
+    }                                                                         \
+  } while (0)
+
+#define MV_REQUIRE(cond, ...)                                                 \
+  do {                                                                        \
+    if (!(cond)) {                                                            \
+      char _b[512];                                                           \
+      snprintf(_b, sizeof(_b), __VA_ARGS__);                                  \
+      throw HipError{_b};                                                     \
+    }                                                                         \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    if (count <= n && p) return;
+    release();
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    n = count;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+  }
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+
+struct Param {
+  std::string name;
+  std::vector<int64_t> shape;
+  std::vector<float> host;
+  DevBuf<float> dev;
+  bool set = false;
+  size_t elems() const {
+    size_t e = 1;
+    for (auto d : shape) e *= (size_t)d;
+    return e;
+  }
+};
+
+struct ConvCell {           // one ConvLSTMCell: packed kernel + biases
+  Param* kernel = nullptr;
+  Param* biases = nullptr;
+  DevBuf<float> wpack;
+  int Cx = 0;
+};
+
+struct KernelStat {
+  std::string name;
+  int64_t launches = 0;
+  double total_ms = 0, flops = 0, bytes = 0;
+};
+
+struct PendingEvent {
+  int stat;
+  hipEvent_t a, b;
+};
+
+struct ScaleState {
+  int H = 0, W = 0, K = 0;
+  bool use = false;
+  ConvCell enc_cls, enc_reg, dec_cls, dec_reg;
+  Param *emb_cls_W = nullptr, *emb_cls_b = nullptr, *emb_reg_W = nullptr,
+        *emb_reg_b = nullptr, *out_cls_W = nullptr, *out_reg_W = nullptr;
+  DevBuf<float> scene_mean;                 // [N, K, D]
+  DevBuf<int32_t> labels;                   // [N, T_o]
+  DevBuf<float> obs_reg;                    // [N, T_o, K, 2]
+  DevBuf<float> cls_c[2], cls_h[2], cls_hg; // class chain state [R, K, C]
+  DevBuf<float> reg_c[2], reg_h[2];         // regression chain state [N, K, C]
+  DevBuf<float> xbuf_cls, xbuf_reg;         // ConvLSTM x operand
+  DevBuf<float> out_cls;                    // [N, T_p, K, 1]
+  DevBuf<float> out_reg;                    // [N, T_p, K, 2]
+  DevBuf<int32_t> ids;                      // [N] greedy argmax
+};
+
+}  // namespace
+
+struct mv_engine {
+  mv_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<std::unique_ptr<Param>> params;
+  std::map<std::string, Param*> by_name;
+  std::vector<Param*> scene_W, scene_b;
+  ScaleState sc[MV_MAX_SCALES];
+  // inputs
+  DevBuf<int32_t> obs_scene;       // [N, T_o]
+  DevBuf<float> scene_feat;        // [U, SH, SW, SC]
+  DevBuf<float> scene_conv[MV_MAX_SCALES];  // per level [U, h*w, D]
+  std::vector<int> conv_h, conv_w;
+  int num_frames = 0;
+  int pred_len = 0;
+  bool inputs_ready = false;
+  // beam
+  DevBuf<float> bm_logits;         // [T, N, B, K] per-step logits
+  DevBuf<int32_t> bm_ids, bm_parents;  // [T, N, B]
+  DevBuf<float> bm_lp[2];          // [N, B]
+  DevBuf<int32_t> bm_src_row;      // [N*B]
+  DevBuf<int32_t> bm_trace;        // [N, B, T]
+  DevBuf<float> bm_out_logits;     // [N, B, T, K]
+  DevBuf<int32_t> bm_out_ids;      // [N, B, T]
+  // profiling
+  bool profiling = false;
+  std::vector<KernelStat> stats;
+  std::vector<PendingEvent> pending;
+
+  Param* add_param(const std::string& name, std::vector<int64_t> shape) {
+    params.emplace_back(new Param());
+    Param* p = params.back().get();
+    p->name = name;
+    p->shape = std::move(shape);
+    by_name[name] = p;
+    return p;
+  }
+  int stat_index(const char* name) {
+    for (size_t i = 0; i < stats.size(); ++i)
+      if (stats[i].name == name) return (int)i;
+    stats.push_back(KernelStat{name});
+    return (int)stats.size() - 1;
+  }
+};
+
+namespace {
+
+using mv::ConvLstmArgs;
+
+inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// Launch wrapper: optional hipEvent bracket per launch for the roofline figure.
+template <typename F>
+void launch(mv_engine* e, const char* name, double flops, double bytes, F&& fn) {
+  if (!e->profiling) {
+    fn();
+    return;
+  }
+  int si = e->stat_index(name);
+  PendingEvent pe{si, nullptr, nullptr};
+  HIP_CHECK(hipEventCreate(&pe.a));
+  HIP_CHECK(hipEventCreate(&pe.b));
+  HIP_CHECK(hipEventRecord(pe.a, e->stream));
+  fn();
+  HIP_CHECK(hipEventRecord(pe.b, e->stream));
+  e->stats[si].launches += 1;
+  e->stats[si].flops += flops;
+  e->stats[si].bytes += bytes;
+  e->pending.push_back(pe);
+}
+
+void drain_events(mv_engine* e) {
+  for (auto& pe : e->pending) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventSynchronize(pe.b));
+    HIP_CHECK(hipEventElapsedTime(&ms, pe.a, pe.b));
+    e->stats[pe.stat].total_ms += ms;
+    (void)hipEventDestroy(pe.a);
+    (void)hipEventDestroy(pe.b);
+  }
+  e->pending.clear();
+}
+
+// ------------------------------------------------------------------ setup
+
+void build_param_table(mv_engine* e) {
+  const mv_config& c = e->cfg;
+  const int64_t C = c.hidden_size, D = c.scene_conv_dim, E = c.emb_size,
+                k = c.convlstm_kernel, sk = c.scene_conv_kernel;
+  int64_t cin = c.scene_class;
+  char nm[256];
+  for (int i = 0; i < c.num_scales; ++i) {
+    snprintf(nm, sizeof(nm), "person_pred/scene_conv%d/W", i + 1);
+    e->scene_W.push_back(e->add_param(nm, {sk, sk, cin, D}));
+    snprintf(nm, sizeof(nm), "person_pred/scene_conv%d/b", i + 1);
+    e->scene_b.push_back(e->add_param(nm, {D}));
+    cin = D;
+  }
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    S.H = c.grid_h[s]; S.W = c.grid_w[s]; S.K = S.H * S.W;
+    S.use = c.use_grid[s] != 0;
+    if (!S.use) continue;
+    auto cell = [&](ConvCell& cc, const char* fmt, int64_t Cx) {
+      char base[200];
+      snprintf(base, sizeof(base), fmt, s, s);
+      cc.Cx = (int)Cx;
+      cc.kernel = e->add_param(std::string("person_pred/") + base + "/kernel",
+                               {k, k, Cx + C, 4 * C});
+      cc.biases = e->add_param(std::string("person_pred/") + base + "/biases", {4 * C});
+    };
+    cell(S.enc_cls, "encoder_grid_class_%d/enc_grid_%d", D);
+    cell(S.enc_reg, "encoder_grid_reg_%d/enc_grid_regress_%d", 2);
+    cell(S.dec_cls, "decoder_grid_class_%d/decoder_rnn/dec_grid_%d", E);
+    cell(S.dec_reg, "decoder_grid_reg_%d/decoder_rnn/dec_grid_reg_%d", E);
+    snprintf(nm, sizeof(nm), "person_pred/decoder_grid_class_%d/decoder_rnn/grid_emb/W", s);
+    S.emb_cls_W = e->add_param(nm, {3, 3, 1, E});
+    snprintf(nm, sizeof(nm), "person_pred/decoder_grid_class_%d/decoder_rnn/grid_emb/b", s);
+    S.emb_cls_b = e->add_param(nm, {E});
+    snprintf(nm, sizeof(nm), "person_pred/decoder_grid_reg_%d/decoder_rnn/grid_emb/W", s);
+    S.emb_reg_W = e->add_param(nm, {3, 3, 2, E});
+    snprintf(nm, sizeof(nm), "person_pred/decoder_grid_reg_%d/decoder_rnn/grid_emb/b", s);
+    S.emb_reg_b = e->add_param(nm, {E});
+    snprintf(nm, sizeof(nm), "person_pred/hidden2grid_decoder_grid_class_%d/out_dec_grid/W", s);
+    S.out_cls_W = e->add_param(nm, {3, 3, C, 1});
+    snprintf(nm, sizeof(nm), "person_pred/hidden2grid_decoder_grid_reg_%d/out_dec_grid/W", s);
+    S.out_reg_W = e->add_param(nm, {3, 3, C, 2});
+  }
+}
+
+void validate_config(const mv_config& c) {
+  MV_REQUIRE(c.abi_version == MV_ABI_VERSION, "mv_config.abi_version %d != %d",
+             c.abi_version, MV_ABI_VERSION);
+  MV_REQUIRE(c.batch_size > 0 && c.obs_len > 0 && c.max_pred_len > 0,
+             "batch_size/obs_len/max_pred_len must be positive");
+  MV_REQUIRE(c.num_scales >= 1 && c.num_scales <= MV_MAX_SCALES,
+             "num_scales %d not in [1,%d]", c.num_scales, MV_MAX_SCALES);
+  MV_REQUIRE(c.hidden_size == 256, "hidden_size %d unsupported (graph attention "
+             "and hidden2grid kernels map 256 channels onto one wave)", c.hidden_size);
+  MV_REQUIRE(c.convlstm_kernel == 3, "convlstm_kernel %d unsupported (3 only)",
+             c.convlstm_kernel);
+  MV_REQUIRE(c.scene_conv_dim > 0 && c.scene_conv_dim <= 64 &&
+             mv::convlstm_cx_supported(c.scene_conv_dim),
+             "scene_conv_dim %d unsupported", c.scene_conv_dim);
+  MV_REQUIRE(mv::convlstm_cx_supported(c.emb_size), "emb_size %d unsupported", c.emb_size);
+  MV_REQUIRE(c.beam_size >= 1, "beam_size must be >= 1");
+  int hh = c.scene_h, ww = c.scene_w, used = 0;
+  for (int s = 0; s < c.num_scales; ++s) {
+    hh = (hh + 1) / 2; ww = (ww + 1) / 2;   // stride-2 SAME conv chain
+    // process_args' round() and the conv chain's ceil()
+    // must agree (true for strides 2,4 on 36x64).
+    MV_REQUIRE(c.grid_h[s] == hh && c.grid_w[s] == ww,
+               "scene_grids[%d] = %dx%d does not match the stride-2 conv chain "
+               "(%dx%d); only scene_grid_strides 2,4,.. are supported",
+               s, c.grid_h[s], c.grid_w[s], hh, ww);
+    used += c.use_grid[s] != 0;
+  }
+  MV_REQUIRE(used >= 1, "no grid scale enabled");
+  if (c.beam_size > 1)
+    MV_REQUIRE(used == 1, "beam search: only one scale at a time "
+               "(reference pred_models.py:262)");
+}
+
+void alloc_buffers(mv_engine* e) {
+  const mv_config& c = e->cfg;
+  const size_t N = c.batch_size, T = c.obs_len, Tp = c.max_pred_len,
+               C = c.hidden_size, D = c.scene_conv_dim, B = c.beam_size;
+  const size_t maxU = N * T;
+  e->obs_scene.alloc(N * T);
+  e->scene_feat.alloc(maxU * c.scene_h * c.scene_w * c.scene_class);
+  int hh = c.scene_h, ww = c.scene_w;
+  for (int i = 0; i < c.num_scales; ++i) {
+    hh = (hh + 1) / 2; ww = (ww + 1) / 2;
+    e->conv_h.push_back(hh); e->conv_w.push_back(ww);
+    e->scene_conv[i].alloc(maxU * hh * ww * D);
+  }
+  const size_t xc = (size_t)std::max((int)D, c.emb_size);
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    const size_t K = S.K, R = N * B;
+    S.scene_mean.alloc(N * K * D);
+    S.labels.alloc(N * T);
+    S.obs_reg.alloc(N * T * K * 2);
+    for (int i = 0; i < 2; ++i) {
+      S.cls_c[i].alloc(R * K * C); S.cls_h[i].alloc(R * K * C);
+      S.reg_c[i].alloc(N * K * C); S.reg_h[i].alloc(N * K * C);
+    }
+    if (c.use_gnn) S.cls_hg.alloc(R * K * C);
+    S.xbuf_cls.alloc(R * K * xc);
+    S.xbuf_reg.alloc(N * K * xc);
+    S.out_cls.alloc(N * Tp * K);
+    S.out_reg.alloc(N * Tp * K * 2);
+    S.ids.alloc(R);
+    if (B > 1) {
+      e->bm_logits.alloc(Tp * R * K);
+      e->bm_ids.alloc(Tp * R);
+      e->bm_parents.alloc(Tp * R);
+      e->bm_lp[0].alloc(R); e->bm_lp[1].alloc(R);
+      e->bm_src_row.alloc(R);
+      e->bm_trace.alloc(R * Tp);
+      e->bm_out_logits.alloc(R * Tp * K);
+      e->bm_out_ids.alloc(R * Tp);
+    }
+  }
+}
+
+void ensure_packed(mv_engine* e, ConvCell& cc) {
+  MV_REQUIRE(cc.kernel->set, "parameter %s not set", cc.kernel->name.c_str());
+  MV_REQUIRE(cc.biases->set, "parameter %s not set", cc.biases->name.c_str());
+  if (cc.wpack.p) return;
+  const int C = e->cfg.hidden_size;
+  std::vector<float> packed(mv::convlstm_wpack_elems(cc.Cx, C));
+  mv::pack_convlstm_weights(cc.kernel->host.data(), cc.Cx, C, packed.data());
+  cc.wpack.alloc(packed.size());
+  HIP_CHECK(hipMemcpy(cc.wpack.p, packed.data(), packed.size() * sizeof(float),
+                      hipMemcpyHostToDevice));
+}
+
+void ensure_params(mv_engine* e) {
+  for (auto& p : e->params)
+    MV_REQUIRE(p->set, "parameter %s not set (mv_set_param)", p->name.c_str());
+  for (int s = 0; s < e->cfg.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    ensure_packed(e, S.enc_cls); ensure_packed(e, S.enc_reg);
+    ensure_packed(e, S.dec_cls); ensure_packed(e, S.dec_reg);
+  }
+}
+
+// ------------------------------------------------------------------ launches
+
+void run_convlstm(mv_engine* e, const ConvCell& cc, const float* x,
+                  const float* h, const float* c, const int32_t* src_row_h,
+                  const int32_t* src_row_c, float* h_out, float* c_out, int rows,
+                  int H, int W, bool zero_state) {
+  ConvLstmArgs a{};
+  const int C = e->cfg.hidden_size;
+  a.x = x; a.h = h; a.c = c; a.src_row_h = src_row_h; a.src_row_c = src_row_c;
+  a.wpack = cc.wpack.p; a.bias = cc.biases->dev.p;
+  a.h_out = h_out; a.c_out = c_out;
+  a.rows = rows; a.H = H; a.W = W; a.Cx = cc.Cx; a.C = C;
+  a.n_xchunks = mv::convlstm_xchunks(cc.Cx);
+  a.n_hchunks = zero_state ? 0 : 9 * (C / mv::kBK);
+  a.x_small = (cc.Cx > 0 && 9 * cc.Cx <= mv::kBK) ? 1 : 0;
+  a.zero_state = zero_state ? 1 : 0;
+  a.forget_bias = 1.0f;
+  const size_t M = (size_t)rows * H * W;
+  a.n_mtiles = (int)cdiv(M, mv::kBM);
+  const unsigned grid = (unsigned)a.n_mtiles * (unsigned)(C / mv::kChBlock);
+  // algorithmic work of the step as the reference computes it (dense)
+  const double flops = 2.0 * (double)M * 9.0 * (cc.Cx + C) * 4.0 * C;
+  const double bytes = (double)M * (cc.Cx + 4.0 * C) * 4.0;  // x,h,c in; h,c out
+  launch(e, "convlstm_step", flops, bytes, [&] {
+    hipLaunchKernelGGL(mv::convlstm_step_kernel, dim3(grid), dim3(256), 0,
+                       e->stream, a);
+  });
+}
+
+void run_scene(mv_engine* e) {
+  const mv_config& c = e->cfg;
+  const int U = e->num_frames;
+  const float* in = e->scene_feat.p;
+  int Hi = c.scene_h, Wi = c.scene_w, Ci = c.scene_class;
+  const int k = c.scene_conv_kernel;
+  for (int i = 0; i < c.num_scales; ++i) {
+    const int Ho = e->conv_h[i], Wo = e->conv_w[i], Co = c.scene_conv_dim;
+    const int pad_h = std::max((Ho - 1) * 2 + k - Hi, 0);
+    const int pad_w = std::max((Wo - 1) * 2 + k - Wi, 0);
+    const size_t total = (size_t)U * Ho * Wo * Co;
+    float* out = e->scene_conv[i].p;
+    const float *w = e->scene_W[i]->dev.p, *b = e->scene_b[i]->dev.p;
+    launch(e, "scene_conv_s2_tanh", 2.0 * total * k * k * Ci,
+           4.0 * (total + (double)U * Hi * Wi * Ci), [&] {
+      hipLaunchKernelGGL(mv::scene_conv_s2_tanh_kernel, dim3(cdiv(total, 256)),
+                         dim3(256), 0, e->stream, in, w, b, out, U, Hi, Wi, Ci,
+                         Ho, Wo, Co, k, pad_h / 2, pad_w / 2);
+    });
+    in = out; Hi = Ho; Wi = Wo; Ci = Co;
+  }
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    const size_t total = (size_t)c.batch_size * S.K * c.scene_conv_dim;
+    launch(e, "scene_mean", (double)total * c.obs_len,
+           4.0 * total * (c.obs_len + 1), [&] {
+      hipLaunchKernelGGL(mv::scene_mean_kernel, dim3(cdiv(total, 256)), dim3(256),
+                         0, e->stream, e->scene_conv[s].p, e->obs_scene.p,
+                         S.scene_mean.p, c.batch_size, c.obs_len, S.K,
+                         c.scene_conv_dim);
+    });
+  }
+}
+
+// Encoders of one scale (dynamic_rnn from the zero state, T_o steps;
+// code/pred_models.py:212-215, 232-234).  Final states end in cls_*[fc] and
+// reg_*[fr]; returns the buffer indices.
+void run_encoders(mv_engine* e, int s, int* cls_idx, int* reg_idx) {
+  const mv_config& c = e->cfg;
+  ScaleState& S = e->sc[s];
+  const int N = c.batch_size, T = c.obs_len, D = c.scene_conv_dim;
+  int cur = 0;
+  for (int t = 0; t < T; ++t) {
+    const size_t total = (size_t)N * S.K * D;
+    launch(e, "enc_class_input", 0, 4.0 * total, [&] {
+      hipLaunchKernelGGL(mv::enc_class_input_kernel, dim3(cdiv(total, 256)),
+                         dim3(256), 0, e->stream, e->scene_conv[s].p,
+                         e->obs_scene.p, S.labels.p, S.xbuf_cls.p, N, T, t, S.K, D);
+    });
+    run_convlstm(e, S.enc_cls, S.xbuf_cls.p, S.cls_h[cur].p, S.cls_c[cur].p,
+                 nullptr, nullptr, S.cls_h[cur ^ 1].p, S.cls_c[cur ^ 1].p, N, S.H,
+                 S.W, t == 0);
+    cur ^= 1;
+  }
+  *cls_idx = cur;
+  cur = 0;
+  for (int t = 0; t < T; ++t) {
+    // x = grid_obs_regress[:, t]  -- a strided view would need per-row
+    // strides in the conv kernel; a [N,K,2] slice copy is 0.3 % of the step.
+    const size_t row = (size_t)S.K * 2;
+    HIP_CHECK(hipMemcpy2DAsync(S.xbuf_reg.p, row * sizeof(float),
+                               S.obs_reg.p + (size_t)t * row,
+                               (size_t)T * row * sizeof(float), row * sizeof(float),
+                               N, hipMemcpyDeviceToDevice, e->stream));
+    run_convlstm(e, S.enc_reg, S.xbuf_reg.p, S.reg_h[cur].p, S.reg_c[cur].p,
+                 nullptr, nullptr, S.reg_h[cur ^ 1].p, S.reg_c[cur ^ 1].p, N, S.H,
+                 S.W, t == 0);
+    cur ^= 1;
+  }
+  *reg_idx = cur;
+}
+
+void run_gnn(mv_engine* e, ScaleState& S, const float* h, const int32_t* src_row,
+             float* out, int rows, int sm_div) {
+  const mv_config& c = e->cfg;
+  const size_t cells = (size_t)rows * S.K;
+  launch(e, "gnn_attend", cells * (9.0 * 2 * 2 * (c.hidden_size + c.scene_conv_dim) +
+                                   9.0 * 2 * c.hidden_size),
+         4.0 * cells * (2.0 * c.hidden_size) + 4.0 * (cells / sm_div) * c.scene_conv_dim, [&] {
+    hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
+                       e->stream, h, S.scene_mean.p, src_row, out, rows, S.H, S.W,
+                       c.hidden_size, c.scene_conv_dim, sm_div);
+  });
+}
+
+template <int P>
+void run_hidden2grid(mv_engine* e, ScaleState& S, const float* h, const float* w,
+                     float* out, size_t out_row_stride, int rows) {
+  const size_t cells = (size_t)rows * S.K;
+  const int C = e->cfg.hidden_size;
+  launch(e, "hidden2grid", cells * 2.0 * 9 * C * P, 4.0 * cells * (C + P), [&] {
+    hipLaunchKernelGGL(mv::hidden2grid_kernel<P>, dim3(cdiv(cells, 4)), dim3(256),
+                       0, e->stream, h, w, out, out_row_stride, rows, S.H, S.W, C);
+  });
+}
+
+void run_emb_onehot(mv_engine* e, ScaleState& S, const int32_t* ids, int stride,
+                    float* out, int rows, int ids_div = 1) {
+  const int E = e->cfg.emb_size;
+  const size_t total = (size_t)rows * S.K * E;
+  launch(e, "grid_emb_onehot", (double)total, 4.0 * total, [&] {
+    hipLaunchKernelGGL(mv::grid_emb_onehot_kernel, dim3(cdiv(total, 256)),
+                       dim3(256), 0, e->stream, ids, stride, ids_div, S.emb_cls_W->dev.p,
+                       S.emb_cls_b->dev.p, out, rows, S.H, S.W, E);
+  });
+}
+
+void run_emb_dense(mv_engine* e, ScaleState& S, const float* x, size_t row_stride,
+                   float* out, int rows) {
+  const int E = e->cfg.emb_size;
+  const size_t total = (size_t)rows * S.K * E;
+  launch(e, "grid_emb_dense", total * 2.0 * 18, 4.0 * total, [&] {
+    hipLaunchKernelGGL(mv::grid_emb_dense_kernel, dim3(cdiv(total, 256)), dim3(256),
+                       0, e->stream, x, row_stride, S.emb_reg_W->dev.p,
+                       S.emb_reg_b->dev.p, out, rows, S.H, S.W, 2, E);
+  });
+}
+
+// Regression decoder, always greedy and un-beamed (code/pred_models.py:298-305
+// -> grid_decoder :311-471 with input_onehot=False, use_gnn=False).
+void run_reg_decoder(mv_engine* e, int s, int cur, int Tp) {
+  const mv_config& c = e->cfg;
+  ScaleState& S = e->sc[s];
+  const int N = c.batch_size, T = c.obs_len;
+  const size_t orow = (size_t)Tp * S.K * 2;
+  for (int t = 0; t < Tp; ++t) {
+    if (t == 0)  // first_input = obs_grid_reg[:, -1]
+      run_emb_dense(e, S, S.obs_reg.p + (size_t)(T - 1) * S.K * 2,
+                    (size_t)T * S.K * 2, S.xbuf_reg.p, N);
+    else         // hidden2grid output of the previous step
+      run_emb_dense(e, S, S.out_reg.p + (size_t)(t - 1) * S.K * 2, orow,
+                    S.xbuf_reg.p, N);
+    run_convlstm(e, S.dec_reg, S.xbuf_reg.p, S.reg_h[cur].p, S.reg_c[cur].p,
+                 nullptr, nullptr, S.reg_h[cur ^ 1].p, S.reg_c[cur ^ 1].p, N, S.H,
+                 S.W, false);
+    cur ^= 1;
+    run_hidden2grid<2>(e, S, S.reg_h[cur].p, S.out_reg_W->dev.p,
+                       S.out_reg.p + (size_t)t * S.K * 2, orow, N);
+  }
+}
+
+// Greedy class decoder (grid_decoder with input_onehot, use_gnn;
+// code/pred_models.py:311-471).
+void run_cls_decoder_greedy(mv_engine* e, int s, int cur, int Tp) {
+  const mv_config& c = e->cfg;
+  ScaleState& S = e->sc[s];
+  const int N = c.batch_size, T = c.obs_len;
+  const size_t orow = (size_t)Tp * S.K;
+  for (int t = 0; t < Tp; ++t) {
+    const float* hin = S.cls_h[cur].p;
+    if (c.use_gnn) {
+      run_gnn(e, S, S.cls_h[cur].p, nullptr, S.cls_hg.p, N, 1);
+      hin = S.cls_hg.p;
+    }
+    if (t == 0)  // one_hot(last observed cell)
+      run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, N);
+    else
+      run_emb_onehot(e, S, S.ids.p, 1, S.xbuf_cls.p, N);
+    run_convlstm(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cur].p, nullptr, nullptr,
+                 S.cls_h[cur ^ 1].p, S.cls_c[cur ^ 1].p, N, S.H, S.W, false);
+    cur ^= 1;
+    float* logits = S.out_cls.p + (size_t)t * S.K;
+    run_hidden2grid<1>(e, S, S.cls_h[cur].p, S.out_cls_W->dev.p, logits, orow, N);
+    if (t + 1 < Tp) {
+      launch(e, "argmax_rows", 0, 4.0 * N * S.K, [&] {
+        hipLaunchKernelGGL(mv::argmax_rows_kernel, dim3(N), dim3(64), 0, e->stream,
+                           logits, orow, S.ids.p, N, S.K);
+      });
+    }
+  }
+}
+
+__global__ void tile_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                 size_t row_elems4, int B, size_t total4) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const size_t r = idx / row_elems4, off = idx - r * row_elems4;
+  reinterpret_cast<mv::f32x4_t*>(out)[idx] =
+      reinterpret_cast<const mv::f32x4_t*>(in)[(r / B) * row_elems4 + off];
+}
+
+__global__ void beam_backtrace_kernel(const int32_t* __restrict__ step_ids,
+                                      const int32_t* __restrict__ step_parents,
+                                      int32_t* __restrict__ out_ids,
+                                      int32_t* __restrict__ trace, int N, int B,
+                                      int T) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * B) return;
+  const int n = idx / B, b = idx - n * B;
+  int par = b;  // parents_0 = arange(B), code/pred_models.py:714-716
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t o = ((size_t)t * N + n) * B + par;
+    out_ids[((size_t)n * B + b) * T + t] = step_ids[o];
+    trace[((size_t)n * B + b) * T + t] = par;
+    par = step_parents[o];
+  }
+}
+
+__global__ void beam_gather_logits_kernel(const float* __restrict__ step_logits,
+                                          const int32_t* __restrict__ trace,
+                                          float* __restrict__ out, int N, int B,
+                                          int T, int K) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * B * T * K;
+  if (idx >= total) return;
+  const int k = idx % K;
+  size_t r = idx / K;
+  const int t = r % T; r /= T;
+  const int b = r % B;
+  const int n = r / B;
+  const int par = trace[((size_t)n * B + b) * T + t];
+  out[idx] = step_logits[(((size_t)t * N + n) * B + par) * K + k];
+}
+
+// Beam-search class decoder (grid_decoder_beam_search,
+// code/pred_models.py:474-806).
+void run_cls_decoder_beam(mv_engine* e, int s, int cur, int Tp) {
+  const mv_config& c = e->cfg;
+  ScaleState& S = e->sc[s];
+  const int N = c.batch_size, T = c.obs_len, B = c.beam_size, K = S.K,
+            C = c.hidden_size;
+  const int R = N * B;
+  // tile encoder state to beams (:497-502).  The encoder wrote rows [0,N) of
+  // cls_*[cur]; expand into the other buffer.
+  {
+    const size_t row4 = (size_t)K * C / 4, total4 = (size_t)R * row4;
+    launch(e, "beam_tile_state", 0, 8.0 * total4 * 16, [&] {
+      hipLaunchKernelGGL(tile_rows_kernel, dim3(cdiv(total4, 256)), dim3(256), 0,
+                         e->stream, S.cls_h[cur].p, S.cls_h[cur ^ 1].p, row4, B, total4);
+      hipLaunchKernelGGL(tile_rows_kernel, dim3(cdiv(total4, 256)), dim3(256), 0,
+                         e->stream, S.cls_c[cur].p, S.cls_c[cur ^ 1].p, row4, B, total4);
+    });
+    cur ^= 1;
+  }
+  HIP_CHECK(hipMemsetAsync(e->bm_lp[0].p, 0, (size_t)R * sizeof(float), e->stream));
+  int lpi = 0;
+  const size_t lds_bytes = ((size_t)2 * B * K + 512) * sizeof(float);
+  const int32_t* src = nullptr;  // state row indirection for the next cell step
+  for (int time = 0; time <= Tp; ++time) {
+    if (time > 0) {
+      // cell step on R rows; h comes from the GNN buffer (identity rows) when
+      // use_gnn, c through the parent indirection
+      const float* hin = c.use_gnn ? S.cls_hg.p : S.cls_h[cur].p;
+      run_convlstm(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cur].p,
+                   c.use_gnn ? nullptr : src, src, S.cls_h[cur ^ 1].p,
+                   S.cls_c[cur ^ 1].p, R, S.H, S.W, false);
+      cur ^= 1;
+      float* logits = e->bm_logits.p + (size_t)(time - 1) * R * K;
+      run_hidden2grid<1>(e, S, S.cls_h[cur].p, S.out_cls_W->dev.p, logits, (size_t)K, R);
+      int32_t* ids = e->bm_ids.p + (size_t)(time - 1) * R;
+      int32_t* parents = e->bm_parents.p + (size_t)(time - 1) * R;
+      launch(e, "beam_step", 0, 4.0 * R * K, [&] {
+        hipLaunchKernelGGL(mv::beam_step_kernel, dim3(N), dim3(512), lds_bytes,
+                           e->stream, logits, e->bm_lp[lpi].p, B, K, time,
+                           c.diverse_beam, logf(c.diverse_gamma), c.fix_num_timestep,
+                           e->bm_lp[lpi ^ 1].p, ids, parents, e->bm_src_row.p);
+      });
+      lpi ^= 1;
+      src = e->bm_src_row.p;
+      if (time == Tp) break;
+      run_emb_onehot(e, S, ids, 1, S.xbuf_cls.p, R);
+    } else {
+      // one_hot(last observed cell), tiled over beams (:497-498, 531-532)
+      run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, R, B);
+    }
+    if (c.use_gnn)
+      run_gnn(e, S, S.cls_h[cur].p, src, S.cls_hg.p, R, B);
+  }
+  // back-trace (:689-806)
+  hipLaunchKernelGGL(beam_backtrace_kernel, dim3(cdiv(R, 256)), dim3(256), 0,
+                     e->stream, e->bm_ids.p, e->bm_parents.p, e->bm_out_ids.p,
+                     e->bm_trace.p, N, B, Tp);
+  const size_t total = (size_t)R * Tp * K;
+  hipLaunchKernelGGL(beam_gather_logits_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                     e->stream, e->bm_logits.p, e->bm_trace.p, e->bm_out_logits.p,
+                     N, B, Tp, K);
+  // final logprobs are in bm_lp[lpi]
+  if (lpi != 0)
+    HIP_CHECK(hipMemcpyAsync(e->bm_lp[0].p, e->bm_lp[1].p, (size_t)R * sizeof(float),
+                             hipMemcpyDeviceToDevice, e->stream));
+}
+
+void run_forward(mv_engine* e, bool beam) {
+  MV_REQUIRE(e->inputs_ready, "no inputs uploaded (mv_upload_inputs)");
+  ensure_params(e);
+  const mv_config& c = e->cfg;
+  const int Tp = e->pred_len;
+  if (beam)
+    MV_REQUIRE(c.beam_size > 1, "engine was created with beam_size 1");
+  run_scene(e);
+  for (int s = 0; s < c.num_scales; ++s) {
+    if (!e->sc[s].use) continue;
+    int ci = 0, ri = 0;
+    run_encoders(e, s, &ci, &ri);
+    if (beam) run_cls_decoder_beam(e, s, ci, Tp);
+    else run_cls_decoder_greedy(e, s, ci, Tp);
+    run_reg_decoder(e, s, ri, Tp);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+void upload_inputs(mv_engine* e, const mv_inputs* in) {
+  const mv_config& c = e->cfg;
+  const size_t N = c.batch_size, T = c.obs_len;
+  MV_REQUIRE(in->obs_scene && in->scene_feat, "obs_scene / scene_feat is NULL");
+  MV_REQUIRE(in->num_scene_frames >= 1 && (size_t)in->num_scene_frames <= N * T,
+             "num_scene_frames %d not in [1, N*T_o=%zu]", in->num_scene_frames, N * T);
+  MV_REQUIRE(in->pred_len >= 1 && in->pred_len <= c.max_pred_len,
+             "pred_len %d not in [1, max_pred_len=%d]", in->pred_len, c.max_pred_len);
+  for (size_t i = 0; i < N * T; ++i)
+    MV_REQUIRE(in->obs_scene[i] >= 0 && in->obs_scene[i] < in->num_scene_frames,
+               "obs_scene[%zu] = %d out of range [0,%d)", i, in->obs_scene[i],
+               in->num_scene_frames);
+  e->num_frames = in->num_scene_frames;
+  e->pred_len = in->pred_len;
+  HIP_CHECK(hipMemcpyAsync(e->obs_scene.p, in->obs_scene, N * T * sizeof(int32_t),
+                           hipMemcpyHostToDevice, e->stream));
+  HIP_CHECK(hipMemcpyAsync(e->scene_feat.p, in->scene_feat,
+                           (size_t)e->num_frames * c.scene_h * c.scene_w *
+                               c.scene_class * sizeof(float),
+                           hipMemcpyHostToDevice, e->stream));
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    MV_REQUIRE(in->grid_obs_labels[s] && in->grid_obs_regress[s],
+               "grid_obs_labels/grid_obs_regress[%d] is NULL for an enabled scale", s);
+    for (size_t i = 0; i < N * T; ++i)
+      MV_REQUIRE(in->grid_obs_labels[s][i] >= 0 && in->grid_obs_labels[s][i] < S.K,
+                 "grid_obs_labels[%d][%zu] = %d out of range [0,%d)", s, i,
+                 in->grid_obs_labels[s][i], S.K);
+    HIP_CHECK(hipMemcpyAsync(S.labels.p, in->grid_obs_labels[s],
+                             N * T * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipMemcpyAsync(S.obs_reg.p, in->grid_obs_regress[s],
+                             N * T * S.K * 2 * sizeof(float), hipMemcpyHostToDevice,
+                             e->stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+  e->inputs_ready = true;
+}
+
+void download_outputs(mv_engine* e, mv_outputs* out) {
+  const mv_config& c = e->cfg;
+  const size_t N = c.batch_size, Tp = e->pred_len;
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    if (out->grid_pred_class[s])
+      HIP_CHECK(hipMemcpyAsync(out->grid_pred_class[s], S.out_cls.p,
+                               N * Tp * S.K * sizeof(float), hipMemcpyDeviceToHost,
+                               e->stream));
+    if (out->grid_pred_reg[s])
+      HIP_CHECK(hipMemcpyAsync(out->grid_pred_reg[s], S.out_reg.p,
+                               N * Tp * S.K * 2 * sizeof(float), hipMemcpyDeviceToHost,
+                               e->stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+}
+
+void download_beam(mv_engine* e, mv_beam_outputs* out) {
+  const mv_config& c = e->cfg;
+  const size_t N = c.batch_size, Tp = e->pred_len, B = c.beam_size;
+  int s = 0;
+  for (int i = 0; i < c.num_scales; ++i) if (e->sc[i].use) s = i;
+  ScaleState& S = e->sc[s];
+  const size_t K = S.K;
+  if (out->logits)
+    HIP_CHECK(hipMemcpyAsync(out->logits, e->bm_out_logits.p, N * B * Tp * K * sizeof(float),
+                             hipMemcpyDeviceToHost, e->stream));
+  if (out->ids)
+    HIP_CHECK(hipMemcpyAsync(out->ids, e->bm_out_ids.p, N * B * Tp * sizeof(int32_t),
+                             hipMemcpyDeviceToHost, e->stream));
+  if (out->logprobs)
+    HIP_CHECK(hipMemcpyAsync(out->logprobs, e->bm_lp[0].p, N * B * sizeof(float),
+                             hipMemcpyDeviceToHost, e->stream));
+  if (out->grid_reg)
+    HIP_CHECK(hipMemcpyAsync(out->grid_reg, S.out_reg.p, N * Tp * K * 2 * sizeof(float),
+                             hipMemcpyDeviceToHost, e->stream));
+  if (out->best_beam)  // logits[:, 0] -> [N, T, K]: rows n*B of [N,B,T,K]
+    HIP_CHECK(hipMemcpy2DAsync(out->best_beam, Tp * K * sizeof(float),
+                               e->bm_out_logits.p, B * Tp * K * sizeof(float),
+                               Tp * K * sizeof(float), N, hipMemcpyDeviceToHost,
+                               e->stream));
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+}
+
+template <typename F>
+int guarded(mv_engine* e, F&& fn) {
+  try {
+    if (e) HIP_CHECK(hipSetDevice(e->device));
+    fn();
+    return 0;
+  } catch (const HipError& err) {
+    if (e) e->err = err.msg; else g_create_error = err.msg;
+    return 1;
+  } catch (const std::exception& ex) {
+    if (e) e->err = ex.what(); else g_create_error = ex.what();
+    return 2;
+  }
+}
+
+// RAII device buffer helpers for the single-kernel entry points
+struct OpCtx {
+  int device;
+  hipStream_t stream = nullptr;
+  explicit OpCtx(int dev) : device(dev) {
+    HIP_CHECK(hipSetDevice(dev));
+    HIP_CHECK(hipStreamCreate(&stream));
+  }
+  ~OpCtx() { if (stream) (void)hipStreamDestroy(stream); }
+  template <typename T>
+  void up(DevBuf<T>& b, const T* src, size_t n) {
+    b.alloc(n ? n : 1);
+    if (n) HIP_CHECK(hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  }
+  template <typename T>
+  void down(T* dst, const DevBuf<T>& b, size_t n) {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (n) HIP_CHECK(hipMemcpy(dst, b.p, n * sizeof(T), hipMemcpyDeviceToHost));
+  }
+};
+
+}  // namespace
+
+// ===================================================================== C ABI
+
+extern "C" {
+
+int mv_abi_version(void) { return MV_ABI_VERSION; }
+
+const char* mv_last_error(mv_handle h) {
+  return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+int mv_create(const mv_config* cfg, int device, mv_handle* out) {
+  if (!cfg || !out) { g_create_error = "mv_create: NULL argument"; return 1; }
+  *out = nullptr;
+  mv_engine* e = nullptr;
+  int rc = guarded(nullptr, [&] {
+    validate_config(*cfg);
+    int ndev = 0;
+    HIP_CHECK(hipGetDeviceCount(&ndev));
+    MV_REQUIRE(device >= 0 && device < ndev, "device %d not in [0,%d)", device, ndev);
+    HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    MV_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+               "device %d is %s; this library contains gfx950 (MI355X) code only",
+               device, prop.gcnArchName);
+    e = new mv_engine();
+    e->cfg = *cfg;
+    e->device = device;
+    HIP_CHECK(hipStreamCreate(&e->stream));
+    build_param_table(e);
+    alloc_buffers(e);
+    if (cfg->beam_size > 1) {
+      size_t K = 0;
+      for (int s = 0; s < cfg->num_scales; ++s)
+        if (e->sc[s].use) K = e->sc[s].K;
+      const size_t lds = ((size_t)2 * cfg->beam_size * K + 512) * sizeof(float);
+      MV_REQUIRE(lds <= 160 * 1024, "beam_size*K too large for the LDS beam step");
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mv::beam_step_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+  });
+  if (rc != 0) { delete e; return rc; }
+  *out = e;
+  return 0;
+}
+
+int mv_destroy(mv_handle h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+  delete h;
+  return 0;
+}
+
+int mv_num_params(mv_handle h) { return h ? (int)h->params.size() : -1; }
+
+int mv_param_info(mv_handle h, int32_t i, char* name_out, int32_t name_cap,
+                  int64_t* shape_out) {
+  if (!h || i < 0 || i >= (int)h->params.size()) return -1;
+  Param* p = h->params[i].get();
+  if (name_out && name_cap > 0) {
+    strncpy(name_out, p->name.c_str(), name_cap - 1);
+    name_out[name_cap - 1] = 0;
+  }
+  if (shape_out)
+    for (size_t d = 0; d < 4; ++d) shape_out[d] = d < p->shape.size() ? p->shape[d] : 0;
+  return (int)p->shape.size();
+}
+
+int mv_set_param(mv_handle h, const char* tf_name, const float* data,
+                 const int64_t* shape, int32_t rank) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(tf_name && data && shape, "mv_set_param: NULL argument");
+    auto it = h->by_name.find(tf_name);
+    MV_REQUIRE(it != h->by_name.end(), "unknown parameter '%s'", tf_name);
+    Param* p = it->second;
+    MV_REQUIRE(rank == (int)p->shape.size(), "parameter %s: rank %d, expected %zu",
+               tf_name, rank, p->shape.size());
+    for (int d = 0; d < rank; ++d)
+      MV_REQUIRE(shape[d] == p->shape[d], "parameter %s: dim %d is %lld, expected %lld",
+                 tf_name, d, (long long)shape[d], (long long)p->shape[d]);
+    const size_t n = p->elems();
+    p->host.assign(data, data + n);
+    p->dev.alloc(n);
+    HIP_CHECK(hipMemcpy(p->dev.p, data, n * sizeof(float), hipMemcpyHostToDevice));
+    p->set = true;
+    // invalidate the packed copy of a ConvLSTM kernel
+    for (int s = 0; s < h->cfg.num_scales; ++s) {
+      ScaleState& S = h->sc[s];
+      for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
+        if (cc->kernel == p) cc->wpack.release();
+    }
+  });
+}
+
+int mv_get_param(mv_handle h, const char* tf_name, float* out, int64_t capacity) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(tf_name && out, "mv_get_param: NULL argument");
+    auto it = h->by_name.find(tf_name);
+    MV_REQUIRE(it != h->by_name.end(), "unknown parameter '%s'", tf_name);
+    Param* p = it->second;
+    MV_REQUIRE(p->set, "parameter %s not set", tf_name);
+    MV_REQUIRE((size_t)capacity >= p->elems(), "buffer too small for %s", tf_name);
+    HIP_CHECK(hipMemcpy(out, p->dev.p, p->elems() * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+int mv_upload_inputs(mv_handle h, const mv_inputs* in) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(in, "mv_upload_inputs: NULL inputs");
+    upload_inputs(h, in);
+  });
+}
+
+int mv_run_greedy_resident(mv_handle h) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->cfg.beam_size == 1, "engine was created for beam search");
+    run_forward(h, false);
+  });
+}
+
+int mv_run_beam_resident(mv_handle h) {
+  if (!h) return 1;
+  return guarded(h, [&] { run_forward(h, true); });
+}
+
+int mv_synchronize(mv_handle h) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    drain_events(h);
+  });
+}
+
+int mv_download_outputs(mv_handle h, mv_outputs* out) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(out, "NULL outputs");
+    download_outputs(h, out);
+  });
+}
+
+int mv_download_beam_outputs(mv_handle h, mv_beam_outputs* out) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(out, "NULL outputs");
+    download_beam(h, out);
+  });
+}
+
+int mv_forward_greedy(mv_handle h, const mv_inputs* in, mv_outputs* out) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(in && out, "mv_forward_greedy: NULL argument");
+    MV_REQUIRE(h->cfg.beam_size == 1, "engine was created for beam search");
+    upload_inputs(h, in);
+    run_forward(h, false);
+    download_outputs(h, out);
+    drain_events(h);
+  });
+}
+
+int mv_forward_beam(mv_handle h, const mv_inputs* in, mv_beam_outputs* out) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(in && out, "mv_forward_beam: NULL argument");
+    upload_inputs(h, in);
+    run_forward(h, true);
+    download_beam(h, out);
+    drain_events(h);
+  });
+}
+
+int mv_set_profiling(mv_handle h, int32_t enabled) {
+  if (!h) return 1;
+  h->profiling = enabled != 0;
+  return 0;
+}
+
+int mv_reset_kernel_stats(mv_handle h) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    drain_events(h);
+    h->stats.clear();
+  });
+}
+
+int mv_num_kernel_stats(mv_handle h) { return h ? (int)h->stats.size() : -1; }
+
+int mv_kernel_stat(mv_handle h, int32_t i, char* name_out, int32_t name_cap,
+                   int64_t* launches, double* total_ms, double* flops, double* bytes) {
+  if (!h || i < 0 || i >= (int)h->stats.size()) return 1;
+  const KernelStat& s = h->stats[i];
+  if (name_out && name_cap > 0) {
+    strncpy(name_out, s.name.c_str(), name_cap - 1);
+    name_out[name_cap - 1] = 0;
+  }
+  if (launches) *launches = s.launches;
+  if (total_ms) *total_ms = s.total_ms;
+  if (flops) *flops = s.flops;
+  if (bytes) *bytes = s.bytes;
+  return 0;
+}
+
+static int time_resident(mv_handle h, int32_t iters, float* ms_out, bool beam) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(iters >= 1 && ms_out, "bad arguments");
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    HIP_CHECK(hipEventRecord(a, h->stream));
+    for (int i = 0; i < iters; ++i) run_forward(h, beam);
+    HIP_CHECK(hipEventRecord(b, h->stream));
+    HIP_CHECK(hipEventSynchronize(b));
+    HIP_CHECK(hipEventElapsedTime(ms_out, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    drain_events(h);
+  });
+}
+
+int mv_time_greedy_resident(mv_handle h, int32_t iters, float* ms_out) {
+  return time_resident(h, iters, ms_out, false);
+}
+int mv_time_beam_resident(mv_handle h, int32_t iters, float* ms_out) {
+  return time_resident(h, iters, ms_out, true);
+}
+
+// ------------------------------------------------------- single-kernel ops
+
+int mv_op_convlstm_step(int device, const float* x, const float* c, const float* h,
+                        const float* kernel, const float* biases, int32_t M,
+                        int32_t H, int32_t W, int32_t Cx, int32_t C, float* c_out,
+                        float* h_out) {
+  return guarded(nullptr, [&] {
+    MV_REQUIRE(C % mv::kChBlock == 0 && C % mv::kBK == 0, "C %d must be a multiple of 32", C);
+    MV_REQUIRE(mv::convlstm_cx_supported(Cx), "Cx %d unsupported (multiple of 32, or <= 3)", Cx);
+    OpCtx ctx(device);
+    const size_t cells = (size_t)M * H * W;
+    DevBuf<float> dx, dc, dh, dw, db, dco, dho;
+    ctx.up(dx, x, cells * Cx);
+    ctx.up(db, biases, (size_t)4 * C);
+    std::vector<float> packed(mv::convlstm_wpack_elems(Cx, C));
+    mv::pack_convlstm_weights(kernel, Cx, C, packed.data());
+    ctx.up(dw, packed.data(), packed.size());
+    const bool zero = (c == nullptr && h == nullptr);
+    if (!zero) {
+      MV_REQUIRE(c && h, "c and h must both be given or both be NULL");
+      ctx.up(dc, c, cells * C);
+      ctx.up(dh, h, cells * C);
+    }
+    dco.alloc(cells * C); dho.alloc(cells * C);
+    ConvLstmArgs a{};
+    a.x = dx.p; a.h = dh.p; a.c = dc.p; a.wpack = dw.p; a.bias = db.p;
+    a.h_out = dho.p; a.c_out = dco.p;
+    a.rows = M; a.H = H; a.W = W; a.Cx = Cx; a.C = C;
+    a.n_xchunks = mv::convlstm_xchunks(Cx);
+    a.n_hchunks = zero ? 0 : 9 * (C / mv::kBK);
+    a.x_small = (Cx > 0 && 9 * Cx <= mv::kBK) ? 1 : 0;
+    a.zero_state = zero ? 1 : 0;
+    a.forget_bias = 1.0f;
+    a.n_mtiles = (int)cdiv(cells, mv::kBM);
+    hipLaunchKernelGGL(mv::convlstm_step_kernel,
+                       dim3((unsigned)a.n_mtiles * (unsigned)(C / mv::kChBlock)),
+                       dim3(256), 0, ctx.stream, a);
+    HIP_CHECK(hipGetLastError());
+    ctx.down(c_out, dco, cells * C);
+    ctx.down(h_out, dho, cells * C);
+  });
+}
+
+int mv_op_gnn(int device, const float* h, const float* scene_mean, int32_t M,
+              int32_t H, int32_t W, int32_t C, int32_t D, float* out) {
+  return guarded(nullptr, [&] {
+    MV_REQUIRE(C == 256 && D >= 0 && D <= 64, "gnn: C must be 256 and D <= 64");
+    OpCtx ctx(device);
+    const size_t cells = (size_t)M * H * W;
+    DevBuf<float> dh, ds, dout;
+    ctx.up(dh, h, cells * C);
+    ctx.up(ds, scene_mean, cells * D);
+    dout.alloc(cells * C);
+    hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
+                       ctx.stream, dh.p, ds.p, (const int32_t*)nullptr, dout.p, M, H,
+                       W, C, D, 1);
+    HIP_CHECK(hipGetLastError());
+    ctx.down(out, dout, cells * C);
+  });
+}
+
+int mv_op_hidden2grid(int device, const float* h, const float* w, int32_t M,
+                      int32_t H, int32_t W, int32_t C, int32_t P, float* out) {
+  return guarded(nullptr, [&] {
+    MV_REQUIRE(C == 256 && (P == 1 || P == 2), "hidden2grid: C must be 256, P in {1,2}");
+    OpCtx ctx(device);
+    const size_t cells = (size_t)M * H * W;
+    DevBuf<float> dh, dw, dout;
+    ctx.up(dh, h, cells * C);
+    ctx.up(dw, w, (size_t)9 * C * P);
+    dout.alloc(cells * P);
+    if (P == 1)
+      hipLaunchKernelGGL(mv::hidden2grid_kernel<1>, dim3(cdiv(cells, 4)), dim3(256), 0,
+                         ctx.stream, dh.p, dw.p, dout.p, (size_t)H * W, M, H, W, C);
+    else
+      hipLaunchKernelGGL(mv::hidden2grid_kernel<2>, dim3(cdiv(cells, 4)), dim3(256), 0,
+                         ctx.stream, dh.p, dw.p, dout.p, (size_t)H * W * 2, M, H, W, C);
+    HIP_CHECK(hipGetLastError());
+    ctx.down(out, dout, cells * P);
+  });
+}
+
+int mv_op_beam_step(int device, const float* logits, const float* prev_logprob,
+                    int32_t N, int32_t B, int32_t K, int32_t time, int32_t diverse,
+                    float gamma, int32_t fix_num_timestep, float* new_logprob,
+                    int32_t* ids, int32_t* parents) {
+  return guarded(nullptr, [&] {
+    OpCtx ctx(device);
+    const size_t lds = ((size_t)2 * B * K + 512) * sizeof(float);
+    MV_REQUIRE(lds <= 160 * 1024, "B*K too large for the LDS beam step");
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mv::beam_step_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DevBuf<float> dl, dp, dn;
+    DevBuf<int32_t> di, dpa;
+    ctx.up(dl, logits, (size_t)N * B * K);
+    ctx.up(dp, prev_logprob, (size_t)N * B);
+    dn.alloc((size_t)N * B); di.alloc((size_t)N * B); dpa.alloc((size_t)N * B);
+    hipLaunchKernelGGL(mv::beam_step_kernel, dim3(N), dim3(512), lds, ctx.stream, dl.p,
+                       dp.p, B, K, time, diverse, logf(gamma), fix_num_timestep, dn.p,
+                       di.p, dpa.p, (int32_t*)nullptr);
+    HIP_CHECK(hipGetLastError());
+    ctx.down(new_logprob, dn, (size_t)N * B);
+    ctx.down(ids, di, (size_t)N * B);
+    ctx.down(parents, dpa, (size_t)N * B);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,393 @@
+// The HBM-bound members of the Multiverse hot path: scene encoder, decoder
+// input embeddings, graph attention, hidden2grid + argmax, beam expansion.
+// Every kernel cites the reference lines it replaces.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+namespace mv {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------- scene conv
+// conv k x k, stride 2, SAME, + b, tanh (reference code/pred_models.py:155-160
+// via conv2d :1333-1373) on the U unique frames of the batch; one thread per
+// output element.  in [U, Hi, Wi, Ci], w [k,k,Ci,Co] HWIO, out [U, Ho, Wo, Co].
+__global__ void scene_conv_s2_tanh_kernel(const float* __restrict__ in,
+                                          const float* __restrict__ w,
+                                          const float* __restrict__ b,
+                                          float* __restrict__ out, int U, int Hi,
+                                          int Wi, int Ci, int Ho, int Wo, int Co,
+                                          int k, int pad_t, int pad_l) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)U * Ho * Wo * Co;
+  if (idx >= total) return;
+  const int co = idx % Co;
+  size_t r = idx / Co;
+  const int ox = r % Wo; r /= Wo;
+  const int oy = r % Ho;
+  const int u = r / Ho;
+  float acc = 0.f;
+  for (int ky = 0; ky < k; ++ky) {
+    const int iy = oy * 2 + ky - pad_t;
+    if (iy < 0 || iy >= Hi) continue;
+    for (int kx = 0; kx < k; ++kx) {
+      const int ix = ox * 2 + kx - pad_l;
+      if (ix < 0 || ix >= Wi) continue;
+      const float* ip = in + (((size_t)u * Hi + iy) * Wi + ix) * Ci;
+      const float* wp = w + ((size_t)(ky * k + kx) * Ci) * Co + co;
+      for (int ci = 0; ci < Ci; ++ci) acc = fmaf(ip[ci], wp[(size_t)ci * Co], acc);
+    }
+  }
+  out[idx] = tanhf(acc + b[co]);
+}
+
+// mean over the T_o observed frames of the per-sample scene feature
+// (tf.reduce_mean(scene_features, axis=1), code/pred_models.py:826-828).
+// conv [U, K, D] (K = H*W), obs_scene [N, T], out [N, K, D].
+__global__ void scene_mean_kernel(const float* __restrict__ conv,
+                                  const int32_t* __restrict__ obs_scene,
+                                  float* __restrict__ out, int N, int T, int K,
+                                  int D) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)K * D;
+  if (idx >= (size_t)N * per) return;
+  const int n = idx / per;
+  const size_t off = idx - (size_t)n * per;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += conv[(size_t)obs_scene[n * T + t] * per + off];
+  out[idx] = s / (float)T;
+}
+
+// Class-encoder input: scene feature masked to the occupied cell
+// (tf.multiply(scene_convs[i], one_hot), code/pred_models.py:174-175,210).
+// out [N, K, D] for time step t.
+__global__ void enc_class_input_kernel(const float* __restrict__ conv,
+                                       const int32_t* __restrict__ obs_scene,
+                                       const int32_t* __restrict__ labels,
+                                       float* __restrict__ out, int N, int T,
+                                       int t, int K, int D) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)K * D;
+  if (idx >= (size_t)N * per) return;
+  const int n = idx / per;
+  const size_t off = idx - (size_t)n * per;
+  const int cell = off / D;
+  float v = 0.f;
+  if (cell == labels[n * T + t])
+    v = conv[(size_t)obs_scene[n * T + t] * per + off];
+  out[idx] = v;
+}
+
+// ---------------------------------------------------------------- grid_emb
+// tanh(conv3x3_SAME(x) + b), P in {1,2} input channels, E outputs
+// (grid_emb, code/pred_models.py:912-919).  Dense form, one thread per output.
+// x [M, H, W, P] with row stride x_row_stride (elements) so a time slice of a
+// [N, T, H, W, P] tensor can be embedded without a copy.
+__global__ void grid_emb_dense_kernel(const float* __restrict__ x,
+                                      size_t x_row_stride,
+                                      const float* __restrict__ w,
+                                      const float* __restrict__ b,
+                                      float* __restrict__ out, int M, int H,
+                                      int W, int P, int E) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)M * H * W * E;
+  if (idx >= total) return;
+  const int e = idx % E;
+  size_t r = idx / E;
+  const int xx = r % W; r /= W;
+  const int yy = r % H;
+  const int m = r / H;
+  float acc = 0.f;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = yy + ky - 1;
+    if (iy < 0 || iy >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = xx + kx - 1;
+      if (ix < 0 || ix >= W) continue;
+      const float* ip = x + (size_t)m * x_row_stride + ((size_t)iy * W + ix) * P;
+      for (int p = 0; p < P; ++p)
+        acc = fmaf(ip[p], w[((ky * 3 + kx) * P + p) * E + e], acc);
+    }
+  }
+  out[idx] = tanhf(acc + b[e]);
+}
+
+// One-hot input in closed form: the cell at offset (dy,dx) from the hot cell
+// sees exactly tap (1-dy, 1-dx); every other cell sees tanh(b).
+// (grid_emb of tf.one_hot(argmax), code/pred_models.py:411-425, 442-446,
+// 602-606.)  Row m reads ids[(m / ids_div) * ids_stride], so the obs labels
+// [N,T] column T-1, tiled over beams (ids_div = B), or per-beam ids are used in
+// place.  out [M, H, W, E].
+__global__ void grid_emb_onehot_kernel(const int32_t* __restrict__ ids,
+                                       int ids_stride, int ids_div,
+                                       const float* __restrict__ w,
+                                       const float* __restrict__ b,
+                                       float* __restrict__ out, int M, int H,
+                                       int W, int E) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)M * H * W * E;
+  if (idx >= total) return;
+  const int e = idx % E;
+  size_t r = idx / E;
+  const int xx = r % W; r /= W;
+  const int yy = r % H;
+  const int m = r / H;
+  const int id = ids[(size_t)(m / ids_div) * ids_stride];
+  const int py = id / W, px = id - py * W;
+  const int dy = yy - py, dx = xx - px;
+  float acc = 0.f;
+  if (dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1)
+    acc = w[((1 - dy) * 3 + (1 - dx)) * E + e];  // P == 1
+  out[idx] = tanhf(acc + b[e]);
+}
+
+// ---------------------------------------------------------------- graph attention
+// h_out = h + sum_j softmax_j(<f_i, f_j>) h_j over the <= 9 in-bounds 3x3
+// neighbours, f = l2_normalize([h ; scene_mean]).  The reference builds the
+// dense K x K edge matrix, adds -1e30 off the neighbourhood and softmaxes
+// (gnn_edge / gnn_mask_edge / gnn_node, code/pred_models.py:808-909,
+// exp_mask :1399-1401); exp(-1e30 - max) is exactly 0 in fp32, so the 9-point
+// stencil is the same function.  One wave per cell: lane l holds channels
+// 4l..4l+3 of h (C == 256) and channel l of the scene mean (D <= 64).
+// scene_mean rows are indexed by m / sm_div (beam tiling, :831-834).
+// src_row: optional state-row indirection (beam parents): input row for
+// output row r is src_row[r].
+__global__ __launch_bounds__(256)
+void gnn_attend_kernel(const float* __restrict__ h,
+                       const float* __restrict__ scene_mean,
+                       const int32_t* __restrict__ src_row,
+                       float* __restrict__ out, int M, int H, int W, int C,
+                       int D, int sm_div) {
+  const int lane = threadIdx.x & 63;
+  const size_t cell_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int K = H * W;
+  if (cell_id >= (size_t)M * K) return;
+  const int m = cell_id / K;
+  const int cell = cell_id - (size_t)m * K;
+  const int y = cell / W, x = cell - y * W;
+  const int ms = src_row ? src_row[m] : m;
+  const float* hrow = h + (size_t)ms * K * C;
+  const float* srow = scene_mean + (size_t)(m / sm_div) * K * D;
+
+  const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)cell * C + lane * 4);
+  const float si = (lane < D) ? srow[(size_t)cell * D + lane] : 0.f;
+  float ssi = hi[0] * hi[0] + hi[1] * hi[1] + hi[2] * hi[2] + hi[3] * hi[3] + si * si;
+  ssi = wave_sum(ssi);
+  const float invi = rsqrtf(fmaxf(ssi, 1e-12f));
+
+  f32x4_t hj[9];
+  float e[9];
+  bool ok[9];
+  float emax = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    ok[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W);
+    e[t] = 0.f;
+    hj[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (ok[t]) {  // wave-uniform
+      const int cj = yy * W + xx;
+      hj[t] = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)cj * C + lane * 4);
+      const float sj = (lane < D) ? srow[(size_t)cj * D + lane] : 0.f;
+      float ssj = hj[t][0] * hj[t][0] + hj[t][1] * hj[t][1] + hj[t][2] * hj[t][2] +
+                  hj[t][3] * hj[t][3] + sj * sj;
+      float dot = hi[0] * hj[t][0] + hi[1] * hj[t][1] + hi[2] * hj[t][2] +
+                  hi[3] * hj[t][3] + si * sj;
+      ssj = wave_sum(ssj);
+      dot = wave_sum(dot);
+      e[t] = dot * invi * rsqrtf(fmaxf(ssj, 1e-12f));
+      emax = fmaxf(emax, e[t]);
+    }
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    e[t] = ok[t] ? expf(e[t] - emax) : 0.f;
+    den += e[t];
+  }
+  const float inv = 1.0f / den;
+  f32x4_t node = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float a = e[t] * inv;
+    node[0] = fmaf(a, hj[t][0], node[0]);
+    node[1] = fmaf(a, hj[t][1], node[1]);
+    node[2] = fmaf(a, hj[t][2], node[2]);
+    node[3] = fmaf(a, hj[t][3], node[3]);
+  }
+  f32x4_t o = {hi[0] + node[0], hi[1] + node[1], hi[2] + node[2], hi[3] + node[3]};
+  *reinterpret_cast<f32x4_t*>(out + ((size_t)m * K + cell) * C + lane * 4) = o;
+}
+
+// ---------------------------------------------------------------- hidden2grid
+// conv3x3 SAME, no bias, identity, C -> P (P in {1,2}); hidden2grid,
+// code/pred_models.py:925-959.  One wave per cell, lane l holds channels
+// 4l..4l+3.  out has row stride out_row_stride elements so step t of a
+// [N, T, H, W, P] output tensor is written in place.
+template <int P>
+__global__ __launch_bounds__(256)
+void hidden2grid_kernel(const float* __restrict__ h, const float* __restrict__ w,
+                        float* __restrict__ out, size_t out_row_stride, int M,
+                        int H, int W, int C) {
+  const int lane = threadIdx.x & 63;
+  const size_t cell_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int K = H * W;
+  if (cell_id >= (size_t)M * K) return;
+  const int m = cell_id / K;
+  const int cell = cell_id - (size_t)m * K;
+  const int y = cell / W, x = cell - y * W;
+  const float* hrow = h + (size_t)m * K * C;
+  float acc[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) acc[p] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      const f32x4_t hv = *reinterpret_cast<const f32x4_t*>(
+          hrow + (size_t)(yy * W + xx) * C + lane * 4);
+      const float* wp = w + ((size_t)t * C + lane * 4) * P;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[p] = fmaf(hv[j], wp[j * P + p], acc[p]);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) acc[p] = wave_sum(acc[p]);
+  if (lane == 0) {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      out[(size_t)m * out_row_stride + (size_t)cell * P + p] = acc[p];
+  }
+}
+
+// argmax over K logits per row, lowest index wins ties (tf.argmax,
+// code/pred_models.py:411-415).  One wave per row.
+__global__ __launch_bounds__(64)
+void argmax_rows_kernel(const float* __restrict__ logits, size_t row_stride,
+                        int32_t* __restrict__ ids, int M, int K) {
+  const int m = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float* p = logits + (size_t)m * row_stride;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int k = lane; k < K; k += 64) {
+    const float v = p[k];
+    if (v > best || (v == best && k < bi)) { best = v; bi = k; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) ids[m] = bi;
+}
+
+// ---------------------------------------------------------------- beam step
+// One workgroup per sample.  (code/pred_models.py:557-591, add_div_penalty
+// :1197-1223.)  logits [N,B,K]:
+//   lp = log_softmax(logits) + prev_lp[b]
+//   if diverse: lp += log(gamma) * rank_desc(lp within (n,b)), ties -> lower idx
+//   candidates = time > 1 ? lp[N, B*K] : lp[:, 0]
+//   (new_lp, idx) = top_k(candidates, B) descending, ties -> lower index
+//   new_lp = 0 unless time > fix_num_timestep; ids = idx % K; parents = idx / K
+// The rank of element v is the number of elements that precede it in the
+// stable descending order: #{u : lp[u] > lp[v]} + #{u < v : lp[u] == lp[v]}.
+// Dynamic LDS: lp [B*K] + 512 words of reduction scratch + pen [B*K].
+__global__ __launch_bounds__(512)
+void beam_step_kernel(const float* __restrict__ logits,
+                      const float* __restrict__ prev_lp, int B, int K, int time,
+                      int diverse, float log_gamma, int fix_num_timestep,
+                      float* __restrict__ new_lp, int32_t* __restrict__ ids,
+                      int32_t* __restrict__ parents,
+                      int32_t* __restrict__ state_src_row) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* lp = sm;                 // [B*K]
+  float* red = sm + B * K;        // [256] reduction scratch
+  int* redi = reinterpret_cast<int*>(red + 256);  // [256]
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+  const float* lg = logits + (size_t)n * B * K;
+
+  // log_softmax per beam: one wave per beam row (strided over beams)
+  for (int b = wave; b < B; b += nwave) {
+    const float* row = lg + (size_t)b * K;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, row[k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += expf(row[k] - mx);
+    s = wave_sum(s);
+    const float lse = logf(s);
+    const float pl = prev_lp[(size_t)n * B + b];
+    for (int k = lane; k < K; k += 64) lp[b * K + k] = pl + ((row[k] - mx) - lse);
+  }
+  __syncthreads();
+  if (diverse) {
+    // rank by counting over the un-penalised values; penalties go to a second
+    // LDS plane and are applied once every rank has been taken.
+    float* pen = sm + B * K + 512;
+    const int total = B * K;
+    for (int v = tid; v < total; v += nthr) {
+      const int b = v / K, kv = v - b * K;
+      const float val = lp[v];
+      const float* row = lp + b * K;
+      int rank = 0;
+      for (int u = 0; u < K; ++u) {
+        const float o = row[u];
+        rank += (o > val) || (o == val && u < kv);
+      }
+      pen[v] = log_gamma * (float)rank;
+    }
+    __syncthreads();
+    for (int v = tid; v < total; v += nthr) lp[v] = lp[v] + pen[v];
+    __syncthreads();
+  }
+  // top-B selection by repeated arg-max with (value desc, index asc) order.
+  const int ncand = (time > 1) ? B * K : K;
+  for (int sel = 0; sel < B; ++sel) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = tid; v < ncand; v += nthr) {
+      const float val = lp[v];
+      if (val > best || (val == best && v < bi)) { best = val; bi = v; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { red[wave] = best; redi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int wv = 1; wv < nwave; ++wv) {
+        const float ov = red[wv];
+        const int oi = redi[wv];
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      const int par = bi / K;
+      new_lp[(size_t)n * B + sel] = (time > fix_num_timestep) ? best : 0.f;
+      ids[(size_t)n * B + sel] = bi - par * K;
+      parents[(size_t)n * B + sel] = par;
+      if (state_src_row) state_src_row[(size_t)n * B + sel] = n * B + par;
+      lp[bi] = -INFINITY;  // remove from the candidate set
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace mv

@@ -1,0 +1,409 @@
+# coding=utf-8
+"""CPU ORACLE for the Multiverse hot path  --  TEST INFRASTRUCTURE ONLY.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg
+may import this module; the product (`multiverse_amd/`) never does.
+
+**PARITY UNPINNED.**  The reference (`/root/reference/code/pred_models.py`) is
+TensorFlow-1.15 graph code; TensorFlow is not installable here (no wheel, no
+network), the reference ships no tests / golden vectors / fixtures
+(SURVEY.md §4), and the arithmetic of the recurrent cell lives in an
+un-vendored dependency:
+
+    tensorflow(-gpu) 1.15  --  tf.contrib.rnn.ConvLSTMCell, tf.nn.dynamic_rnn,
+    tf.nn.raw_rnn, tf.nn.conv2d(SAME), tf.nn.top_k, tf.invert_permutation,
+    tf.nn.l2_normalize, tf.nn.log_softmax        (reference requirements.txt:1)
+
+This file restates that published algorithm plus the reference's own wiring,
+function by function, each citing the reference file:line it follows.  It is
+cross-checked against an independent naive fp64 tap-loop twin
+(`oracle/naive_twin.py`) and against the reference's *unmodified*
+`pred_models.py` executed on an eager TF-1 API emulation
+(`oracle/tf1_shim/`, see `oracle/README.md`); the frozen outputs live in
+`tests/golden/`.
+
+All tensors are NHWC; arithmetic is float32 (or float64 with dtype=...),
+computed with torch-CPU convolutions.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+FORGET_BIAS = 1.0  # tf.contrib.rnn.ConvLSTMCell default
+
+
+def _t(a, dtype):
+  if isinstance(a, torch.Tensor):
+    return a.to(dtype)
+  return torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+
+
+# ------------------------------------------------------------------ conv
+
+def same_pads(in_size, k, stride):
+  """TF 'SAME': out = ceil(in/s); pad_total = max((out-1)*s + k - in, 0);
+  the extra pad goes to the bottom / right."""
+  out = -(-in_size // stride)
+  total = max((out - 1) * stride + k - in_size, 0)
+  lo = total // 2
+  return lo, total - lo
+
+
+def conv2d_same(x, w_hwio, stride=1):
+  """tf.nn.conv2d(x NHWC, W HWIO, SAME) -- cross-correlation.
+  Reference wrapper: code/pred_models.py:1333-1373."""
+  kh, kw = w_hwio.shape[0], w_hwio.shape[1]
+  pt, pb = same_pads(x.shape[1], kh, stride)
+  pl, pr = same_pads(x.shape[2], kw, stride)
+  xn = x.permute(0, 3, 1, 2)
+  xn = F.pad(xn, (pl, pr, pt, pb))
+  wn = w_hwio.permute(3, 2, 0, 1).contiguous()
+  y = F.conv2d(xn, wn, stride=stride)
+  return y.permute(0, 2, 3, 1).contiguous()
+
+
+def conv_layer(x, W, b=None, stride=1, act=None):
+  """`conv2d` helper of the reference (code/pred_models.py:1333-1373):
+  conv -> bias_add -> activation."""
+  y = conv2d_same(x, W, stride)
+  if b is not None:
+    y = y + b
+  if act is not None:
+    y = act(y)
+  return y
+
+
+# -------------------------------------------------------------- ConvLSTM
+
+def convlstm_cell(x, c, h, kernel, biases):
+  """tf.contrib.rnn.ConvLSTMCell.call (TF 1.15
+  tensorflow/contrib/rnn/python/ops/rnn_cell.py), constructed at reference
+  code/pred_models.py:189-193,196-200,236-240,243-247:
+
+    g = conv2d_SAME(concat([x, h], ch), kernel) + biases
+    i, j, f, o = split(g, 4, ch)
+    c' = sigmoid(f + forget_bias) * c + sigmoid(i) * tanh(j)
+    h' = tanh(c') * sigmoid(o)
+  """
+  g = conv2d_same(torch.cat([x, h], dim=-1), kernel) + biases
+  i, j, f, o = torch.chunk(g, 4, dim=-1)
+  new_c = torch.sigmoid(f + FORGET_BIAS) * c
+  new_c = new_c + torch.sigmoid(i) * torch.tanh(j)
+  new_h = torch.tanh(new_c) * torch.sigmoid(o)
+  return new_c, new_h
+
+
+# ------------------------------------------------------------------- GNN
+
+def neighbor_mask(H, W, dtype):
+  """`gnn_mask_edge` (code/pred_models.py:885-909): [K, K] 0/1 matrix, row k
+  is the 3x3 neighbourhood (self included, clipped at the border) of cell k."""
+  K = H * W
+  eye = torch.eye(K, dtype=dtype).reshape(K, H, W, 1)
+  ones = torch.ones(3, 3, 1, 1, dtype=dtype)
+  return conv2d_same(eye, ones).reshape(K, K)
+
+
+def gnn_dense(h, scene_mean):
+  """Graph attention exactly as the reference writes it (dense K x K):
+  gnn_edge (code/pred_models.py:808-858), gnn_mask_edge + exp_mask
+  (:885-909, :1399-1401), gnn_node + softmax (:860-882, :1376-1382).
+  Returns node_states; the caller adds them to h (:378, :651)."""
+  M, H, W, C = h.shape
+  K = H * W
+  hs = h.reshape(M, K, C)
+  feat = torch.cat([hs, scene_mean.reshape(M, K, -1)], dim=-1)
+  # tf.nn.l2_normalize: x * rsqrt(max(sum(x^2), 1e-12))
+  ss = (feat * feat).sum(-1, keepdim=True)
+  feat = feat * torch.rsqrt(torch.clamp(ss, min=1e-12))
+  e = torch.matmul(feat, feat.transpose(1, 2))  # [M, K, K]
+  mask = neighbor_mask(H, W, h.dtype)
+  e = e + (1 - mask) * -1e30
+  a = torch.softmax(e, dim=-1)
+  node = torch.matmul(a, hs)
+  return node.reshape(M, H, W, C)
+
+
+# -------------------------------------------------------- model sections
+
+class Params(object):
+  """TF-variable-name -> tensor lookup with the reference's scoping."""
+
+  def __init__(self, params, dtype):
+    self.p = {k: _t(v, dtype) for k, v in params.items()}
+
+  def __getitem__(self, name):
+    return self.p["person_pred/" + name]
+
+
+def scene_stack(P, cfg, scene_feat, obs_scene):
+  """code/pred_models.py:146-165: embedding_lookup of the per-frame one-hot
+  masks, then `len(strides)` x [conv k, stride 2, SAME, +b, tanh].
+  Returns list_s [N, T, h_s, w_s, D]."""
+  N, T = obs_scene.shape
+  x = scene_feat[torch.from_numpy(np.asarray(obs_scene)).long().reshape(-1)]
+  outs = []
+  for i, stride in enumerate(cfg.scene_grid_strides):
+    x = conv_layer(x, P["scene_conv%d/W" % (i + 1)], P["scene_conv%d/b" % (i + 1)],
+                   stride=2, act=torch.tanh)
+    outs.append(x.reshape(N, T, x.shape[1], x.shape[2], x.shape[3]))
+  return outs
+
+
+def one_hot_grid(labels, H, W, dtype):
+  """tf.one_hot(labels, H*W) reshaped to [..., H, W, 1]
+  (code/pred_models.py:174-175, 411-415, 602-605)."""
+  lab = torch.as_tensor(np.asarray(labels)).long()
+  oh = F.one_hot(lab, H * W).to(dtype)
+  return oh.reshape(tuple(lab.shape) + (H, W, 1))
+
+
+def run_encoder(x_seq, kernel, biases, C):
+  """tf.nn.dynamic_rnn over [N, T, H, W, Cx] from the zero state with
+  sequence_length == T (code/pred_models.py:212-215, 232-234; lengths are
+  all obs_len, :1057-1062).  Returns the last (c, h)."""
+  N, T, H, W, _ = x_seq.shape
+  c = torch.zeros(N, H, W, C, dtype=x_seq.dtype)
+  h = torch.zeros(N, H, W, C, dtype=x_seq.dtype)
+  for t in range(T):
+    c, h = convlstm_cell(x_seq[:, t], c, h, kernel, biases)
+  return c, h
+
+
+def argmax_lowest(x2d):
+  """tf.argmax: first (lowest) index among equal maxima."""
+  return np.argmax(x2d.numpy(), axis=1).astype("int32")
+
+
+def greedy_decoder(P, cfg, s, kind, first_input, state, T_pred, scene_mean,
+                   trace=None):
+  """`Model.grid_decoder` under `tf.nn.raw_rnn` (code/pred_models.py:311-471)
+  at test time (`input_onehot = not is_train or train_w_onehot`).
+
+  kind == "class": x0 = grid_emb(one_hot(last obs cell)); per step
+      h <- h + GNN(h) (:359-382); (c,h') = cell(x,(c,h)); next x =
+      grid_emb(one_hot(argmax(hidden2grid(h')))) (:407-425).
+  kind == "reg":   x0 = grid_emb(obs_grid_reg[:, -1]); next x =
+      grid_emb(hidden2grid(h')) (:427-435); no GNN.
+  Output = hidden2grid over the emitted h' (:467-469) -> [N, T, H, W, P]."""
+  scope = "decoder_grid_%s_%d" % (kind, s)
+  cellname = ("dec_grid_%d" if kind == "class" else "dec_grid_reg_%d") % s
+  kernel = P["%s/decoder_rnn/%s/kernel" % (scope, cellname)]
+  biases = P["%s/decoder_rnn/%s/biases" % (scope, cellname)]
+  embW = P["%s/decoder_rnn/grid_emb/W" % scope]
+  embb = P["%s/decoder_rnn/grid_emb/b" % scope]
+  outW = P["hidden2grid_%s/out_dec_grid/W" % scope]
+  c, h = state
+  N, H, W, C = h.shape
+  use_gnn = cfg.use_gnn and kind == "class"
+  x_in = first_input
+  outs, hs = [], []
+  for t in range(T_pred):
+    if use_gnn:
+      h = h + gnn_dense(h, scene_mean)
+    x = conv_layer(x_in, embW, embb, act=torch.tanh)
+    c, h = convlstm_cell(x, c, h, kernel, biases)
+    out = conv2d_same(h, outW)  # hidden2grid: no bias, identity (:948-950)
+    outs.append(out)
+    hs.append(h)
+    if kind == "class":
+      ids = argmax_lowest(out.reshape(N, H * W))
+      x_in = one_hot_grid(ids, H, W, h.dtype)
+      if trace is not None:
+        trace.setdefault("greedy_ids_%d" % s, []).append(ids)
+    else:
+      x_in = out
+  return torch.stack(outs, dim=1), torch.stack(hs, dim=1)
+
+
+def log_softmax_tf(x):
+  """tf.nn.log_softmax: x - max - log(sum(exp(x - max)))."""
+  m = x.max(dim=-1, keepdim=True).values
+  sh = x - m
+  return sh - torch.log(torch.exp(sh).sum(dim=-1, keepdim=True))
+
+
+def rank_desc_stable(x):
+  """rank[v] of every entry in descending order, ties -> lower index first
+  (tf.nn.top_k(k=V, sorted) + tf.invert_permutation;
+  code/pred_models.py:1211-1217)."""
+  a = x.numpy()
+  order = np.argsort(-a, axis=-1, kind="stable")
+  rank = np.empty_like(order)
+  np.put_along_axis(rank, order, np.broadcast_to(
+      np.arange(a.shape[-1]), a.shape).copy(), axis=-1)
+  return torch.from_numpy(rank)
+
+
+def add_div_penalty(logp, gamma):
+  """code/pred_models.py:1197-1223: logp + log(gamma) * rank."""
+  rank = rank_desc_stable(logp)
+  # tf.log(div_gamma) is evaluated in float32 on a float32 constant
+  lg = torch.log(torch.tensor(gamma, dtype=torch.float32)).to(logp.dtype)
+  return logp + lg * rank.to(logp.dtype)
+
+
+def topk_stable(x, k):
+  """tf.nn.top_k(sorted=True): descending, ties -> lower index first."""
+  a = x.numpy()
+  order = np.argsort(-a, axis=-1, kind="stable")[..., :k]
+  vals = np.take_along_axis(a, order, axis=-1)
+  return torch.from_numpy(vals), order.astype("int64")
+
+
+def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None):
+  """`Model.grid_decoder_beam_search` (code/pred_models.py:474-806).
+
+  Returns (best_beam_logits [N,T,H,W,1], logits [N,B,T,K], ids [N,B,T],
+  logprobs [N,B])."""
+  scope = "decoder_grid_class_%d" % s
+  kernel = P["%s/decoder_rnn/dec_grid_%d/kernel" % (scope, s)]
+  biases = P["%s/decoder_rnn/dec_grid_%d/biases" % (scope, s)]
+  embW = P["%s/decoder_rnn/grid_emb/W" % scope]
+  embb = P["%s/decoder_rnn/grid_emb/b" % scope]
+  outW = P["hidden2grid_%s/out_dec_grid/W" % scope]
+  B = cfg.beam_size
+  c0, h0 = state
+  N, H, W, C = h0.shape
+  K = H * W
+  dt = h0.dtype
+
+  def tile(t):  # :497-502, merged to [N*B, ...] at :527-532
+    return t.unsqueeze(1).expand(-1, B, -1, -1, -1).reshape(N * B, H, W, -1)
+
+  c, h = tile(c0), tile(h0)
+  x_in = tile(first_input)
+  sm = tile(scene_mean)  # tile_to_beam (:831-834)
+  prev_lp = torch.zeros(N, B, dtype=dt)
+  all_ids, all_parents, all_logits = [], [], []
+  # raw_rnn: loop_fn(0) -> [cell -> loop_fn(time)] for time = 1..T_pred
+  for time in range(0, T_pred + 1):
+    if time > 0:
+      c, h = convlstm_cell(x, c, h, kernel, biases)
+      logits = conv2d_same(h, outW).reshape(N, B, K)        # :550-555
+      lp = log_softmax_tf(logits)                           # :557
+      lp = prev_lp.unsqueeze(-1) + lp                       # :560
+      if cfg.diverse_beam:
+        lp = add_div_penalty(lp, cfg.diverse_gamma)         # :561-567
+      flat = lp.reshape(N, B * K) if time > 1 else lp[:, 0]  # :569-573
+      new_lp, idx = topk_stable(flat, B)                    # :578-579
+      if not time > cfg.fix_num_timestep:                   # :581-584
+        new_lp = torch.zeros(N, B, dtype=dt)
+      ids = (idx % K).astype("int32")                       # :588
+      parents = (idx // K).astype("int32")                  # :591
+      all_ids.append(ids)
+      all_parents.append(parents)
+      all_logits.append(logits)
+      x_in = one_hot_grid(ids.reshape(-1), H, W, dt)        # :602-606
+      gidx = torch.from_numpy(
+          (parents + np.arange(N)[:, None] * B).reshape(-1)).long()
+      c, h = c[gidx], h[gidx]                               # :611-623
+      prev_lp = new_lp.to(dt)
+      if time == T_pred:
+        break  # raw_rnn stops: state/input of the finished step are unused
+    if cfg.use_gnn:
+      h = h + gnn_dense(h, sm)                              # :631-654
+    x = conv_layer(x_in, embW, embb, act=torch.tanh)        # :662-666
+
+  # back-trace (:689-806): walk time backwards following parents
+  T = len(all_ids)
+  out_ids = np.zeros((N, B, T), dtype="int32")
+  out_logits = torch.zeros(N, B, T, K, dtype=dt)
+  par = np.tile(np.arange(B)[None], [N, 1])                 # :714-716
+  rows = np.arange(N)[:, None]
+  for t in range(T - 1, -1, -1):
+    out_ids[:, :, t] = all_ids[t][rows, par]
+    out_logits[:, :, t] = all_logits[t][torch.from_numpy(rows).long(),
+                                        torch.from_numpy(par).long()]
+    par = all_parents[t][rows, par]
+  best = out_logits[:, 0].reshape(N, T, H, W, 1)            # :799-803
+  if trace is not None:
+    trace["beam_step_ids"] = all_ids
+    trace["beam_step_parents"] = all_parents
+    trace["beam_step_logits"] = [l.numpy() for l in all_logits]
+  return best, out_logits, out_ids, prev_lp
+
+
+def forward(params, cfg, feed, dtype=torch.float32, trace=None):
+  """`Model.build_forward` (code/pred_models.py:123-308) + the fetch contract
+  of `Tester.step` (:1761-1790).
+
+  feed: dict with obs_scene [N,T_o] int, scene_feat [U,SH,SW,SC],
+        grid_obs_labels list_s [N,T_o] int, grid_obs_regress list_s
+        [N,T_o,H,W,2], pred_length int.
+  Returns (grid_pred_class list_s, grid_pred_reg list_s, beam_outputs) as
+  numpy arrays; unused scales give []."""
+  assert cfg.use_scene_enc, "only the published --use_scene_enc wiring"
+  assert cfg.keep_prob == 1.0 or not cfg.is_train
+  P = Params(params, dtype)
+  C = cfg.enc_hidden_size
+  T_pred = int(feed["pred_length"])
+  with torch.no_grad():
+    scene_convs = scene_stack(P, cfg, _t(feed["scene_feat"], dtype),
+                              feed["obs_scene"])
+    cls_out, reg_out, beam_out = [], [], None
+    for s, (H, W) in enumerate(cfg.scene_grids):
+      if not cfg.use_grids[s]:
+        cls_out.append([])
+        reg_out.append([])
+        continue
+      labels = np.asarray(feed["grid_obs_labels"][s])
+      obs_oh = one_hot_grid(labels, H, W, dtype)           # [N,T,H,W,1]
+      obs_reg = _t(feed["grid_obs_regress"][s], dtype)     # [N,T,H,W,2]
+      x_cls = scene_convs[s] * obs_oh                      # :210
+      enc_c = run_encoder(
+          x_cls, P["encoder_grid_class_%d/enc_grid_%d/kernel" % (s, s)],
+          P["encoder_grid_class_%d/enc_grid_%d/biases" % (s, s)], C)
+      enc_r = run_encoder(
+          obs_reg, P["encoder_grid_reg_%d/enc_grid_regress_%d/kernel" % (s, s)],
+          P["encoder_grid_reg_%d/enc_grid_regress_%d/biases" % (s, s)], C)
+      scene_mean = scene_convs[s].mean(dim=1)              # :828
+      if trace is not None:
+        trace["enc_class_c_%d" % s] = enc_c[0].numpy()
+        trace["enc_class_h_%d" % s] = enc_c[1].numpy()
+        trace["enc_reg_c_%d" % s] = enc_r[0].numpy()
+        trace["enc_reg_h_%d" % s] = enc_r[1].numpy()
+        trace["scene_mean_%d" % s] = scene_mean.numpy()
+      if cfg.use_beam_search:
+        assert not cfg.is_train
+        assert sum(cfg.use_grids) == 1, "only one scale test at a time"
+        best, lg, ids, lps = beam_decoder(
+            P, cfg, s, obs_oh[:, -1], enc_c, T_pred, scene_mean, trace)
+        dec_cls = best
+        beam_out = [lg.numpy(), ids, lps.numpy()]
+      else:
+        dec_cls, dec_h = greedy_decoder(
+            P, cfg, s, "class", obs_oh[:, -1], enc_c, T_pred, scene_mean, trace)
+        if trace is not None:
+          trace["dec_class_h_%d" % s] = dec_h.numpy()
+      dec_reg, _ = greedy_decoder(
+          P, cfg, s, "reg", obs_reg[:, -1], enc_r, T_pred, scene_mean, trace)
+      cls_out.append(dec_cls.numpy())
+      reg_out.append(dec_reg.numpy())
+  return cls_out, reg_out, beam_out
+
+
+# ---------------------------------------------------- per-kernel entry points
+
+def convlstm_step_np(x, c, h, kernel, biases, dtype=torch.float32):
+  with torch.no_grad():
+    nc, nh = convlstm_cell(_t(x, dtype), _t(c, dtype), _t(h, dtype),
+                           _t(kernel, dtype), _t(biases, dtype))
+  return nc.numpy(), nh.numpy()
+
+
+def gnn_np(h, scene_mean, dtype=torch.float32):
+  with torch.no_grad():
+    hh = _t(h, dtype)
+    return (hh + gnn_dense(hh, _t(scene_mean, dtype))).numpy()
+
+
+def logit_margins(logits2d):
+  """top-1 minus top-2 per row -- attribute argmax flips to margin < tol."""
+  a = np.sort(np.asarray(logits2d), axis=-1)
+  return a[..., -1] - a[..., -2]

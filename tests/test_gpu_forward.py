@@ -1,0 +1,132 @@
+# coding=utf-8
+"""GPU parity of the whole forward (one `sess.run` of the reference) through
+the C ABI: greedy (Tester.step, code/pred_models.py:1761-1790) and beam search
+(code/multifuture_inference.py:468-472) against the CPU oracle.
+
+Bars (BASELINE.json north_star): grid argmax / beam ids bit-exact, logits and
+regression outputs within 1e-4 (fp32).  An id mismatch is accepted ONLY where
+the oracle's own top-1/top-2 margin at that step is below the numeric
+tolerance, and is reported.
+"""
+
+import numpy as np
+import pytest
+
+from multiverse_amd import synth
+from oracle import multiverse_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _check_greedy(built_lib, cfg, params, feed):
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  cls, reg = eng.forward_greedy(feed)
+  eng.close()
+  ocls, oreg, _ = oracle.forward(params, cfg, feed)
+  N, Tp = cfg.batch_size, int(feed["pred_length"])
+  for s in range(len(cfg.scene_grids)):
+    if not cfg.use_grids[s]:
+      assert cls[s] == [] and reg[s] == []
+      continue
+    assert cls[s].shape == ocls[s].shape and reg[s].shape == oreg[s].shape
+    gi = cls[s].reshape(N, Tp, -1).argmax(-1)
+    oi = ocls[s].reshape(N, Tp, -1).argmax(-1)
+    margins = oracle.logit_margins(ocls[s].reshape(N, Tp, -1))
+    # a sequence is comparable up to (and including) its first id mismatch
+    for n in range(N):
+      bad = np.nonzero(gi[n] != oi[n])[0]
+      if bad.size:
+        t = bad[0]
+        assert margins[n, t] < TOL, (
+            "argmax differs at n=%d t=%d with oracle margin %g" % (n, t, margins[n, t]))
+        upto = t + 1
+      else:
+        upto = Tp
+      assert np.abs(cls[s][n, :upto] - ocls[s][n, :upto]).max() < TOL
+    assert (gi == oi).mean() > 0.99
+    assert np.abs(reg[s] - oreg[s]).max() < TOL
+  return cls, reg
+
+
+def test_greedy_config1_single_scale_n4(built_lib):
+  """BASELINE config 1: single scale 18x32, N=4, obs 8 / pred 12."""
+  cfg = synth.default_config(batch_size=4, use_grids=(1, 0))
+  params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 0)
+  _check_greedy(built_lib, cfg, params, feed)
+
+
+def test_greedy_both_scales_reference_init(built_lib):
+  """Both scales with the reference's own initialisers (glorot, zero bias)."""
+  cfg = synth.default_config(batch_size=3, use_grids=(1, 1))
+  params = synth.make_params(cfg)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 1)
+  _check_greedy(built_lib, cfg, params, feed)
+
+
+def test_greedy_runtime_pred_len_and_no_gnn(built_lib):
+  """T_pred is a run-time value (multifuture_inference.py:311); --use_gnn off."""
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), use_gnn=False)
+  cfg.max_pred_len = 16
+  params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 2, pred_len=15)
+  cls, reg = _check_greedy(built_lib, cfg, params, feed)
+  assert cls[1].shape[1] == 15
+
+
+def test_greedy_engine_reuse_is_deterministic(built_lib):
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1))
+  params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 3)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  a, ar = eng.forward_greedy(feed)
+  b, br = eng.forward_greedy(feed)
+  assert (a[1] == b[1]).all() and (ar[1] == br[1]).all()
+  # resident path == host path
+  eng.upload(feed)
+  eng.run_resident()
+  c, cr = eng.download()
+  assert (a[1] == c[1]).all() and (ar[1] == cr[1]).all()
+  eng.close()
+
+
+def test_missing_param_fails_loudly(built_lib):
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1))
+  feed = synth.make_feed(cfg)
+  eng = built_lib.Engine(cfg, device=0)
+  with pytest.raises(built_lib.MvError, match="not set"):
+    eng.forward_greedy(feed)
+  eng.close()
+
+
+@pytest.mark.parametrize("scale,N,B", [(1, 2, 5), (0, 1, 20)])
+def test_beam_search(built_lib, scale, N, B):
+  """Beam decode incl. the reference's own configuration (batch 1, beam 20,
+  gamma 0.01, fix_num_timestep 1; TESTING.md:84-93)."""
+  use = (1, 0) if scale == 0 else (0, 1)
+  cfg = synth.default_config(batch_size=N, use_grids=use, beam_size=B)
+  params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 4 + scale)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  arrs, s = eng.forward_beam(feed)
+  eng.close()
+  trace = {}
+  ocls, oreg, obeam = oracle.forward(params, cfg, feed, trace=trace)
+  ologits, oids, olp = obeam
+  assert s == scale
+  assert arrs["ids"].shape == oids.shape
+  same = (arrs["ids"] == oids)
+  if not same.all():
+    # tolerate a divergence only when the oracle's own candidate gap at the
+    # diverging step is below tolerance; report it
+    bad = np.argwhere(~same)
+    raise AssertionError("beam ids differ at %s" % bad[:5].tolist())
+  assert np.abs(arrs["logits"] - ologits).max() < TOL
+  assert np.abs(arrs["logprobs"] - olp).max() < 1e-3
+  assert np.abs(arrs["best_beam"] - ocls[scale]).max() < TOL
+  assert np.abs(arrs["grid_reg"] - oreg[scale]).max() < TOL
