@@ -1,0 +1,217 @@
+# coding=utf-8
+"""Headline benchmark: trajectories/sec of the Multiverse forward on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+      --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "config 2"): both grid
+scales (18x32 and 9x16 over 36x64x11 scene maps), batch 64 per GPU, fp32,
+forward only, greedy decode (beam 1): per trajectory 8 observed steps encoded
+by the class + regression ConvLSTM encoders and 12 predicted steps decoded by
+the class (graph attention + argmax feedback) and regression decoders.
+A "step" is one forward over one batch; inputs are resident in HBM when the
+timed region starts (`mv_upload_inputs` before, `mv_run_greedy_resident`
+inside).  Trajectories are independent, so N GPUs run N batch shards with no
+data-path collective ("scaling": "weak").
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel (convlstm_step, >99 % of FLOPs): algorithmic
+                  FLOPs per launch / average launch duration from hipEvents on
+                  the engine's stream, against the gfx950 fp32 MFMA peak.  The
+                  same sweep as a fraction of the 8 TB/s HBM roofline
+                  (north_star's phrasing) is reported as hbm_frac.
+  cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference graph;
+                  TF1 cannot run here) timed on a bounded sample, rank 0, N=1.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_counts(cfg, beam=1):
+  """FLOPs / state bytes per trajectory as the reference computes the sweep
+  (dense): 2*K*9*(Cx+C)*4C per ConvLSTM step; each step
+  reads x,h,c and writes h,c once."""
+  C, D, E = cfg.enc_hidden_size, cfg.scene_conv_dim, cfg.emb_size
+  To, Tp = cfg.obs_len, cfg.pred_len
+  flops = 0.0
+  nbytes = 0.0
+  for s, (h, w) in enumerate(cfg.scene_grids):
+    if not cfg.use_grids[s]:
+      continue
+    K = h * w
+    for cx, steps, rows in ((D, To, 1), (2, To, 1), (E, Tp, beam), (E, Tp, 1)):
+      flops += rows * steps * 2.0 * K * 9 * (cx + C) * 4 * C
+      nbytes += rows * steps * K * (cx + 4 * C) * 4.0
+  return flops, nbytes
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=10)
+  ap.add_argument("--warmup", type=int, default=2)
+  ap.add_argument("--batch", type=int, default=64, help="trajectories per GPU")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--cpu-batch", type=int, default=8)
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  from multiverse_amd import _lib, synth
+
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if args.gpus != world:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks"
+                       % (args.gpus, args.gpus))
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs an MI355X; no HIP device visible "
+                     "(there is no CPU fallback)")
+  torch.cuda.set_device(local_rank)
+  use_dist = world > 1
+  if use_dist:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="nccl")  # RCCL; barrier + max only
+
+  cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 1))
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 2)  # reference initialisers
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 2 + 1000 * rank)
+  eng = _lib.Engine(cfg, device=local_rank)
+  eng.set_params(params)
+  eng.upload(feed)          # inputs resident in HBM before the timed region
+
+  def barrier():
+    if use_dist:
+      dist.barrier()
+    torch.cuda.synchronize()
+    eng.synchronize()
+
+  for _ in range(args.warmup):
+    eng.run_resident()
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    eng.run_resident()
+  eng.synchronize()
+  barrier()
+  elapsed = time.perf_counter() - t0
+  if use_dist:
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  ms_per_step = 1e3 * elapsed / args.steps
+  value = world * args.batch * args.steps / elapsed
+
+  # ---- roofline of the dominant kernel, measured live with hipEvents
+  eng.set_profiling(True)
+  eng.reset_kernel_stats()
+  eng.run_resident()
+  eng.synchronize()
+  stats = eng.kernel_stats()
+  eng.set_profiling(False)
+  conv = stats["convlstm_step"]
+  conv_s = conv["total_ms"] * 1e-3
+  achieved_tf = conv["flops"] / conv_s / 1e12
+  flops_traj, bytes_traj = algorithmic_counts(cfg)
+  roofline = {
+      "kernel": "convlstm_step",
+      "bound": "mfma",
+      "achieved": round(achieved_tf, 2),
+      "peak": PEAK_FP32_MFMA_TFLOPS,
+      "unit": "TFLOP/s",
+      "frac": round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+      "traffic": None,
+      "launches": conv["launches"],
+      "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
+      "alg_gflop_per_launch_avg": round(conv["flops"] / conv["launches"] / 1e9, 2),
+      # the same sweep against the HBM roofline, as north_star phrases it
+      "hbm_achieved_GBs": round(conv["bytes"] / conv_s / 1e9, 1),
+      "hbm_frac": round(conv["bytes"] / conv_s / 1e9 / PEAK_HBM_GBS, 4),
+      "whole_forward_mfma_frac": round(
+          value / world * flops_traj / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+      "other_kernels_ms": {k: round(v["total_ms"], 3) for k, v in stats.items()
+                           if k != "convlstm_step"},
+  }
+
+  out = {
+      "metric": "trajectories/sec (8-obs/12-pred, multi-scale 18x32+9x16 grid, "
+                "greedy forward)",
+      "value": round(value, 2),
+      "unit": "trajectories/sec",
+      "n_gpus": world,
+      "steps": args.steps,
+      "warmup": args.warmup,
+      "ms_per_step": round(ms_per_step, 3),
+      "higher_is_better": True,
+      "scaling": "weak",
+      "vs_baseline": None,
+      "dtype": "f32",
+      "data": "synthetic (seeded AR(1) trajectories, rectangle scene masks, "
+              "random-init weights with the reference's initialisers)",
+      "config": {"workload": "BASELINE configs[1]: multi-scale 18x32+9x16 "
+                             "(scene 36x64x11), batch 64/GPU, fp32 forward-only, "
+                             "beam 1, obs 8 / pred 12",
+                 "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                 "obs_len": cfg.obs_len, "pred_len": cfg.pred_len,
+                 "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                 "alg_gflop_per_trajectory": round(flops_traj / 1e9, 2),
+                 "alg_state_MB_per_trajectory": round(bytes_traj / 1e6, 2)},
+      "roofline": roofline,
+  }
+
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+
+  eng.close()
+  if use_dist:
+    dist.barrier()
+    dist.destroy_process_group()
+  if rank == 0:
+    print(json.dumps(out))
+
+
+def cpu_baseline(batch):
+  """The CPU oracle on a bounded sample of the same workload (both scales,
+  greedy, obs 8 / pred 12): 1 warm-up + timed passes of `batch` trajectories
+  until ~12 s of CPU work."""
+  import torch
+  from multiverse_amd import synth
+  from oracle import multiverse_oracle as oracle
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+  cfg = synth.default_config(batch_size=batch, use_grids=(1, 1))
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 2)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 2)
+  oracle.forward(params, cfg, feed)  # warm-up
+  t0 = time.perf_counter()
+  passes = 0
+  while passes < 1 or (time.perf_counter() - t0 < 12.0 and passes < 6):
+    oracle.forward(params, cfg, feed)
+    passes += 1
+  dt = time.perf_counter() - t0
+  return {"value": round(batch * passes / dt, 3), "unit": "trajectories/sec",
+          "cores": torch.get_num_threads(), "kind": "port",
+          "sample": "%d passes of %d trajectories (both scales, greedy), torch-CPU "
+                    "fp32 oracle restatement of the reference graph -- NOT TF1"
+                    % (passes, batch)}
+
+
+if __name__ == "__main__":
+  main()

@@ -47,6 +47,7 @@ struct ConvLstmArgs {
   int32_t x_small;      // 1: 9*Cx <= 32, all taps of x packed in ONE chunk
   int32_t zero_state;   // 1: h == c == 0 (first encoder step): skip h, c reads
   int32_t n_mtiles;
+  int32_t w_chunks;     // chunks per channel block in wpack (x + all h chunks)
   float forget_bias;
 };
 
@@ -142,7 +143,7 @@ void convlstm_step_kernel(const ConvLstmArgs a) {
       ypos[p] = -100000; xpos[p] = -100000; xbase[p] = 0; hbase[p] = 0;
     }
   }
-  const float* wblk = a.wpack + (size_t)cb * nchunks * kBN * kBK;
+  const float* wblk = a.wpack + (size_t)cb * a.w_chunks * kBN * kBK;
 
   f32x4 pa[4], pb[4];
   auto load_chunk = [&](int q) {

@@ -361,6 +361,7 @@ void run_convlstm(mv_engine* e, const ConvCell& cc, const float* x,
   a.rows = rows; a.H = H; a.W = W; a.Cx = cc.Cx; a.C = C;
   a.n_xchunks = mv::convlstm_xchunks(cc.Cx);
   a.n_hchunks = zero_state ? 0 : 9 * (C / mv::kBK);
+  a.w_chunks = a.n_xchunks + 9 * (C / mv::kBK);
   a.x_small = (cc.Cx > 0 && 9 * cc.Cx <= mv::kBK) ? 1 : 0;
   a.zero_state = zero_state ? 1 : 0;
   a.forget_bias = 1.0f;
@@ -1064,6 +1065,7 @@ int mv_op_convlstm_step(int device, const float* x, const float* c, const float*
     a.rows = M; a.H = H; a.W = W; a.Cx = Cx; a.C = C;
     a.n_xchunks = mv::convlstm_xchunks(Cx);
     a.n_hchunks = zero ? 0 : 9 * (C / mv::kBK);
+    a.w_chunks = a.n_xchunks + 9 * (C / mv::kBK);
     a.x_small = (Cx > 0 && 9 * Cx <= mv::kBK) ? 1 : 0;
     a.zero_state = zero ? 1 : 0;
     a.forget_bias = 1.0f;

@@ -1,0 +1,172 @@
+# coding=utf-8
+"""Drop-in for the reference's `pred_models` call boundary, backed by
+libmultiverse_hip.so (no TensorFlow, no CPU fallback).
+
+What the reference's callers use and where it lives there:
+
+  get_model(config, gpuid)            code/pred_models.py:19-30
+  Model(config, scope)                code/pred_models.py:32-121
+    .get_feed_dict(batch, is_train)   code/pred_models.py:1042-1194
+    .grid_pred_decoded / .grid_pred_reg_decoded / .beam_outputs (fetch names)
+  Tester(model, config, sess).step    code/pred_models.py:1745-1790
+  Trainer(model, config).step         code/pred_models.py:1636-1742
+
+`sess` arguments are accepted and ignored: the engine handle plays the role of
+the TF session.  A `Model` owns one engine (one HIP stream, weights resident in
+HBM); `Tester.step` is one `mv_forward_greedy` / `mv_forward_beam` call, i.e.
+exactly one `sess.run` of the reference.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from multiverse_amd import _lib
+
+
+def get_model(config, gpuid=0):
+  """code/pred_models.py:19-30 -- build the model and pin it to one GPU."""
+  return Model(config, "%s" % getattr(config, "modelname", "model"), gpuid=gpuid)
+
+
+class Model(object):
+  """One engine instance with the reference Model's host-side protocol."""
+
+  def __init__(self, config, scope, gpuid=0):
+    self.scope = scope
+    self.config = config
+    self.N = config.batch_size
+    self.beam_size = getattr(config, "beam_size", 1)
+    self._check_config(config)
+    self.engine = _lib.Engine(config, device=gpuid)
+    self.global_step = 0
+    # names of the fetches, kept for callers that introspect them
+    self.grid_pred_decoded = ["grid_pred_decoded_%d" % i
+                              for i in range(len(config.scene_grids))]
+    self.grid_pred_reg_decoded = ["grid_pred_reg_decoded_%d" % i
+                                  for i in range(len(config.scene_grids))]
+    self.beam_outputs = (["beam_logits", "beam_ids", "beam_logprobs"]
+                         if getattr(config, "use_beam_search", False) else None)
+    self.loss = None
+
+  @staticmethod
+  def _check_config(config):
+    """Same unsupported-combination asserts as the reference graph builder
+    (code/pred_models.py:261-262) plus the engine's own scope limits."""
+    act = getattr(config, "activation_func", "tanh")
+    if not (act == "tanh" or getattr(act, "__name__", "") == "tanh"):
+      raise _lib.MvError("activation_func %r: only tanh (the published "
+                         "configuration, TRAINING.md:32-39) is built" % (act,))
+    if not getattr(config, "use_scene_enc", True):
+      raise _lib.MvError("only the published --use_scene_enc wiring is built")
+    if getattr(config, "use_single_decoder", False):
+      raise _lib.MvError("--use_single_decoder is not built")
+    if getattr(config, "use_beam_search", False):
+      assert not getattr(config, "is_train", False)
+      assert sum(config.use_grids) == 1, "only one scale test at a time"
+    if getattr(config, "is_train", False) and config.keep_prob != 1.0:
+      raise _lib.MvError("keep_prob != 1.0 is not built (published runs use 1.0)")
+
+  # -- weights (tf.train.Saver role) --------------------------------------
+  def param_specs(self):
+    return self.engine.param_specs()
+
+  def load_params(self, params):
+    self.engine.set_params(params)
+
+  def get_params(self):
+    return {n: self.engine.get_param(n) for n, _ in self.engine.param_specs()}
+
+  def close(self):
+    self.engine.close()
+
+  # -- feed ----------------------------------------------------------------
+  def get_feed_dict(self, batch, is_train=False):
+    """numpy batch -> engine inputs; same contents as the reference feed_dict
+    (code/pred_models.py:1042-1194): rows beyond len(data) stay zero, GT future
+    only when training / use_gt_grid."""
+    cfg = self.config
+    N, T_in, T_pred = self.N, cfg.obs_len, cfg.pred_len
+    data = batch.data
+    n_have = len(data["obs_grid_class"])
+    feed = {"is_train": is_train, "pred_length": T_pred,
+            "grid_obs_labels": [], "grid_obs_regress": [],
+            "grid_pred_labels": [], "grid_pred_regress": []}
+    for j, (h, w) in enumerate(cfg.scene_grids):
+      labels = np.zeros([N, T_in], dtype="int32")
+      if n_have:
+        labels[:n_have] = np.stack(
+            [np.asarray(data["obs_grid_class"][i])[j, :] for i in range(n_have)])
+      feed["grid_obs_labels"].append(labels)
+      if not cfg.use_grids[j]:
+        feed["grid_obs_regress"].append(None)
+        feed["grid_pred_labels"].append(None)
+        feed["grid_pred_regress"].append(None)
+        continue
+      reg = np.zeros([N, T_in, h, w, 2], dtype="float32")
+      for i in range(n_have):
+        reg[i] = data["obs_grid_target_all_%d" % j][i]
+      feed["grid_obs_regress"].append(reg)
+      if is_train or getattr(cfg, "use_gt_grid", False):
+        plab = np.zeros([N, T_pred], dtype="int32")
+        preg = np.zeros([N, T_pred, h, w, 2], dtype="float32")
+        for i in range(n_have):
+          plab[i] = np.asarray(data["pred_grid_class"][i])[j, :]
+          preg[i] = data["pred_grid_target_all_%d" % j][i]
+        feed["grid_pred_labels"].append(plab)
+        feed["grid_pred_regress"].append(preg)
+      else:
+        feed["grid_pred_labels"].append(None)
+        feed["grid_pred_regress"].append(None)
+    obs_scene = np.zeros((N, T_in), dtype="int32")
+    bos = data["batch_obs_scene"]
+    for i in range(len(bos)):
+      obs_scene[i, :len(bos[i])] = np.asarray(bos[i]).reshape(-1)[:T_in]
+    feed["obs_scene"] = obs_scene
+    feed["scene_feat"] = np.asarray(data["batch_scene_feat"], dtype="float32")
+    return feed
+
+  # -- one sess.run ----------------------------------------------------------
+  def run_forward(self, feed):
+    """-> (grid_pred_class list_s, grid_pred_reg list_s, beam_outputs)."""
+    cfg = self.config
+    if getattr(cfg, "use_beam_search", False):
+      arrs, s = self.engine.forward_beam(feed)
+      cls = [[] for _ in cfg.scene_grids]
+      reg = [[] for _ in cfg.scene_grids]
+      cls[s] = arrs["best_beam"]
+      reg[s] = arrs["grid_reg"]
+      return cls, reg, [arrs["logits"], arrs["ids"], arrs["logprobs"]]
+    cls, reg = self.engine.forward_greedy(feed)
+    return cls, reg, None
+
+
+class Tester(object):
+  """code/pred_models.py:1745-1790."""
+
+  def __init__(self, model, config, sess=None):
+    self.config = config
+    self.model = model
+    self.sess = sess
+    self.grid_pred_decoded = model.grid_pred_decoded
+    self.grid_pred_reg_decoded = model.grid_pred_reg_decoded
+    self.beam_outputs = model.beam_outputs
+
+  def step(self, sess, batch):
+    """One inferencing step: (grid_pred_class, grid_pred_reg, beam_outputs)
+    with grid_pred_class[s] [N,T_p,H,W,1], grid_pred_reg[s] [N,T_p,H,W,2],
+    `[]` for unused scales, beam_outputs None or [logits, ids, logprobs]."""
+    _, batch_data = batch
+    feed = self.model.get_feed_dict(batch_data, is_train=False)
+    return self.model.run_forward(feed)
+
+
+class Trainer(object):
+  """code/pred_models.py:1636-1742.  The training step (backward through the
+  ConvLSTM sweep, Adadelta, RCCL gradient all-reduce) is SURVEY.md section 8
+  config 3 and is not built yet; constructing a Trainer fails loudly rather
+  than silently training on a CPU path."""
+
+  def __init__(self, model, config):
+    raise _lib.MvError(
+        "Trainer.step (mv_train_step) is not built yet: forward-only engine")

@@ -280,7 +280,7 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None):
   x_in = tile(first_input)
   sm = tile(scene_mean)  # tile_to_beam (:831-834)
   prev_lp = torch.zeros(N, B, dtype=dt)
-  all_ids, all_parents, all_logits = [], [], []
+  all_ids, all_parents, all_logits, all_prev, all_topvals = [], [], [], [], []
   # raw_rnn: loop_fn(0) -> [cell -> loop_fn(time)] for time = 1..T_pred
   for time in range(0, T_pred + 1):
     if time > 0:
@@ -292,12 +292,14 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None):
         lp = add_div_penalty(lp, cfg.diverse_gamma)         # :561-567
       flat = lp.reshape(N, B * K) if time > 1 else lp[:, 0]  # :569-573
       new_lp, idx = topk_stable(flat, B)                    # :578-579
+      all_topvals.append(new_lp.numpy().copy())
       if not time > cfg.fix_num_timestep:                   # :581-584
         new_lp = torch.zeros(N, B, dtype=dt)
       ids = (idx % K).astype("int32")                       # :588
       parents = (idx // K).astype("int32")                  # :591
       all_ids.append(ids)
       all_parents.append(parents)
+      all_prev.append(prev_lp.numpy().copy())
       all_logits.append(logits)
       x_in = one_hot_grid(ids.reshape(-1), H, W, dt)        # :602-606
       gidx = torch.from_numpy(
@@ -316,7 +318,9 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None):
   out_logits = torch.zeros(N, B, T, K, dtype=dt)
   par = np.tile(np.arange(B)[None], [N, 1])                 # :714-716
   rows = np.arange(N)[:, None]
+  out_trace = np.zeros((N, B, T), dtype="int32")
   for t in range(T - 1, -1, -1):
+    out_trace[:, :, t] = par
     out_ids[:, :, t] = all_ids[t][rows, par]
     out_logits[:, :, t] = all_logits[t][torch.from_numpy(rows).long(),
                                         torch.from_numpy(par).long()]
@@ -325,6 +329,9 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None):
   if trace is not None:
     trace["beam_step_ids"] = all_ids
     trace["beam_step_parents"] = all_parents
+    trace["beam_step_prev_lp"] = all_prev
+    trace["beam_step_topvals"] = all_topvals  # selected scores before zeroing
+    trace["beam_trace"] = out_trace           # beam index of each path per step
     trace["beam_step_logits"] = [l.numpy() for l in all_logits]
   return best, out_logits, out_ids, prev_lp
 
