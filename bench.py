@@ -187,6 +187,22 @@ def main():
     print(json.dumps(out))
 
 
+def effective_cores():
+  """CPUs this process may actually use: min(affinity, cgroup cpu.max quota).
+  (The GPU box exposes 256 logical CPUs under a 16-CPU cgroup quota; 256
+  torch threads there throttle to a crawl.)"""
+  n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (
+      os.cpu_count() or 1)
+  try:
+    with open("/sys/fs/cgroup/cpu.max") as f:
+      quota, period = f.read().split()[:2]
+    if quota != "max":
+      n = min(n, max(1, int(int(quota) / int(period))))
+  except (OSError, ValueError):
+    pass
+  return max(1, n)
+
+
 def cpu_baseline(batch):
   """The CPU oracle on a bounded sample of the same workload (both scales,
   greedy, obs 8 / pred 12): 1 warm-up + timed passes of `batch` trajectories
@@ -194,7 +210,7 @@ def cpu_baseline(batch):
   import torch
   from multiverse_amd import synth
   from oracle import multiverse_oracle as oracle
-  cores = os.cpu_count() or 1
+  cores = effective_cores()
   torch.set_num_threads(cores)
   cfg = synth.default_config(batch_size=batch, use_grids=(1, 1))
   params = synth.make_params(cfg, seed=synth.SEED_BASE + 2)
@@ -202,7 +218,7 @@ def cpu_baseline(batch):
   oracle.forward(params, cfg, feed)  # warm-up
   t0 = time.perf_counter()
   passes = 0
-  while passes < 1 or (time.perf_counter() - t0 < 12.0 and passes < 6):
+  while passes < 1 or (time.perf_counter() - t0 < 10.0 and passes < 6):
     oracle.forward(params, cfg, feed)
     passes += 1
   dt = time.perf_counter() - t0

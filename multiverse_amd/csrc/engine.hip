@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -23,6 +24,8 @@
 namespace {
 
 thread_local std::string g_create_error;
+
+
 
 struct HipError { std::string msg; };
 
@@ -163,8 +166,6 @@ struct mv_engine {
 };
 
 namespace {
-
-using mv::ConvLstmArgs;
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
@@ -349,31 +350,34 @@ void ensure_params(mv_engine* e) {
 
 // ------------------------------------------------------------------ launches
 
-void run_convlstm(mv_engine* e, const ConvCell& cc, const float* x,
-                  const float* h, const float* c, const int32_t* src_row_h,
-                  const int32_t* src_row_c, float* h_out, float* c_out, int rows,
-                  int H, int W, bool zero_state) {
+using mv::ConvLstmArgs;
+
+ConvLstmArgs conv_problem(mv_engine* e, const ConvCell& cc, const float* x,
+                          const float* h, const float* c, const int32_t* src_row_h,
+                          const int32_t* src_row_c, float* h_out, float* c_out,
+                          int rows, int H, int W, bool zero_state) {
   ConvLstmArgs a{};
-  const int C = e->cfg.hidden_size;
   a.x = x; a.h = h; a.c = c; a.src_row_h = src_row_h; a.src_row_c = src_row_c;
   a.wpack = cc.wpack.p; a.bias = cc.biases->dev.p;
   a.h_out = h_out; a.c_out = c_out;
-  a.rows = rows; a.H = H; a.W = W; a.Cx = cc.Cx; a.C = C;
-  a.n_xchunks = mv::convlstm_xchunks(cc.Cx);
-  a.n_hchunks = zero_state ? 0 : 9 * (C / mv::kBK);
-  a.w_chunks = a.n_xchunks + 9 * (C / mv::kBK);
-  a.x_small = (cc.Cx > 0 && 9 * cc.Cx <= mv::kBK) ? 1 : 0;
-  a.zero_state = zero_state ? 1 : 0;
-  a.forget_bias = 1.0f;
-  const size_t M = (size_t)rows * H * W;
-  a.n_mtiles = (int)cdiv(M, mv::kBM);
-  const unsigned grid = (unsigned)a.n_mtiles * (unsigned)(C / mv::kChBlock);
-  // algorithmic work of the step as the reference computes it (dense)
-  const double flops = 2.0 * (double)M * 9.0 * (cc.Cx + C) * 4.0 * C;
-  const double bytes = (double)M * (cc.Cx + 4.0 * C) * 4.0;  // x,h,c in; h,c out
+  a.rows = rows; a.H = H; a.W = W; a.Cx = cc.Cx; a.C = e->cfg.hidden_size;
+  mv::convlstm_finish_args(a, zero_state);
+  return a;
+}
+
+// One launch for up to four independent ConvLSTM steps (class / regression
+// chain of each scale advance in lockstep).
+void run_conv_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs) {
+  if (probs.empty()) return;
+  double flops = 0, bytes = 0;
+  for (const auto& a : probs) {
+    const double M = (double)a.rows * a.H * a.W;
+    // algorithmic work of the step as the reference computes it (dense)
+    flops += 2.0 * M * 9.0 * (a.Cx + a.C) * 4.0 * a.C;
+    bytes += M * (a.Cx + 4.0 * a.C) * 4.0;   // x,h,c in; h,c out
+  }
   launch(e, "convlstm_step", flops, bytes, [&] {
-    hipLaunchKernelGGL(mv::convlstm_step_kernel, dim3(grid), dim3(256), 0,
-                       e->stream, a);
+    mv::launch_convlstm_steps(probs.data(), (int)probs.size(), e->stream);
   });
 }
 
@@ -412,42 +416,44 @@ void run_scene(mv_engine* e) {
   }
 }
 
-// Encoders of one scale (dynamic_rnn from the zero state, T_o steps;
-// code/pred_models.py:212-215, 232-234).  Final states end in cls_*[fc] and
-// reg_*[fr]; returns the buffer indices.
-void run_encoders(mv_engine* e, int s, int* cls_idx, int* reg_idx) {
+struct Cursors {                 // which ping-pong buffer holds the live state
+  int cls[MV_MAX_SCALES] = {0, 0};
+  int reg[MV_MAX_SCALES] = {0, 0};
+};
+
+// Encoders of every enabled scale (dynamic_rnn from the zero state, T_o steps;
+// code/pred_models.py:212-215, 232-234), all chains advanced in lockstep.
+void run_encoders(mv_engine* e, Cursors& cur) {
   const mv_config& c = e->cfg;
-  ScaleState& S = e->sc[s];
   const int N = c.batch_size, T = c.obs_len, D = c.scene_conv_dim;
-  int cur = 0;
   for (int t = 0; t < T; ++t) {
-    const size_t total = (size_t)N * S.K * D;
-    launch(e, "enc_class_input", 0, 4.0 * total, [&] {
-      hipLaunchKernelGGL(mv::enc_class_input_kernel, dim3(cdiv(total, 256)),
-                         dim3(256), 0, e->stream, e->scene_conv[s].p,
-                         e->obs_scene.p, S.labels.p, S.xbuf_cls.p, N, T, t, S.K, D);
-    });
-    run_convlstm(e, S.enc_cls, S.xbuf_cls.p, S.cls_h[cur].p, S.cls_c[cur].p,
-                 nullptr, nullptr, S.cls_h[cur ^ 1].p, S.cls_c[cur ^ 1].p, N, S.H,
-                 S.W, t == 0);
-    cur ^= 1;
+    std::vector<ConvLstmArgs> probs;
+    for (int s = 0; s < c.num_scales; ++s) {
+      ScaleState& S = e->sc[s];
+      if (!S.use) continue;
+      const size_t total = (size_t)N * S.K * D;
+      launch(e, "enc_class_input", 0, 4.0 * total, [&] {
+        hipLaunchKernelGGL(mv::enc_class_input_kernel, dim3(cdiv(total, 256)),
+                           dim3(256), 0, e->stream, e->scene_conv[s].p,
+                           e->obs_scene.p, S.labels.p, S.xbuf_cls.p, N, T, t, S.K, D);
+      });
+      // x = grid_obs_regress[:, t]: a [N,K,2] slice copy is 0.3 % of the step
+      const size_t row = (size_t)S.K * 2;
+      HIP_CHECK(hipMemcpy2DAsync(S.xbuf_reg.p, row * sizeof(float),
+                                 S.obs_reg.p + (size_t)t * row,
+                                 (size_t)T * row * sizeof(float), row * sizeof(float),
+                                 N, hipMemcpyDeviceToDevice, e->stream));
+      const int cc = cur.cls[s], cr = cur.reg[s];
+      probs.push_back(conv_problem(e, S.enc_cls, S.xbuf_cls.p, S.cls_h[cc].p,
+                                   S.cls_c[cc].p, nullptr, nullptr, S.cls_h[cc ^ 1].p,
+                                   S.cls_c[cc ^ 1].p, N, S.H, S.W, t == 0));
+      probs.push_back(conv_problem(e, S.enc_reg, S.xbuf_reg.p, S.reg_h[cr].p,
+                                   S.reg_c[cr].p, nullptr, nullptr, S.reg_h[cr ^ 1].p,
+                                   S.reg_c[cr ^ 1].p, N, S.H, S.W, t == 0));
+      cur.cls[s] ^= 1; cur.reg[s] ^= 1;
+    }
+    run_conv_group(e, probs);
   }
-  *cls_idx = cur;
-  cur = 0;
-  for (int t = 0; t < T; ++t) {
-    // x = grid_obs_regress[:, t]  -- a strided view would need per-row
-    // strides in the conv kernel; a [N,K,2] slice copy is 0.3 % of the step.
-    const size_t row = (size_t)S.K * 2;
-    HIP_CHECK(hipMemcpy2DAsync(S.xbuf_reg.p, row * sizeof(float),
-                               S.obs_reg.p + (size_t)t * row,
-                               (size_t)T * row * sizeof(float), row * sizeof(float),
-                               N, hipMemcpyDeviceToDevice, e->stream));
-    run_convlstm(e, S.enc_reg, S.xbuf_reg.p, S.reg_h[cur].p, S.reg_c[cur].p,
-                 nullptr, nullptr, S.reg_h[cur ^ 1].p, S.reg_c[cur ^ 1].p, N, S.H,
-                 S.W, t == 0);
-    cur ^= 1;
-  }
-  *reg_idx = cur;
 }
 
 void run_gnn(mv_engine* e, ScaleState& S, const float* h, const int32_t* src_row,
@@ -496,56 +502,73 @@ void run_emb_dense(mv_engine* e, ScaleState& S, const float* x, size_t row_strid
   });
 }
 
-// Regression decoder, always greedy and un-beamed (code/pred_models.py:298-305
-// -> grid_decoder :311-471 with input_onehot=False, use_gnn=False).
-void run_reg_decoder(mv_engine* e, int s, int cur, int Tp) {
+// Regression decoder step t, always greedy and un-beamed
+// (code/pred_models.py:298-305 -> grid_decoder :311-471 with input_onehot=False,
+// use_gnn=False): input embedding + the conv problem; the caller launches it.
+ConvLstmArgs reg_decoder_problem(mv_engine* e, int s, Cursors& cur, int t, int Tp) {
   const mv_config& c = e->cfg;
   ScaleState& S = e->sc[s];
   const int N = c.batch_size, T = c.obs_len;
   const size_t orow = (size_t)Tp * S.K * 2;
-  for (int t = 0; t < Tp; ++t) {
-    if (t == 0)  // first_input = obs_grid_reg[:, -1]
-      run_emb_dense(e, S, S.obs_reg.p + (size_t)(T - 1) * S.K * 2,
-                    (size_t)T * S.K * 2, S.xbuf_reg.p, N);
-    else         // hidden2grid output of the previous step
-      run_emb_dense(e, S, S.out_reg.p + (size_t)(t - 1) * S.K * 2, orow,
-                    S.xbuf_reg.p, N);
-    run_convlstm(e, S.dec_reg, S.xbuf_reg.p, S.reg_h[cur].p, S.reg_c[cur].p,
-                 nullptr, nullptr, S.reg_h[cur ^ 1].p, S.reg_c[cur ^ 1].p, N, S.H,
-                 S.W, false);
-    cur ^= 1;
-    run_hidden2grid<2>(e, S, S.reg_h[cur].p, S.out_reg_W->dev.p,
-                       S.out_reg.p + (size_t)t * S.K * 2, orow, N);
-  }
+  if (t == 0)  // first_input = obs_grid_reg[:, -1]
+    run_emb_dense(e, S, S.obs_reg.p + (size_t)(T - 1) * S.K * 2, (size_t)T * S.K * 2,
+                  S.xbuf_reg.p, N);
+  else         // hidden2grid output of the previous step
+    run_emb_dense(e, S, S.out_reg.p + (size_t)(t - 1) * S.K * 2, orow, S.xbuf_reg.p, N);
+  const int cr = cur.reg[s];
+  cur.reg[s] ^= 1;
+  return conv_problem(e, S.dec_reg, S.xbuf_reg.p, S.reg_h[cr].p, S.reg_c[cr].p, nullptr,
+                      nullptr, S.reg_h[cr ^ 1].p, S.reg_c[cr ^ 1].p, N, S.H, S.W, false);
 }
 
-// Greedy class decoder (grid_decoder with input_onehot, use_gnn;
-// code/pred_models.py:311-471).
-void run_cls_decoder_greedy(mv_engine* e, int s, int cur, int Tp) {
-  const mv_config& c = e->cfg;
+void reg_decoder_output(mv_engine* e, int s, const Cursors& cur, int t, int Tp) {
   ScaleState& S = e->sc[s];
+  const size_t orow = (size_t)Tp * S.K * 2;
+  run_hidden2grid<2>(e, S, S.reg_h[cur.reg[s]].p, S.out_reg_W->dev.p,
+                     S.out_reg.p + (size_t)t * S.K * 2, orow, e->cfg.batch_size);
+}
+
+// Greedy decoders of every enabled scale in lockstep: class decoder
+// (grid_decoder with input_onehot, use_gnn; code/pred_models.py:311-471) and
+// regression decoder.
+void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
+  const mv_config& c = e->cfg;
   const int N = c.batch_size, T = c.obs_len;
-  const size_t orow = (size_t)Tp * S.K;
   for (int t = 0; t < Tp; ++t) {
-    const float* hin = S.cls_h[cur].p;
-    if (c.use_gnn) {
-      run_gnn(e, S, S.cls_h[cur].p, nullptr, S.cls_hg.p, N, 1);
-      hin = S.cls_hg.p;
+    std::vector<ConvLstmArgs> probs;
+    for (int s = 0; s < c.num_scales; ++s) {
+      ScaleState& S = e->sc[s];
+      if (!S.use) continue;
+      const int cc = cur.cls[s];
+      const float* hin = S.cls_h[cc].p;
+      if (c.use_gnn) {
+        run_gnn(e, S, S.cls_h[cc].p, nullptr, S.cls_hg.p, N, 1);
+        hin = S.cls_hg.p;
+      }
+      if (t == 0)  // one_hot(last observed cell)
+        run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, N);
+      else
+        run_emb_onehot(e, S, S.ids.p, 1, S.xbuf_cls.p, N);
+      probs.push_back(conv_problem(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cc].p,
+                                   nullptr, nullptr, S.cls_h[cc ^ 1].p,
+                                   S.cls_c[cc ^ 1].p, N, S.H, S.W, false));
+      cur.cls[s] ^= 1;
+      probs.push_back(reg_decoder_problem(e, s, cur, t, Tp));
     }
-    if (t == 0)  // one_hot(last observed cell)
-      run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, N);
-    else
-      run_emb_onehot(e, S, S.ids.p, 1, S.xbuf_cls.p, N);
-    run_convlstm(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cur].p, nullptr, nullptr,
-                 S.cls_h[cur ^ 1].p, S.cls_c[cur ^ 1].p, N, S.H, S.W, false);
-    cur ^= 1;
-    float* logits = S.out_cls.p + (size_t)t * S.K;
-    run_hidden2grid<1>(e, S, S.cls_h[cur].p, S.out_cls_W->dev.p, logits, orow, N);
-    if (t + 1 < Tp) {
-      launch(e, "argmax_rows", 0, 4.0 * N * S.K, [&] {
-        hipLaunchKernelGGL(mv::argmax_rows_kernel, dim3(N), dim3(64), 0, e->stream,
-                           logits, orow, S.ids.p, N, S.K);
-      });
+    run_conv_group(e, probs);
+    for (int s = 0; s < c.num_scales; ++s) {
+      ScaleState& S = e->sc[s];
+      if (!S.use) continue;
+      const size_t orow = (size_t)Tp * S.K;
+      float* logits = S.out_cls.p + (size_t)t * S.K;
+      run_hidden2grid<1>(e, S, S.cls_h[cur.cls[s]].p, S.out_cls_W->dev.p, logits, orow, N);
+      if (t + 1 < Tp) {
+        launch(e, "argmax_rows", 0, 4.0 * N * S.K, [&] {
+          hipLaunchKernelGGL(mv::argmax_rows_kernel, dim3(N), dim3(64), 0, e->stream,
+                             logits, orow, S.ids.p, N, S.K);
+        });
+      }
+      reg_decoder_output(e, s, cur, t, Tp);
     }
   }
 }
@@ -593,8 +616,9 @@ __global__ void beam_gather_logits_kernel(const float* __restrict__ step_logits,
 }
 
 // Beam-search class decoder (grid_decoder_beam_search,
-// code/pred_models.py:474-806).
-void run_cls_decoder_beam(mv_engine* e, int s, int cur, int Tp) {
+// code/pred_models.py:474-806) with the un-beamed regression decoder advanced
+// in lockstep (its step t shares a launch with beam time t+1).
+void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
   const mv_config& c = e->cfg;
   ScaleState& S = e->sc[s];
   const int N = c.batch_size, T = c.obs_len, B = c.beam_size, K = S.K,
@@ -603,14 +627,15 @@ void run_cls_decoder_beam(mv_engine* e, int s, int cur, int Tp) {
   // tile encoder state to beams (:497-502).  The encoder wrote rows [0,N) of
   // cls_*[cur]; expand into the other buffer.
   {
+    const int cc = cur.cls[s];
     const size_t row4 = (size_t)K * C / 4, total4 = (size_t)R * row4;
     launch(e, "beam_tile_state", 0, 8.0 * total4 * 16, [&] {
       hipLaunchKernelGGL(tile_rows_kernel, dim3(cdiv(total4, 256)), dim3(256), 0,
-                         e->stream, S.cls_h[cur].p, S.cls_h[cur ^ 1].p, row4, B, total4);
+                         e->stream, S.cls_h[cc].p, S.cls_h[cc ^ 1].p, row4, B, total4);
       hipLaunchKernelGGL(tile_rows_kernel, dim3(cdiv(total4, 256)), dim3(256), 0,
-                         e->stream, S.cls_c[cur].p, S.cls_c[cur ^ 1].p, row4, B, total4);
+                         e->stream, S.cls_c[cc].p, S.cls_c[cc ^ 1].p, row4, B, total4);
     });
-    cur ^= 1;
+    cur.cls[s] ^= 1;
   }
   HIP_CHECK(hipMemsetAsync(e->bm_lp[0].p, 0, (size_t)R * sizeof(float), e->stream));
   int lpi = 0;
@@ -620,13 +645,19 @@ void run_cls_decoder_beam(mv_engine* e, int s, int cur, int Tp) {
     if (time > 0) {
       // cell step on R rows; h comes from the GNN buffer (identity rows) when
       // use_gnn, c through the parent indirection
-      const float* hin = c.use_gnn ? S.cls_hg.p : S.cls_h[cur].p;
-      run_convlstm(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cur].p,
-                   c.use_gnn ? nullptr : src, src, S.cls_h[cur ^ 1].p,
-                   S.cls_c[cur ^ 1].p, R, S.H, S.W, false);
-      cur ^= 1;
+      const int cc = cur.cls[s];
+      const float* hin = c.use_gnn ? S.cls_hg.p : S.cls_h[cc].p;
+      std::vector<ConvLstmArgs> probs;
+      probs.push_back(conv_problem(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cc].p,
+                                   c.use_gnn ? nullptr : src, src, S.cls_h[cc ^ 1].p,
+                                   S.cls_c[cc ^ 1].p, R, S.H, S.W, false));
+      cur.cls[s] ^= 1;
+      probs.push_back(reg_decoder_problem(e, s, cur, time - 1, Tp));
+      run_conv_group(e, probs);
+      reg_decoder_output(e, s, cur, time - 1, Tp);
       float* logits = e->bm_logits.p + (size_t)(time - 1) * R * K;
-      run_hidden2grid<1>(e, S, S.cls_h[cur].p, S.out_cls_W->dev.p, logits, (size_t)K, R);
+      run_hidden2grid<1>(e, S, S.cls_h[cur.cls[s]].p, S.out_cls_W->dev.p, logits,
+                         (size_t)K, R);
       int32_t* ids = e->bm_ids.p + (size_t)(time - 1) * R;
       int32_t* parents = e->bm_parents.p + (size_t)(time - 1) * R;
       launch(e, "beam_step", 0, 4.0 * R * K, [&] {
@@ -644,7 +675,7 @@ void run_cls_decoder_beam(mv_engine* e, int s, int cur, int Tp) {
       run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, R, B);
     }
     if (c.use_gnn)
-      run_gnn(e, S, S.cls_h[cur].p, src, S.cls_hg.p, R, B);
+      run_gnn(e, S, S.cls_h[cur.cls[s]].p, src, S.cls_hg.p, R, B);
   }
   // back-trace (:689-806)
   hipLaunchKernelGGL(beam_backtrace_kernel, dim3(cdiv(R, 256)), dim3(256), 0,
@@ -668,13 +699,14 @@ void run_forward(mv_engine* e, bool beam) {
   if (beam)
     MV_REQUIRE(c.beam_size > 1, "engine was created with beam_size 1");
   run_scene(e);
-  for (int s = 0; s < c.num_scales; ++s) {
-    if (!e->sc[s].use) continue;
-    int ci = 0, ri = 0;
-    run_encoders(e, s, &ci, &ri);
-    if (beam) run_cls_decoder_beam(e, s, ci, Tp);
-    else run_cls_decoder_greedy(e, s, ci, Tp);
-    run_reg_decoder(e, s, ri, Tp);
+  Cursors cur;
+  run_encoders(e, cur);
+  if (beam) {
+    int s = 0;
+    for (int i = 0; i < c.num_scales; ++i) if (e->sc[i].use) s = i;
+    run_decoders_beam(e, s, cur, Tp);
+  } else {
+    run_decoders_greedy(e, cur, Tp);
   }
   HIP_CHECK(hipGetLastError());
 }
@@ -1059,20 +1091,12 @@ int mv_op_convlstm_step(int device, const float* x, const float* c, const float*
       ctx.up(dh, h, cells * C);
     }
     dco.alloc(cells * C); dho.alloc(cells * C);
-    ConvLstmArgs a{};
+    mv::ConvLstmArgs a{};
     a.x = dx.p; a.h = dh.p; a.c = dc.p; a.wpack = dw.p; a.bias = db.p;
     a.h_out = dho.p; a.c_out = dco.p;
     a.rows = M; a.H = H; a.W = W; a.Cx = Cx; a.C = C;
-    a.n_xchunks = mv::convlstm_xchunks(Cx);
-    a.n_hchunks = zero ? 0 : 9 * (C / mv::kBK);
-    a.w_chunks = a.n_xchunks + 9 * (C / mv::kBK);
-    a.x_small = (Cx > 0 && 9 * Cx <= mv::kBK) ? 1 : 0;
-    a.zero_state = zero ? 1 : 0;
-    a.forget_bias = 1.0f;
-    a.n_mtiles = (int)cdiv(cells, mv::kBM);
-    hipLaunchKernelGGL(mv::convlstm_step_kernel,
-                       dim3((unsigned)a.n_mtiles * (unsigned)(C / mv::kChBlock)),
-                       dim3(256), 0, ctx.stream, a);
+    mv::convlstm_finish_args(a, zero);
+    mv::launch_convlstm_steps(&a, 1, ctx.stream);
     HIP_CHECK(hipGetLastError());
     ctx.down(c_out, dco, cells * C);
     ctx.down(h_out, dho, cells * C);
