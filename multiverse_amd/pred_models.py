@@ -29,6 +29,52 @@ def get_model(config, gpuid=0):
   return Model(config, "%s" % getattr(config, "modelname", "model"), gpuid=gpuid)
 
 
+def build_feed_dict(cfg, batch, is_train=False):
+  """numpy batch -> engine inputs; same contents as the reference feed_dict
+  (code/pred_models.py:1042-1194): rows beyond len(data) stay zero, GT future
+  only when training / use_gt_grid.  Pure host code (no engine needed)."""
+  N, T_in, T_pred = cfg.batch_size, cfg.obs_len, cfg.pred_len
+  data = batch.data
+  n_have = len(data["obs_grid_class"])
+  feed = {"is_train": is_train, "pred_length": T_pred,
+          "grid_obs_labels": [], "grid_obs_regress": [],
+          "grid_pred_labels": [], "grid_pred_regress": []}
+  for j, (h, w) in enumerate(cfg.scene_grids):
+    labels = np.zeros([N, T_in], dtype="int32")
+    if n_have:
+      labels[:n_have] = np.stack(
+          [np.asarray(data["obs_grid_class"][i])[j, :] for i in range(n_have)])
+    feed["grid_obs_labels"].append(labels)
+    if not cfg.use_grids[j]:
+      feed["grid_obs_regress"].append(None)
+      feed["grid_pred_labels"].append(None)
+      feed["grid_pred_regress"].append(None)
+      continue
+    reg = np.zeros([N, T_in, h, w, 2], dtype="float32")
+    for i in range(n_have):
+      reg[i] = data["obs_grid_target_all_%d" % j][i]
+    feed["grid_obs_regress"].append(reg)
+    if is_train or getattr(cfg, "use_gt_grid", False):
+      plab = np.zeros([N, T_pred], dtype="int32")
+      preg = np.zeros([N, T_pred, h, w, 2], dtype="float32")
+      for i in range(n_have):
+        plab[i] = np.asarray(data["pred_grid_class"][i])[j, :]
+        preg[i] = data["pred_grid_target_all_%d" % j][i]
+      feed["grid_pred_labels"].append(plab)
+      feed["grid_pred_regress"].append(preg)
+    else:
+      feed["grid_pred_labels"].append(None)
+      feed["grid_pred_regress"].append(None)
+  obs_scene = np.zeros((N, T_in), dtype="int32")
+  bos = data["batch_obs_scene"]
+  for i in range(len(bos)):
+    row = np.asarray(bos[i]).reshape(-1)[:T_in]
+    obs_scene[i, :len(row)] = row
+  feed["obs_scene"] = obs_scene
+  feed["scene_feat"] = np.asarray(data["batch_scene_feat"], dtype="float32")
+  return feed
+
+
 class Model(object):
   """One engine instance with the reference Model's host-side protocol."""
 
@@ -82,49 +128,7 @@ class Model(object):
 
   # -- feed ----------------------------------------------------------------
   def get_feed_dict(self, batch, is_train=False):
-    """numpy batch -> engine inputs; same contents as the reference feed_dict
-    (code/pred_models.py:1042-1194): rows beyond len(data) stay zero, GT future
-    only when training / use_gt_grid."""
-    cfg = self.config
-    N, T_in, T_pred = self.N, cfg.obs_len, cfg.pred_len
-    data = batch.data
-    n_have = len(data["obs_grid_class"])
-    feed = {"is_train": is_train, "pred_length": T_pred,
-            "grid_obs_labels": [], "grid_obs_regress": [],
-            "grid_pred_labels": [], "grid_pred_regress": []}
-    for j, (h, w) in enumerate(cfg.scene_grids):
-      labels = np.zeros([N, T_in], dtype="int32")
-      if n_have:
-        labels[:n_have] = np.stack(
-            [np.asarray(data["obs_grid_class"][i])[j, :] for i in range(n_have)])
-      feed["grid_obs_labels"].append(labels)
-      if not cfg.use_grids[j]:
-        feed["grid_obs_regress"].append(None)
-        feed["grid_pred_labels"].append(None)
-        feed["grid_pred_regress"].append(None)
-        continue
-      reg = np.zeros([N, T_in, h, w, 2], dtype="float32")
-      for i in range(n_have):
-        reg[i] = data["obs_grid_target_all_%d" % j][i]
-      feed["grid_obs_regress"].append(reg)
-      if is_train or getattr(cfg, "use_gt_grid", False):
-        plab = np.zeros([N, T_pred], dtype="int32")
-        preg = np.zeros([N, T_pred, h, w, 2], dtype="float32")
-        for i in range(n_have):
-          plab[i] = np.asarray(data["pred_grid_class"][i])[j, :]
-          preg[i] = data["pred_grid_target_all_%d" % j][i]
-        feed["grid_pred_labels"].append(plab)
-        feed["grid_pred_regress"].append(preg)
-      else:
-        feed["grid_pred_labels"].append(None)
-        feed["grid_pred_regress"].append(None)
-    obs_scene = np.zeros((N, T_in), dtype="int32")
-    bos = data["batch_obs_scene"]
-    for i in range(len(bos)):
-      obs_scene[i, :len(bos[i])] = np.asarray(bos[i]).reshape(-1)[:T_in]
-    feed["obs_scene"] = obs_scene
-    feed["scene_feat"] = np.asarray(data["batch_scene_feat"], dtype="float32")
-    return feed
+    return build_feed_dict(self.config, batch, is_train=is_train)
 
   # -- one sess.run ----------------------------------------------------------
   def run_forward(self, feed):

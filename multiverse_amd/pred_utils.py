@@ -1,0 +1,306 @@
+# coding=utf-8
+"""Host-side data / evaluation utilities with the reference's semantics
+(`code/pred_utils.py`), TensorFlow-free.  Plain numpy; nothing here touches the
+GPU -- these are the callers either side of the hot path:
+
+  process_args        code/pred_utils.py:70-146   (grid dims from strides)
+  read_data           code/pred_utils.py:208-300  (data_{split}.npz -> Dataset)
+  Dataset.get_batches code/pred_utils.py:609-706  (padding, per-batch scene table)
+  evaluate            code/pred_utils.py:354-586  (grid acc, ADE / FDE)
+  initialize          code/pred_utils.py:149-205  (weights -> model; here from
+                      an .npz keyed by TF variable name, see save_params)
+"""
+
+from __future__ import annotations
+
+import collections
+import itertools
+import math
+import os
+import pickle
+import random
+
+import numpy as np
+
+
+def process_args(args):
+  """Derive the fields the model reads from the CLI flags.  Grid sizes use
+  Python round() like the reference (code/pred_utils.py:127-132); the engine
+  separately checks they match the stride-2 conv chain."""
+  if getattr(args, "activation_func", "tanh") not in ("tanh",):
+    if not callable(args.activation_func):
+      raise ValueError("activation_func %r: only tanh is built" % args.activation_func)
+  args.seq_len = args.obs_len + args.pred_len
+  if getattr(args, "outbasepath", None) is not None:
+    args.outpath = os.path.join(args.outbasepath, args.modelname,
+                                str(args.runId).zfill(2))
+    args.save_dir = os.path.join(args.outpath, "save")
+    args.save_dir_model = os.path.join(args.save_dir, "save")
+    args.save_dir_best = os.path.join(args.outpath, "best")
+    args.save_dir_best_model = os.path.join(args.save_dir_best, "save-best")
+    for d in (args.outpath, args.save_dir, args.save_dir_best):
+      os.makedirs(d, exist_ok=True)
+  if isinstance(args.scene_grid_strides, str):
+    args.scene_grid_strides = [int(o) for o in args.scene_grid_strides.split(",")]
+  if isinstance(args.use_grids, str):
+    args.use_grids = [bool(int(o)) for o in args.use_grids.split(",")]
+  assert len(args.scene_grid_strides) == len(args.use_grids)
+  assert sum(args.use_grids) <= 2, \
+      "Currently only supports at most two scale training at a time"
+  args.scene_grids = []
+  for stride in args.scene_grid_strides:
+    this_h = int(round(args.scene_h * 1.0 / stride))
+    this_w = int(round(args.scene_w * 1.0 / stride))
+    args.scene_grids.append((this_h, this_w))
+  if getattr(args, "load_best", False) or getattr(args, "load_from", None) is not None:
+    args.load = True
+  if not getattr(args, "is_train", False):
+    args.load = True
+    args.num_epochs = 1
+    args.keep_prob = 1.0
+  return args
+
+
+# ------------------------------------------------------------------ weights
+
+def save_params(path, params):
+  """Checkpoint = .npz keyed by TF-1 variable name, HWIO layout (what
+  tf.train.Saver stores; a TF tensor-bundle reader is SURVEY.md section 8f N1)."""
+  np.savez(path, **{k.replace("/", "__"): v for k, v in params.items()})
+
+
+def load_params(path):
+  with np.load(path) as z:
+    return {k.replace("__", "/"): z[k] for k in z.files}
+
+
+def initialize(load, load_best, args, model):
+  """code/pred_utils.py:149-205 role: put weights into the model.  `model`
+  plays the session's part.  Only the `person_pred` scope is consumed, like the
+  inference script (code/multifuture_inference.py:287-289)."""
+  if not load:
+    raise ValueError("random initialisation lives in multiverse_amd.synth.make_params")
+  path = getattr(args, "load_from", None)
+  if path is None:
+    path = args.save_dir_best_model if load_best else args.save_dir_model
+  if os.path.isdir(path):
+    cands = sorted(f for f in os.listdir(path) if f.endswith(".npz"))
+    if not cands:
+      raise IOError("Model not exists: no .npz under %s" % path)
+    path = os.path.join(path, cands[-1])
+  if not os.path.exists(path):
+    raise IOError("Model not exists: %s" % path)
+  params = {k: v for k, v in load_params(path).items() if k.startswith("person_pred/")}
+  model.load_params(params)
+
+
+# ------------------------------------------------------------------ data
+
+def read_data(args, data_type):
+  """code/pred_utils.py:208-300: npz -> Dataset(per-example data, shared)."""
+  data_path = os.path.join(args.prepropath, "data_%s.npz" % data_type)
+  data = dict(np.load(data_path, allow_pickle=True))
+  return dataset_from_npz_dict(data, data_type, args)
+
+
+def dataset_from_npz_dict(data, data_type, args):
+  shares = ["scene_feat", "video_wh", "scene_grid_strides", "vid2name",
+            "person_boxkey2id", "person_boxid2key"]
+  excludes = ["seq_start_end", "obs_kp_rel", "obs_kp", "cur_activity", "obs_box",
+              "future_activity", "pred_kp", "obs_other_box", "person_boxid2key"]
+  if "video_wh" in data:
+    args.box_img_w, args.box_img_h = [int(v) for v in np.asarray(data["video_wh"])]
+  else:
+    args.box_img_w, args.box_img_h = 1920, 1080
+  for i in range(len(args.scene_grid_strides)):
+    shares.append("grid_center_%d" % i)
+  shared = {}
+  for key in data:
+    if key in shares:
+      val = np.asarray(data[key]) if not isinstance(data[key], np.ndarray) else data[key]
+      shared[key] = val.item() if not val.shape else val
+  num_examples = len(data["obs_traj"])
+  newdata = {}
+  for key in data:
+    if key in excludes or key in shares:
+      continue
+    if len(data[key]) != num_examples:
+      print("warning, ignoring %s.." % key)
+      continue
+    newdata[key] = data[key]
+  assert np.asarray(shared["scene_grid_strides"])[0] == args.scene_grid_strides[0]
+  if "person_boxid2key" in shared:
+    boxid2key = shared["person_boxid2key"]
+    newdata["traj_key"] = [boxid2key[newdata["obs_boxid"][i][0]]
+                           for i in range(num_examples)]
+  return Dataset(newdata, data_type, shared=shared, config=args)
+
+
+class Dataset(object):
+  """Batching with the reference's rules (code/pred_utils.py:586-706)."""
+
+  def __init__(self, data, data_type, config=None, shared=None):
+    self.data = data
+    self.data_type = data_type
+    self.valid_idxs = range(self.get_data_size())
+    self.num_examples = len(self.valid_idxs)
+    self.shared = shared
+    self.config = config
+
+  def get_data_size(self):
+    return len(self.data["obs_traj"])
+
+  def get_by_idxs(self, idxs):
+    out = collections.defaultdict(list)
+    for key, val in self.data.items():
+      out[key].extend(val[idx] for idx in idxs)
+    return out
+
+  def get_batches(self, batch_size, num_steps=0, shuffle=True, cap=False,
+                  full=False):
+    """Yields (batch_idxs, Dataset).  Short batches are padded with their last
+    item to `batch_size` and carry `original_batch_size`; every batch gets a
+    compacted scene table (`batch_scene_feat` float32 [U,SH,SW,SC],
+    `batch_obs_scene` int32 [N,T_o,1]).  Shuffling draws ONE permutation that
+    every epoch reuses, like the reference (:638-644)."""
+    per_epoch = int(math.ceil(self.num_examples / float(batch_size)))
+    if full:
+      num_steps = per_epoch
+    if cap and num_steps > per_epoch:
+      num_steps = per_epoch
+    num_epochs = int(math.ceil(num_steps / float(per_epoch))) if per_epoch else 0
+    order = (random.sample(list(self.valid_idxs), len(self.valid_idxs))
+             if shuffle else list(self.valid_idxs))
+
+    def groups():
+      for i in range(0, len(order), batch_size):
+        yield tuple(order[i:i + batch_size])
+
+    stream = itertools.chain.from_iterable(groups() for _ in range(num_epochs))
+    config = self.config
+    for _ in range(num_steps):
+      batch_idxs = next(stream)
+      original = len(batch_idxs)
+      if original < batch_size:
+        batch_idxs = tuple(list(batch_idxs) + [batch_idxs[-1]] * (batch_size - original))
+      batch_data = self.get_by_idxs(batch_idxs)
+      batch_data["original_batch_size"] = original
+      old2new = {}
+      new_obs_scene = np.zeros((config.batch_size, config.obs_len, 1), dtype="int32")
+      for i, seq in enumerate(batch_data["obs_scene"]):
+        for j in range(len(seq)):
+          oldid = int(np.asarray(seq[j]).reshape(-1)[0])
+          if oldid not in old2new:
+            old2new[oldid] = len(old2new)
+          new_obs_scene[i, j, 0] = old2new[oldid]
+      scene_feat = np.zeros((len(old2new), config.scene_h, config.scene_w,
+                             config.scene_class), dtype="float32")
+      for oldid, newid in old2new.items():
+        scene_feat[newid] = self.shared["scene_feat"][oldid]
+      batch_data["batch_obs_scene"] = new_obs_scene
+      batch_data["batch_scene_feat"] = scene_feat
+      yield batch_idxs, Dataset(batch_data, self.data_type, shared=self.shared)
+
+
+# ------------------------------------------------------------------ metrics
+
+def evaluate(dataset, config, sess, tester):
+  """code/pred_utils.py:354-586: grid classification accuracy (overall and per
+  step), trajectory ADE / FDE from centre + regressed offset, and the
+  centre-only variants; same keys, same arithmetic, vectorised per sample."""
+  pred_len = config.pred_len
+  n_scale = len(config.scene_grids)
+  l2 = [[] for _ in range(n_scale)]
+  l2_center = [[] for _ in range(n_scale)]
+  hits = [[] for _ in range(n_scale)]
+  out_data = None
+  if getattr(config, "save_output", None) is not None:
+    out_data = {"obs_list": [], "pred_gt_list": [], "seq_ids": []}
+    for i in range(n_scale):
+      out_data["grid%s_class" % i] = []
+      out_data["grid%s_gt_class" % i] = []
+      out_data["grid%s_pred_traj" % i] = []
+      out_data["grid_center_%d" % i] = dataset.shared["grid_center_%d" % i]
+    if getattr(config, "use_beam_search", False):
+      out_data["beam_grid_ids"] = []
+      out_data["beam_logprobs"] = []
+  for evalbatch in dataset.get_batches(config.batch_size, full=True, shuffle=False):
+    grid_pred_class, grid_pred_reg, beam_outputs = tester.step(sess, evalbatch)
+    _, batch = evalbatch
+    N = batch.data["original_batch_size"]
+    if getattr(config, "use_beam_search", False):
+      assert sum(config.use_grids) == 1
+      _, beam_grid_ids, beam_logprobs = beam_outputs
+    for j, (H, W) in enumerate(config.scene_grids):
+      if not config.use_grids[j]:
+        continue
+      grid_class = np.asarray(grid_pred_class[j])[:N].reshape([N, pred_len, H * W])
+      selected = np.argmax(grid_class, axis=2)
+      gt_class = np.array([np.asarray(batch.data["pred_grid_class"][i])[j, :]
+                           for i in range(N)])
+      if getattr(config, "use_gt_grid", False):
+        selected = gt_class
+      grid_reg = np.asarray(grid_pred_reg[j])[:N].reshape([N, pred_len, H * W, 2])
+      centers = np.asarray(batch.shared["grid_center_%s" % j]).reshape([-1, 2])
+      for i in range(N):
+        hits[j].append(gt_class[i] == selected[i])
+        this_center = centers[selected[i]]                       # [T, 2]
+        offs = grid_reg[i, np.arange(pred_len), selected[i], :]   # [T, 2]
+        traj = this_center + offs
+        gt_traj = np.asarray(batch.data["pred_traj"][i])
+        l2[j].append(np.sqrt(np.sum((gt_traj - traj) ** 2, axis=1)))
+        l2_center[j].append(np.sqrt(np.sum((gt_traj - this_center) ** 2, axis=1)))
+        if out_data is not None:
+          if j == 0 and "traj_key" in batch.data:
+            out_data["seq_ids"].append(batch.data["traj_key"][i])
+          if j == 0:
+            out_data["obs_list"].append(batch.data["obs_traj"][i])
+            out_data["pred_gt_list"].append(batch.data["pred_traj"][i])
+          out_data["grid%s_pred_traj" % j].append(traj)
+          out_data["grid%s_gt_class" % j].append(gt_class[i])
+          out_data["grid%s_class" % j].append(grid_class[i])
+          if getattr(config, "use_beam_search", False):
+            out_data["beam_grid_ids"].append(beam_grid_ids[i])
+            out_data["beam_logprobs"].append(beam_logprobs[i])
+  p = {}
+  for j in range(n_scale):
+    if not config.use_grids[j]:
+      continue
+    h = np.array(hits[j])                      # [M, T] bool
+    p["grid%d_acc" % j] = np.mean(h)
+    for t in range(pred_len):
+      p["grid%d_acc_@T=%d" % (j, t)] = np.mean(h[:, t])
+    d = np.array(l2[j])
+    p["grid%d_traj_ade" % j] = np.mean(d)
+    p["grid%d_traj_fde" % j] = np.mean(d[:, -1])
+    dc = np.array(l2_center[j])
+    p["grid%d_traj_centerOnly_ade" % j] = np.mean(dc)
+    p["grid%d_traj_centerOnly_fde" % j] = np.mean(dc[:, -1])
+  if out_data is not None:
+    with open(config.save_output, "wb") as f:
+      pickle.dump(out_data, f)
+  return p
+
+
+def relative_to_abs(rel_traj, start_pos):
+  """code/pred_utils.py:735-749."""
+  return np.cumsum(rel_traj, axis=0) + np.array([start_pos])
+
+
+class FIFO_ME(object):
+  """Moving average over the last N values (code/pred_utils.py:310-331)."""
+
+  def __init__(self, N):
+    self.N = N
+    self.lst = []
+
+  def put(self, val):
+    if val is None:
+      return None
+    self.lst.append(val)
+    if len(self.lst) > self.N:
+      self.lst.pop(0)
+    return 1
+
+  def me(self):
+    return float(np.mean(self.lst)) if self.lst else None

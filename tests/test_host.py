@@ -1,0 +1,176 @@
+# coding=utf-8
+"""CPU: host-side logic and the C-ABI surface (no compute calls without a GPU)."""
+import argparse
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from multiverse_amd import pred_models, pred_utils, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+  with open(os.path.join(ROOT, "include", "multiverse_hip.h")) as f:
+    src = f.read()
+  src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+  return sorted(set(re.findall(r"\b(mv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+  lib = ctypes.CDLL(built_lib.LIB_PATH)
+  declared = _header_symbols()
+  assert len(declared) >= 20
+  for name in declared:
+    assert hasattr(lib, name), "libmultiverse_hip.so does not export %s" % name
+  assert sorted(built_lib.EXPORTED_SYMBOLS) == declared
+  assert lib.mv_abi_version() == built_lib.MV_ABI_VERSION
+
+
+def test_struct_layout_matches_header(built_lib):
+  # 21 int32/float fields + 3 arrays of MV_MAX_SCALES -> 4-byte packed
+  assert ctypes.sizeof(built_lib.mv_config) == 4 * (18 + 3 * built_lib.MV_MAX_SCALES)
+  assert ctypes.sizeof(built_lib.mv_inputs) == 8 * 2 + 4 * 2 + 8 * 2 * built_lib.MV_MAX_SCALES
+  assert ctypes.sizeof(built_lib.mv_outputs) == 8 * 2 * built_lib.MV_MAX_SCALES
+  assert ctypes.sizeof(built_lib.mv_beam_outputs) == 8 * 5
+
+
+def test_create_without_gpu_fails_loudly(built_lib):
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip("a GPU is visible")
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1))
+  with pytest.raises(built_lib.MvError):
+    built_lib.Engine(cfg, device=0)      # no CPU fallback
+
+
+def test_bad_config_is_rejected_before_touching_the_device(built_lib):
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1), beam_size=5)
+  with pytest.raises(built_lib.MvError, match="one scale"):
+    built_lib.Engine(cfg, device=0)
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 0))
+  cfg.scene_grids = [(4, 8), (9, 16)]   # stride 8: round() != conv chain
+  with pytest.raises(built_lib.MvError, match="conv chain"):
+    built_lib.Engine(cfg, device=0)
+
+
+def test_process_args_grid_dims():
+  a = argparse.Namespace(obs_len=8, pred_len=12, scene_grid_strides="2,4",
+                         use_grids="1,0", scene_h=36, scene_w=64,
+                         activation_func="tanh", is_train=False)
+  a = pred_utils.process_args(a)
+  assert a.scene_grids == [(18, 32), (9, 16)]
+  assert a.use_grids == [True, False] and a.seq_len == 20 and a.keep_prob == 1.0
+
+
+def _dataset(cfg, M, seed=3):
+  data = synth.make_npz_data(cfg, M, seed=seed)
+  return pred_utils.dataset_from_npz_dict(data, "test", cfg), data
+
+
+def test_batcher_pads_and_compacts_scene_table():
+  cfg = synth.default_config(batch_size=4, use_grids=(1, 1))
+  ds, raw = _dataset(cfg, 10)
+  batches = list(ds.get_batches(4, full=True, shuffle=False))
+  assert len(batches) == 3
+  idxs, last = batches[-1]
+  assert last.data["original_batch_size"] == 2
+  assert idxs == (8, 9, 9, 9)                       # padded with the last item
+  for _, b in batches:
+    sf, os_ = b.data["batch_scene_feat"], b.data["batch_obs_scene"]
+    assert sf.dtype == np.float32 and sf.shape[1:] == (36, 64, 11)
+    assert os_.shape == (4, 8, 1) and os_.max() == sf.shape[0] - 1
+    # compaction preserves content
+    for i, gi in enumerate(_idx for _idx in b.data["obs_scene"]):
+      old = int(np.asarray(gi[0]).reshape(-1)[0])
+      assert (sf[os_[i, 0, 0]] == raw["scene_feat"][old]).all()
+
+
+def test_feed_dict_contents():
+  cfg = synth.default_config(batch_size=4, use_grids=(1, 0))
+  ds, raw = _dataset(cfg, 3)
+  (_, b), = list(ds.get_batches(4, full=True, shuffle=False))
+  feed = pred_models.build_feed_dict(cfg, b, is_train=False)
+  assert feed["grid_obs_labels"][0].shape == (4, 8)
+  assert (feed["grid_obs_labels"][0][:3] == raw["obs_grid_class"][:, 0, :]).all()
+  assert feed["grid_obs_regress"][0].shape == (4, 8, 18, 32, 2)
+  assert feed["grid_obs_regress"][1] is None            # unused scale
+  assert feed["grid_pred_regress"][0] is None           # not training
+  assert feed["obs_scene"].shape == (4, 8) and feed["scene_feat"].ndim == 4
+  # regression target = xy - centre (preprocess.py:463-475)
+  c = raw["grid_center_0"]
+  want = raw["obs_traj"][1, 5].astype("f8") - c[7, 9]
+  assert np.allclose(feed["grid_obs_regress"][0][1, 5, 7, 9], want, atol=1e-3)
+  tr = pred_models.build_feed_dict(cfg, b, is_train=True)
+  assert tr["grid_pred_labels"][0].shape == (4, 12)
+
+
+class _PerfectTester(object):
+  """Emits one-hot GT logits and the GT offsets: ADE/FDE must be ~0."""
+
+  def __init__(self, cfg):
+    self.cfg = cfg
+
+  def step(self, sess, batch):
+    cfg = self.cfg
+    _, b = batch
+    N = cfg.batch_size
+    cls, reg = [], []
+    for j, (h, w) in enumerate(cfg.scene_grids):
+      if not cfg.use_grids[j]:
+        cls.append([]); reg.append([]); continue
+      c = np.zeros((N, cfg.pred_len, h * w), "f4")
+      r = np.zeros((N, cfg.pred_len, h, w, 2), "f4")
+      for i in range(len(b.data["pred_grid_class"])):
+        lab = np.asarray(b.data["pred_grid_class"][i])[j]
+        c[i, np.arange(cfg.pred_len), lab] = 5.0
+        r[i] = b.data["pred_grid_target_all_%d" % j][i]
+      cls.append(c.reshape(N, cfg.pred_len, h, w, 1)); reg.append(r)
+    return cls, reg, None
+
+
+def test_evaluate_arithmetic():
+  cfg = synth.default_config(batch_size=4, use_grids=(1, 1))
+  ds, raw = _dataset(cfg, 6)
+  p = pred_utils.evaluate(ds, cfg, None, _PerfectTester(cfg))
+  for j in (0, 1):
+    assert p["grid%d_acc" % j] == 1.0 and p["grid%d_acc_@T=11" % j] == 1.0
+    assert p["grid%d_traj_ade" % j] < 1e-3 and p["grid%d_traj_fde" % j] < 1e-3
+    # centre-only error is bounded by half a cell diagonal
+    h, w = cfg.scene_grids[j]
+    assert 0 < p["grid%d_traj_centerOnly_ade" % j] < 0.5 * np.hypot(1920 / w, 1080 / h)
+
+
+def test_grid_class_rule():
+  """x_idx = ceil(x / w_gap) (0 -> 1) - 1, class = y_idx * W + x_idx
+  (code/preprocess.py:442-459)."""
+  cfg = synth.default_config()
+  traj = np.array([[[0.0, 0.0], [60.0, 60.0], [60.0001, 59.9], [1919.9, 1079.9]]])
+  cls, tg = synth.grid_class_and_targets(cfg, traj)
+  assert cls[0, 0].tolist() == [0, 0, 1, 18 * 32 - 1]     # 18x32: 60 px cells
+  assert tg[0].shape == (1, 4, 18, 32, 2)
+  assert np.allclose(tg[0][0, 1, 0, 0], [60 - 30, 60 - 30])
+
+
+def test_checkpoint_roundtrip(tmp_path):
+  cfg = synth.default_config(use_grids=(0, 1))
+  params = synth.make_params(cfg)
+  path = str(tmp_path / "save-1.npz")
+  pred_utils.save_params(path, params)
+  back = pred_utils.load_params(path)
+  assert sorted(back) == sorted(params)
+  assert all((back[k] == params[k]).all() for k in params)
+  shapes = synth.param_shapes(cfg)
+  assert shapes["person_pred/decoder_grid_class_1/decoder_rnn/dec_grid_1/kernel"] == (3, 3, 288, 1024)
+  total = sum(int(np.prod(s)) for s in synth.param_shapes(
+      synth.default_config(use_grids=(1, 1))).values())
+  assert total == 21337728
+
+
+def test_trainer_fails_loudly():
+  from multiverse_amd import _lib
+  with pytest.raises(_lib.MvError, match="not built"):
+    pred_models.Trainer(None, None)

@@ -1,0 +1,69 @@
+# coding=utf-8
+"""CPU, world_size 2 over gloo: the batch-sharded multi-GPU scheme of
+bench.py / multiverse_amd.parallel -- no data-path collective, shards
+concatenate to the single-process result, timing is the MAX over ranks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def _worker(rank, world, port, outdir):
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  torch.set_num_threads(2)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  from multiverse_amd import parallel, synth
+  from oracle import multiverse_oracle as oracle
+  N = 3                                    # uneven split: 2 + 1
+  cfg = synth.default_config(batch_size=N, use_grids=(0, 1))
+  params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=21)
+  shard, (lo, hi) = parallel.shard_feed(feed, rank, world, N)
+  scfg = synth.default_config(batch_size=hi - lo, use_grids=(0, 1))
+  cls, reg, _ = oracle.forward(params, scfg, shard)      # stands in for the engine
+  full_cls = parallel.gather_to_rank0(cls[1])
+  full_reg = parallel.gather_to_rank0(reg[1])
+  t = parallel.max_over_ranks(1.0 + rank)
+  assert t == float(world)
+  dist.barrier()
+  if rank == 0:
+    ref_cls, ref_reg, _ = oracle.forward(params, cfg, feed)
+    np.savez(os.path.join(outdir, "res.npz"),
+             dc=np.abs(full_cls - ref_cls[1]).max(), dr=np.abs(full_reg - ref_reg[1]).max(),
+             n=full_cls.shape[0])
+  dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+  from multiverse_amd import parallel
+  for n in (1, 7, 64, 65):
+    for world in (1, 2, 4, 8):
+      spans = [parallel.shard_range(n, r, world) for r in range(world)]
+      assert spans[0][0] == 0 and spans[-1][1] == n
+      assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+      sizes = [b - a for a, b in spans]
+      assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_batch_sharding_matches_single_process(tmp_path):
+  world = 2
+  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  r = np.load(os.path.join(str(tmp_path), "res.npz"))
+  assert int(r["n"]) == 3
+  assert float(r["dc"]) < 1e-5 and float(r["dr"]) < 1e-5
