@@ -9,6 +9,8 @@ import pytest
 
 from multiverse_amd import pred_models, pred_utils, synth
 
+from beam_compare import compare_beams
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = 1e-4
@@ -53,14 +55,8 @@ def test_golden_beam(built_lib):
   arrs, s = eng.forward_beam(feed)
   eng.close()
   assert s == 1
-  # this fixture has no tied candidate scores (checked here), so ids AND the
-  # per-beam logits must match position by position
-  tv = g["beam_topvals"].astype("f8")
-  assert np.abs(np.diff(tv, axis=1)).min() > 2e-5
-  assert (arrs["ids"] == g["beam_ids"]).all()
-  assert np.abs(arrs["logits"] - g["beam_logits"]).max() < TOL
-  assert np.abs(arrs["logprobs"] - g["beam_logprobs"]).max() < 1e-3
-  assert np.abs(arrs["grid_reg"] - g["reg_1"]).max() < TOL
+  compare_beams(arrs, g["reg_1"], g["beam_logits"], g["beam_ids"], g["beam_logprobs"],
+                g["beam_topvals"], g["beam_trace"])
 
 
 def test_tester_step_and_evaluate_through_the_boundary(built_lib):
