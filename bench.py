@@ -64,7 +64,15 @@ def main():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=10)
   ap.add_argument("--warmup", type=int, default=2)
-  ap.add_argument("--batch", type=int, default=64, help="trajectories per GPU")
+  ap.add_argument("--batch", type=int, default=None,
+                  help="trajectories per GPU (default 64 greedy / 128 beam)")
+  ap.add_argument("--workload", choices=("greedy", "beam"), default="greedy",
+                  help="greedy = BASELINE configs[1] (the headline line); beam = "
+                       "configs[3]: scale 0, beam 20, batch 128, hipGraph replay")
+  ap.add_argument("--beam", type=int, default=20)
+  ap.add_argument("--graph", type=int, default=None,
+                  help="1: replay the forward as a captured hipGraph "
+                       "(default: 0 greedy, 1 beam)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-batch", type=int, default=8)
   args = ap.parse_args()
@@ -89,12 +97,22 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend="nccl")  # RCCL; barrier + max only
 
-  cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 1))
+  beam = args.workload == "beam"
+  if args.batch is None:
+    args.batch = 128 if beam else 64
+  if args.graph is None:
+    args.graph = 1 if beam else 0
+  if beam:
+    cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 0),
+                               beam_size=args.beam)
+  else:
+    cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 1))
   params = synth.make_params(cfg, seed=synth.SEED_BASE + 2)  # reference initialisers
   feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 2 + 1000 * rank)
   eng = _lib.Engine(cfg, device=local_rank)
   eng.set_params(params)
   eng.upload(feed)          # inputs resident in HBM before the timed region
+  eng.set_graph_mode(bool(args.graph))
 
   def barrier():
     if use_dist:
@@ -103,11 +121,11 @@ def main():
     eng.synchronize()
 
   for _ in range(args.warmup):
-    eng.run_resident()
+    eng.run_resident(beam)
   barrier()
   t0 = time.perf_counter()
   for _ in range(args.steps):
-    eng.run_resident()
+    eng.run_resident(beam)
   eng.synchronize()
   barrier()
   elapsed = time.perf_counter() - t0
@@ -122,14 +140,14 @@ def main():
   # ---- roofline of the dominant kernel, measured live with hipEvents
   eng.set_profiling(True)
   eng.reset_kernel_stats()
-  eng.run_resident()
+  eng.run_resident(beam)
   eng.synchronize()
   stats = eng.kernel_stats()
   eng.set_profiling(False)
   conv = stats["convlstm_step"]
   conv_s = conv["total_ms"] * 1e-3
   achieved_tf = conv["flops"] / conv_s / 1e12
-  flops_traj, bytes_traj = algorithmic_counts(cfg)
+  flops_traj, bytes_traj = algorithmic_counts(cfg, args.beam if beam else 1)
   roofline = {
       "kernel": "convlstm_step",
       "bound": "mfma",
@@ -155,7 +173,7 @@ def main():
   # gfx950); bench.py cannot collect PMCs itself, so it quotes the committed
   # profile when the workload matches, else null.
   pmc_path = os.path.join(ROOT, "profiles", "r1_convlstm_pmc.json")
-  if args.batch == 64 and os.path.exists(pmc_path):
+  if args.batch == 64 and not beam and os.path.exists(pmc_path):
     with open(pmc_path) as f:
       pmc = json.load(f)
     hb = pmc.get("hbm_bytes_per_launch")
@@ -166,9 +184,21 @@ def main():
       roofline["traffic_source"] = "profiles/r1_convlstm_pmc.json"
       roofline["alg_MB_per_launch"] = round(conv["bytes"] / conv["launches"] / 1e6, 1)
 
+  if beam:
+    metric = ("trajectories/sec (8-obs/12-pred, 18x32 grid, diverse beam-%d "
+              "multi-future decode)" % args.beam)
+    workload = ("BASELINE configs[3]: scale 0 (18x32, scene 36x64x11), beam %d "
+                "(diverse, gamma 0.01, fix_num_timestep 1), batch %d/GPU, fp32, "
+                "obs 8 / pred 12, %s" % (args.beam, args.batch,
+                "hipGraph replay" if args.graph else "stream launches"))
+  else:
+    metric = ("trajectories/sec (8-obs/12-pred, multi-scale 18x32+9x16 grid, "
+              "greedy forward)")
+    workload = ("BASELINE configs[1]: multi-scale 18x32+9x16 (scene 36x64x11), "
+                "batch %d/GPU, fp32 forward-only, beam 1, obs 8 / pred 12%s"
+                % (args.batch, ", hipGraph replay" if args.graph else ""))
   out = {
-      "metric": "trajectories/sec (8-obs/12-pred, multi-scale 18x32+9x16 grid, "
-                "greedy forward)",
+      "metric": metric,
       "value": round(value, 2),
       "unit": "trajectories/sec",
       "n_gpus": world,
@@ -181,9 +211,7 @@ def main():
       "dtype": "f32",
       "data": "synthetic (seeded AR(1) trajectories, rectangle scene masks, "
               "random-init weights with the reference's initialisers)",
-      "config": {"workload": "BASELINE configs[1]: multi-scale 18x32+9x16 "
-                             "(scene 36x64x11), batch 64/GPU, fp32 forward-only, "
-                             "beam 1, obs 8 / pred 12",
+      "config": {"workload": workload,
                  "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                  "obs_len": cfg.obs_len, "pred_len": cfg.pred_len,
                  "parallelism": "batch-sharded x%d, no data-path collective" % world,
@@ -192,7 +220,7 @@ def main():
       "roofline": roofline,
   }
 
-  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and not beam:
     out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
 
   eng.close()

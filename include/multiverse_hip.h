@@ -120,6 +120,11 @@ int  mv_synchronize(mv_handle h);
 int  mv_download_outputs(mv_handle h, mv_outputs* out);
 int  mv_download_beam_outputs(mv_handle h, mv_beam_outputs* out);
 
+/* Replay the forward as a captured hipGraph (one graph per (mode, T_pred, U)):
+ * the reference's whole forward is ONE sess.run (pred_models.py:1779), here it
+ * is one hipGraphLaunch instead of ~150 kernel launches.  Off by default. */
+int  mv_set_graph_mode(mv_handle h, int32_t enabled);
+
 /* -- measurement --------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on the handle's
  * stream; totals are read back per kernel name. */

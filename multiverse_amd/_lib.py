@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "mv_forward_greedy", "mv_forward_beam",
     "mv_upload_inputs", "mv_run_greedy_resident", "mv_run_beam_resident",
     "mv_synchronize", "mv_download_outputs", "mv_download_beam_outputs",
-    "mv_set_profiling", "mv_reset_kernel_stats", "mv_num_kernel_stats",
+    "mv_set_graph_mode", "mv_set_profiling", "mv_reset_kernel_stats", "mv_num_kernel_stats",
     "mv_kernel_stat", "mv_time_greedy_resident", "mv_time_beam_resident",
     "mv_op_convlstm_step", "mv_op_gnn", "mv_op_hidden2grid", "mv_op_beam_step",
 ]
@@ -122,6 +122,7 @@ def load():
   lib.mv_download_outputs.argtypes = [h, C.POINTER(mv_outputs)]
   lib.mv_download_beam_outputs.argtypes = [h, C.POINTER(mv_beam_outputs)]
   lib.mv_set_profiling.argtypes = [h, C.c_int32]
+  lib.mv_set_graph_mode.argtypes = [h, C.c_int32]
   lib.mv_reset_kernel_stats.argtypes = [h]
   lib.mv_num_kernel_stats.argtypes = [h]
   lib.mv_kernel_stat.argtypes = [h, C.c_int32, C.c_char_p, C.c_int32,
@@ -354,6 +355,9 @@ class Engine(object):
     out, arrs, s = self._alloc_beam(self._pred_len)
     check(self.lib.mv_download_beam_outputs(self.handle, C.byref(out)), self.handle)
     return arrs, s
+
+  def set_graph_mode(self, on):
+    check(self.lib.mv_set_graph_mode(self.handle, 1 if on else 0), self.handle)
 
   # ---- measurement
   def set_profiling(self, on):

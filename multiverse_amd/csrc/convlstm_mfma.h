@@ -61,6 +61,8 @@ struct ConvLstmArgs {
   float* h_out;         // [rows, H, W, C]
   float* c_out;         // [rows, H, W, C]
   int32_t rows, H, W, Cx, C;
+  int32_t x_row_stride; // elements between consecutive rows of x (0: H*W*Cx), so a
+                        // time slice of an [N, T, H, W, Cx] tensor is read in place
   int32_t n_xchunks;    // K chunks taken from x
   int32_t n_hchunks;    // K chunks taken from h (0 when the state is known zero)
   int32_t w_chunks;     // chunks per channel block in wpack (x + all h chunks)
@@ -153,8 +155,9 @@ __device__ __forceinline__ void convlstm_step_body(const ConvLstmArgs& a, int bl
   const int m_wave = mt * kBlockRows + wave * kWaveRows;
   if (m_wave >= M_total) return;   // whole wave past the end (no barriers here)
 
-  // each lane owns cell (lane & 31) of its wave's 32 cells
-  int ypos, xpos, xcell, hcell;
+  // each lane owns cell (lane & 31) of its wave's 32 cells; xoff / hoff are the
+  // element offsets of that cell in x and h (all offsets < 2^31, host-checked)
+  int ypos, xpos, xoff, hoff;
   {
     const int m = m_wave + (lane & 31);
     if (m < M_total) {
@@ -162,10 +165,10 @@ __device__ __forceinline__ void convlstm_step_body(const ConvLstmArgs& a, int bl
       const int y = cell / W;
       ypos = y; xpos = cell - y * W;
       const int sr = a.src_row_h ? a.src_row_h[r] : r;
-      xcell = m;
-      hcell = sr * HW + cell;
+      xoff = r * a.x_row_stride + cell * Cx;
+      hoff = (sr * HW + cell) * C;
     } else {
-      ypos = -100000; xpos = -100000; xcell = 0; hcell = 0;
+      ypos = -100000; xpos = -100000; xoff = 0; hoff = 0;
     }
   }
   const int khalf = (lane >> 5) * 4;
@@ -192,7 +195,7 @@ __device__ __forceinline__ void convlstm_step_body(const ConvLstmArgs& a, int bl
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const int yy = ypos + dy, xx = xpos + dx;
         const bool ok = (k < 9 * Cx) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-        int off = (xcell + dy * W + dx) * Cx + ch;
+        int off = xoff + (dy * W + dx) * Cx + ch;
         off = ok ? off : 0;
         const float tv = a.x[off];
         v[j] = ok ? tv : 0.f;
@@ -208,8 +211,7 @@ __device__ __forceinline__ void convlstm_step_body(const ConvLstmArgs& a, int bl
       const int cs = is_x ? Cx : C;
       const int yy = ypos + dy, xx = xpos + dx;
       const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-      const int cellidx = (is_x ? xcell : hcell) + dy * W + dx;
-      int off = cellidx * cs + cg * kBK + kk * 8 + khalf;  // < 2^31 (host-checked)
+      int off = (is_x ? xoff : hoff) + (dy * W + dx) * cs + cg * kBK + kk * 8 + khalf;
       off = ok ? off : 0;
       f.a = *reinterpret_cast<const f32x4*>(base + off);
       f.ok = ok ? 0xffffffffu : 0u;
@@ -302,6 +304,7 @@ static inline void convlstm_finish_args(ConvLstmArgs& a, bool zero_state) {
   a.w_chunks = a.n_xchunks + 9 * (a.C / kBK);
   a.x_small = (a.Cx > 0 && 9 * a.Cx <= kBK) ? 1 : 0;
   a.zero_state = zero_state ? 1 : 0;
+  if (a.x_row_stride == 0) a.x_row_stride = a.H * a.W * a.Cx;
   a.forget_bias = 1.0f;   // tf.contrib.rnn.ConvLSTMCell default
 }
 

@@ -16,6 +16,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "convlstm_mfma.h"
@@ -144,6 +145,13 @@ struct mv_engine {
   DevBuf<int32_t> bm_trace;        // [N, B, T]
   DevBuf<float> bm_out_logits;     // [N, B, T, K]
   DevBuf<int32_t> bm_out_ids;      // [N, B, T]
+  // hipGraph replay of the forward (one graph per (mode, T_pred, U))
+  bool graph_mode = false;
+  std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
+  void drop_graphs() {
+    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    graphs.clear();
+  }
   // profiling
   bool profiling = false;
   std::vector<KernelStat> stats;
@@ -355,8 +363,16 @@ using mv::ConvLstmArgs;
 ConvLstmArgs conv_problem(mv_engine* e, const ConvCell& cc, const float* x,
                           const float* h, const float* c, const int32_t* src_row_h,
                           const int32_t* src_row_c, float* h_out, float* c_out,
-                          int rows, int H, int W, bool zero_state) {
+                          int rows, int H, int W, bool zero_state,
+                          size_t x_row_stride = 0) {
   ConvLstmArgs a{};
+  // the kernel forms element offsets in 32-bit registers
+  const size_t xrs = x_row_stride ? x_row_stride : (size_t)H * W * cc.Cx;
+  MV_REQUIRE((size_t)rows * H * W * e->cfg.hidden_size < ((size_t)1 << 31) &&
+             (size_t)rows * xrs < ((size_t)1 << 31),
+             "ConvLSTM state of %d rows exceeds the 2^31-element addressing of one "
+             "launch; lower batch_size x beam_size", rows);
+  a.x_row_stride = (int32_t)xrs;
   a.x = x; a.h = h; a.c = c; a.src_row_h = src_row_h; a.src_row_c = src_row_c;
   a.wpack = cc.wpack.p; a.bias = cc.biases->dev.p;
   a.h_out = h_out; a.c_out = c_out;
@@ -437,19 +453,16 @@ void run_encoders(mv_engine* e, Cursors& cur) {
                            dim3(256), 0, e->stream, e->scene_conv[s].p,
                            e->obs_scene.p, S.labels.p, S.xbuf_cls.p, N, T, t, S.K, D);
       });
-      // x = grid_obs_regress[:, t]: a [N,K,2] slice copy is 0.3 % of the step
+      // x = grid_obs_regress[:, t] is read in place through the row stride
       const size_t row = (size_t)S.K * 2;
-      HIP_CHECK(hipMemcpy2DAsync(S.xbuf_reg.p, row * sizeof(float),
-                                 S.obs_reg.p + (size_t)t * row,
-                                 (size_t)T * row * sizeof(float), row * sizeof(float),
-                                 N, hipMemcpyDeviceToDevice, e->stream));
       const int cc = cur.cls[s], cr = cur.reg[s];
       probs.push_back(conv_problem(e, S.enc_cls, S.xbuf_cls.p, S.cls_h[cc].p,
                                    S.cls_c[cc].p, nullptr, nullptr, S.cls_h[cc ^ 1].p,
                                    S.cls_c[cc ^ 1].p, N, S.H, S.W, t == 0));
-      probs.push_back(conv_problem(e, S.enc_reg, S.xbuf_reg.p, S.reg_h[cr].p,
-                                   S.reg_c[cr].p, nullptr, nullptr, S.reg_h[cr ^ 1].p,
-                                   S.reg_c[cr ^ 1].p, N, S.H, S.W, t == 0));
+      probs.push_back(conv_problem(e, S.enc_reg, S.obs_reg.p + (size_t)t * row,
+                                   S.reg_h[cr].p, S.reg_c[cr].p, nullptr, nullptr,
+                                   S.reg_h[cr ^ 1].p, S.reg_c[cr ^ 1].p, N, S.H, S.W,
+                                   t == 0, (size_t)T * row));
       cur.cls[s] ^= 1; cur.reg[s] ^= 1;
     }
     run_conv_group(e, probs);
@@ -691,13 +704,9 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
                              hipMemcpyDeviceToDevice, e->stream));
 }
 
-void run_forward(mv_engine* e, bool beam) {
-  MV_REQUIRE(e->inputs_ready, "no inputs uploaded (mv_upload_inputs)");
-  ensure_params(e);
+void enqueue_forward(mv_engine* e, bool beam) {
   const mv_config& c = e->cfg;
   const int Tp = e->pred_len;
-  if (beam)
-    MV_REQUIRE(c.beam_size > 1, "engine was created with beam_size 1");
   run_scene(e);
   Cursors cur;
   run_encoders(e, cur);
@@ -709,6 +718,40 @@ void run_forward(mv_engine* e, bool beam) {
     run_decoders_greedy(e, cur, Tp);
   }
   HIP_CHECK(hipGetLastError());
+}
+
+// One forward = one `sess.run`.  In graph mode the ~150 (greedy) / ~120 (beam)
+// launches of a forward are captured once per (mode, T_pred, U) into a hipGraph
+// and replayed; every device pointer in it is engine-owned and stable.
+void run_forward(mv_engine* e, bool beam) {
+  MV_REQUIRE(e->inputs_ready, "no inputs uploaded (mv_upload_inputs)");
+  ensure_params(e);
+  if (beam)
+    MV_REQUIRE(e->cfg.beam_size > 1, "engine was created with beam_size 1");
+  if (!e->graph_mode || e->profiling) {
+    enqueue_forward(e, beam);
+    return;
+  }
+  const auto key = std::make_tuple(beam ? 1 : 0, e->pred_len, e->num_frames);
+  auto it = e->graphs.find(key);
+  if (it == e->graphs.end()) {
+    hipGraph_t g = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    try {
+      enqueue_forward(e, beam);
+    } catch (...) {
+      (void)hipStreamEndCapture(e->stream, &g);
+      if (g) (void)hipGraphDestroy(g);
+      throw;
+    }
+    HIP_CHECK(hipStreamEndCapture(e->stream, &g));
+    hipGraphExec_t ex = nullptr;
+    hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIP_CHECK(ie);
+    it = e->graphs.emplace(key, ex).first;
+  }
+  HIP_CHECK(hipGraphLaunch(it->second, e->stream));
 }
 
 void upload_inputs(mv_engine* e, const mv_inputs* in) {
@@ -882,7 +925,9 @@ int mv_create(const mv_config* cfg, int device, mv_handle* out) {
 int mv_destroy(mv_handle h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
-  if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->drop_graphs();
+  if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
 }
@@ -920,6 +965,7 @@ int mv_set_param(mv_handle h, const char* tf_name, const float* data,
     p->dev.alloc(n);
     HIP_CHECK(hipMemcpy(p->dev.p, data, n * sizeof(float), hipMemcpyHostToDevice));
     p->set = true;
+    h->drop_graphs();   // captured launches hold the old device pointers
     // invalidate the packed copy of a ConvLSTM kernel
     for (int s = 0; s < h->cfg.num_scales; ++s) {
       ScaleState& S = h->sc[s];
@@ -1013,6 +1059,12 @@ int mv_forward_beam(mv_handle h, const mv_inputs* in, mv_beam_outputs* out) {
 int mv_set_profiling(mv_handle h, int32_t enabled) {
   if (!h) return 1;
   h->profiling = enabled != 0;
+  return 0;
+}
+
+int mv_set_graph_mode(mv_handle h, int32_t enabled) {
+  if (!h) return 1;
+  h->graph_mode = enabled != 0;
   return 0;
 }
 

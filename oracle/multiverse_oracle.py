@@ -177,7 +177,7 @@ def run_encoder(x_seq, kernel, biases, C):
 
 def argmax_lowest(x2d):
   """tf.argmax: first (lowest) index among equal maxima."""
-  return np.argmax(x2d.numpy(), axis=1).astype("int32")
+  return np.argmax(x2d.detach().numpy(), axis=1).astype("int32")
 
 
 def greedy_decoder(P, cfg, s, kind, first_input, state, T_pred, scene_mean,
@@ -336,63 +336,190 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None):
   return best, out_logits, out_ids, prev_lp
 
 
+def forward_tensors(P, cfg, feed, dtype=torch.float32, trace=None):
+  """`Model.build_forward` (code/pred_models.py:123-308) on torch tensors
+  (autograd-capable: the training oracle differentiates through it).
+  Returns (grid_pred_decoded list_s, grid_pred_reg_decoded list_s, beam)."""
+  assert cfg.use_scene_enc, "only the published --use_scene_enc wiring"
+  assert cfg.keep_prob == 1.0 or not cfg.is_train
+  C = cfg.enc_hidden_size
+  T_pred = int(feed["pred_length"])
+  scene_convs = scene_stack(P, cfg, _t(feed["scene_feat"], dtype),
+                            feed["obs_scene"])
+  cls_out, reg_out, beam_out = [], [], None
+  for s, (H, W) in enumerate(cfg.scene_grids):
+    if not cfg.use_grids[s]:
+      cls_out.append([])
+      reg_out.append([])
+      continue
+    labels = np.asarray(feed["grid_obs_labels"][s])
+    obs_oh = one_hot_grid(labels, H, W, dtype)           # [N,T,H,W,1]
+    obs_reg = _t(feed["grid_obs_regress"][s], dtype)     # [N,T,H,W,2]
+    x_cls = scene_convs[s] * obs_oh                      # :210
+    enc_c = run_encoder(
+        x_cls, P["encoder_grid_class_%d/enc_grid_%d/kernel" % (s, s)],
+        P["encoder_grid_class_%d/enc_grid_%d/biases" % (s, s)], C)
+    enc_r = run_encoder(
+        obs_reg, P["encoder_grid_reg_%d/enc_grid_regress_%d/kernel" % (s, s)],
+        P["encoder_grid_reg_%d/enc_grid_regress_%d/biases" % (s, s)], C)
+    scene_mean = scene_convs[s].mean(dim=1)              # :828
+    if trace is not None:
+      trace["enc_class_c_%d" % s] = enc_c[0].detach().numpy()
+      trace["enc_class_h_%d" % s] = enc_c[1].detach().numpy()
+      trace["enc_reg_c_%d" % s] = enc_r[0].detach().numpy()
+      trace["enc_reg_h_%d" % s] = enc_r[1].detach().numpy()
+      trace["scene_mean_%d" % s] = scene_mean.detach().numpy()
+    if cfg.use_beam_search:
+      assert not cfg.is_train
+      assert sum(cfg.use_grids) == 1, "only one scale test at a time"
+      best, lg, ids, lps = beam_decoder(
+          P, cfg, s, obs_oh[:, -1], enc_c, T_pred, scene_mean, trace)
+      dec_cls = best
+      beam_out = [lg, ids, lps]
+    else:
+      # input_onehot = not is_train or train_w_onehot (:285)
+      assert (not cfg.is_train) or cfg.train_w_onehot, \
+          "training oracle: only the published --train_w_onehot wiring"
+      assert not (cfg.is_train and cfg.use_teacher_forcing)
+      dec_cls, dec_h = greedy_decoder(
+          P, cfg, s, "class", obs_oh[:, -1], enc_c, T_pred, scene_mean, trace)
+      if trace is not None:
+        trace["dec_class_h_%d" % s] = dec_h.detach().numpy()
+    dec_reg, _ = greedy_decoder(
+        P, cfg, s, "reg", obs_reg[:, -1], enc_r, T_pred, scene_mean, trace)
+    cls_out.append(dec_cls)
+    reg_out.append(dec_reg)
+  return cls_out, reg_out, beam_out
+
+
 def forward(params, cfg, feed, dtype=torch.float32, trace=None):
-  """`Model.build_forward` (code/pred_models.py:123-308) + the fetch contract
-  of `Tester.step` (:1761-1790).
+  """`Model.build_forward` + the fetch contract of `Tester.step`
+  (code/pred_models.py:1761-1790).
 
   feed: dict with obs_scene [N,T_o] int, scene_feat [U,SH,SW,SC],
         grid_obs_labels list_s [N,T_o] int, grid_obs_regress list_s
         [N,T_o,H,W,2], pred_length int.
   Returns (grid_pred_class list_s, grid_pred_reg list_s, beam_outputs) as
   numpy arrays; unused scales give []."""
-  assert cfg.use_scene_enc, "only the published --use_scene_enc wiring"
-  assert cfg.keep_prob == 1.0 or not cfg.is_train
   P = Params(params, dtype)
-  C = cfg.enc_hidden_size
-  T_pred = int(feed["pred_length"])
   with torch.no_grad():
-    scene_convs = scene_stack(P, cfg, _t(feed["scene_feat"], dtype),
-                              feed["obs_scene"])
-    cls_out, reg_out, beam_out = [], [], None
-    for s, (H, W) in enumerate(cfg.scene_grids):
-      if not cfg.use_grids[s]:
-        cls_out.append([])
-        reg_out.append([])
-        continue
-      labels = np.asarray(feed["grid_obs_labels"][s])
-      obs_oh = one_hot_grid(labels, H, W, dtype)           # [N,T,H,W,1]
-      obs_reg = _t(feed["grid_obs_regress"][s], dtype)     # [N,T,H,W,2]
-      x_cls = scene_convs[s] * obs_oh                      # :210
-      enc_c = run_encoder(
-          x_cls, P["encoder_grid_class_%d/enc_grid_%d/kernel" % (s, s)],
-          P["encoder_grid_class_%d/enc_grid_%d/biases" % (s, s)], C)
-      enc_r = run_encoder(
-          obs_reg, P["encoder_grid_reg_%d/enc_grid_regress_%d/kernel" % (s, s)],
-          P["encoder_grid_reg_%d/enc_grid_regress_%d/biases" % (s, s)], C)
-      scene_mean = scene_convs[s].mean(dim=1)              # :828
-      if trace is not None:
-        trace["enc_class_c_%d" % s] = enc_c[0].numpy()
-        trace["enc_class_h_%d" % s] = enc_c[1].numpy()
-        trace["enc_reg_c_%d" % s] = enc_r[0].numpy()
-        trace["enc_reg_h_%d" % s] = enc_r[1].numpy()
-        trace["scene_mean_%d" % s] = scene_mean.numpy()
-      if cfg.use_beam_search:
-        assert not cfg.is_train
-        assert sum(cfg.use_grids) == 1, "only one scale test at a time"
-        best, lg, ids, lps = beam_decoder(
-            P, cfg, s, obs_oh[:, -1], enc_c, T_pred, scene_mean, trace)
-        dec_cls = best
-        beam_out = [lg.numpy(), ids, lps.numpy()]
-      else:
-        dec_cls, dec_h = greedy_decoder(
-            P, cfg, s, "class", obs_oh[:, -1], enc_c, T_pred, scene_mean, trace)
-        if trace is not None:
-          trace["dec_class_h_%d" % s] = dec_h.numpy()
-      dec_reg, _ = greedy_decoder(
-          P, cfg, s, "reg", obs_reg[:, -1], enc_r, T_pred, scene_mean, trace)
-      cls_out.append(dec_cls.numpy())
-      reg_out.append(dec_reg.numpy())
+    cls_out, reg_out, beam_out = forward_tensors(P, cfg, feed, dtype, trace)
+  cls_out = [c if isinstance(c, list) else c.numpy() for c in cls_out]
+  reg_out = [r if isinstance(r, list) else r.numpy() for r in reg_out]
+  if beam_out is not None:
+    beam_out = [beam_out[0].numpy(), beam_out[1], beam_out[2].numpy()]
   return cls_out, reg_out, beam_out
+
+
+# ------------------------------------------------------------- training
+
+def huber_tf(pred, labels, delta=1.0):
+  """tf.losses.huber_loss(..., reduction=MEAN) with unit weights
+  (code/pred_models.py:1020-1022): error = pred - labels;
+  q = min(|e|, delta); 0.5 q^2 + delta (|e| - q); mean over all elements."""
+  err = pred - labels
+  ab = err.abs()
+  q = torch.clamp(ab, max=delta)
+  lin = ab - q
+  return (0.5 * q * q + delta * lin).mean()
+
+
+def build_loss(P, cfg, cls_out, reg_out, feed, dtype=torch.float32):
+  """`Model.build_loss` (code/pred_models.py:961-1040), published switches
+  (hard labels, unmasked regression).  Returns (loss, wd_loss,
+  pred_grid_loss list [cls_0, reg_0, cls_1, ...])."""
+  assert not cfg.use_soft_grid_class and not cfg.mask_grid_regression
+  losses, pred_grid_loss = [], []
+  for s, (H, W) in enumerate(cfg.scene_grids):
+    if not cfg.use_grids[s]:
+      continue
+    labels = torch.from_numpy(
+        np.asarray(feed["grid_pred_labels"][s]).astype("int64").reshape(-1))
+    logits = cls_out[s].reshape(-1, H * W)                       # :984
+    lse = torch.logsumexp(logits, dim=-1)
+    ce = lse - logits.gather(1, labels[:, None])[:, 0]           # :991-993
+    cls_loss = ce.mean() * cfg.grid_loss_weight                  # :995, 1024
+    reg_loss = huber_tf(reg_out[s], _t(feed["grid_pred_regress"][s], dtype)) \
+        * cfg.grid_reg_loss_weight                               # :1020-1027
+    pred_grid_loss += [cls_loss, reg_loss]
+    losses += [cls_loss, reg_loss]
+  # wd_cost(".*/W", wd): wd * tf.nn.l2_loss(p) = wd * sum(p^2) / 2  (:1033, 1253-1275)
+  wd = None
+  for name in sorted(P.p):
+    if name.endswith("/W"):
+      term = cfg.wd * 0.5 * (P.p[name] * P.p[name]).sum()
+      wd = term if wd is None else wd + term
+  if wd is not None:
+    losses.append(wd)
+  loss = losses[0]
+  for l in losses[1:]:
+    loss = loss + l
+  return loss, wd, pred_grid_loss
+
+
+def learning_rate(cfg, global_step):
+  """Trainer.__init__ (code/pred_models.py:1645-1665)."""
+  if cfg.use_cosine_lr:
+    max_steps = int(cfg.train_num_examples / cfg.batch_size * cfg.num_epochs)
+    gs = min(global_step, max_steps)
+    lr = cfg.init_lr * 0.5 * (1 + math.cos(math.pi * gs / max_steps))
+  elif cfg.learning_rate_decay is not None:
+    decay_steps = int(cfg.train_num_examples / cfg.batch_size *
+                      cfg.num_epoch_per_decay)
+    lr = cfg.init_lr * cfg.learning_rate_decay ** (global_step // decay_steps)
+  else:
+    lr = cfg.init_lr
+  return lr * cfg.emb_lr
+
+
+def loss_and_grads(params, cfg, feed, dtype=torch.float32):
+  """tf.gradients(loss, trainable_variables) (code/pred_models.py:1694-1698).
+  Returns (loss, wd_loss, pred_grid_loss, grads dict name -> numpy)."""
+  P = Params(params, dtype)
+  for v in P.p.values():
+    v.requires_grad_(True)
+  cls_out, reg_out, _ = forward_tensors(P, cfg, feed, dtype)
+  loss, wd, pgl = build_loss(P, cfg, cls_out, reg_out, feed, dtype)
+  names = sorted(P.p)
+  gs = torch.autograd.grad(loss, [P.p[n] for n in names], allow_unused=True)
+  grads = {n: (None if g is None else g.numpy()) for n, g in zip(names, gs)}
+  return (float(loss), float(wd) if wd is not None else 0.0,
+          [float(l) for l in pgl], grads)
+
+
+def adadelta_init(params):
+  return {n: (np.zeros_like(v), np.zeros_like(v)) for n, v in params.items()}
+
+
+def train_step(params, opt_state, global_step, cfg, feed, dtype=torch.float32):
+  """`Trainer.step` (code/pred_models.py:1719-1742): loss, gradients,
+  element-wise clip (:1700-1705), tf.train.AdadeltaOptimizer(lr, rho=0.95,
+  epsilon=1e-8).apply_gradients (:1671-1672, 1716), global_step += 1.
+  TF ApplyAdadelta:  accum = rho accum + (1-rho) g^2;
+    update = sqrt(accum_update + eps) * rsqrt(accum + eps) * g;
+    var -= lr * update;  accum_update = rho accum_update + (1-rho) update^2.
+  Returns (loss, wd_loss, pred_grid_loss, new_params, new_state, grads)."""
+  assert cfg.optimizer == "adadelta"
+  loss, wd, pgl, grads = loss_and_grads(params, cfg, feed, dtype)
+  lr = learning_rate(cfg, global_step)
+  npd = np.float64 if dtype == torch.float64 else np.float32
+  rho, eps = npd(0.95), npd(1e-8)
+  new_params, new_state = {}, {}
+  for n, v in params.items():
+    g = grads.get(n)
+    acc, acc_up = opt_state[n]
+    if g is None:
+      new_params[n], new_state[n] = v, (acc, acc_up)
+      continue
+    g = g.astype(npd)
+    if cfg.clip_gradient_norm is not None:
+      g = np.clip(g, -cfg.clip_gradient_norm, cfg.clip_gradient_norm)
+    acc = acc.astype(npd) * rho + g * g * (npd(1) - rho)
+    upd = np.sqrt(acc_up.astype(npd) + eps) * (npd(1) / np.sqrt(acc + eps)) * g
+    new_params[n] = (v.astype(npd) - upd * npd(lr)).astype(npd)
+    acc_up = acc_up.astype(npd) * rho + upd * upd * (npd(1) - rho)
+    new_state[n] = (acc, acc_up)
+  return loss, wd, pgl, new_params, new_state, grads
 
 
 # ---------------------------------------------------- per-kernel entry points

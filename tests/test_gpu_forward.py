@@ -123,3 +123,44 @@ def test_beam_search(built_lib, scale, N, B):
   assert s == scale
   compare_beams(arrs, oreg[scale], ologits, oids, olp,
                 np.stack(trace["beam_step_topvals"], axis=-1), trace["beam_trace"])
+
+
+def test_graph_replay_is_bitwise_identical(built_lib):
+  """hipGraph replay of the forward (mv_set_graph_mode) == stream launches,
+  greedy (both scales) and beam; a second replay reuses the captured graph and
+  a parameter update drops it."""
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1))
+  params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 11)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  a, ar = eng.forward_greedy(feed)
+  eng.set_graph_mode(True)
+  for _ in range(2):
+    b, br = eng.forward_greedy(feed)
+    for s in range(2):
+      assert (a[s] == b[s]).all() and (ar[s] == br[s]).all()
+  # new weights -> new packed pointers -> the graph must be re-captured
+  params2 = synth.make_params(cfg, seed=synth.SEED_BASE + 99, recurrent_gain=3.0,
+                              bias_scale=0.1)
+  eng.set_params(params2)
+  c, cr = eng.forward_greedy(feed)
+  eng.set_graph_mode(False)
+  d, dr = eng.forward_greedy(feed)
+  for s in range(2):
+    assert (c[s] == d[s]).all() and (cr[s] == dr[s]).all()
+    assert not (c[s] == a[s]).all()
+  eng.close()
+
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), beam_size=5)
+  params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 12)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  x, _ = eng.forward_beam(feed)
+  eng.set_graph_mode(True)
+  for _ in range(2):
+    y, _ = eng.forward_beam(feed)
+    for k in x:
+      assert (x[k] == y[k]).all(), k
+  eng.close()
