@@ -91,6 +91,38 @@ typedef struct mv_beam_outputs {
   float*   logprobs;    /* [N, B] */
 } mv_beam_outputs;
 
+/* -- training step: Trainer (pred_models.py:1636-1742) ------------------- */
+/* The optimizer / loss fields Trainer.__init__ and Model.build_loss read from
+ * the config (train.py:25-138 after process_args). */
+typedef struct mv_train_config {
+  int32_t optimizer;          /* 0 = adadelta (the published configuration) */
+  float   init_lr, emb_lr;
+  int32_t use_cosine_lr;      /* --use_cosine_lr */
+  int32_t has_decay;          /* learning_rate_decay is not None */
+  float   learning_rate_decay;
+  int32_t decay_steps;        /* int(train_num_examples / batch_size * num_epoch_per_decay) */
+  int32_t max_steps;          /* cosine: int(train_num_examples / batch_size * num_epochs) */
+  int32_t do_clip;            /* clip_gradient_norm is not None */
+  float   clip_gradient_norm; /* ELEMENT-WISE clip_by_value bound (pred_models.py:1700-1705) */
+  float   wd;                 /* weight decay on every variable named .../W */
+  float   grid_loss_weight, grid_reg_loss_weight;
+} mv_train_config;
+
+/* Training-only placeholders of Model.get_feed_dict(is_train=True)
+ * (pred_models.py:1149-1152). */
+typedef struct mv_targets {
+  const int32_t* grid_pred_labels[MV_MAX_SCALES];   /* [N, T_p] */
+  const float*   grid_pred_regress[MV_MAX_SCALES];  /* [N, T_p, H, W, 2] */
+} mv_targets;
+
+/* Fetches of Trainer.step: loss, wd_loss, pred_grid_loss = [cls_s, reg_s, ...]
+ * over the enabled scales (pred_models.py:1029, 1719-1742). */
+typedef struct mv_losses {
+  float   loss, wd_loss;
+  float   pred_grid_loss[2 * MV_MAX_SCALES];
+  int32_t num_pred_grid_loss;
+} mv_losses;
+
 /* -- lifetime ------------------------------------------------------------ */
 int  mv_create(const mv_config* cfg, int device, mv_handle* out);
 int  mv_destroy(mv_handle h);
@@ -119,6 +151,32 @@ int  mv_run_beam_resident(mv_handle h);
 int  mv_synchronize(mv_handle h);
 int  mv_download_outputs(mv_handle h, mv_outputs* out);
 int  mv_download_beam_outputs(mv_handle h, mv_beam_outputs* out);
+
+/* -- training: one call == sess.run([loss, train_op, wd_loss, pred_grid_loss]) */
+int  mv_train_init(mv_handle h, const mv_train_config* tc);
+/* forward (is_train, --train_w_onehot wiring) + loss + backward + clip +
+ * Adadelta + global_step++ on one device */
+int  mv_train_step(mv_handle h, const mv_inputs* in, const mv_targets* tg,
+                   mv_losses* out);
+/* data-parallel form: gradients of the LOCAL batch mean are left in one flat
+ * device buffer (mv_grad_buffer) for the caller's all-reduce(sum) over the
+ * ranks (RCCL via torch.distributed), then mv_train_apply(1/world) clips,
+ * applies Adadelta and advances global_step -- clip AFTER the all-reduce, as a
+ * single-device step over the global batch would. */
+int  mv_train_forward_backward(mv_handle h, const mv_inputs* in,
+                               const mv_targets* tg, mv_losses* out);
+int  mv_grad_buffer(mv_handle h, float** device_ptr, int64_t* elems);
+int  mv_train_apply(mv_handle h, float grad_scale);
+/* tf.gradients(loss, var) of the last forward_backward, by variable name */
+int  mv_get_grad(mv_handle h, const char* tf_name, float* out, int64_t capacity_elems);
+int  mv_get_global_step(mv_handle h, int64_t* step);
+int  mv_set_global_step(mv_handle h, int64_t step);
+/* optimizer slots for checkpoint save / restore: slot 0 = accum ("Adadelta"),
+ * 1 = accum_update ("Adadelta_1") */
+int  mv_get_opt_slot(mv_handle h, const char* tf_name, int32_t slot, float* out,
+                     int64_t capacity_elems);
+int  mv_set_opt_slot(mv_handle h, const char* tf_name, int32_t slot,
+                     const float* data, int64_t elems);
 
 /* Replay the forward as a captured hipGraph (one graph per (mode, T_pred, U)):
  * the reference's whole forward is ONE sess.run (pred_models.py:1779), here it
@@ -158,6 +216,19 @@ int  mv_op_beam_step(int device, const float* logits, const float* prev_logprob,
                      int32_t N, int32_t B, int32_t K, int32_t time,
                      int32_t diverse, float gamma, int32_t fix_num_timestep,
                      float* new_logprob, int32_t* ids, int32_t* parents);
+
+/* Backward of one ConvLSTMCell step (tf.gradients through the cell): inputs as
+ * mv_op_convlstm_step (c == h == NULL: zero state) plus d h', d c' [M,H,W,C];
+ * outputs d x [M,H,W,Cx], d h, d c [M,H,W,C], d kernel [3,3,Cx+C,4C], d biases [4C]. */
+int  mv_op_convlstm_bwd(int device, const float* x, const float* c, const float* h,
+                        const float* kernel, const float* biases,
+                        const float* dh_new, const float* dc_new, int32_t M,
+                        int32_t H, int32_t W, int32_t Cx, int32_t C, float* dx,
+                        float* dh, float* dc, float* dkernel, float* dbiases);
+/* Backward of h + GNN(h) given g = d out: d h [M,H,W,C], d scene_mean [M,H,W,D]. */
+int  mv_op_gnn_bwd(int device, const float* h, const float* scene_mean,
+                   const float* g, int32_t M, int32_t H, int32_t W, int32_t C,
+                   int32_t D, float* dh, float* dscene_mean);
 
 #ifdef __cplusplus
 }

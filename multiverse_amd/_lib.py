@@ -29,6 +29,10 @@ EXPORTED_SYMBOLS = [
     "mv_set_graph_mode", "mv_set_profiling", "mv_reset_kernel_stats", "mv_num_kernel_stats",
     "mv_kernel_stat", "mv_time_greedy_resident", "mv_time_beam_resident",
     "mv_op_convlstm_step", "mv_op_gnn", "mv_op_hidden2grid", "mv_op_beam_step",
+    "mv_train_init", "mv_train_step", "mv_train_forward_backward",
+    "mv_grad_buffer", "mv_train_apply", "mv_get_grad", "mv_get_global_step",
+    "mv_set_global_step", "mv_get_opt_slot", "mv_set_opt_slot",
+    "mv_op_convlstm_bwd", "mv_op_gnn_bwd",
 ]
 
 
@@ -88,6 +92,34 @@ class mv_beam_outputs(C.Structure):
   ]
 
 
+class mv_train_config(C.Structure):
+  _fields_ = [
+      ("optimizer", C.c_int32),
+      ("init_lr", C.c_float), ("emb_lr", C.c_float),
+      ("use_cosine_lr", C.c_int32),
+      ("has_decay", C.c_int32), ("learning_rate_decay", C.c_float),
+      ("decay_steps", C.c_int32), ("max_steps", C.c_int32),
+      ("do_clip", C.c_int32), ("clip_gradient_norm", C.c_float),
+      ("wd", C.c_float),
+      ("grid_loss_weight", C.c_float), ("grid_reg_loss_weight", C.c_float),
+  ]
+
+
+class mv_targets(C.Structure):
+  _fields_ = [
+      ("grid_pred_labels", _ip * MV_MAX_SCALES),
+      ("grid_pred_regress", _fp * MV_MAX_SCALES),
+  ]
+
+
+class mv_losses(C.Structure):
+  _fields_ = [
+      ("loss", C.c_float), ("wd_loss", C.c_float),
+      ("pred_grid_loss", C.c_float * (2 * MV_MAX_SCALES)),
+      ("num_pred_grid_loss", C.c_int32),
+  ]
+
+
 _lib = None
 
 
@@ -137,6 +169,19 @@ def load():
   lib.mv_op_beam_step.argtypes = [C.c_int, _fp, _fp, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                   C.c_int32, _fp, _ip, _ip]
+  lib.mv_train_init.argtypes = [h, C.POINTER(mv_train_config)]
+  lib.mv_train_step.argtypes = [h, C.POINTER(mv_inputs), C.POINTER(mv_targets),
+                                C.POINTER(mv_losses)]
+  lib.mv_train_forward_backward.argtypes = lib.mv_train_step.argtypes
+  lib.mv_grad_buffer.argtypes = [h, C.POINTER(_fp), C.POINTER(C.c_int64)]
+  lib.mv_train_apply.argtypes = [h, C.c_float]
+  lib.mv_get_grad.argtypes = [h, C.c_char_p, _fp, C.c_int64]
+  lib.mv_get_global_step.argtypes = [h, C.POINTER(C.c_int64)]
+  lib.mv_set_global_step.argtypes = [h, C.c_int64]
+  lib.mv_get_opt_slot.argtypes = [h, C.c_char_p, C.c_int32, _fp, C.c_int64]
+  lib.mv_set_opt_slot.argtypes = [h, C.c_char_p, C.c_int32, _fp, C.c_int64]
+  lib.mv_op_convlstm_bwd.argtypes = [C.c_int] + [_fp] * 7 + [C.c_int32] * 5 + [_fp] * 5
+  lib.mv_op_gnn_bwd.argtypes = [C.c_int, _fp, _fp, _fp] + [C.c_int32] * 5 + [_fp, _fp]
   if lib.mv_abi_version() != MV_ABI_VERSION:
     raise MvError("ABI version mismatch: library %d, binding %d"
                   % (lib.mv_abi_version(), MV_ABI_VERSION))
@@ -194,6 +239,38 @@ def make_config(cfg):
   c.diverse_gamma = float(getattr(cfg, "diverse_gamma", 1.0))
   c.fix_num_timestep = int(getattr(cfg, "fix_num_timestep", 0))
   return c
+
+
+def make_train_config(cfg):
+  """Trainer.__init__ / Model.build_loss fields of the config
+  (reference code/pred_models.py:1636-1717, 961-1040) -> mv_train_config."""
+  if cfg.optimizer != "adadelta":
+    raise MvError("optimizer %r is not implemented (adadelta only, the published "
+                  "configuration)" % (cfg.optimizer,))
+  if getattr(cfg, "use_soft_grid_class", False) or \
+      getattr(cfg, "mask_grid_regression", False):
+    raise MvError("use_soft_grid_class / mask_grid_regression are not implemented")
+  if not cfg.train_w_onehot or getattr(cfg, "use_teacher_forcing", False):
+    raise MvError("training is implemented for the published wiring only: "
+                  "--train_w_onehot without --use_teacher_forcing")
+  if cfg.keep_prob != 1.0:
+    raise MvError("keep_prob != 1.0 is not implemented")
+  t = mv_train_config()
+  t.optimizer = 0
+  t.init_lr = float(cfg.init_lr)
+  t.emb_lr = float(cfg.emb_lr)
+  t.use_cosine_lr = 1 if getattr(cfg, "use_cosine_lr", False) else 0
+  t.has_decay = 0 if cfg.learning_rate_decay is None else 1
+  t.learning_rate_decay = float(cfg.learning_rate_decay or 1.0)
+  t.decay_steps = int(cfg.train_num_examples / cfg.batch_size *
+                      cfg.num_epoch_per_decay)
+  t.max_steps = int(cfg.train_num_examples / cfg.batch_size * cfg.num_epochs)
+  t.do_clip = 0 if cfg.clip_gradient_norm is None else 1
+  t.clip_gradient_norm = float(cfg.clip_gradient_norm or 0.0)
+  t.wd = float(cfg.wd or 0.0)
+  t.grid_loss_weight = float(cfg.grid_loss_weight)
+  t.grid_reg_loss_weight = float(cfg.grid_reg_loss_weight)
+  return t
 
 
 class Engine(object):
@@ -356,6 +433,85 @@ class Engine(object):
     check(self.lib.mv_download_beam_outputs(self.handle, C.byref(out)), self.handle)
     return arrs, s
 
+  # ---- training (Trainer.step)
+  def train_init(self, cfg=None):
+    self._tc = make_train_config(cfg or self.cfg)
+    check(self.lib.mv_train_init(self.handle, C.byref(self._tc)), self.handle)
+
+  def _targets(self, feed):
+    cfg = self.cfg
+    N, Tp = cfg.batch_size, int(feed.get("pred_length", cfg.pred_len))
+    tg = mv_targets()
+    keep = []
+    for s, (h, w) in enumerate(cfg.scene_grids):
+      if not cfg.use_grids[s]:
+        continue
+      lab = i32(feed["grid_pred_labels"][s]).reshape(N, Tp)
+      reg = f32(feed["grid_pred_regress"][s]).reshape(N, Tp, h, w, 2)
+      keep += [lab, reg]
+      tg.grid_pred_labels[s] = iptr(lab)
+      tg.grid_pred_regress[s] = fptr(reg)
+    self._keep_t = keep
+    return tg
+
+  @staticmethod
+  def _losses(L):
+    return (float(L.loss), float(L.wd_loss),
+            [float(L.pred_grid_loss[i]) for i in range(L.num_pred_grid_loss)])
+
+  def train_step(self, feed):
+    """-> (loss, wd_loss, pred_grid_loss list)"""
+    inp, tg, L = self._inputs(feed), self._targets(feed), mv_losses()
+    check(self.lib.mv_train_step(self.handle, C.byref(inp), C.byref(tg), C.byref(L)),
+          self.handle)
+    return self._losses(L)
+
+  def train_forward_backward(self, feed):
+    inp, tg, L = self._inputs(feed), self._targets(feed), mv_losses()
+    check(self.lib.mv_train_forward_backward(self.handle, C.byref(inp), C.byref(tg),
+                                             C.byref(L)), self.handle)
+    return self._losses(L)
+
+  def train_apply(self, grad_scale=1.0):
+    check(self.lib.mv_train_apply(self.handle, float(grad_scale)), self.handle)
+
+  def grad_buffer(self):
+    """(device pointer, element count) of the flat gradient buffer."""
+    p, n = _fp(), C.c_int64()
+    check(self.lib.mv_grad_buffer(self.handle, C.byref(p), C.byref(n)), self.handle)
+    return C.cast(p, C.c_void_p).value, int(n.value)
+
+  def get_grad(self, name):
+    shape = dict(self.param_specs())[name]
+    out = np.empty(shape, dtype=np.float32)
+    check(self.lib.mv_get_grad(self.handle, name.encode(), fptr(out), out.size),
+          self.handle)
+    return out
+
+  def get_opt_slot(self, name, slot):
+    shape = dict(self.param_specs())[name]
+    out = np.empty(shape, dtype=np.float32)
+    check(self.lib.mv_get_opt_slot(self.handle, name.encode(), int(slot), fptr(out),
+                                   out.size), self.handle)
+    return out
+
+  def set_opt_slot(self, name, slot, value):
+    a = f32(value)
+    check(self.lib.mv_set_opt_slot(self.handle, name.encode(), int(slot), fptr(a),
+                                   a.size), self.handle)
+
+  @property
+  def global_step(self):
+    v = C.c_int64()
+    if self.lib.mv_get_global_step(self.handle, C.byref(v)) != 0:
+      raise MvError("mv_train_init has not been called")
+    return int(v.value)
+
+  @global_step.setter
+  def global_step(self, step):
+    if self.lib.mv_set_global_step(self.handle, int(step)) != 0:
+      raise MvError("mv_train_init has not been called")
+
   def set_graph_mode(self, on):
     check(self.lib.mv_set_graph_mode(self.handle, 1 if on else 0), self.handle)
 
@@ -429,3 +585,38 @@ def op_beam_step(logits, prev_lp, time, diverse, gamma, fix_num_timestep, device
                             1 if diverse else 0, float(gamma), int(fix_num_timestep),
                             fptr(new_lp), iptr(ids), iptr(parents)))
   return new_lp, ids, parents
+
+
+def op_convlstm_bwd(x, c, h, kernel, biases, dh_new, dc_new, device=0):
+  """-> (dx, dh, dc, dkernel, dbiases)"""
+  lib = load()
+  x = f32(x)
+  M, H, W, Cx = x.shape
+  Cc = int(kernel.shape[3]) // 4
+  kernel, biases = f32(kernel), f32(biases)
+  dh_new, dc_new = f32(dh_new), f32(dc_new)
+  if c is None:
+    cp, hp = _fp(), _fp()
+  else:
+    c, h = f32(c), f32(h)
+    cp, hp = fptr(c), fptr(h)
+  dx = np.empty((M, H, W, Cx), dtype=np.float32)
+  dh = np.empty((M, H, W, Cc), dtype=np.float32)
+  dc = np.empty((M, H, W, Cc), dtype=np.float32)
+  dk = np.empty(kernel.shape, dtype=np.float32)
+  db = np.empty(biases.shape, dtype=np.float32)
+  check(lib.mv_op_convlstm_bwd(device, fptr(x), cp, hp, fptr(kernel), fptr(biases),
+                               fptr(dh_new), fptr(dc_new), M, H, W, Cx, Cc, fptr(dx),
+                               fptr(dh), fptr(dc), fptr(dk), fptr(db)))
+  return dx, dh, dc, dk, db
+
+
+def op_gnn_bwd(h, scene_mean, g, device=0):
+  lib = load()
+  h, scene_mean, g = f32(h), f32(scene_mean), f32(g)
+  M, H, W, Cc = h.shape
+  dh = np.empty_like(h)
+  ds = np.empty_like(scene_mean)
+  check(lib.mv_op_gnn_bwd(device, fptr(h), fptr(scene_mean), fptr(g), M, H, W, Cc,
+                          scene_mean.shape[-1], fptr(dh), fptr(ds)))
+  return dh, ds

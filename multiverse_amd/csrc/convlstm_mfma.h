@@ -60,6 +60,16 @@ struct ConvLstmArgs {
   const float* bias;    // [4C] TF order (i|j|f|o)
   float* h_out;         // [rows, H, W, C]
   float* c_out;         // [rows, H, W, C]
+  float* gates_out;     // optional [rows, H, W, 4, C]: sigm(i), tanh(j), sigm(f+fb),
+                        // sigm(o) saved for the backward pass (training forward)
+  // --- plain-store epilogue (dgrad of the gate conv, see convlstm_dgrad_kernel):
+  // column block cb covers output columns [cb*128, cb*128+128); columns
+  // < out0_cols go to out0 [M, out0_cols], the next out1_cols to out1.
+  float* out0;
+  float* out1;
+  int32_t out0_cols, out1_cols;
+  int32_t n_colblocks;  // column blocks of 128 (LSTM epilogue: C/32)
+  int32_t ng_last;      // active 32-column sub-blocks in the last column block
   int32_t rows, H, W, Cx, C;
   int32_t x_row_stride; // elements between consecutive rows of x (0: H*W*Cx), so a
                         // time slice of an [N, T, H, W, Cx] tensor is read in place
@@ -132,12 +142,17 @@ static inline void pack_convlstm_weights(const float* w, int Cx, int C, float* o
 __device__ __forceinline__ float tanh_(float v) { return tanhf(v); }
 __device__ __forceinline__ float sigm_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+template <int NG>
 struct ConvFrag {
   f32x4 a;        // A: 4 consecutive k of this lane's cell
-  f32x4 b[4];     // B: one fragment per gate
+  f32x4 b[NG];    // B: one fragment per gate / 32-column sub-block
   uint32_t ok;    // all-ones when the tap is inside the image, else 0
 };
 
+constexpr int kEpiLstm = 0;    // fused LSTM update (forward)
+constexpr int kEpiStore = 1;   // plain store of the NG x 32 columns (dgrad)
+
+template <int EPI, int NG>
 __device__ __forceinline__ void convlstm_step_body(const ConvLstmArgs& a, int block) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -145,7 +160,7 @@ __device__ __forceinline__ void convlstm_step_body(const ConvLstmArgs& a, int bl
   // block -> (channel block, m tile).  Workgroups are observed to round-robin
   // over the 8 XCDs by linear id, so cb = id % 8 keeps each XCD's L2 on ONE 1/8
   // slice of the packed weights (speed only, never correctness).
-  const int ncb = a.C / kChBlock;
+  const int ncb = a.n_colblocks;
   const int cb = block % ncb;
   const int mt = block / ncb;
   const int H = a.H, W = a.W, HW = H * W, C = a.C, Cx = a.Cx;
@@ -180,11 +195,11 @@ __device__ __forceinline__ void convlstm_step_body(const ConvLstmArgs& a, int bl
   // element 0 of the tensor (always mapped) and is zeroed by a bit mask when it
   // is CONSUMED, so the prefetch never waits for its own data and the loop body
   // has no divergent control flow around its loads.
-  auto load_step = [&](int s, ConvFrag& f) {
+  auto load_step = [&](int s, ConvFrag<NG>& f) {
     const int q = s >> 2, kk = s & 3;
     const f32x4* wsrc = wblk + (size_t)s * (4 * 64);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) f.b[g] = wsrc[g * 64];
+    for (int g = 0; g < NG; ++g) f.b[g] = wsrc[g * 64];
     if (xsmall && q == 0) {
       // all 9 taps x Cx (<= 3) channels of x packed into one chunk: k = tap*Cx + ch
       f32x4 v;
@@ -218,20 +233,20 @@ __device__ __forceinline__ void convlstm_step_body(const ConvLstmArgs& a, int bl
     }
   };
 
-  f32x16 acc[4];
+  f32x16 acc[NG];
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
 
-  auto mma_step = [&](const ConvFrag& f) {
+  auto mma_step = [&](const ConvFrag<NG>& f) {
     f32x4 am;
 #pragma unroll
     for (int j = 0; j < 4; ++j) am[j] = __uint_as_float(__float_as_uint(f.a[j]) & f.ok);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < NG; ++g)
         acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(am[j], f.b[g][j], acc[g], 0, 0, 0);
   };
 
@@ -239,7 +254,7 @@ __device__ __forceinline__ void convlstm_step_body(const ConvLstmArgs& a, int bl
   // The (clamped) prefetch is unconditional: a straight-line body lets the
   // compiler use counted vmcnt waits; the final re-read is harmless.
   const int nsteps = nchunks * 4;
-  ConvFrag f0, f1;
+  ConvFrag<NG> f0, f1;
   if (nsteps > 0) load_step(0, f0);
   for (int s = 0; s < nsteps; s += 2) {     // nsteps is a multiple of 4
     load_step(s + 1, f1);
@@ -249,27 +264,54 @@ __device__ __forceinline__ void convlstm_step_body(const ConvLstmArgs& a, int bl
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int ch = cb * kChBlock + (lane & 31);
-  const float bi = a.bias[ch], bj = a.bias[C + ch], bf = a.bias[2 * C + ch],
-              bo = a.bias[3 * C + ch];
+  if constexpr (EPI == kEpiLstm) {
+    const int ch = cb * kChBlock + (lane & 31);
+    const float bi = a.bias[ch], bj = a.bias[C + ch], bf = a.bias[2 * C + ch],
+                bo = a.bias[3 * C + ch];
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    const int m = m_wave + row;
-    if (m < M_total) {
-      float cprev = 0.f;
-      if (!a.zero_state) {
-        const int r = m / HW, cell = m - r * HW;
-        const int sr = a.src_row_c ? a.src_row_c[r] : r;
-        cprev = a.c[((size_t)sr * HW + cell) * C + ch];
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      const int m = m_wave + row;
+      if (m < M_total) {
+        float cprev = 0.f;
+        if (!a.zero_state) {
+          const int r = m / HW, cell = m - r * HW;
+          const int sr = a.src_row_c ? a.src_row_c[r] : r;
+          cprev = a.c[((size_t)sr * HW + cell) * C + ch];
+        }
+        const float gi = acc[0][reg] + bi, gj = acc[1][reg] + bj,
+                    gf = acc[2][reg] + bf, go = acc[3][reg] + bo;
+        const float si = sigm_(gi), tj = tanh_(gj), sf = sigm_(gf + a.forget_bias),
+                    so = sigm_(go);
+        float cn = sf * cprev;
+        cn = cn + si * tj;
+        const float hn = tanh_(cn) * so;
+        a.c_out[(size_t)m * C + ch] = cn;
+        a.h_out[(size_t)m * C + ch] = hn;
+        if (a.gates_out) {
+          float* gp = a.gates_out + (size_t)m * 4 * C + ch;
+          gp[0] = si; gp[C] = tj; gp[2 * C] = sf; gp[3 * C] = so;
+        }
       }
-      const float gi = acc[0][reg] + bi, gj = acc[1][reg] + bj,
-                  gf = acc[2][reg] + bf, go = acc[3][reg] + bo;
-      float cn = sigm_(gf + a.forget_bias) * cprev;
-      cn = cn + sigm_(gi) * tanh_(gj);
-      const float hn = tanh_(cn) * sigm_(go);
-      a.c_out[(size_t)m * C + ch] = cn;
-      a.h_out[(size_t)m * C + ch] = hn;
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int col = cb * kBN + g * 32 + (lane & 31);
+      float* dst = nullptr;
+      int stride = 0, cc = col;
+      if (col < a.out0_cols) { dst = a.out0; stride = a.out0_cols; }
+      else if (col - a.out0_cols < a.out1_cols) {
+        dst = a.out1; stride = a.out1_cols; cc = col - a.out0_cols;
+      }
+      if (dst) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+          const int m = m_wave + row;
+          if (m < M_total) dst[(size_t)m * stride + cc] = acc[g][reg];
+        }
+      }
     }
   }
 }
@@ -285,16 +327,47 @@ void convlstm_step_kernel(const ConvLstmGroup g) {
   if (pi > 0) block -= g.block_end[pi - 1];
   // select by value so every field of the chosen problem lives in SGPRs
   switch (pi) {
-    case 0: convlstm_step_body(g.p[0], block); break;
-    case 1: convlstm_step_body(g.p[1], block); break;
-    case 2: convlstm_step_body(g.p[2], block); break;
-    default: convlstm_step_body(g.p[3], block); break;
+    case 0: convlstm_step_body<kEpiLstm, 4>(g.p[0], block); break;
+    case 1: convlstm_step_body<kEpiLstm, 4>(g.p[1], block); break;
+    case 2: convlstm_step_body<kEpiLstm, 4>(g.p[2], block); break;
+    default: convlstm_step_body<kEpiLstm, 4>(g.p[3], block); break;
+  }
+}
+
+// dgrad of the gate convolution: d[h | x] = conv3x3_SAME(G, W^T flipped), the
+// same implicit GEMM with the saved gate gradients G [M, 4C] as the "h"
+// operand (4C input channels) and the Cx + C input channels as output
+// columns (pack_convlstm_dgrad_weights).  The last column block usually has
+// fewer than four active 32-column sub-blocks (Cx = 32 -> 1, Cx = 64 -> 2).
+__device__ __forceinline__ void convlstm_dgrad_dispatch(const ConvLstmArgs& a, int block) {
+  const int cb = block % a.n_colblocks;
+  if (cb == a.n_colblocks - 1 && a.ng_last == 1)
+    convlstm_step_body<kEpiStore, 1>(a, block);
+  else if (cb == a.n_colblocks - 1 && a.ng_last == 2)
+    convlstm_step_body<kEpiStore, 2>(a, block);
+  else
+    convlstm_step_body<kEpiStore, 4>(a, block);
+}
+
+__global__ __launch_bounds__(256, 2)
+void convlstm_dgrad_kernel(const ConvLstmGroup g) {
+  int block = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxGroup - 1; ++i)
+    if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
+  if (pi > 0) block -= g.block_end[pi - 1];
+  switch (pi) {
+    case 0: convlstm_dgrad_dispatch(g.p[0], block); break;
+    case 1: convlstm_dgrad_dispatch(g.p[1], block); break;
+    case 2: convlstm_dgrad_dispatch(g.p[2], block); break;
+    default: convlstm_dgrad_dispatch(g.p[3], block); break;
   }
 }
 
 static inline unsigned convlstm_blocks(const ConvLstmArgs& a) {
   const size_t M = (size_t)a.rows * a.H * a.W;
-  return (unsigned)((M + kBlockRows - 1) / kBlockRows) * (unsigned)(a.C / kChBlock);
+  return (unsigned)((M + kBlockRows - 1) / kBlockRows) * (unsigned)a.n_colblocks;
 }
 
 // Fill the derived fields of one problem.
@@ -305,7 +378,65 @@ static inline void convlstm_finish_args(ConvLstmArgs& a, bool zero_state) {
   a.x_small = (a.Cx > 0 && 9 * a.Cx <= kBK) ? 1 : 0;
   a.zero_state = zero_state ? 1 : 0;
   if (a.x_row_stride == 0) a.x_row_stride = a.H * a.W * a.Cx;
+  a.n_colblocks = a.C / kChBlock;
+  a.ng_last = 4;
   a.forget_bias = 1.0f;   // tf.contrib.rnn.ConvLSTMCell default
+}
+
+// ---- dgrad problem: G [rows,H,W,4C] -> dh [rows,H,W,C], dx [rows,H,W,Cx]
+static inline int convlstm_dgrad_colblocks(int Cx, int C) {
+  return (C + Cx + kBN - 1) / kBN;
+}
+static inline size_t convlstm_dgrad_wpack_elems(int Cx, int C) {
+  return (size_t)convlstm_dgrad_colblocks(Cx, C) * 9 * (size_t)(4 * C / kBK) * kBN * kBK;
+}
+// Host-side pack of the transposed, tap-flipped kernel for the dgrad launch:
+//   wd[cb][chunk][kk][g][lane][4], chunk = (gate-column group of 32, tap'),
+//   element (lane, j): k = kk*8 + (lane>>5)*4 + j -> gate column n = grp*32 + k,
+//   output column col = cb*128 + g*32 + (lane&31):
+//     col <  C       -> input channel Cx + col  (an h channel)
+//     col <  C + Cx  -> input channel col - C   (an x channel)
+//   value = W[8 - tap'][ci][n]   (d in[m] = sum_tap G[m - d_tap] W[tap], so the
+//   launch's tap' reads offset d_tap' = -d_tap).
+static inline void pack_convlstm_dgrad_weights(const float* w, int Cx, int C, float* out) {
+  const int Cin = Cx + C, N4 = 4 * C;
+  const int ncb = convlstm_dgrad_colblocks(Cx, C), nch = 9 * (N4 / kBK);
+  for (int cb = 0; cb < ncb; ++cb)
+    for (int q = 0; q < nch; ++q) {
+      float* tile = out + ((size_t)cb * nch + q) * kBN * kBK;
+      const int grp = q / 9, tap = q % 9;
+      for (int kk = 0; kk < 4; ++kk)
+        for (int g = 0; g < 4; ++g)
+          for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 4; ++j) {
+              const int k = kk * 8 + (l >> 5) * 4 + j;
+              const int n = grp * kBK + k;
+              const int col = cb * kBN + g * 32 + (l & 31);
+              int ci = -1;
+              if (col < C) ci = Cx + col;
+              else if (col - C < Cx) ci = col - C;
+              tile[((kk * 4 + g) * 64 + l) * 4 + j] =
+                  (ci < 0) ? 0.f : w[((size_t)(8 - tap) * Cin + ci) * N4 + n];
+            }
+    }
+}
+// Fill a dgrad problem: g = G [rows,H,W,4C]; dh [rows,H,W,C]; dx [rows,H,W,Cx]
+// (dx may be NULL: its columns are still computed in the shared last block
+// when Cx > 0 and need_dx, else the block is dropped).
+static inline void convlstm_dgrad_args(ConvLstmArgs& a, const float* g, const float* wdpack,
+                                       float* dh, float* dx, int rows, int H, int W,
+                                       int Cx, int C, bool need_dh, bool need_dx) {
+  a = ConvLstmArgs{};
+  a.x = nullptr; a.h = g; a.c = nullptr; a.wpack = wdpack; a.bias = nullptr;
+  a.rows = rows; a.H = H; a.W = W; a.Cx = 0; a.C = 4 * C;
+  a.n_xchunks = 0; a.n_hchunks = 9 * (4 * C / kBK); a.w_chunks = a.n_hchunks;
+  a.x_small = 0; a.zero_state = 0; a.x_row_stride = 0; a.forget_bias = 0.f;
+  a.out0 = need_dh ? dh : nullptr; a.out0_cols = C;
+  a.out1 = need_dx ? dx : nullptr; a.out1_cols = Cx;
+  const int ncb = convlstm_dgrad_colblocks(Cx, C);
+  a.n_colblocks = need_dx ? ncb : C / kBN;
+  const int rem = (C + Cx) - (ncb - 1) * kBN;   // columns in the last block
+  a.ng_last = need_dx ? (rem <= 32 ? 1 : rem <= 64 ? 2 : 4) : 4;
 }
 
 // Launch n (<= kMaxGroup) independent ConvLSTM steps as one grid.
@@ -321,6 +452,20 @@ static inline void launch_convlstm_steps(const ConvLstmArgs* probs, int n,
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
   hipLaunchKernelGGL(convlstm_step_kernel, dim3(total), dim3(256), 0, stream, g);
+}
+
+static inline void launch_convlstm_dgrads(const ConvLstmArgs* probs, int n,
+                                          hipStream_t stream) {
+  ConvLstmGroup g{};
+  g.n = n;
+  unsigned total = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = probs[i];
+    total += convlstm_blocks(probs[i]);
+    g.block_end[i] = (int32_t)total;
+  }
+  for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
+  hipLaunchKernelGGL(convlstm_dgrad_kernel, dim3(total), dim3(256), 0, stream, g);
 }
 
 }  // namespace mv

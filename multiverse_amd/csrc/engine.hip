@@ -20,7 +20,11 @@
 #include <vector>
 
 #include "convlstm_mfma.h"
+#include "convlstm_wgrad.h"
 #include "kernels_misc.h"
+#include "train_kernels.h"
+
+struct mv_train_holder;
 
 namespace {
 
@@ -152,6 +156,9 @@ struct mv_engine {
     for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
     graphs.clear();
   }
+  // training state (mv_train_init)
+  mv_train_holder* train = nullptr;
+  bool train_packs_valid = false;
   // profiling
   bool profiling = false;
   std::vector<KernelStat> stats;
@@ -853,6 +860,12 @@ int guarded(mv_engine* e, F&& fn) {
   }
 }
 
+}  // namespace
+
+#include "engine_train.h"
+
+namespace {
+
 // RAII device buffer helpers for the single-kernel entry points
 struct OpCtx {
   int device;
@@ -927,6 +940,7 @@ int mv_destroy(mv_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->drop_graphs();
+  delete h->train;
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -966,6 +980,7 @@ int mv_set_param(mv_handle h, const char* tf_name, const float* data,
     HIP_CHECK(hipMemcpy(p->dev.p, data, n * sizeof(float), hipMemcpyHostToDevice));
     p->set = true;
     h->drop_graphs();   // captured launches hold the old device pointers
+    h->train_packs_valid = false;
     // invalidate the packed copy of a ConvLSTM kernel
     for (int s = 0; s < h->cfg.num_scales; ++s) {
       ScaleState& S = h->sc[s];
@@ -1060,6 +1075,113 @@ int mv_set_profiling(mv_handle h, int32_t enabled) {
   if (!h) return 1;
   h->profiling = enabled != 0;
   return 0;
+}
+
+int mv_train_init(mv_handle h, const mv_train_config* tc) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(tc, "mv_train_init: NULL config");
+    MV_REQUIRE(tc->optimizer == 0, "optimizer %d unsupported (0 = adadelta, the "
+               "published configuration)", tc->optimizer);
+    MV_REQUIRE(h->cfg.beam_size == 1, "training needs a greedy (beam_size 1) engine "
+               "(reference pred_models.py:261)");
+    if (!h->train) {
+      h->train = new mv_train_holder();
+      train_alloc(h);
+    }
+    h->train->st.tc = *tc;
+  });
+}
+
+int mv_train_forward_backward(mv_handle h, const mv_inputs* in, const mv_targets* tg,
+                              mv_losses* out) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(in && tg, "mv_train_forward_backward: NULL argument");
+    train_fwd_bwd(h, in, tg, out);
+  });
+}
+
+int mv_train_apply(mv_handle h, float grad_scale) {
+  if (!h) return 1;
+  return guarded(h, [&] { train_apply(h, grad_scale); });
+}
+
+int mv_train_step(mv_handle h, const mv_inputs* in, const mv_targets* tg, mv_losses* out) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(in && tg, "mv_train_step: NULL argument");
+    train_fwd_bwd(h, in, tg, out);
+    train_apply(h, 1.0f);
+  });
+}
+
+int mv_grad_buffer(mv_handle h, float** device_ptr, int64_t* elems) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train, "mv_train_init has not been called");
+    MV_REQUIRE(device_ptr && elems, "mv_grad_buffer: NULL argument");
+    *device_ptr = TS(h).grad.p;
+    *elems = (int64_t)TS(h).total_elems;
+  });
+}
+
+static Param* find_param(mv_handle h, const char* tf_name) {
+  MV_REQUIRE(tf_name, "NULL parameter name");
+  auto it = h->by_name.find(tf_name);
+  MV_REQUIRE(it != h->by_name.end(), "unknown parameter '%s'", tf_name);
+  return it->second;
+}
+
+int mv_get_grad(mv_handle h, const char* tf_name, float* out, int64_t capacity) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train && TS(h).have_grads, "no gradients (mv_train_forward_backward)");
+    Param* p = find_param(h, tf_name);
+    MV_REQUIRE(out && (size_t)capacity >= p->elems(), "buffer too small for %s", tf_name);
+    HIP_CHECK(hipMemcpy(out, grad_of(h, p), p->elems() * sizeof(float),
+                        hipMemcpyDeviceToHost));
+  });
+}
+
+int mv_get_global_step(mv_handle h, int64_t* step) {
+  if (!h || !step || !h->train) return 1;
+  *step = h->train->st.global_step;
+  return 0;
+}
+
+int mv_set_global_step(mv_handle h, int64_t step) {
+  if (!h || !h->train) return 1;
+  h->train->st.global_step = step;
+  return 0;
+}
+
+int mv_get_opt_slot(mv_handle h, const char* tf_name, int32_t slot, float* out,
+                    int64_t capacity) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train, "mv_train_init has not been called");
+    MV_REQUIRE(slot == 0 || slot == 1, "slot must be 0 (accum) or 1 (accum_update)");
+    Param* p = find_param(h, tf_name);
+    MV_REQUIRE(out && (size_t)capacity >= p->elems(), "buffer too small for %s", tf_name);
+    const float* src = (slot == 0 ? TS(h).accum.p : TS(h).accum_update.p) +
+                       TS(h).goff[param_index(h, p)];
+    HIP_CHECK(hipMemcpy(out, src, p->elems() * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+int mv_set_opt_slot(mv_handle h, const char* tf_name, int32_t slot, const float* data,
+                    int64_t elems) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train, "mv_train_init has not been called");
+    MV_REQUIRE(slot == 0 || slot == 1, "slot must be 0 (accum) or 1 (accum_update)");
+    Param* p = find_param(h, tf_name);
+    MV_REQUIRE(data && (size_t)elems == p->elems(), "size mismatch for %s", tf_name);
+    float* dst = (slot == 0 ? TS(h).accum.p : TS(h).accum_update.p) +
+                 TS(h).goff[param_index(h, p)];
+    HIP_CHECK(hipMemcpy(dst, data, p->elems() * sizeof(float), hipMemcpyHostToDevice));
+  });
 }
 
 int mv_set_graph_mode(mv_handle h, int32_t enabled) {
@@ -1216,6 +1338,124 @@ int mv_op_beam_step(int device, const float* logits, const float* prev_logprob,
     ctx.down(new_logprob, dn, (size_t)N * B);
     ctx.down(ids, di, (size_t)N * B);
     ctx.down(parents, dpa, (size_t)N * B);
+  });
+}
+
+int mv_op_convlstm_bwd(int device, const float* x, const float* c, const float* h,
+                       const float* kernel, const float* biases, const float* dh_new,
+                       const float* dc_new, int32_t M, int32_t H, int32_t W, int32_t Cx,
+                       int32_t C, float* dx, float* dh, float* dc, float* dkernel,
+                       float* dbiases) {
+  return guarded(nullptr, [&] {
+    MV_REQUIRE(C == 256, "convlstm_bwd: C must be 256");
+    MV_REQUIRE(mv::convlstm_cx_supported(Cx), "Cx %d unsupported", Cx);
+    OpCtx ctx(device);
+    const size_t cells = (size_t)M * H * W;
+    DevBuf<float> dx_, dc_, dh_, dw, db, dco, dho, dg, ddh, ddc, dwd, dxo, dho2, part, dW,
+        dB, tmp;
+    ctx.up(dx_, x, cells * Cx);
+    ctx.up(db, biases, (size_t)4 * C);
+    std::vector<float> packed(mv::convlstm_wpack_elems(Cx, C));
+    mv::pack_convlstm_weights(kernel, Cx, C, packed.data());
+    ctx.up(dw, packed.data(), packed.size());
+    std::vector<float> packedT(mv::convlstm_dgrad_wpack_elems(Cx, C));
+    mv::pack_convlstm_dgrad_weights(kernel, Cx, C, packedT.data());
+    ctx.up(dwd, packedT.data(), packedT.size());
+    const bool zero = (c == nullptr && h == nullptr);
+    dc_.alloc(cells * C); dh_.alloc(cells * C);
+    if (!zero) {
+      MV_REQUIRE(c && h, "c and h must both be given or both be NULL");
+      HIP_CHECK(hipMemcpy(dc_.p, c, cells * C * sizeof(float), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(dh_.p, h, cells * C * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+      HIP_CHECK(hipMemset(dc_.p, 0, cells * C * sizeof(float)));
+      HIP_CHECK(hipMemset(dh_.p, 0, cells * C * sizeof(float)));
+    }
+    dco.alloc(cells * C); dho.alloc(cells * C); dg.alloc(cells * 4 * C);
+    ctx.up(ddh, dh_new, cells * C);
+    ctx.up(ddc, dc_new, cells * C);
+    // forward with saved gate activations
+    mv::ConvLstmArgs a{};
+    a.x = dx_.p; a.h = dh_.p; a.c = dc_.p; a.wpack = dw.p; a.bias = db.p;
+    a.h_out = dho.p; a.c_out = dco.p; a.gates_out = dg.p;
+    a.rows = M; a.H = H; a.W = W; a.Cx = Cx; a.C = C;
+    mv::convlstm_finish_args(a, zero);
+    mv::launch_convlstm_steps(&a, 1, ctx.stream);
+    // pointwise backward: gates -> G in place, ddc -> d c
+    const size_t total = cells * C;
+    hipLaunchKernelGGL(mv::lstm_gate_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                       ctx.stream, dg.p, dc_.p, dco.p, ddh.p, ddc.p, total, C);
+    // dgrad
+    dxo.alloc(cells * (Cx ? Cx : 1)); dho2.alloc(cells * C);
+    mv::ConvLstmArgs d{};
+    mv::convlstm_dgrad_args(d, dg.p, dwd.p, dho2.p, dxo.p, M, H, W, Cx, C, true, Cx > 0);
+    mv::launch_convlstm_dgrads(&d, 1, ctx.stream);
+    // wgrad (device-side packs are checked against the host packs on the way)
+    mv::WgradArgs wa{};
+    wa.x = Cx ? dx_.p : nullptr; wa.h = dh_.p; wa.g = dg.p;
+    wa.R = M; wa.H = H; wa.W = W; wa.Cx = Cx; wa.C = C;
+    mv::wgrad_plan(wa, 3072);
+    part.alloc(mv::wgrad_partial_elems(wa));
+    wa.partial = part.p;
+    hipLaunchKernelGGL(mv::convlstm_wgrad_kernel, dim3(mv::wgrad_blocks(wa)), dim3(256), 0,
+                       ctx.stream, wa);
+    const size_t ncols = (size_t)9 * (Cx + C) * 4 * C;
+    dW.alloc(ncols);
+    hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv(ncols, 256)), dim3(256), 0,
+                       ctx.stream, part.p, dW.p, (size_t)wa.nsplit, ncols,
+                       (size_t)wa.nsplit);
+    dB.alloc((size_t)4 * C);
+    hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv((size_t)4 * C, 256)), dim3(256), 0,
+                       ctx.stream, dg.p, dB.p, cells, (size_t)4 * C, cells);
+    // device packs == host packs (the training step repacks on the device)
+    {
+      DevBuf<float> wsrc, p1, p2;
+      ctx.up(wsrc, kernel, (size_t)9 * (Cx + C) * 4 * C);
+      const int nx = mv::convlstm_xchunks(Cx), nch = nx + 9 * (C / mv::kBK);
+      p1.alloc(packed.size()); p2.alloc(packedT.size());
+      hipLaunchKernelGGL(mv::pack_fwd_kernel, dim3(cdiv(packed.size(), 256)), dim3(256), 0,
+                         ctx.stream, wsrc.p, p1.p, Cx, C, nx, nch,
+                         (Cx > 0 && 9 * Cx <= mv::kBK) ? 1 : 0, packed.size());
+      hipLaunchKernelGGL(mv::pack_dgrad_kernel, dim3(cdiv(packedT.size(), 256)), dim3(256),
+                         0, ctx.stream, wsrc.p, p2.p, Cx, C, 9 * (4 * C / mv::kBK),
+                         packedT.size());
+      std::vector<float> c1(packed.size()), c2(packedT.size());
+      ctx.down(c1.data(), p1, c1.size());
+      ctx.down(c2.data(), p2, c2.size());
+      MV_REQUIRE(memcmp(c1.data(), packed.data(), c1.size() * 4) == 0,
+                 "device forward weight pack differs from the host pack");
+      MV_REQUIRE(memcmp(c2.data(), packedT.data(), c2.size() * 4) == 0,
+                 "device dgrad weight pack differs from the host pack");
+    }
+    HIP_CHECK(hipGetLastError());
+    if (dx && Cx) ctx.down(dx, dxo, cells * Cx);
+    ctx.down(dh, dho2, cells * C);
+    ctx.down(dc, ddc, cells * C);
+    ctx.down(dkernel, dW, ncols);
+    ctx.down(dbiases, dB, (size_t)4 * C);
+  });
+}
+
+int mv_op_gnn_bwd(int device, const float* h, const float* scene_mean, const float* g,
+                  int32_t M, int32_t H, int32_t W, int32_t C, int32_t D, float* dh,
+                  float* dscene_mean) {
+  return guarded(nullptr, [&] {
+    MV_REQUIRE(C == 256 && D >= 0 && D <= 64, "gnn_bwd: C must be 256 and D <= 64");
+    OpCtx ctx(device);
+    const size_t cells = (size_t)M * H * W;
+    DevBuf<float> dh_, ds_, dg_, a, de, n, odh, ods;
+    ctx.up(dh_, h, cells * C);
+    ctx.up(ds_, scene_mean, cells * D);
+    ctx.up(dg_, g, cells * C);
+    a.alloc(cells * 9); de.alloc(cells * 9); n.alloc(cells);
+    odh.alloc(cells * C); ods.alloc(cells * (D ? D : 1));
+    hipLaunchKernelGGL(mv::gnn_bwd_a_kernel, dim3(cdiv(cells, 4)), dim3(256), 0, ctx.stream,
+                       dh_.p, ds_.p, dg_.p, a.p, de.p, n.p, M, H, W, C, D);
+    hipLaunchKernelGGL(mv::gnn_bwd_b_kernel, dim3(cdiv(cells, 4)), dim3(256), 0, ctx.stream,
+                       dh_.p, ds_.p, dg_.p, a.p, de.p, n.p, odh.p, ods.p, M, H, W, C, D, 0);
+    HIP_CHECK(hipGetLastError());
+    ctx.down(dh, odh, cells * C);
+    if (dscene_mean && D) ctx.down(dscene_mean, ods, cells * D);
   });
 }
 

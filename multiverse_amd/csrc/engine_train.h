@@ -1,0 +1,719 @@
+// Training step of the engine (included by engine.hip after the inference
+// path): the role of `Trainer.step` = sess.run([loss, train_op, wd_loss,
+// pred_grid_loss]) at reference code/pred_models.py:1719-1742 over
+//   Model.build_forward (:123-308, is_train, --train_w_onehot wiring),
+//   Model.build_loss (:961-1040),
+//   tf.gradients + clip_by_value + AdadeltaOptimizer.apply_gradients (:1667-1717).
+//
+// Memory plan (288 GB HBM: keep everything, recompute nothing).  Per scale and
+// branch (class / regression) the h and c states of all T_o + T_p + 1 time
+// slots live in ONE time-major buffer [slot][N][K][C], so that the h operand of
+// every step of a cell is a contiguous [T*N] image batch for the batched wgrad.
+// Per cell the saved gate activations [T][N][K][4C] are overwritten IN PLACE by
+// the gate gradients G during the backward sweep.
+#pragma once
+
+namespace {
+
+struct TrainChain {               // one ConvLSTM cell over its T steps
+  ConvCell* cell = nullptr;
+  int T = 0, Cx = 0;
+  DevBuf<float> xs;               // [T][N][K][Cx]   x operand of every step
+  DevBuf<float> dxs;              // [T][N][K][Cx]   d x (then d pre-activation)
+  DevBuf<float> gates;            // [T][N][K][4C]   activations -> G in place
+  DevBuf<float> wdpack;           // dgrad weight pack
+};
+
+struct TrainScale {
+  DevBuf<float> hs[2], cs[2];     // branch 0 = class, 1 = regression: [To+Tp+1][N][K][C]
+  TrainChain enc[2], dec[2];
+  DevBuf<float> hg;               // [Tp][N][K][C]  h + GNN(h), class decoder h operand
+  DevBuf<float> logits;           // [Tp][N][K]     time-major class logits
+  DevBuf<float> regio;            // [Tp+1][N][K][2] slot 0 = obs_reg[:, -1]; slot t+1 = out_reg[t]
+  DevBuf<int32_t> ids;            // [Tp][N] class-decoder input id per step (slot 0 unused)
+  DevBuf<float> onehot;           // [Tp][N][K]
+  DevBuf<float> dlogits, dreg;    // [Tp][N][K], [Tp][N][K][2]
+  DevBuf<float> loss_row, loss_elem;
+  DevBuf<float> dh_a[2], dh_b[2], dc[2];   // [N][K][C]
+  DevBuf<float> gnn_a, gnn_de, gnn_n;      // [N*K*9] x2, [N*K]
+  DevBuf<float> dsmean;           // [N][K][D]
+  DevBuf<int32_t> pred_labels;    // [N][Tp]
+  DevBuf<float> pred_reg;         // [N][Tp][K][2]
+};
+
+struct TrainState {
+  mv_train_config tc{};
+  int64_t global_step = 0;
+  size_t total_elems = 0;
+  std::vector<size_t> goff;       // per param: offset into the flat buffers
+  DevBuf<float> grad, accum, accum_update;
+  TrainScale sc[MV_MAX_SCALES];
+  DevBuf<float> dys[MV_MAX_SCALES], dpre_sc[MV_MAX_SCALES];   // scene stack backward
+  DevBuf<float> partial;          // split-K partials / reduction scratch
+  DevBuf<float> scratch;          // second-stage scratch
+  DevBuf<float> losses;           // [2*MV_MAX_SCALES + 1 + nW] device scalars
+  bool have_grads = false;
+  mv_losses last{};
+};
+
+}  // namespace
+
+struct mv_train_holder { TrainState st; };
+
+namespace {
+
+inline TrainState& TS(mv_engine* e) { return e->train->st; }
+
+size_t param_index(mv_engine* e, const Param* p) {
+  for (size_t i = 0; i < e->params.size(); ++i)
+    if (e->params[i].get() == p) return i;
+  throw HipError{"internal: unknown parameter"};
+}
+float* grad_of(mv_engine* e, const Param* p) {
+  return TS(e).grad.p + TS(e).goff[param_index(e, p)];
+}
+
+void train_alloc(mv_engine* e) {
+  TrainState& t = TS(e);
+  const mv_config& c = e->cfg;
+  const size_t N = c.batch_size, To = c.obs_len, Tp = c.max_pred_len, C = c.hidden_size,
+               D = c.scene_conv_dim, E = c.emb_size;
+  t.goff.clear();
+  size_t off = 0;
+  for (auto& p : e->params) {
+    t.goff.push_back(off);
+    off += (p->elems() + 63) & ~(size_t)63;
+  }
+  t.total_elems = off;
+  t.grad.alloc(off); t.accum.alloc(off); t.accum_update.alloc(off);
+  HIP_CHECK(hipMemset(t.grad.p, 0, off * sizeof(float)));
+  HIP_CHECK(hipMemset(t.accum.p, 0, off * sizeof(float)));
+  HIP_CHECK(hipMemset(t.accum_update.p, 0, off * sizeof(float)));
+  size_t max_partial = 1 << 20;
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    TrainScale& R = t.sc[s];
+    const size_t K = S.K, NK = N * K, slots = To + Tp + 1;
+    for (int b = 0; b < 2; ++b) {
+      R.hs[b].alloc(slots * NK * C); R.cs[b].alloc(slots * NK * C);
+      HIP_CHECK(hipMemset(R.hs[b].p, 0, NK * C * sizeof(float)));   // slot 0: zero state
+      HIP_CHECK(hipMemset(R.cs[b].p, 0, NK * C * sizeof(float)));
+      R.dh_a[b].alloc(NK * C); R.dh_b[b].alloc(NK * C); R.dc[b].alloc(NK * C);
+    }
+    auto chain = [&](TrainChain& ch, ConvCell* cell, size_t T, bool need_dx) {
+      ch.cell = cell; ch.T = (int)T; ch.Cx = cell->Cx;
+      ch.xs.alloc(T * NK * cell->Cx);
+      if (need_dx) ch.dxs.alloc(T * NK * cell->Cx);
+      ch.gates.alloc(T * NK * 4 * C);
+      ch.wdpack.alloc(mv::convlstm_dgrad_wpack_elems(cell->Cx, (int)C));
+      mv::WgradArgs wa{};
+      wa.R = (int)(T * N); wa.H = S.H; wa.W = S.W; wa.Cx = cell->Cx; wa.C = (int)C;
+      mv::wgrad_plan(wa, 3072);
+      max_partial = std::max(max_partial, mv::wgrad_partial_elems(wa));
+    };
+    chain(R.enc[0], &S.enc_cls, To, true);
+    chain(R.enc[1], &S.enc_reg, To, false);
+    chain(R.dec[0], &S.dec_cls, Tp, true);
+    chain(R.dec[1], &S.dec_reg, Tp, true);
+    if (c.use_gnn) {
+      R.hg.alloc(Tp * NK * C);
+      R.gnn_a.alloc(NK * 9); R.gnn_de.alloc(NK * 9); R.gnn_n.alloc(NK);
+      R.dsmean.alloc(NK * D);
+    }
+    R.logits.alloc(Tp * NK); R.regio.alloc((Tp + 1) * NK * 2);
+    R.ids.alloc(Tp * N); R.onehot.alloc(Tp * NK);
+    R.dlogits.alloc(Tp * NK); R.dreg.alloc(Tp * NK * 2);
+    R.loss_row.alloc(Tp * N); R.loss_elem.alloc(Tp * NK * 2);
+    R.pred_labels.alloc(N * Tp); R.pred_reg.alloc(N * Tp * K * 2);
+    // small-conv wgrad partials: blocks x 9 x Ci*Co (<= 512)
+    max_partial = std::max(max_partial, (size_t)1024 * 9 * 512);
+    // bias column sums: slabs x 4C
+    max_partial = std::max(max_partial, (size_t)1024 * 4 * C);
+    (void)E;
+  }
+  for (int i = 0; i < c.num_scales; ++i) {
+    const size_t n = (size_t)N * To * e->conv_h[i] * e->conv_w[i] * D;
+    t.dys[i].alloc(n); t.dpre_sc[i].alloc(n);
+  }
+  t.partial.alloc(max_partial);
+  t.scratch.alloc((size_t)1 << 20);
+  t.losses.alloc(64);
+}
+
+// deterministic column sum of X [rows, ncols] into out [ncols]
+void run_colsum(mv_engine* e, const float* x, size_t rows, size_t ncols, float* out,
+                float* tmp /* >= 1024*ncols */) {
+  size_t nslab = std::min<size_t>(1024, (rows + 63) / 64);
+  if (nslab < 1) nslab = 1;
+  const size_t rps = (rows + nslab - 1) / nslab;
+  nslab = (rows + rps - 1) / rps;
+  const unsigned gy = cdiv(ncols, 256);
+  if (nslab == 1) {
+    hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, gy), dim3(256), 0, e->stream, x, out,
+                       rows, ncols, rows);
+    return;
+  }
+  hipLaunchKernelGGL(mv::colsum_kernel, dim3((unsigned)nslab, gy), dim3(256), 0,
+                     e->stream, x, tmp, rows, ncols, rps);
+  hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, gy), dim3(256), 0, e->stream, tmp, out,
+                     nslab, ncols, nslab);
+}
+
+void run_small_dgrad(mv_engine* e, const float* dout, size_t dout_rs, const float* w,
+                     float* din, size_t din_rs, int M, int H, int W, int Ci, int Co,
+                     bool accumulate) {
+  const size_t total = (size_t)M * H * W * Ci;
+  launch(e, "conv3x3_small_dgrad", 2.0 * total * 9 * Co, 4.0 * total * 2, [&] {
+    hipLaunchKernelGGL(mv::conv3x3_small_dgrad_kernel, dim3(cdiv(total, 256)), dim3(256),
+                       0, e->stream, dout, dout_rs, w, din, din_rs, M, H, W, Ci, Co,
+                       accumulate ? 1 : 0);
+  });
+}
+
+// dW [9][Ci][Co] of a small 3x3 conv over R images
+void run_small_wgrad(mv_engine* e, const float* in, const float* dout, float* dw, int R,
+                     int H, int W, int Ci, int Co) {
+  TrainState& t = TS(e);
+  MV_REQUIRE(Ci * Co <= 512, "small wgrad: Ci*Co %d > 512", Ci * Co);
+  const long long cells = (long long)R * H * W;
+  long long nblk = std::min<long long>(1024, (cells + 255) / 256);
+  const int cpb = (int)((cells + nblk - 1) / nblk);
+  nblk = (cells + cpb - 1) / cpb;
+  const int threads = ((Ci * Co + 63) / 64) * 64;
+  const size_t ncols = (size_t)9 * Ci * Co;
+  launch(e, "conv3x3_small_wgrad", 2.0 * cells * 9 * Ci * Co,
+         4.0 * cells * (9.0 * Ci + Co), [&] {
+    hipLaunchKernelGGL(mv::conv3x3_small_wgrad_kernel, dim3((unsigned)nblk), dim3(threads),
+                       0, e->stream, in, dout, t.partial.p, R, H, W, Ci, Co, cpb);
+    hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv(ncols, 256)), dim3(256), 0,
+                       e->stream, t.partial.p, dw, (size_t)nblk, ncols, (size_t)nblk);
+  });
+}
+
+void run_pack(mv_engine* e, TrainChain& ch) {
+  const int C = e->cfg.hidden_size, Cx = ch.Cx;
+  ConvCell& cc = *ch.cell;
+  {
+    const size_t total = mv::convlstm_wpack_elems(Cx, C);
+    const int nx = mv::convlstm_xchunks(Cx), nch = nx + 9 * (C / mv::kBK);
+    cc.wpack.alloc(total);
+    hipLaunchKernelGGL(mv::pack_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                       e->stream, cc.kernel->dev.p, cc.wpack.p, Cx, C, nx, nch,
+                       (Cx > 0 && 9 * Cx <= mv::kBK) ? 1 : 0, total);
+  }
+  {
+    const size_t total = mv::convlstm_dgrad_wpack_elems(Cx, C);
+    const int nch = 9 * (4 * C / mv::kBK);
+    hipLaunchKernelGGL(mv::pack_dgrad_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                       e->stream, cc.kernel->dev.p, ch.wdpack.p, Cx, C, nch, total);
+  }
+}
+
+void train_pack_all(mv_engine* e) {
+  for (int s = 0; s < e->cfg.num_scales; ++s) {
+    if (!e->sc[s].use) continue;
+    TrainScale& R = TS(e).sc[s];
+    for (int b = 0; b < 2; ++b) { run_pack(e, R.enc[b]); run_pack(e, R.dec[b]); }
+  }
+}
+
+void upload_targets(mv_engine* e, const mv_targets* tg) {
+  const mv_config& c = e->cfg;
+  const size_t N = c.batch_size, Tp = e->pred_len;
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    MV_REQUIRE(tg->grid_pred_labels[s] && tg->grid_pred_regress[s],
+               "grid_pred_labels/grid_pred_regress[%d] is NULL for an enabled scale", s);
+    for (size_t i = 0; i < N * Tp; ++i)
+      MV_REQUIRE(tg->grid_pred_labels[s][i] >= 0 && tg->grid_pred_labels[s][i] < S.K,
+                 "grid_pred_labels[%d][%zu] = %d out of range [0,%d)", s, i,
+                 tg->grid_pred_labels[s][i], S.K);
+    TrainScale& R = TS(e).sc[s];
+    HIP_CHECK(hipMemcpyAsync(R.pred_labels.p, tg->grid_pred_labels[s],
+                             N * Tp * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipMemcpyAsync(R.pred_reg.p, tg->grid_pred_regress[s],
+                             N * Tp * S.K * 2 * sizeof(float), hipMemcpyHostToDevice,
+                             e->stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+}
+
+ConvLstmArgs train_problem(mv_engine* e, TrainChain& ch, const float* x, const float* h,
+                           const float* c, float* h_out, float* c_out, float* gates,
+                           int H, int W, bool zero_state) {
+  ConvLstmArgs a = conv_problem(e, *ch.cell, x, h, c, nullptr, nullptr, h_out, c_out,
+                                e->cfg.batch_size, H, W, zero_state);
+  a.gates_out = gates;
+  return a;
+}
+
+// ------------------------------------------------------------ forward (is_train)
+void train_forward(mv_engine* e) {
+  const mv_config& c = e->cfg;
+  TrainState& t = TS(e);
+  const int N = c.batch_size, To = c.obs_len, Tp = e->pred_len, C = c.hidden_size,
+            D = c.scene_conv_dim, E = c.emb_size;
+  run_scene(e);
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    TrainScale& R = t.sc[s];
+    // regression-encoder x operand, time-major
+    const size_t tot = (size_t)N * To * S.K * 2;
+    hipLaunchKernelGGL(mv::transpose_nt_kernel, dim3(cdiv(tot, 256)), dim3(256), 0,
+                       e->stream, S.obs_reg.p, R.enc[1].xs.p, N, To, (size_t)S.K * 2);
+  }
+  // encoders, all chains in lockstep (dynamic_rnn from the zero state)
+  for (int ts = 0; ts < To; ++ts) {
+    std::vector<ConvLstmArgs> probs;
+    for (int s = 0; s < c.num_scales; ++s) {
+      ScaleState& S = e->sc[s];
+      if (!S.use) continue;
+      TrainScale& R = t.sc[s];
+      const size_t NKC = (size_t)N * S.K * C;
+      float* xc = R.enc[0].xs.p + (size_t)ts * N * S.K * D;
+      const size_t total = (size_t)N * S.K * D;
+      launch(e, "enc_class_input", 0, 4.0 * total, [&] {
+        hipLaunchKernelGGL(mv::enc_class_input_kernel, dim3(cdiv(total, 256)), dim3(256),
+                           0, e->stream, e->scene_conv[s].p, e->obs_scene.p, S.labels.p,
+                           xc, N, To, ts, S.K, D);
+      });
+      for (int b = 0; b < 2; ++b) {
+        const float* x = b == 0 ? xc : R.enc[1].xs.p + (size_t)ts * N * S.K * 2;
+        probs.push_back(train_problem(
+            e, R.enc[b], x, R.hs[b].p + ts * NKC, R.cs[b].p + ts * NKC,
+            R.hs[b].p + (ts + 1) * NKC, R.cs[b].p + (ts + 1) * NKC,
+            R.enc[b].gates.p + (size_t)ts * 4 * NKC, S.H, S.W, ts == 0));
+      }
+    }
+    run_conv_group(e, probs);
+  }
+  // decoders (grid_decoder under raw_rnn, input_onehot for the class decoder)
+  for (int ts = 0; ts < Tp; ++ts) {
+    std::vector<ConvLstmArgs> probs;
+    for (int s = 0; s < c.num_scales; ++s) {
+      ScaleState& S = e->sc[s];
+      if (!S.use) continue;
+      TrainScale& R = t.sc[s];
+      const size_t NK = (size_t)N * S.K, NKC = NK * C;
+      const int slot = To + ts;
+      // class decoder
+      const float* hin = R.hs[0].p + slot * NKC;
+      if (c.use_gnn) {
+        run_gnn(e, S, hin, nullptr, R.hg.p + ts * NKC, N, 1);
+        hin = R.hg.p + ts * NKC;
+      }
+      float* xc = R.dec[0].xs.p + (size_t)ts * NK * E;
+      if (ts == 0) run_emb_onehot(e, S, S.labels.p + (To - 1), To, xc, N);
+      else run_emb_onehot(e, S, R.ids.p + (size_t)ts * N, 1, xc, N);
+      probs.push_back(train_problem(e, R.dec[0], xc, hin, R.cs[0].p + slot * NKC,
+                                    R.hs[0].p + (slot + 1) * NKC,
+                                    R.cs[0].p + (slot + 1) * NKC,
+                                    R.dec[0].gates.p + (size_t)ts * 4 * NKC, S.H, S.W,
+                                    false));
+      // regression decoder
+      float* xr = R.dec[1].xs.p + (size_t)ts * NK * E;
+      if (ts == 0) {   // regio slot 0 = obs_grid_reg[:, -1]
+        const size_t row = (size_t)S.K * 2;
+        HIP_CHECK(hipMemcpy2DAsync(R.regio.p, row * sizeof(float),
+                                   S.obs_reg.p + (size_t)(To - 1) * row,
+                                   (size_t)To * row * sizeof(float), row * sizeof(float),
+                                   N, hipMemcpyDeviceToDevice, e->stream));
+      }
+      run_emb_dense(e, S, R.regio.p + (size_t)ts * NK * 2, (size_t)S.K * 2, xr, N);
+      probs.push_back(train_problem(e, R.dec[1], xr, R.hs[1].p + slot * NKC,
+                                    R.cs[1].p + slot * NKC, R.hs[1].p + (slot + 1) * NKC,
+                                    R.cs[1].p + (slot + 1) * NKC,
+                                    R.dec[1].gates.p + (size_t)ts * 4 * NKC, S.H, S.W,
+                                    false));
+    }
+    run_conv_group(e, probs);
+    for (int s = 0; s < c.num_scales; ++s) {
+      ScaleState& S = e->sc[s];
+      if (!S.use) continue;
+      TrainScale& R = t.sc[s];
+      const size_t NK = (size_t)N * S.K, NKC = NK * C;
+      const int slot = To + ts + 1;
+      float* lg = R.logits.p + (size_t)ts * NK;
+      run_hidden2grid<1>(e, S, R.hs[0].p + slot * NKC, S.out_cls_W->dev.p, lg,
+                         (size_t)S.K, N);
+      if (ts + 1 < Tp) {
+        launch(e, "argmax_rows", 0, 4.0 * NK, [&] {
+          hipLaunchKernelGGL(mv::argmax_rows_kernel, dim3(N), dim3(64), 0, e->stream, lg,
+                             (size_t)S.K, R.ids.p + (size_t)(ts + 1) * N, N, S.K);
+        });
+      }
+      run_hidden2grid<2>(e, S, R.hs[1].p + slot * NKC, S.out_reg_W->dev.p,
+                         R.regio.p + (size_t)(ts + 1) * NK * 2, (size_t)S.K * 2, N);
+    }
+  }
+}
+
+// ------------------------------------------------------------ losses
+void train_losses(mv_engine* e) {
+  const mv_config& c = e->cfg;
+  TrainState& t = TS(e);
+  const int N = c.batch_size, Tp = e->pred_len;
+  int li = 0;
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    TrainScale& R = t.sc[s];
+    const size_t NK = (size_t)N * S.K;
+    const float cs = t.tc.grid_loss_weight / (float)((size_t)N * Tp);
+    launch(e, "ce_loss", 0, 8.0 * Tp * NK, [&] {
+      hipLaunchKernelGGL(mv::ce_loss_kernel, dim3(Tp * N), dim3(64), 0, e->stream,
+                         R.logits.p, R.pred_labels.p, R.loss_row.p, R.dlogits.p, Tp, N,
+                         S.K, cs);
+      hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream,
+                         R.loss_row.p, (size_t)Tp * N, t.losses.p + li, cs, 0);
+    });
+    const size_t nel = (size_t)Tp * NK * 2;
+    const float rs = t.tc.grid_reg_loss_weight / (float)nel;
+    launch(e, "huber_loss", 0, 16.0 * nel, [&] {
+      hipLaunchKernelGGL(mv::huber_loss_kernel, dim3(cdiv(nel, 256)), dim3(256), 0,
+                         e->stream, R.regio.p + NK * 2, R.pred_reg.p, R.loss_elem.p,
+                         R.dreg.p, Tp, N, S.K * 2, rs);
+      hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream,
+                         R.loss_elem.p, nel, t.losses.p + li + 1, rs, 0);
+    });
+    li += 2;
+  }
+}
+
+// ------------------------------------------------------------ backward
+void run_gate_bwd(mv_engine* e, float* gates, const float* c_prev, const float* c_new,
+                  const float* dh, float* dc, size_t cells, int C) {
+  const size_t total = cells * C;
+  launch(e, "lstm_gate_bwd", 30.0 * total, 4.0 * total * 13, [&] {
+    hipLaunchKernelGGL(mv::lstm_gate_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                       e->stream, gates, c_prev, c_new, dh, dc, total, C);
+  });
+}
+
+void run_dgrad_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
+                     const std::vector<double>& flops) {
+  if (probs.empty()) return;
+  double fl = 0, by = 0;
+  for (size_t i = 0; i < probs.size(); ++i) {
+    fl += flops[i];
+    by += (double)probs[i].rows * probs[i].H * probs[i].W * (probs[i].C + 288.0) * 4.0;
+  }
+  launch(e, "convlstm_dgrad", fl, by, [&] {
+    mv::launch_convlstm_dgrads(probs.data(), (int)probs.size(), e->stream);
+  });
+}
+
+void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H, int W) {
+  TrainState& t = TS(e);
+  const int N = e->cfg.batch_size, C = e->cfg.hidden_size;
+  mv::WgradArgs wa{};
+  wa.x = ch.Cx ? ch.xs.p : nullptr; wa.h = hin; wa.g = ch.gates.p;
+  wa.partial = t.partial.p;
+  wa.R = Tsteps * N; wa.H = H; wa.W = W; wa.Cx = ch.Cx; wa.C = C;
+  mv::wgrad_plan(wa, 3072);
+  MV_REQUIRE(mv::wgrad_partial_elems(wa) <= t.partial.n, "internal: wgrad partial buffer");
+  const double cells = (double)wa.R * H * W;
+  const size_t ncols = (size_t)9 * (ch.Cx + C) * 4 * C;
+  launch(e, "convlstm_wgrad", 2.0 * cells * 9 * (ch.Cx + C) * 4.0 * C,
+         cells * (ch.Cx + 5.0 * C) * 4.0, [&] {
+    hipLaunchKernelGGL(mv::convlstm_wgrad_kernel, dim3(mv::wgrad_blocks(wa)), dim3(256), 0,
+                       e->stream, wa);
+  });
+  launch(e, "wgrad_reduce", 0, 4.0 * ncols * (wa.nsplit + 1), [&] {
+    hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv(ncols, 256)), dim3(256), 0,
+                       e->stream, t.partial.p, grad_of(e, ch.cell->kernel),
+                       (size_t)wa.nsplit, ncols, (size_t)wa.nsplit);
+  });
+  // biases: column sums of G
+  launch(e, "bias_colsum", 0, cells * 4.0 * C * 4.0, [&] {
+    run_colsum(e, ch.gates.p, (size_t)cells, (size_t)4 * C, grad_of(e, ch.cell->biases),
+               t.partial.p);
+  });
+}
+
+void train_backward(mv_engine* e) {
+  const mv_config& c = e->cfg;
+  TrainState& t = TS(e);
+  const int N = c.batch_size, To = c.obs_len, Tp = e->pred_len, C = c.hidden_size,
+            D = c.scene_conv_dim, E = c.emb_size;
+  float* dh_a[MV_MAX_SCALES][2];
+  float* dh_b[MV_MAX_SCALES][2];
+  for (int s = 0; s < c.num_scales; ++s) {
+    if (!e->sc[s].use) continue;
+    TrainScale& R = t.sc[s];
+    const size_t NKC = (size_t)N * e->sc[s].K * C;
+    for (int b = 0; b < 2; ++b) {
+      dh_a[s][b] = R.dh_a[b].p; dh_b[s][b] = R.dh_b[b].p;
+      HIP_CHECK(hipMemsetAsync(R.dh_a[b].p, 0, NKC * sizeof(float), e->stream));
+      HIP_CHECK(hipMemsetAsync(R.dc[b].p, 0, NKC * sizeof(float), e->stream));
+    }
+    if (c.use_gnn)
+      HIP_CHECK(hipMemsetAsync(R.dsmean.p, 0, (size_t)N * e->sc[s].K * D * sizeof(float),
+                               e->stream));
+  }
+  // ---- decoders, t = Tp-1 .. 0
+  for (int ts = Tp - 1; ts >= 0; --ts) {
+    std::vector<ConvLstmArgs> probs;
+    std::vector<double> flops;
+    for (int s = 0; s < c.num_scales; ++s) {
+      ScaleState& S = e->sc[s];
+      if (!S.use) continue;
+      TrainScale& R = t.sc[s];
+      const size_t NK = (size_t)N * S.K, NKC = NK * C;
+      const int slot = To + ts;
+      // d logits / d out_reg of this step -> d h'  (hidden2grid backward)
+      run_small_dgrad(e, R.dlogits.p + (size_t)ts * NK, (size_t)S.K, S.out_cls_W->dev.p,
+                      dh_a[s][0], (size_t)S.K * C, N, S.H, S.W, C, 1, true);
+      run_small_dgrad(e, R.dreg.p + (size_t)ts * NK * 2, (size_t)S.K * 2,
+                      S.out_reg_W->dev.p, dh_a[s][1], (size_t)S.K * C, N, S.H, S.W, C, 2,
+                      true);
+      for (int b = 0; b < 2; ++b) {
+        float* G = R.dec[b].gates.p + (size_t)ts * 4 * NKC;
+        run_gate_bwd(e, G, R.cs[b].p + slot * NKC, R.cs[b].p + (slot + 1) * NKC,
+                     dh_a[s][b], R.dc[b].p, NK, C);
+        ConvLstmArgs a;
+        mv::convlstm_dgrad_args(a, G, R.dec[b].wdpack.p, dh_b[s][b],
+                                R.dec[b].dxs.p + (size_t)ts * NK * E, N, S.H, S.W, E, C,
+                                true, true);
+        probs.push_back(a);
+        flops.push_back(2.0 * NK * 9 * (E + C) * 4.0 * C);
+      }
+    }
+    run_dgrad_group(e, probs, flops);
+    for (int s = 0; s < c.num_scales; ++s) {
+      ScaleState& S = e->sc[s];
+      if (!S.use) continue;
+      TrainScale& R = t.sc[s];
+      const size_t NK = (size_t)N * S.K, NKC = NK * C;
+      const int slot = To + ts;
+      // class branch: d(h + GNN(h)) -> d h, d scene_mean
+      if (c.use_gnn) {
+        const float* hsrc = R.hs[0].p + slot * NKC;
+        launch(e, "gnn_bwd", NK * (9.0 * 2 * 3 * (C + D) + 9.0 * 4 * C),
+               4.0 * NK * (4.0 * C + 2.0 * D), [&] {
+          hipLaunchKernelGGL(mv::gnn_bwd_a_kernel, dim3(cdiv(NK, 4)), dim3(256), 0,
+                             e->stream, hsrc, S.scene_mean.p, dh_b[s][0], R.gnn_a.p,
+                             R.gnn_de.p, R.gnn_n.p, N, S.H, S.W, C, D);
+          hipLaunchKernelGGL(mv::gnn_bwd_b_kernel, dim3(cdiv(NK, 4)), dim3(256), 0,
+                             e->stream, hsrc, S.scene_mean.p, dh_b[s][0], R.gnn_a.p,
+                             R.gnn_de.p, R.gnn_n.p, dh_a[s][0], R.dsmean.p, N, S.H, S.W,
+                             C, D, 1);
+        });
+      } else {
+        std::swap(dh_a[s][0], dh_b[s][0]);
+      }
+      std::swap(dh_a[s][1], dh_b[s][1]);
+      // decoder input embeddings: d x -> d pre-activation (in place)
+      for (int b = 0; b < 2; ++b) {
+        float* dx = R.dec[b].dxs.p + (size_t)ts * NK * E;
+        const size_t total = NK * E;
+        launch(e, "tanh_bwd", 3.0 * total, 12.0 * total, [&] {
+          hipLaunchKernelGGL(mv::tanh_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                             e->stream, dx, R.dec[b].xs.p + (size_t)ts * NK * E, dx, total);
+        });
+      }
+      // regression decoder: the step's input was grid_emb(out_reg[t-1]) -> d out_reg[t-1]
+      if (ts > 0)
+        run_small_dgrad(e, R.dec[1].dxs.p + (size_t)ts * NK * E, (size_t)S.K * E,
+                        S.emb_reg_W->dev.p, R.dreg.p + (size_t)(ts - 1) * NK * 2,
+                        (size_t)S.K * 2, N, S.H, S.W, 2, E, true);
+    }
+  }
+  // ---- encoders, t = To-1 .. 0
+  for (int ts = To - 1; ts >= 0; --ts) {
+    std::vector<ConvLstmArgs> probs;
+    std::vector<double> flops;
+    for (int s = 0; s < c.num_scales; ++s) {
+      ScaleState& S = e->sc[s];
+      if (!S.use) continue;
+      TrainScale& R = t.sc[s];
+      const size_t NK = (size_t)N * S.K, NKC = NK * C;
+      for (int b = 0; b < 2; ++b) {
+        float* G = R.enc[b].gates.p + (size_t)ts * 4 * NKC;
+        run_gate_bwd(e, G, R.cs[b].p + ts * NKC, R.cs[b].p + (ts + 1) * NKC, dh_a[s][b],
+                     R.dc[b].p, NK, C);
+        const bool need_dh = ts > 0, need_dx = (b == 0);
+        if (!need_dh && !need_dx) continue;
+        ConvLstmArgs a;
+        mv::convlstm_dgrad_args(a, G, R.enc[b].wdpack.p, dh_b[s][b],
+                                need_dx ? R.enc[b].dxs.p + (size_t)ts * NK * D : nullptr,
+                                N, S.H, S.W, R.enc[b].Cx, C, need_dh, need_dx);
+        probs.push_back(a);
+        flops.push_back(2.0 * NK * 9 * ((need_dx ? R.enc[b].Cx : 0) + C) * 4.0 * C);
+      }
+    }
+    run_dgrad_group(e, probs, flops);
+    for (int s = 0; s < c.num_scales; ++s) {
+      if (!e->sc[s].use) continue;
+      for (int b = 0; b < 2; ++b) std::swap(dh_a[s][b], dh_b[s][b]);
+    }
+  }
+  // ---- parameter gradients
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    TrainScale& R = t.sc[s];
+    const size_t NK = (size_t)N * S.K, NKC = NK * C;
+    for (int b = 0; b < 2; ++b) {
+      run_wgrad(e, R.enc[b], R.hs[b].p, To, S.H, S.W);
+      const float* hin = (b == 0 && c.use_gnn) ? R.hg.p : R.hs[b].p + (size_t)To * NKC;
+      run_wgrad(e, R.dec[b], hin, Tp, S.H, S.W);
+    }
+    // class-decoder grid_emb on one-hot maps
+    hipLaunchKernelGGL(mv::onehot_map_kernel, dim3(cdiv(NK, 256)), dim3(256), 0, e->stream,
+                       S.labels.p + (To - 1), To, R.onehot.p, N, S.K);
+    if (Tp > 1)
+      hipLaunchKernelGGL(mv::onehot_map_kernel, dim3(cdiv((size_t)(Tp - 1) * NK, 256)),
+                         dim3(256), 0, e->stream, R.ids.p + N, 1, R.onehot.p + NK,
+                         (Tp - 1) * N, S.K);
+    run_small_wgrad(e, R.onehot.p, R.dec[0].dxs.p, grad_of(e, S.emb_cls_W), Tp * N, S.H,
+                    S.W, 1, E);
+    run_colsum(e, R.dec[0].dxs.p, (size_t)Tp * NK, E, grad_of(e, S.emb_cls_b), t.partial.p);
+    run_small_wgrad(e, R.regio.p, R.dec[1].dxs.p, grad_of(e, S.emb_reg_W), Tp * N, S.H,
+                    S.W, 2, E);
+    run_colsum(e, R.dec[1].dxs.p, (size_t)Tp * NK, E, grad_of(e, S.emb_reg_b), t.partial.p);
+    // hidden2grid
+    run_small_wgrad(e, R.hs[0].p + (size_t)(To + 1) * NKC, R.dlogits.p,
+                    grad_of(e, S.out_cls_W), Tp * N, S.H, S.W, C, 1);
+    run_small_wgrad(e, R.hs[1].p + (size_t)(To + 1) * NKC, R.dreg.p,
+                    grad_of(e, S.out_reg_W), Tp * N, S.H, S.W, C, 2);
+  }
+  // ---- scene stack
+  const int U = e->num_frames, L = c.num_scales, k = c.scene_conv_kernel;
+  for (int i = L - 1; i >= 0; --i) {
+    const int Ho = e->conv_h[i], Wo = e->conv_w[i];
+    const int Hi = i == 0 ? c.scene_h : e->conv_h[i - 1];
+    const int Wi = i == 0 ? c.scene_w : e->conv_w[i - 1];
+    const int Ci = i == 0 ? c.scene_class : D;
+    const size_t n = (size_t)U * Ho * Wo * D;
+    if (e->sc[i].use) {
+      TrainScale& R = t.sc[i];
+      launch(e, "scene_grad_gather", 0, 4.0 * n * N, [&] {
+        hipLaunchKernelGGL(mv::scene_grad_gather_kernel, dim3(cdiv(n, 256)), dim3(256), 0,
+                           e->stream, c.use_gnn ? R.dsmean.p : (const float*)nullptr,
+                           R.enc[0].dxs.p, e->obs_scene.p, e->sc[i].labels.p, t.dys[i].p,
+                           U, N, To, Ho * Wo, D);
+      });
+    } else {
+      HIP_CHECK(hipMemsetAsync(t.dys[i].p, 0, n * sizeof(float), e->stream));
+    }
+    if (i + 1 < L) {
+      const int Ho2 = e->conv_h[i + 1], Wo2 = e->conv_w[i + 1];
+      const int ph = std::max((Ho2 - 1) * 2 + k - Ho, 0), pw = std::max((Wo2 - 1) * 2 + k - Wo, 0);
+      launch(e, "scene_conv_dgrad", 2.0 * n * k * k * D / 4, 8.0 * n, [&] {
+        hipLaunchKernelGGL(mv::conv_s2_dgrad_kernel, dim3(cdiv(n, 256)), dim3(256), 0,
+                           e->stream, t.dpre_sc[i + 1].p, e->scene_W[i + 1]->dev.p,
+                           t.dys[i].p, U, Ho, Wo, D, Ho2, Wo2, D, k, ph / 2, pw / 2, 1);
+      });
+    }
+    hipLaunchKernelGGL(mv::tanh_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, e->stream,
+                       t.dys[i].p, e->scene_conv[i].p, t.dpre_sc[i].p, n);
+    const int ph = std::max((Ho - 1) * 2 + k - Hi, 0), pw = std::max((Wo - 1) * 2 + k - Wi, 0);
+    const size_t nw = (size_t)k * k * Ci * D;
+    const float* in = i == 0 ? e->scene_feat.p : e->scene_conv[i - 1].p;
+    launch(e, "scene_conv_wgrad", 2.0 * n * k * k * Ci, 4.0 * nw, [&] {
+      hipLaunchKernelGGL(mv::conv_s2_wgrad_kernel, dim3(cdiv(nw, 256)), dim3(256), 0,
+                         e->stream, in, t.dpre_sc[i].p, grad_of(e, e->scene_W[i]), U, Hi,
+                         Wi, Ci, Ho, Wo, D, k, ph / 2, pw / 2);
+    });
+    run_colsum(e, t.dpre_sc[i].p, (size_t)U * Ho * Wo, D, grad_of(e, e->scene_b[i]),
+               t.partial.p);
+  }
+  // ---- weight decay on every */W (wd_cost(".*/W"), code/pred_models.py:1033)
+  {
+    int nW = 0;
+    const int base = 2 * MV_MAX_SCALES;
+    for (auto& p : e->params) {
+      const std::string& nm = p->name;
+      if (nm.size() < 2 || nm.compare(nm.size() - 2, 2, "/W") != 0) continue;
+      MV_REQUIRE(base + 1 + nW < 64, "too many W tensors");
+      const size_t n = p->elems();
+      hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream, p->dev.p,
+                         n, t.losses.p + base + 1 + nW, 0.5f * t.tc.wd, 1);
+      hipLaunchKernelGGL(mv::add_scaled_kernel, dim3(cdiv(n, 256)), dim3(256), 0,
+                         e->stream, grad_of(e, p.get()), p->dev.p, t.tc.wd, n);
+      ++nW;
+    }
+    hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream,
+                       t.losses.p + base + 1, (size_t)nW, t.losses.p + base, 1.0f, 0);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+float train_learning_rate(const TrainState& t) {
+  const mv_train_config& c = t.tc;
+  double lr = c.init_lr;
+  if (c.use_cosine_lr) {
+    const double gs = (double)std::min<int64_t>(t.global_step, c.max_steps);
+    lr = c.init_lr * 0.5 * (1.0 + cos(M_PI * gs / (double)c.max_steps));
+  } else if (c.has_decay) {
+    const int64_t p = c.decay_steps > 0 ? t.global_step / c.decay_steps : 0;
+    lr = c.init_lr * pow((double)c.learning_rate_decay, (double)p);
+  }
+  return (float)(lr * c.emb_lr);
+}
+
+void train_fwd_bwd(mv_engine* e, const mv_inputs* in, const mv_targets* tg, mv_losses* out) {
+  MV_REQUIRE(e->train, "mv_train_init has not been called");
+  MV_REQUIRE(e->cfg.beam_size == 1, "training needs a greedy (beam_size 1) engine");
+  TrainState& t = TS(e);
+  upload_inputs(e, in);
+  upload_targets(e, tg);
+  ensure_params(e);
+  if (!e->train_packs_valid) {   // first step / after mv_set_param
+    train_pack_all(e);
+    e->train_packs_valid = true;
+  }
+  train_forward(e);
+  train_losses(e);
+  train_backward(e);
+  t.have_grads = true;
+  // losses to the host
+  float hl[64];
+  HIP_CHECK(hipMemcpyAsync(hl, t.losses.p, 64 * sizeof(float), hipMemcpyDeviceToHost,
+                           e->stream));
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+  drain_events(e);
+  mv_losses L{};
+  int li = 0;
+  double total = 0;
+  for (int s = 0; s < e->cfg.num_scales; ++s) {
+    if (!e->sc[s].use) continue;
+    L.pred_grid_loss[li] = hl[li]; L.pred_grid_loss[li + 1] = hl[li + 1];
+    total += (double)hl[li] + (double)hl[li + 1];
+    li += 2;
+  }
+  L.num_pred_grid_loss = li;
+  L.wd_loss = hl[2 * MV_MAX_SCALES];
+  // tf.add_n(losses): fp32 left-to-right
+  float acc = 0.f;
+  for (int i = 0; i < li; ++i) acc = i == 0 ? L.pred_grid_loss[0] : acc + L.pred_grid_loss[i];
+  L.loss = acc + L.wd_loss;
+  (void)total;
+  t.last = L;
+  if (out) *out = L;
+}
+
+void train_apply(mv_engine* e, float grad_scale) {
+  MV_REQUIRE(e->train, "mv_train_init has not been called");
+  TrainState& t = TS(e);
+  MV_REQUIRE(t.have_grads, "mv_train_apply before mv_train_forward_backward");
+  const float lr = train_learning_rate(t);
+  for (size_t i = 0; i < e->params.size(); ++i) {
+    Param* p = e->params[i].get();
+    const size_t n = p->elems(), o = t.goff[i];
+    hipLaunchKernelGGL(mv::adadelta_kernel, dim3(cdiv(n, 256)), dim3(256), 0, e->stream,
+                       p->dev.p, t.accum.p + o, t.accum_update.p + o, t.grad.p + o,
+                       grad_scale, t.tc.clip_gradient_norm, t.tc.do_clip, lr, 0.95f, 1e-8f,
+                       n);
+  }
+  train_pack_all(e);
+  t.global_step += 1;
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+}
+
+}  // namespace

@@ -1,0 +1,544 @@
+// Backward / loss / optimizer kernels of the training step
+// (reference: Model.build_loss code/pred_models.py:961-1040, Trainer
+// :1636-1742 = tf.gradients + clip_by_value + AdadeltaOptimizer).
+// Everything except the two gate-conv GEMMs (convlstm_mfma.h dgrad,
+// convlstm_wgrad.h) is HBM-bound elementwise / stencil / reduction work.
+// All reductions are two-stage with a fixed order: gradients are bitwise
+// reproducible run to run.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "kernels_misc.h"
+
+namespace mv {
+
+// ------------------------------------------------------------ LSTM pointwise
+// Backward of  c' = sf*c + si*tj ; h' = tanh(c')*so  given the saved
+// activations gates = [si | tj | sf | so] ([M,4,C]), c (previous), c' and the
+// incoming dh', dc'.  Writes the pre-activation gate gradients G [M,4C] in the
+// reference's column order (i|j|f|o) IN PLACE over `gates`, and dc (w.r.t. the
+// previous cell state) in place over dc_io.
+__global__ void lstm_gate_bwd_kernel(float* __restrict__ gates,
+                                     const float* __restrict__ c_prev,
+                                     const float* __restrict__ c_new,
+                                     const float* __restrict__ dh,
+                                     float* __restrict__ dc_io, size_t total, int C) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t m = idx / C;
+  const int ch = (int)(idx - m * C);
+  float* gp = gates + m * 4 * (size_t)C + ch;
+  const float si = gp[0], tj = gp[C], sf = gp[2 * C], so = gp[3 * C];
+  const float tc = tanhf(c_new[idx]);
+  const float dhv = dh[idx];
+  const float dcv = dc_io[idx] + dhv * so * (1.f - tc * tc);
+  const float cp = c_prev ? c_prev[idx] : 0.f;
+  gp[0] = dcv * tj * (si * (1.f - si));
+  gp[C] = dcv * si * (1.f - tj * tj);
+  gp[2 * C] = dcv * cp * (sf * (1.f - sf));
+  gp[3 * C] = dhv * tc * (so * (1.f - so));
+  dc_io[idx] = dcv * sf;
+}
+
+// ------------------------------------------------------------ graph attention
+// Backward of h_out = h + sum_j a_ij h_j, a = softmax_j(f_i . f_j),
+// f = l2_normalize([h ; s]) (gnn_edge/gnn_mask_edge/gnn_node,
+// code/pred_models.py:808-909), 9-neighbour form.
+// Pass A (one wave per cell i): recompute n_i = rsqrt(max(|u_i|^2,1e-12)),
+// e_ij, a_ij; da_ij = g_i . h_j; de_ij = a_ij (da_ij - sum_k a_ik da_ik).
+// Stores a, de [M*K, 9] (0 for out-of-grid taps) and n [M*K].
+__global__ __launch_bounds__(256)
+void gnn_bwd_a_kernel(const float* __restrict__ h, const float* __restrict__ smean,
+                      const float* __restrict__ g, float* __restrict__ a_out,
+                      float* __restrict__ de_out, float* __restrict__ n_out, int M,
+                      int H, int W, int C, int D) {
+  const int lane = threadIdx.x & 63;
+  const size_t cell_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int K = H * W;
+  if (cell_id >= (size_t)M * K) return;
+  const int m = cell_id / K;
+  const int cell = cell_id - (size_t)m * K;
+  const int y = cell / W, x = cell - y * W;
+  const float* hrow = h + (size_t)m * K * C;
+  const float* srow = smean + (size_t)m * K * D;
+  const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)cell * C + lane * 4);
+  const f32x4_t gi = *reinterpret_cast<const f32x4_t*>(g + cell_id * C + lane * 4);
+  const float si = (lane < D) ? srow[(size_t)cell * D + lane] : 0.f;
+  float ssi = hi[0] * hi[0] + hi[1] * hi[1] + hi[2] * hi[2] + hi[3] * hi[3] + si * si;
+  ssi = wave_sum(ssi);
+  const float invi = rsqrtf(fmaxf(ssi, 1e-12f));
+  float e[9], da[9];
+  bool ok[9];
+  float emax = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    ok[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W);
+    e[t] = 0.f; da[t] = 0.f;
+    if (ok[t]) {
+      const int cj = yy * W + xx;
+      const f32x4_t hj = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)cj * C + lane * 4);
+      const float sj = (lane < D) ? srow[(size_t)cj * D + lane] : 0.f;
+      float ssj = hj[0] * hj[0] + hj[1] * hj[1] + hj[2] * hj[2] + hj[3] * hj[3] + sj * sj;
+      float dot = hi[0] * hj[0] + hi[1] * hj[1] + hi[2] * hj[2] + hi[3] * hj[3] + si * sj;
+      float dg = gi[0] * hj[0] + gi[1] * hj[1] + gi[2] * hj[2] + gi[3] * hj[3];
+      ssj = wave_sum(ssj);
+      dot = wave_sum(dot);
+      da[t] = wave_sum(dg);
+      e[t] = dot * invi * rsqrtf(fmaxf(ssj, 1e-12f));
+      emax = fmaxf(emax, e[t]);
+    }
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    e[t] = ok[t] ? expf(e[t] - emax) : 0.f;
+    den += e[t];
+  }
+  const float inv = 1.0f / den;
+  float dsum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    e[t] = e[t] * inv;            // a_t
+    dsum += e[t] * da[t];
+  }
+  float my_a = 0.f, my_de = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+    if (lane == t) { my_a = e[t]; my_de = e[t] * (da[t] - dsum); }
+  if (lane < 9) {
+    a_out[cell_id * 9 + lane] = my_a;
+    de_out[cell_id * 9 + lane] = my_de;
+  }
+  if (lane == 0) n_out[cell_id] = invi;
+}
+
+// Pass B (one wave per cell j), gathers instead of scattering:
+//   dh_j = g_j + sum_t a[j+d_t][8-t] g_{j+d_t} + du_j[:C]
+//   df_j = sum_t (de[j][t] + de[j+d_t][8-t]) f_{j+d_t},  f_k = n_k u_k
+//   du_j = n_j (df_j - f_j (f_j . df_j))      (n_j clamped: du_j = n_j df_j)
+//   ds_j = du_j[C:]
+__global__ __launch_bounds__(256)
+void gnn_bwd_b_kernel(const float* __restrict__ h, const float* __restrict__ smean,
+                      const float* __restrict__ g, const float* __restrict__ a_in,
+                      const float* __restrict__ de_in, const float* __restrict__ n_in,
+                      float* __restrict__ dh, float* __restrict__ ds, int M, int H,
+                      int W, int C, int D, int ds_accumulate) {
+  const int lane = threadIdx.x & 63;
+  const size_t cell_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int K = H * W;
+  if (cell_id >= (size_t)M * K) return;
+  const int m = cell_id / K;
+  const int cell = cell_id - (size_t)m * K;
+  const int y = cell / W, x = cell - y * W;
+  const size_t rbase = (size_t)m * K;
+  const float* hrow = h + rbase * C;
+  const float* srow = smean + rbase * D;
+  const float* grow = g + rbase * C;
+  const f32x4_t hj = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)cell * C + lane * 4);
+  const float sj = (lane < D) ? srow[(size_t)cell * D + lane] : 0.f;
+  const float nj = n_in[cell_id];
+  const f32x4_t gj = *reinterpret_cast<const f32x4_t*>(grow + (size_t)cell * C + lane * 4);
+  f32x4_t acc = gj;                    // residual + attention-weighted neighbours
+  f32x4_t dfh = {0.f, 0.f, 0.f, 0.f};  // df_j, h part
+  float dfs = 0.f;                     // df_j, scene part (lane < D)
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {   // wave-uniform
+      const int ck = yy * W + xx;
+      const size_t kid = rbase + ck;
+      const float a_kj = a_in[kid * 9 + (8 - t)];
+      const float w = de_in[cell_id * 9 + t] + de_in[kid * 9 + (8 - t)];
+      const float nk = n_in[kid];
+      const f32x4_t gk = *reinterpret_cast<const f32x4_t*>(grow + (size_t)ck * C + lane * 4);
+      const f32x4_t hk = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)ck * C + lane * 4);
+      const float sk = (lane < D) ? srow[(size_t)ck * D + lane] : 0.f;
+      const float wn = w * nk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[q] = fmaf(a_kj, gk[q], acc[q]);
+        dfh[q] = fmaf(wn, hk[q], dfh[q]);
+      }
+      dfs = fmaf(wn, sk, dfs);
+    }
+  }
+  // projection f_j . df_j
+  float proj = (hj[0] * dfh[0] + hj[1] * dfh[1] + hj[2] * dfh[2] + hj[3] * dfh[3] +
+                sj * dfs) * nj;
+  proj = wave_sum(proj);
+  const bool clamped = nj >= 1.0e6f;   // |u|^2 <= 1e-12: l2_normalize is u * 1e6
+  f32x4_t o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float du = clamped ? nj * dfh[q] : nj * (dfh[q] - (hj[q] * nj) * proj);
+    o[q] = acc[q] + du;
+  }
+  *reinterpret_cast<f32x4_t*>(dh + cell_id * C + lane * 4) = o;
+  if (lane < D) {
+    const float du = clamped ? nj * dfs : nj * (dfs - (sj * nj) * proj);
+    float* o2 = ds + cell_id * D + lane;
+    *o2 = ds_accumulate ? *o2 + du : du;
+  }
+}
+
+// ------------------------------------------------------------ small 3x3 convs
+// dgrad of a 3x3 SAME conv with few output channels (hidden2grid: Ci=C, Co=P;
+// reg-decoder grid_emb: Ci=2, Co=E):
+//   din[m][ci] (+)= sum_tap sum_co dout[m - d_tap][co] * W[tap][ci][co]
+// One thread per (cell, ci).  Row strides in elements (time slices in place).
+__global__ void conv3x3_small_dgrad_kernel(const float* __restrict__ dout,
+                                           size_t dout_row_stride,
+                                           const float* __restrict__ w,
+                                           float* __restrict__ din,
+                                           size_t din_row_stride, int M, int H, int W,
+                                           int Ci, int Co, int accumulate) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)M * H * W * Ci;
+  if (idx >= total) return;
+  const int ci = idx % Ci;
+  size_t r = idx / Ci;
+  const int xx = r % W; r /= W;
+  const int yy = r % H;
+  const int m = r / H;
+  float acc = 0.f;
+  for (int t = 0; t < 9; ++t) {
+    const int sy = yy - (t / 3 - 1), sx = xx - (t % 3 - 1);
+    if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+    const float* dp = dout + (size_t)m * dout_row_stride + ((size_t)sy * W + sx) * Co;
+    const float* wp = w + ((size_t)t * Ci + ci) * Co;
+    for (int co = 0; co < Co; ++co) acc = fmaf(dp[co], wp[co], acc);
+  }
+  float* o = din + (size_t)m * din_row_stride + ((size_t)yy * W + xx) * Ci + ci;
+  *o = accumulate ? *o + acc : acc;
+}
+
+// wgrad of a 3x3 SAME conv with Ci*Co <= 512 (hidden2grid, grid_emb):
+//   partial[blk][tap][ci][co] = sum_{m in slab} in[m + d_tap][ci] * dout[m][co]
+// in [R, HW, Ci], dout [R, HW, Co] contiguous; one thread per (ci, co), one
+// workgroup per slab of cells; reduce with colsum_kernel afterwards.
+__global__ void conv3x3_small_wgrad_kernel(const float* __restrict__ in,
+                                           const float* __restrict__ dout,
+                                           float* __restrict__ partial, int R, int H,
+                                           int W, int Ci, int Co, int cells_per_block) {
+  const int tid = threadIdx.x;
+  if (tid >= Ci * Co) return;
+  const int ci = tid / Co, co = tid - ci * Co;
+  const long long total = (long long)R * H * W;
+  const long long m0 = (long long)blockIdx.x * cells_per_block;
+  long long m1 = m0 + cells_per_block;
+  if (m1 > total) m1 = total;
+  const int HW = H * W;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  for (long long m = m0; m < m1; ++m) {
+    const int cell = (int)(m % HW);
+    const int y = cell / W, x = cell - y * W;
+    const float d = dout[(size_t)m * Co + co];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        acc[t] = fmaf(in[(size_t)(m + (t / 3 - 1) * W + (t % 3 - 1)) * Ci + ci], d, acc[t]);
+    }
+  }
+  float* p = partial + (size_t)blockIdx.x * 9 * Ci * Co;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) p[((size_t)t * Ci + ci) * Co + co] = acc[t];
+}
+
+// dpre = dy * (1 - y^2)   (backward of tanh); in place over dy allowed.
+__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                float* __restrict__ dpre, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const float v = y[idx];
+  dpre[idx] = dy[idx] * (1.f - v * v);
+}
+
+// out[s][col] = sum over the rows of slab s of in[row][col]; grid (nslab,
+// ceil(ncols/256)).  Used twice for a deterministic column sum (bias
+// gradients) and once with one slab to fold split-K partials.
+__global__ void colsum_kernel(const float* __restrict__ in, float* __restrict__ out,
+                              size_t rows, size_t ncols, size_t rows_per_slab) {
+  const size_t col = (size_t)blockIdx.y * blockDim.x + threadIdx.x;
+  if (col >= ncols) return;
+  const size_t r0 = (size_t)blockIdx.x * rows_per_slab;
+  size_t r1 = r0 + rows_per_slab;
+  if (r1 > rows) r1 = rows;
+  float acc = 0.f;
+  for (size_t r = r0; r < r1; ++r) acc += in[r * ncols + col];
+  out[(size_t)blockIdx.x * ncols + col] = acc;
+}
+
+// out[0] = scale * sum(in[0..n)) (optionally of squares); ONE workgroup, fixed
+// order: thread-strided partial sums, then an LDS tree.
+__global__ __launch_bounds__(256)
+void reduce_sum_kernel(const float* __restrict__ in, size_t n, float* __restrict__ out,
+                       float scale, int squares) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    const float v = in[i];
+    acc += squares ? v * v : v;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+// ------------------------------------------------------------ losses
+// sparse softmax cross entropy (code/pred_models.py:991-995) on the
+// time-major logits [T, N, K]; labels [N, T] as the host hands them.
+// One wave per (t, n) row: loss_row = lse - logit[label];
+// dlogits = (softmax - onehot) * scale,  scale = grid_loss_weight / (N*T).
+__global__ __launch_bounds__(64)
+void ce_loss_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                    float* __restrict__ loss_row, float* __restrict__ dlogits, int T,
+                    int N, int K, float scale) {
+  const int r = blockIdx.x;          // t * N + n
+  const int t = r / N, n = r - t * N;
+  const int lane = threadIdx.x;
+  const float* p = logits + (size_t)r * K;
+  float mx = -INFINITY;
+  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, p[k]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += expf(p[k] - mx);
+  s = wave_sum(s);
+  const float lse = logf(s) + mx;
+  const int lab = labels[(size_t)n * T + t];
+  if (lane == 0) loss_row[r] = lse - p[lab];
+  const float inv = 1.0f / s;
+  float* d = dlogits + (size_t)r * K;
+  for (int k = lane; k < K; k += 64) {
+    const float sm = expf(p[k] - mx) * inv;
+    d[k] = (sm - (k == lab ? 1.f : 0.f)) * scale;
+  }
+}
+
+// Huber (delta = 1), tf.losses.huber_loss(reduction=MEAN)
+// (code/pred_models.py:1020-1022): pred time-major [T, N, KP], target [N, T, KP].
+// loss_elem = 0.5 q^2 + (|e| - q), q = min(|e|, 1);  dpred = clamp(e,-1,1) * scale.
+__global__ void huber_loss_kernel(const float* __restrict__ pred,
+                                  const float* __restrict__ target,
+                                  float* __restrict__ loss_elem,
+                                  float* __restrict__ dpred, int T, int N, int KP,
+                                  float scale) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)T * N * KP;
+  if (idx >= total) return;
+  const int kp = idx % KP;
+  const size_t r = idx / KP;
+  const int n = r % N;
+  const int t = r / N;
+  const float e = pred[idx] - target[((size_t)n * T + t) * KP + kp];
+  const float ab = fabsf(e);
+  const float q = fminf(ab, 1.f);
+  loss_elem[idx] = 0.5f * q * q + (ab - q);
+  dpred[idx] = fminf(fmaxf(e, -1.f), 1.f) * scale;
+}
+
+// ------------------------------------------------------------ scene stack
+// d scene_conv_s [U, K, D] gathered from (a) the graph attention's d scene_mean
+// [N, K, D] (reduce_mean over T_o: each observed frame gets 1/T) and (b) the
+// class encoder's dx_t [T, N, K, D] at the occupied cell
+// (scene_conv * one_hot, code/pred_models.py:174-175, 210).
+__global__ void scene_grad_gather_kernel(const float* __restrict__ dmean,
+                                         const float* __restrict__ dxenc,
+                                         const int32_t* __restrict__ obs_scene,
+                                         const int32_t* __restrict__ labels,
+                                         float* __restrict__ dsc, int U, int N, int T,
+                                         int K, int D) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)K * D;
+  if (idx >= (size_t)U * per) return;
+  const int u = idx / per;
+  const size_t off = idx - (size_t)u * per;
+  const int cell = off / D;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n)
+    for (int t = 0; t < T; ++t) {
+      if (obs_scene[n * T + t] != u) continue;
+      if (dmean) acc += dmean[(size_t)n * per + off] / (float)T;
+      if (labels[n * T + t] == cell)
+        acc += dxenc[((size_t)t * N + n) * per + off];
+    }
+  dsc[idx] = acc;
+}
+
+// dgrad of conv k x k, stride 2, SAME: din[u][iy][ix][ci] (+)= sum dpre[u][oy][ox][co] W[ky][kx][ci][co]
+// over (ky,kx) with 2*oy + ky - pad_t == iy.
+__global__ void conv_s2_dgrad_kernel(const float* __restrict__ dpre,
+                                     const float* __restrict__ w,
+                                     float* __restrict__ din, int U, int Hi, int Wi,
+                                     int Ci, int Ho, int Wo, int Co, int k, int pad_t,
+                                     int pad_l, int accumulate) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)U * Hi * Wi * Ci;
+  if (idx >= total) return;
+  const int ci = idx % Ci;
+  size_t r = idx / Ci;
+  const int ix = r % Wi; r /= Wi;
+  const int iy = r % Hi;
+  const int u = r / Hi;
+  float acc = 0.f;
+  for (int ky = 0; ky < k; ++ky) {
+    const int ty = iy + pad_t - ky;
+    if (ty < 0 || (ty & 1)) continue;
+    const int oy = ty >> 1;
+    if (oy >= Ho) continue;
+    for (int kx = 0; kx < k; ++kx) {
+      const int tx = ix + pad_l - kx;
+      if (tx < 0 || (tx & 1)) continue;
+      const int ox = tx >> 1;
+      if (ox >= Wo) continue;
+      const float* dp = dpre + (((size_t)u * Ho + oy) * Wo + ox) * Co;
+      const float* wp = w + ((size_t)(ky * k + kx) * Ci + ci) * Co;
+      for (int co = 0; co < Co; ++co) acc = fmaf(dp[co], wp[co], acc);
+    }
+  }
+  din[idx] = accumulate ? din[idx] + acc : acc;
+}
+
+// wgrad of conv k x k, stride 2, SAME; one thread per (ky,kx,ci,co), direct sum.
+__global__ void conv_s2_wgrad_kernel(const float* __restrict__ in,
+                                     const float* __restrict__ dpre,
+                                     float* __restrict__ dw, int U, int Hi, int Wi,
+                                     int Ci, int Ho, int Wo, int Co, int k, int pad_t,
+                                     int pad_l) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)k * k * Ci * Co;
+  if (idx >= total) return;
+  const int co = idx % Co;
+  size_t r = idx / Co;
+  const int ci = r % Ci; r /= Ci;
+  const int kx = r % k;
+  const int ky = r / k;
+  float acc = 0.f;
+  for (int u = 0; u < U; ++u)
+    for (int oy = 0; oy < Ho; ++oy) {
+      const int iy = oy * 2 + ky - pad_t;
+      if (iy < 0 || iy >= Hi) continue;
+      for (int ox = 0; ox < Wo; ++ox) {
+        const int ix = ox * 2 + kx - pad_l;
+        if (ix < 0 || ix >= Wi) continue;
+        acc = fmaf(in[(((size_t)u * Hi + iy) * Wi + ix) * Ci + ci],
+                   dpre[(((size_t)u * Ho + oy) * Wo + ox) * Co + co], acc);
+      }
+    }
+  dw[idx] = acc;
+}
+
+// ------------------------------------------------------------ optimizer
+// grad += wd * w  (the d/dw of wd * l2_loss(w), wd_cost code/pred_models.py:1253-1275)
+__global__ void add_scaled_kernel(float* __restrict__ g, const float* __restrict__ w,
+                                  float s, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) g[i] = g[i] + s * w[i];
+}
+
+// clip_by_value (code/pred_models.py:1700-1705) + TF ApplyAdadelta
+// (AdadeltaOptimizer(lr, rho=0.95, epsilon=1e-8), :1671-1672):
+//   accum = rho accum + (1-rho) g^2
+//   update = sqrt(accum_update + eps) * rsqrt(accum + eps) * g
+//   var -= lr * update;  accum_update = rho accum_update + (1-rho) update^2
+__global__ void adadelta_kernel(float* __restrict__ var, float* __restrict__ accum,
+                                float* __restrict__ accum_update,
+                                const float* __restrict__ grad, float gscale, float clip,
+                                int do_clip, float lr, float rho, float eps, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float g = grad[i] * gscale;
+  if (do_clip) g = fminf(fmaxf(g, -clip), clip);
+  const float a = accum[i] * rho + g * g * (1.f - rho);
+  const float upd = sqrtf(accum_update[i] + eps) * (1.0f / sqrtf(a + eps)) * g;
+  var[i] = var[i] - upd * lr;
+  accum_update[i] = accum_update[i] * rho + upd * upd * (1.f - rho);
+  accum[i] = a;
+}
+
+// ------------------------------------------------------------ layout helpers
+// dense one-hot map [R, K] from ids (row r reads ids[r * stride])
+__global__ void onehot_map_kernel(const int32_t* __restrict__ ids, int stride,
+                                  float* __restrict__ out, int R, int K) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)R * K) return;
+  const int r = idx / K, k = idx - (size_t)r * K;
+  out[idx] = (ids[(size_t)r * stride] == k) ? 1.f : 0.f;
+}
+
+// [N, T, E] -> [T, N, E]
+__global__ void transpose_nt_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                    int N, int T, size_t E) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * T * E) return;
+  const size_t e = idx % E;
+  const size_t r = idx / E;
+  const int n = r % N;
+  const int t = r / N;
+  out[idx] = in[((size_t)n * T + t) * E + e];
+}
+
+// Device-side weight packs (same maps as pack_convlstm_weights /
+// pack_convlstm_dgrad_weights in convlstm_mfma.h), run after every optimizer
+// step.  One thread per packed element.
+__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                int Cx, int C, int nx, int nch, int small, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = idx & 3;
+  const int l = (idx >> 2) & 63;
+  const int g = (idx >> 8) & 3;
+  const int kk = (idx >> 10) & 3;
+  const size_t tile = idx >> 12;
+  const int q = tile % nch;
+  const int cb = tile / nch;
+  const int k = kk * 8 + (l >> 5) * 4 + j;
+  const int n = g * C + cb * 32 + (l & 31);
+  const int Cin = Cx + C, N4 = 4 * C;
+  int tap = -1, ci = -1;
+  if (q < nx) {
+    if (small) {
+      if (k < 9 * Cx) { tap = k / Cx; ci = k % Cx; }
+    } else {
+      tap = q % 9; ci = (q / 9) * 32 + k;
+    }
+  } else {
+    const int qq = q - nx;
+    tap = qq % 9; ci = Cx + (qq / 9) * 32 + k;
+  }
+  out[idx] = (tap < 0) ? 0.f : w[((size_t)tap * Cin + ci) * N4 + n];
+}
+
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                  int Cx, int C, int nch, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = idx & 3;
+  const int l = (idx >> 2) & 63;
+  const int g = (idx >> 8) & 3;
+  const int kk = (idx >> 10) & 3;
+  const size_t tile = idx >> 12;
+  const int q = tile % nch;
+  const int cb = tile / nch;
+  const int grp = q / 9, tap = q % 9;
+  const int k = kk * 8 + (l >> 5) * 4 + j;
+  const int n = grp * 32 + k;
+  const int col = cb * 128 + g * 32 + (l & 31);
+  const int Cin = Cx + C, N4 = 4 * C;
+  int ci = -1;
+  if (col < C) ci = Cx + col;
+  else if (col - C < Cx) ci = col - C;
+  out[idx] = (ci < 0) ? 0.f : w[((size_t)(8 - tap) * Cin + ci) * N4 + n];
+}
+
+}  // namespace mv

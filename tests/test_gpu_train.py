@@ -1,0 +1,191 @@
+# coding=utf-8
+"""GPU parity of the training step (Trainer.step, reference
+code/pred_models.py:1719-1742) through the C ABI against the CPU oracle's
+torch-autograd restatement of tf.gradients + clip + Adadelta.
+
+Tolerances: gradients are long fp32 sums in a different order than the CPU
+convolutions; every tensor must agree to 2e-3 of its own max |.| (measured
+errors are printed) and the fp64 oracle arbitrates: the GPU's error against
+fp64 must be of the same order as the fp32 oracle's own.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from multiverse_amd import synth
+from oracle import multiverse_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+  a = np.asarray(a, dtype=np.float64)
+  b = np.asarray(b, dtype=np.float64)
+  return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("Cx,zero", [(32, False), (64, False), (2, False), (64, True)])
+def test_convlstm_backward_op(built_lib, Cx, zero):
+  """One ConvLSTMCell step: gate backward + MFMA dgrad + MFMA wgrad + bias
+  column sums vs torch.autograd through the oracle's cell."""
+  rng = np.random.default_rng(100 + Cx)
+  M, H, W, C = 3, 9, 16, 256
+  x = rng.normal(0, 1, (M, H, W, Cx)).astype("float32")
+  c = rng.normal(0, 0.5, (M, H, W, C)).astype("float32")
+  h = np.tanh(rng.normal(0, 1, (M, H, W, C))).astype("float32")
+  k = (rng.normal(0, 1, (3, 3, Cx + C, 4 * C)) * 0.03).astype("float32")
+  b = (rng.normal(0, 1, (4 * C,)) * 0.1).astype("float32")
+  dhn = rng.normal(0, 1, (M, H, W, C)).astype("float32")
+  dcn = rng.normal(0, 1, (M, H, W, C)).astype("float32")
+  if zero:
+    c = np.zeros_like(c)
+    h = np.zeros_like(h)
+  got = built_lib.op_convlstm_bwd(x, None if zero else c, None if zero else h, k, b,
+                                  dhn, dcn)
+
+  def ref(dtype):
+    ts = [torch.tensor(v, dtype=dtype, requires_grad=True) for v in (x, c, h, k, b)]
+    nc, nh = oracle.convlstm_cell(*ts)
+    loss = (nh * torch.tensor(dhn, dtype=dtype)).sum() + \
+        (nc * torch.tensor(dcn, dtype=dtype)).sum()
+    gs = torch.autograd.grad(loss, ts)
+    return [g.numpy() for g in gs]
+
+  r32, r64 = ref(torch.float32), ref(torch.float64)
+  names = ["dx", "dc", "dh", "dkernel", "dbiases"]   # autograd order (x, c, h, k, b)
+  # the op returns (dx, dh, dc, dkernel, dbiases)
+  for nm, gi, ri in zip(names, [got[0], got[2], got[1], got[3], got[4]], range(5)):
+    e_gpu, e_cpu = _rel(gi, r64[ri]), _rel(r32[ri], r64[ri])
+    print("convlstm_bwd Cx=%d zero=%s %-8s rel err gpu %.2e (cpu fp32 %.2e)"
+          % (Cx, zero, nm, e_gpu, e_cpu))
+    assert e_gpu < 2e-4, nm
+
+
+def test_gnn_backward_op(built_lib):
+  rng = np.random.default_rng(7)
+  M, H, W, C, D = 2, 9, 16, 256, 64
+  h = np.tanh(rng.normal(0, 1, (M, H, W, C))).astype("float32")
+  s = np.tanh(rng.normal(0, 1, (M, H, W, D))).astype("float32")
+  g = rng.normal(0, 1, (M, H, W, C)).astype("float32")
+  dh, ds = built_lib.op_gnn_bwd(h, s, g)
+
+  def ref(dtype):
+    th = torch.tensor(h, dtype=dtype, requires_grad=True)
+    tsm = torch.tensor(s, dtype=dtype, requires_grad=True)
+    out = th + oracle.gnn_dense(th, tsm)
+    return [v.numpy() for v in torch.autograd.grad(
+        (out * torch.tensor(g, dtype=dtype)).sum(), [th, tsm])]
+
+  r32, r64 = ref(torch.float32), ref(torch.float64)
+  for nm, a, i in (("dh", dh, 0), ("dscene_mean", ds, 1)):
+    print("gnn_bwd %-12s rel err gpu %.2e (cpu fp32 %.2e)"
+          % (nm, _rel(a, r64[i]), _rel(r32[i], r64[i])))
+    assert _rel(a, r64[i]) < 1e-4, nm
+
+
+def _train_case(use_grids, N, seed, gnn=True):
+  cfg = synth.default_config(batch_size=N, use_grids=use_grids, is_train=True,
+                             use_gnn=gnn)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + seed, recurrent_gain=2.0,
+                             bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 50 + seed)
+  return cfg, params, feed
+
+
+@pytest.mark.parametrize("use_grids,N,gnn", [((0, 1), 3, True), ((1, 1), 2, True),
+                                               ((0, 1), 2, False)])
+def test_gradients_match_oracle(built_lib, use_grids, N, gnn):
+  """tf.gradients(loss, trainable_variables): every parameter tensor."""
+  cfg, params, feed = _train_case(use_grids, N, 1, gnn)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.train_init()
+  loss, wd, pgl = eng.train_forward_backward(feed)
+  oloss, owd, opgl, ograds = oracle.loss_and_grads(params, cfg, feed)
+  _, _, _, ograds64 = oracle.loss_and_grads(params, cfg, feed, dtype=torch.float64)
+  print("loss gpu %.6f oracle %.6f | wd %.6g / %.6g | parts %s / %s"
+        % (loss, oloss, wd, owd, pgl, opgl))
+  assert abs(loss - oloss) < 1e-4 * max(1.0, abs(oloss))
+  assert abs(wd - owd) < 1e-5 * max(1.0, abs(owd))
+  assert np.allclose(pgl, opgl, rtol=1e-4, atol=1e-5)
+  worst = 0.0
+  for name, _ in eng.param_specs():
+    g = eng.get_grad(name)
+    e_gpu = _rel(g, ograds64[name])
+    e_cpu = _rel(ograds[name], ograds64[name])
+    worst = max(worst, e_gpu)
+    print("%-78s rel err gpu %.2e (cpu fp32 %.2e) max|g| %.3g"
+          % (name, e_gpu, e_cpu, np.abs(ograds64[name]).max()))
+  eng.close()
+  assert worst < 2e-3
+
+
+def test_train_steps_match_oracle(built_lib):
+  """Three Trainer.step calls: losses, updated variables, Adadelta slots and
+  global_step; then the inference forward with the trained weights (device-side
+  weight repack) against the oracle with the oracle-trained weights."""
+  cfg, params, feed = _train_case((0, 1), 2, 2)
+  cfg.train_num_examples = 2      # decay_steps = 2 -> the staircase LR moves at step 2
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.train_init()
+  p, st = dict(params), oracle.adadelta_init(params)
+  feeds = [synth.make_feed(cfg, seed=synth.SEED_BASE + 70 + i) for i in range(3)]
+  for step, fd in enumerate(feeds):
+    loss, wd, pgl = eng.train_step(fd)
+    oloss, owd, opgl, p, st, _ = oracle.train_step(p, st, step, cfg, fd)
+    print("step %d loss gpu %.6f oracle %.6f" % (step, loss, oloss))
+    assert abs(loss - oloss) < 2e-4 * max(1.0, abs(oloss))
+    assert eng.global_step == step + 1
+  worst = 0.0
+  for name, _ in eng.param_specs():
+    d = np.abs(eng.get_param(name) - p[name]).max()
+    upd = np.abs(p[name] - params[name]).max()
+    worst = max(worst, d / max(upd, 1e-12))
+    print("%-78s |gpu-oracle| %.2e of update %.2e" % (name, d, upd))
+    assert _rel(eng.get_opt_slot(name, 0), st[name][0]) < 5e-3
+  assert worst < 5e-3
+  # forward with the trained weights (is_train False)
+  cfg_t = synth.default_config(batch_size=2, use_grids=(0, 1))
+  cls, reg = eng.forward_greedy(feeds[0])
+  trained = {n: eng.get_param(n) for n, _ in eng.param_specs()}
+  ocls, oreg, _ = oracle.forward(trained, cfg_t, feeds[0])
+  assert np.abs(cls[1] - ocls[1]).max() < 1e-4
+  assert np.abs(reg[1] - oreg[1]).max() < 1e-4
+  eng.close()
+
+
+def test_train_is_deterministic_and_split_apply_equals_step(built_lib):
+  """Bitwise run-to-run determinism of the gradients (no atomics), and
+  forward_backward + apply(1.0) == train_step."""
+  cfg, params, feed = _train_case((0, 1), 2, 3)
+  outs = []
+  for mode in ("step", "split"):
+    eng = built_lib.Engine(cfg, device=0)
+    eng.set_params(params)
+    eng.train_init()
+    if mode == "step":
+      eng.train_step(feed)
+    else:
+      eng.train_forward_backward(feed)
+      eng.train_apply(1.0)
+    outs.append(({n: eng.get_grad(n) for n, _ in eng.param_specs()},
+                 {n: eng.get_param(n) for n, _ in eng.param_specs()}))
+    eng.close()
+  for n in outs[0][0]:
+    assert (outs[0][0][n] == outs[1][0][n]).all(), n
+    assert (outs[0][1][n] == outs[1][1][n]).all(), n
+
+
+def test_train_rejects_unsupported(built_lib):
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), is_train=True)
+  cfg.optimizer = "adam"
+  eng = built_lib.Engine(cfg, device=0)
+  with pytest.raises(built_lib.MvError, match="adadelta"):
+    eng.train_init()
+  feed = synth.make_feed(cfg)
+  eng.set_params(synth.make_params(cfg))
+  with pytest.raises(built_lib.MvError, match="mv_train_init"):
+    eng.train_forward_backward(feed)
+  eng.close()
