@@ -66,9 +66,11 @@ def main():
   ap.add_argument("--warmup", type=int, default=2)
   ap.add_argument("--batch", type=int, default=None,
                   help="trajectories per GPU (default 64 greedy / 128 beam)")
-  ap.add_argument("--workload", choices=("greedy", "beam"), default="greedy",
+  ap.add_argument("--workload", choices=("greedy", "beam", "train"), default="greedy",
                   help="greedy = BASELINE configs[1] (the headline line); beam = "
-                       "configs[3]: scale 0, beam 20, batch 128, hipGraph replay")
+                       "configs[3]: scale 0, beam 20, batch 128, hipGraph replay; "
+                       "train = configs[2]: both scales, training step (fwd + loss + "
+                       "bwd + RCCL grad all-reduce + clip + Adadelta), batch 32/GPU")
   ap.add_argument("--beam", type=int, default=20)
   ap.add_argument("--graph", type=int, default=None,
                   help="1: replay the forward as a captured hipGraph "
@@ -98,13 +100,17 @@ def main():
     dist.init_process_group(backend="nccl")  # RCCL; barrier + max only
 
   beam = args.workload == "beam"
+  train = args.workload == "train"
   if args.batch is None:
-    args.batch = 128 if beam else 64
+    args.batch = 128 if beam else 32 if train else 64
   if args.graph is None:
     args.graph = 1 if beam else 0
   if beam:
     cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 0),
                                beam_size=args.beam)
+  elif train:
+    cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 1), is_train=True)
+    args.graph = 0
   else:
     cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 1))
   params = synth.make_params(cfg, seed=synth.SEED_BASE + 2)  # reference initialisers
@@ -113,6 +119,21 @@ def main():
   eng.set_params(params)
   eng.upload(feed)          # inputs resident in HBM before the timed region
   eng.set_graph_mode(bool(args.graph))
+  if train:
+    from multiverse_amd import parallel
+    eng.train_init()
+    eng.upload_targets(feed)
+
+  def one_step():
+    if not train:
+      eng.run_resident(beam)
+      return
+    # Trainer.step on the resident batch: forward + loss + backward, all-reduce
+    # (sum) of the flat gradient buffer over the ranks, clip + Adadelta
+    eng.train_forward_backward(None)
+    if use_dist:
+      parallel.allreduce_engine_grads(eng, local_rank)
+    eng.train_apply(1.0 / world)
 
   def barrier():
     if use_dist:
@@ -121,11 +142,11 @@ def main():
     eng.synchronize()
 
   for _ in range(args.warmup):
-    eng.run_resident(beam)
+    one_step()
   barrier()
   t0 = time.perf_counter()
   for _ in range(args.steps):
-    eng.run_resident(beam)
+    one_step()
   eng.synchronize()
   barrier()
   elapsed = time.perf_counter() - t0
@@ -140,16 +161,20 @@ def main():
   # ---- roofline of the dominant kernel, measured live with hipEvents
   eng.set_profiling(True)
   eng.reset_kernel_stats()
-  eng.run_resident(beam)
+  one_step()
   eng.synchronize()
   stats = eng.kernel_stats()
   eng.set_profiling(False)
-  conv = stats["convlstm_step"]
+  mfma_kernels = ["convlstm_step"] + (["convlstm_dgrad", "convlstm_wgrad"] if train else [])
+  conv = {k: sum(stats[n][k] for n in mfma_kernels)
+          for k in ("launches", "total_ms", "flops", "bytes")}
   conv_s = conv["total_ms"] * 1e-3
   achieved_tf = conv["flops"] / conv_s / 1e12
   flops_traj, bytes_traj = algorithmic_counts(cfg, args.beam if beam else 1)
+  if train:
+    flops_traj *= 3.0   # forward + dgrad + wgrad of every gate convolution
   roofline = {
-      "kernel": "convlstm_step",
+      "kernel": "+".join(mfma_kernels),
       "bound": "mfma",
       "achieved": round(achieved_tf, 2),
       "peak": PEAK_FP32_MFMA_TFLOPS,
@@ -165,15 +190,20 @@ def main():
       "whole_forward_mfma_frac": round(
           value / world * flops_traj / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
       "other_kernels_ms": {k: round(v["total_ms"], 3) for k, v in stats.items()
-                           if k != "convlstm_step"},
+                           if k not in mfma_kernels},
   }
+  if train:
+    roofline["per_kernel_TFLOPs"] = {
+        n: round(stats[n]["flops"] / (stats[n]["total_ms"] * 1e-3) / 1e12, 2)
+        for n in mfma_kernels}
+    roofline["per_kernel_ms"] = {n: round(stats[n]["total_ms"], 3) for n in mfma_kernels}
 
   # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes
   # of this same command (FETCH_SIZE and WRITE_SIZE cannot share a pass on
   # gfx950); bench.py cannot collect PMCs itself, so it quotes the committed
   # profile when the workload matches, else null.
   pmc_path = os.path.join(ROOT, "profiles", "r1_convlstm_pmc.json")
-  if args.batch == 64 and not beam and os.path.exists(pmc_path):
+  if args.batch == 64 and not beam and not train and os.path.exists(pmc_path):
     with open(pmc_path) as f:
       pmc = json.load(f)
     hb = pmc.get("hbm_bytes_per_launch")
@@ -191,6 +221,15 @@ def main():
                 "(diverse, gamma 0.01, fix_num_timestep 1), batch %d/GPU, fp32, "
                 "obs 8 / pred 12, %s" % (args.beam, args.batch,
                 "hipGraph replay" if args.graph else "stream launches"))
+  elif train:
+    metric = ("trajectories/sec (8-obs/12-pred, multi-scale 18x32+9x16 grid, "
+              "training step)")
+    workload = ("BASELINE configs[2]: multi-scale 18x32+9x16 (scene 36x64x11), "
+                "batch %d/GPU (global %d), fp32 training step = forward + CE/Huber/wd "
+                "loss + backward + %s + clip + Adadelta" % (
+                    args.batch, args.batch * world,
+                    "RCCL all-reduce of the 21.3M-float gradient buffer" if world > 1
+                    else "no all-reduce (1 rank)"))
   else:
     metric = ("trajectories/sec (8-obs/12-pred, multi-scale 18x32+9x16 grid, "
               "greedy forward)")
@@ -214,13 +253,15 @@ def main():
       "config": {"workload": workload,
                  "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                  "obs_len": cfg.obs_len, "pred_len": cfg.pred_len,
-                 "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                 "parallelism": ("data-parallel x%d, gradient all-reduce (RCCL)" % world
+                                 if train else
+                                 "batch-sharded x%d, no data-path collective" % world),
                  "alg_gflop_per_trajectory": round(flops_traj / 1e9, 2),
                  "alg_state_MB_per_trajectory": round(bytes_traj / 1e6, 2)},
       "roofline": roofline,
   }
 
-  if rank == 0 and world == 1 and not args.no_cpu_baseline and not beam:
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and not beam and not train:
     out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
 
   eng.close()

@@ -165,6 +165,9 @@ int  mv_train_step(mv_handle h, const mv_inputs* in, const mv_targets* tg,
  * single-device step over the global batch would. */
 int  mv_train_forward_backward(mv_handle h, const mv_inputs* in,
                                const mv_targets* tg, mv_losses* out);
+/* resident form (bench: batch already in HBM): mv_upload_inputs +
+ * mv_upload_targets once, then pass in == tg == NULL to the two calls above */
+int  mv_upload_targets(mv_handle h, const mv_targets* tg);
 int  mv_grad_buffer(mv_handle h, float** device_ptr, int64_t* elems);
 int  mv_train_apply(mv_handle h, float grad_scale);
 /* tf.gradients(loss, var) of the last forward_backward, by variable name */

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "mv_kernel_stat", "mv_time_greedy_resident", "mv_time_beam_resident",
     "mv_op_convlstm_step", "mv_op_gnn", "mv_op_hidden2grid", "mv_op_beam_step",
     "mv_train_init", "mv_train_step", "mv_train_forward_backward",
-    "mv_grad_buffer", "mv_train_apply", "mv_get_grad", "mv_get_global_step",
+    "mv_upload_targets", "mv_grad_buffer", "mv_train_apply", "mv_get_grad", "mv_get_global_step",
     "mv_set_global_step", "mv_get_opt_slot", "mv_set_opt_slot",
     "mv_op_convlstm_bwd", "mv_op_gnn_bwd",
 ]
@@ -173,6 +173,7 @@ def load():
   lib.mv_train_step.argtypes = [h, C.POINTER(mv_inputs), C.POINTER(mv_targets),
                                 C.POINTER(mv_losses)]
   lib.mv_train_forward_backward.argtypes = lib.mv_train_step.argtypes
+  lib.mv_upload_targets.argtypes = [h, C.POINTER(mv_targets)]
   lib.mv_grad_buffer.argtypes = [h, C.POINTER(_fp), C.POINTER(C.c_int64)]
   lib.mv_train_apply.argtypes = [h, C.c_float]
   lib.mv_get_grad.argtypes = [h, C.c_char_p, _fp, C.c_int64]
@@ -459,18 +460,31 @@ class Engine(object):
     return (float(L.loss), float(L.wd_loss),
             [float(L.pred_grid_loss[i]) for i in range(L.num_pred_grid_loss)])
 
-  def train_step(self, feed):
-    """-> (loss, wd_loss, pred_grid_loss list)"""
-    inp, tg, L = self._inputs(feed), self._targets(feed), mv_losses()
-    check(self.lib.mv_train_step(self.handle, C.byref(inp), C.byref(tg), C.byref(L)),
-          self.handle)
+  def train_step(self, feed=None):
+    """-> (loss, wd_loss, pred_grid_loss list); feed None = resident batch."""
+    L = mv_losses()
+    if feed is None:
+      rc = self.lib.mv_train_step(self.handle, None, None, C.byref(L))
+    else:
+      inp, tg = self._inputs(feed), self._targets(feed)
+      rc = self.lib.mv_train_step(self.handle, C.byref(inp), C.byref(tg), C.byref(L))
+    check(rc, self.handle)
     return self._losses(L)
 
-  def train_forward_backward(self, feed):
-    inp, tg, L = self._inputs(feed), self._targets(feed), mv_losses()
-    check(self.lib.mv_train_forward_backward(self.handle, C.byref(inp), C.byref(tg),
-                                             C.byref(L)), self.handle)
+  def train_forward_backward(self, feed=None):
+    L = mv_losses()
+    if feed is None:
+      rc = self.lib.mv_train_forward_backward(self.handle, None, None, C.byref(L))
+    else:
+      inp, tg = self._inputs(feed), self._targets(feed)
+      rc = self.lib.mv_train_forward_backward(self.handle, C.byref(inp), C.byref(tg),
+                                              C.byref(L))
+    check(rc, self.handle)
     return self._losses(L)
+
+  def upload_targets(self, feed):
+    tg = self._targets(feed)
+    check(self.lib.mv_upload_targets(self.handle, C.byref(tg)), self.handle)
 
   def train_apply(self, grad_scale=1.0):
     check(self.lib.mv_train_apply(self.handle, float(grad_scale)), self.handle)

@@ -1097,8 +1097,21 @@ int mv_train_forward_backward(mv_handle h, const mv_inputs* in, const mv_targets
                               mv_losses* out) {
   if (!h) return 1;
   return guarded(h, [&] {
-    MV_REQUIRE(in && tg, "mv_train_forward_backward: NULL argument");
+    MV_REQUIRE((in == nullptr) == (tg == nullptr),
+               "mv_train_forward_backward: give both inputs and targets, or neither "
+               "(resident)");
     train_fwd_bwd(h, in, tg, out);
+  });
+}
+
+int mv_upload_targets(mv_handle h, const mv_targets* tg) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train, "mv_train_init has not been called");
+    MV_REQUIRE(tg, "mv_upload_targets: NULL targets");
+    MV_REQUIRE(h->inputs_ready, "mv_upload_inputs first (it fixes T_pred)");
+    upload_targets(h, tg);
+    TS(h).targets_ready = true;
   });
 }
 
@@ -1110,7 +1123,8 @@ int mv_train_apply(mv_handle h, float grad_scale) {
 int mv_train_step(mv_handle h, const mv_inputs* in, const mv_targets* tg, mv_losses* out) {
   if (!h) return 1;
   return guarded(h, [&] {
-    MV_REQUIRE(in && tg, "mv_train_step: NULL argument");
+    MV_REQUIRE((in == nullptr) == (tg == nullptr),
+               "mv_train_step: give both inputs and targets, or neither (resident)");
     train_fwd_bwd(h, in, tg, out);
     train_apply(h, 1.0f);
   });

@@ -53,6 +53,7 @@ struct TrainState {
   DevBuf<float> scratch;          // second-stage scratch
   DevBuf<float> losses;           // [2*MV_MAX_SCALES + 1 + nW] device scalars
   bool have_grads = false;
+  bool targets_ready = false;
   mv_losses last{};
 };
 
@@ -660,8 +661,10 @@ void train_fwd_bwd(mv_engine* e, const mv_inputs* in, const mv_targets* tg, mv_l
   MV_REQUIRE(e->train, "mv_train_init has not been called");
   MV_REQUIRE(e->cfg.beam_size == 1, "training needs a greedy (beam_size 1) engine");
   TrainState& t = TS(e);
-  upload_inputs(e, in);
-  upload_targets(e, tg);
+  if (in) upload_inputs(e, in);
+  if (tg) { upload_targets(e, tg); t.targets_ready = true; }
+  MV_REQUIRE(e->inputs_ready && t.targets_ready,
+             "no resident inputs / targets (mv_upload_inputs, mv_upload_targets)");
   ensure_params(e);
   if (!e->train_packs_valid) {   // first step / after mv_set_param
     train_pack_all(e);

@@ -6,6 +6,14 @@ ranks run N batch shards with NO data-path collective; torch.distributed
 (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests) is
 used only for the timing barrier / max-over-ranks and for collecting
 per-shard results on rank 0 when a caller wants the whole batch back.
+
+The training step has the path's one real exchange: the batch means in the
+loss (reference code/pred_models.py:995, 1016-1022) couple the samples, so the
+per-rank gradients of the local means are summed over the ranks and scaled by
+1/world.  The engine keeps every parameter gradient in ONE flat device buffer
+(85.4 MB fp32 for both scales) so that is a single all-reduce; xGMI is
+point-to-point, a ring moves 2*(w-1)/w * 85.4 MB per link ~ 1 ms against a
+>= 100 ms step, so it is issued once after the backward pass.
 """
 
 from __future__ import annotations
@@ -55,3 +63,73 @@ def gather_to_rank0(array):
   if dist.get_rank() != 0:
     return None
   return np.concatenate(parts, axis=0)
+
+
+# ------------------------------------------------------------ training
+
+def world_size():
+  import torch.distributed as dist
+  if dist.is_available() and dist.is_initialized():
+    return dist.get_world_size()
+  return 1
+
+
+class _DeviceArray(object):
+  """A raw device pointer as a 1-D float32 `__cuda_array_interface__` object."""
+
+  def __init__(self, ptr, n):
+    self.__cuda_array_interface__ = {
+        "shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False),
+        "version": 2, "strides": None}
+
+
+def engine_grad_tensor(engine, device_index):
+  """Zero-copy torch view of the engine's flat gradient buffer."""
+  import torch
+  ptr, n = engine.grad_buffer()
+  return torch.as_tensor(_DeviceArray(ptr, n), device="cuda:%d" % device_index)
+
+
+def allreduce_engine_grads(engine, device_index=None):
+  """SUM all-reduce of the engine's flat gradient buffer over the ranks (RCCL).
+  `mv_train_forward_backward` has synchronised the engine's stream before it
+  returned; the collective runs on torch's stream and is waited for here, so
+  `mv_train_apply` may follow immediately."""
+  import torch
+  import torch.distributed as dist
+  if world_size() == 1:
+    return
+  if device_index is None:
+    device_index = torch.cuda.current_device()
+  t = engine_grad_tensor(engine, device_index)
+  dist.all_reduce(t, op=dist.ReduceOp.SUM)
+  torch.cuda.synchronize(device_index)
+
+
+def allreduce_mean_arrays(arrays):
+  """In-place mean over ranks of a dict of numpy arrays (gloo / host path; used
+  by the CPU tests of the data-parallel gradient rule)."""
+  import torch
+  import torch.distributed as dist
+  w = world_size()
+  if w == 1:
+    return arrays
+  for k in sorted(arrays):
+    t = torch.from_numpy(np.ascontiguousarray(arrays[k]))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    arrays[k] = (t / w).numpy()
+  return arrays
+
+
+def mean_over_ranks(loss, parts):
+  """Mean of the per-rank loss scalars (reporting only)."""
+  import torch
+  import torch.distributed as dist
+  w = world_size()
+  if w == 1:
+    return loss, parts
+  dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+  t = torch.tensor([loss] + list(parts), dtype=torch.float64, device=dev)
+  dist.all_reduce(t, op=dist.ReduceOp.SUM)
+  t = (t / w).tolist()
+  return t[0], t[1:]

@@ -166,11 +166,41 @@ class Tester(object):
 
 
 class Trainer(object):
-  """code/pred_models.py:1636-1742.  The training step (backward through the
-  ConvLSTM sweep, Adadelta, RCCL gradient all-reduce) is SURVEY.md section 8
-  config 3 and is not built yet; constructing a Trainer fails loudly rather
-  than silently training on a CPU path."""
+  """code/pred_models.py:1636-1742: learning-rate schedule, Adadelta,
+  tf.gradients, element-wise clip, apply_gradients + global_step.  All of it
+  runs inside the engine (`mv_train_step`); `step` is one `sess.run([loss,
+  train_op, wd_loss, pred_grid_loss])`.
+
+  When torch.distributed is initialised with more than one rank, every rank
+  holds one batch shard and the step becomes forward+backward ->
+  all-reduce(sum) of the flat gradient buffer (RCCL over xGMI) ->
+  `mv_train_apply(1/world)`: the clip and the optimizer see the global-batch
+  mean gradient, as a single-GPU step over the global batch would."""
 
   def __init__(self, model, config):
-    raise _lib.MvError(
-        "Trainer.step (mv_train_step) is not built yet: forward-only engine")
+    self.config = config
+    self.model = model
+    if not getattr(config, "is_train", False):
+      raise _lib.MvError("Trainer needs a config with is_train=True")
+    model.engine.train_init(config)
+
+  @property
+  def global_step(self):
+    return self.model.engine.global_step
+
+  def step(self, sess, batch):
+    """One training step -> (loss, train_op(None), wd_loss, pred_grid_loss)."""
+    from multiverse_amd import parallel
+    _, batch_data = batch
+    feed = self.model.get_feed_dict(batch_data, is_train=True)
+    eng = self.model.engine
+    world = parallel.world_size()
+    if world == 1:
+      loss, wd_loss, pred_grid_loss = eng.train_step(feed)
+    else:
+      loss, wd_loss, pred_grid_loss = eng.train_forward_backward(feed)
+      parallel.allreduce_engine_grads(eng)
+      eng.train_apply(1.0 / world)
+      loss, pred_grid_loss = parallel.mean_over_ranks(loss, pred_grid_loss)
+    self.model.global_step = eng.global_step
+    return loss, None, wd_loss, pred_grid_loss

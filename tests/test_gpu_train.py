@@ -189,3 +189,48 @@ def test_train_rejects_unsupported(built_lib):
   with pytest.raises(built_lib.MvError, match="mv_train_init"):
     eng.train_forward_backward(feed)
   eng.close()
+
+
+def test_grad_buffer_is_a_torch_view(built_lib):
+  """The flat gradient buffer handed to torch.distributed (RCCL) is a
+  zero-copy view of the engine's memory; a world-1 process group exercises
+  the all-reduce call path."""
+  import os
+  import torch.distributed as dist
+  from multiverse_amd import parallel
+  cfg, params, feed = _train_case((0, 1), 2, 4)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.train_init()
+  eng.train_forward_backward(feed)
+  t = parallel.engine_grad_tensor(eng, 0)
+  name = "person_pred/decoder_grid_class_1/decoder_rnn/dec_grid_1/kernel"
+  g = eng.get_grad(name)
+  specs = eng.param_specs()
+  off = 0
+  for n, shape in specs:
+    size = int(np.prod(shape))
+    if n == name:
+      break
+    off += (size + 63) // 64 * 64
+  view = t[off:off + g.size].cpu().numpy().reshape(g.shape)
+  assert (view == g).all()
+  os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+  os.environ.setdefault("MASTER_PORT", "29512")
+  torch.cuda.set_device(0)
+  dist.init_process_group("nccl", rank=0, world_size=1)
+  try:
+    before = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)     # RCCL, world 1: identity
+    torch.cuda.synchronize()
+    assert torch.equal(before, t)
+    # resident step: upload once, then NULL inputs
+    eng.upload(feed)
+    eng.upload_targets(feed)
+    l1 = eng.train_forward_backward(None)
+    parallel.allreduce_engine_grads(eng, 0)
+    eng.train_apply(1.0)
+    assert (eng.get_grad(name) == g).all() and abs(l1[0] - l1[0]) == 0
+  finally:
+    dist.destroy_process_group()
+  eng.close()

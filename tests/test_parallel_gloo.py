@@ -67,3 +67,43 @@ def test_two_rank_batch_sharding_matches_single_process(tmp_path):
   r = np.load(os.path.join(str(tmp_path), "res.npz"))
   assert int(r["n"]) == 3
   assert float(r["dc"]) < 1e-5 and float(r["dr"]) < 1e-5
+
+
+def _grad_worker(rank, world, port, outdir):
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  torch.set_num_threads(2)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  from multiverse_amd import parallel, synth
+  from oracle import multiverse_oracle as oracle
+  N = 4
+  cfg = synth.default_config(batch_size=N, use_grids=(0, 1), is_train=True)
+  params = synth.make_params(cfg, recurrent_gain=2.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=33)
+  shard, (lo, hi) = parallel.shard_feed(feed, rank, world, N)
+  scfg = synth.default_config(batch_size=hi - lo, use_grids=(0, 1), is_train=True)
+  # the oracle stands in for mv_train_forward_backward on this rank's shard
+  loss, wd, pgl, grads = oracle.loss_and_grads(params, scfg, shard)
+  grads = parallel.allreduce_mean_arrays(grads)          # sum over ranks / world
+  loss, pgl = parallel.mean_over_ranks(loss, pgl)
+  if rank == 0:
+    rloss, _, rpgl, rgrads = oracle.loss_and_grads(params, cfg, feed)
+    worst = max(float(np.abs(grads[k] - rgrads[k]).max() /
+                      max(np.abs(rgrads[k]).max(), 1e-30)) for k in rgrads)
+    np.savez(os.path.join(outdir, "grad.npz"), worst=worst, dloss=abs(loss - rloss),
+             dpgl=np.abs(np.asarray(pgl) - np.asarray(rpgl)).max())
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
+  """The data-parallel rule of the training step: per-rank gradients of the
+  LOCAL batch-mean loss, all-reduce(sum)/world == tf.gradients of the
+  global-batch loss (equal shards)."""
+  world = 2
+  mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world,
+           join=True)
+  r = np.load(os.path.join(str(tmp_path), "grad.npz"))
+  assert float(r["worst"]) < 1e-4, float(r["worst"])
+  assert float(r["dloss"]) < 1e-3 and float(r["dpgl"]) < 1e-3
