@@ -4,7 +4,7 @@
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg
 may import this module; the product (`multiverse_amd/`) never does.
 
-**PARITY UNPINNED.**  The reference (`/root/reference/code/pred_models.py`) is
+**How it is pinned.**  The reference (`/root/reference/code/pred_models.py`) is
 TensorFlow-1.15 graph code; TensorFlow is not installable here (no wheel, no
 network), the reference ships no tests / golden vectors / fixtures
 (SURVEY.md §4), and the arithmetic of the recurrent cell lives in an
@@ -16,11 +16,12 @@ un-vendored dependency:
 
 This file restates that published algorithm plus the reference's own wiring,
 function by function, each citing the reference file:line it follows.  It is
-cross-checked against an independent naive fp64 tap-loop twin
-(`oracle/naive_twin.py`) and against the reference's *unmodified*
-`pred_models.py` executed on an eager TF-1 API emulation
-(`oracle/tf1_shim/`, see `oracle/README.md`); the frozen outputs live in
-`tests/golden/`.
+checked against (a) outputs of the reference's *unmodified* `pred_models.py`
+executed on an eager TF-1 API emulation (`oracle/tf1_shim/`, fixtures
+`tests/golden/golden_shim_*.npz`, test `tests/test_reference_pin.py`: forward,
+beam search, loss, every gradient, three Trainer steps) and (b) an independent
+naive fp64 tap-loop twin (`oracle/naive_twin.py`).  The TF primitives themselves
+are emulated, not executed -- see `oracle/README.md` for that caveat.
 
 All tensors are NHWC; arithmetic is float32 (or float64 with dtype=...),
 computed with torch-CPU convolutions.
@@ -483,8 +484,8 @@ def loss_and_grads(params, cfg, feed, dtype=torch.float32):
   names = sorted(P.p)
   gs = torch.autograd.grad(loss, [P.p[n] for n in names], allow_unused=True)
   grads = {n: (None if g is None else g.numpy()) for n, g in zip(names, gs)}
-  return (float(loss), float(wd) if wd is not None else 0.0,
-          [float(l) for l in pgl], grads)
+  return (float(loss.detach()), float(wd.detach()) if wd is not None else 0.0,
+          [float(l.detach()) for l in pgl], grads)
 
 
 def adadelta_init(params):

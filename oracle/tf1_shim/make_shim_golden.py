@@ -1,0 +1,102 @@
+#!/usr/bin/env python
+# coding=utf-8
+"""Freeze outputs of the reference's UNMODIFIED code/pred_models.py (executed
+on the eager TF-1 shim next to this file) into tests/golden/golden_shim_*.npz.
+
+    python oracle/tf1_shim/make_shim_golden.py          # needs /root/reference
+
+These fixtures are what pins oracle/multiverse_oracle.py and, on the GPU box
+(where /root/reference does not exist), the HIP engine itself:
+  - greedy forward (Tester.step): BASELINE config 1 (single scale, N=4), both scales;
+  - beam search: scale 1 N=2 B=5, and the reference's own inference
+    configuration batch 1 / beam 20 / gamma 0.01 / fix_num_timestep 1 on scale 0;
+  - one Trainer.step on both scales and two consecutive steps on scale 1:
+    loss, wd_loss, pred_grid_loss, and for every variable the gradient and the
+    updated value as (sum, sum|.|, max|.|, every STRIDE-th element);
+  - the variable names / shapes the reference code asks tf.get_variable for.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from multiverse_amd import synth  # noqa: E402
+from oracle.tf1_shim import run_reference as rr  # noqa: E402
+
+STRIDE = 997
+
+
+def digest(a):
+  a = np.asarray(a, dtype=np.float32).reshape(-1)
+  return np.concatenate([
+      np.array([a.astype(np.float64).sum(), np.abs(a).astype(np.float64).sum(),
+                np.abs(a).max()], dtype=np.float64),
+      a[::STRIDE].astype(np.float64)])
+
+
+def forward_case(name, cfg, seed, gain, bias):
+  params = synth.make_params(cfg, seed=seed, recurrent_gain=gain, bias_scale=bias)
+  feed = synth.make_feed(cfg, seed=seed)
+  cls, reg, beam = rr.forward(cfg, params, feed)
+  out = {"seed": np.array([seed]), "gain": np.array([gain]), "bias": np.array([bias]),
+         "var_names": np.array(["%s|%s" % (n, ",".join(map(str, s)))
+                                for n, s in rr.variable_names()])}
+  for s in range(len(cfg.scene_grids)):
+    if not cfg.use_grids[s]:
+      assert cls[s] == [] and reg[s] == []
+      continue
+    out["cls_%d" % s] = np.asarray(cls[s])
+    out["reg_%d" % s] = np.asarray(reg[s])
+  if beam is not None:
+    out["beam_logits"], out["beam_ids"], out["beam_logprobs"] = [np.asarray(b) for b in beam]
+  np.savez_compressed(os.path.join(GOLD, name), **out)
+  print("wrote", name, {k: v.shape for k, v in out.items()})
+
+
+def train_case(name, cfg, seed, steps):
+  params = synth.make_params(cfg, seed=seed, recurrent_gain=2.0, bias_scale=0.1)
+  out = {"seed": np.array([seed]), "steps": np.array([steps])}
+  slots, gs = {}, 0
+  for step in range(steps):
+    feed = synth.make_feed(cfg, seed=seed + 100 + step)
+    loss, wd, pgl, grads, params, slots, gs = rr.train_step(cfg, params, feed, slots, gs)
+    out["loss_%d" % step] = np.array([loss, wd] + pgl, dtype=np.float64)
+    for n in sorted(grads):
+      out["grad_%d|%s" % (step, n)] = digest(grads[n])
+    print(name, "step", step, "loss", loss, "global_step", gs)
+  for n in sorted(params):
+    out["param|%s" % n] = digest(params[n])
+  out["global_step"] = np.array([gs])
+  np.savez_compressed(os.path.join(GOLD, name), **out)
+  print("wrote", name)
+
+
+def main():
+  assert rr.available(), "needs the reference checkout (/root/reference)"
+  forward_case("golden_shim_greedy_cfg1.npz",
+               synth.default_config(batch_size=4, use_grids=(1, 0)),
+               synth.SEED_BASE + 0, 3.0, 0.1)
+  forward_case("golden_shim_greedy_both.npz",
+               synth.default_config(batch_size=2, use_grids=(1, 1)),
+               synth.SEED_BASE + 1, 1.0, 0.0)
+  forward_case("golden_shim_beam_s1.npz",
+               synth.default_config(batch_size=2, use_grids=(0, 1), beam_size=5),
+               synth.SEED_BASE + 5, 3.0, 0.1)
+  forward_case("golden_shim_beam20_s0.npz",
+               synth.default_config(batch_size=1, use_grids=(1, 0), beam_size=20),
+               synth.SEED_BASE + 6, 3.0, 0.1)
+  train_case("golden_shim_train_both.npz",
+             synth.default_config(batch_size=2, use_grids=(1, 1), is_train=True),
+             synth.SEED_BASE + 7, 1)
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), is_train=True)
+  cfg.train_num_examples = 2     # decay_steps = 2: the LR staircase moves inside the run
+  train_case("golden_shim_train_s1_3steps.npz", cfg, synth.SEED_BASE + 8, 3)
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,69 @@
+# coding=utf-8
+"""Helpers for the fixtures written by oracle/tf1_shim/make_shim_golden.py
+(outputs of the reference's unmodified pred_models.py on the TF-1 shim)."""
+import os
+
+import numpy as np
+
+from multiverse_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STRIDE = 997
+
+FORWARD_CASES = {
+    "golden_shim_greedy_cfg1.npz": dict(batch_size=4, use_grids=(1, 0)),
+    "golden_shim_greedy_both.npz": dict(batch_size=2, use_grids=(1, 1)),
+    "golden_shim_beam_s1.npz": dict(batch_size=2, use_grids=(0, 1), beam_size=5),
+    "golden_shim_beam20_s0.npz": dict(batch_size=1, use_grids=(1, 0), beam_size=20),
+}
+
+
+def load(name):
+  return np.load(os.path.join(GOLD, name))
+
+
+def forward_case(name):
+  g = load(name)
+  cfg = synth.default_config(**FORWARD_CASES[name])
+  seed = int(g["seed"][0])
+  params = synth.make_params(cfg, seed=seed, recurrent_gain=float(g["gain"][0]),
+                             bias_scale=float(g["bias"][0]))
+  feed = synth.make_feed(cfg, seed=seed)
+  return g, cfg, params, feed
+
+
+def train_case(name):
+  g = load(name)
+  seed, steps = int(g["seed"][0]), int(g["steps"][0])
+  if name == "golden_shim_train_both.npz":
+    cfg = synth.default_config(batch_size=2, use_grids=(1, 1), is_train=True)
+  else:
+    cfg = synth.default_config(batch_size=2, use_grids=(0, 1), is_train=True)
+    cfg.train_num_examples = 2
+  params = synth.make_params(cfg, seed=seed, recurrent_gain=2.0, bias_scale=0.1)
+  feeds = [synth.make_feed(cfg, seed=seed + 100 + s) for s in range(steps)]
+  return g, cfg, params, feeds
+
+
+def digest(a):
+  a = np.asarray(a, dtype=np.float32).reshape(-1)
+  return np.concatenate([
+      np.array([a.astype(np.float64).sum(), np.abs(a).astype(np.float64).sum(),
+                np.abs(a).max()], dtype=np.float64),
+      a[::STRIDE].astype(np.float64)])
+
+
+def digest_err(a, gold):
+  """max |sample - gold sample| / max|gold|, and the relative error of sum|.|"""
+  d = digest(a)
+  scale = max(gold[2], 1e-30)
+  return (float(np.abs(d[3:] - gold[3:]).max() / scale),
+          float(abs(d[1] - gold[1]) / max(gold[1], 1e-30)))
+
+
+def var_table(g):
+  out = {}
+  for s in g["var_names"]:
+    n, shp = str(s).split("|")
+    out[n] = tuple(int(x) for x in shp.split(",")) if shp else ()
+  return out

@@ -1,0 +1,73 @@
+# coding=utf-8
+"""The oracle is pinned by the reference's own code: `golden_shim_*.npz` hold
+outputs of /root/reference/code/pred_models.py executed UNMODIFIED on the
+eager TF-1 shim (oracle/tf1_shim).  Here (CPU) the oracle restatement must
+reproduce them; on the GPU box the HIP engine is held to the same files
+(tests/test_gpu_reference_pin.py)."""
+import numpy as np
+import pytest
+
+from multiverse_amd import synth
+from oracle import multiverse_oracle as oracle
+from oracle.tf1_shim import run_reference as rr
+
+import shim_golden as sg
+
+
+@pytest.mark.parametrize("name", sorted(sg.FORWARD_CASES))
+def test_oracle_forward_equals_reference_run(name):
+  g, cfg, params, feed = sg.forward_case(name)
+  cls, reg, beam = oracle.forward(params, cfg, feed)
+  for s in range(2):
+    if not cfg.use_grids[s]:
+      continue
+    assert np.abs(cls[s] - g["cls_%d" % s]).max() <= 2e-5
+    assert np.abs(reg[s] - g["reg_%d" % s]).max() <= 2e-5
+    assert (cls[s].reshape(cfg.batch_size, 12, -1).argmax(-1) ==
+            g["cls_%d" % s].reshape(cfg.batch_size, 12, -1).argmax(-1)).all()
+  if beam is not None:
+    assert (beam[1] == g["beam_ids"]).all()
+    assert np.abs(beam[0] - g["beam_logits"]).max() <= 2e-5
+    assert np.abs(beam[2] - g["beam_logprobs"]).max() <= 2e-5
+
+
+def test_variable_names_are_the_ones_the_reference_creates():
+  """tf.get_variable names / shapes requested by the reference code (under the
+  shim's TF-1 scoping rules) == the table the engine and synth use."""
+  for name, kw in sg.FORWARD_CASES.items():
+    ref = sg.var_table(sg.load(name))
+    assert ref.pop("global_step") == ()
+    ours = synth.param_shapes(synth.default_config(**kw))
+    if sum(kw["use_grids"]) == 1:   # scene_conv2 exists even when scale 1 is unused
+      pass
+    assert ours == ref, (set(ours) ^ set(ref))
+
+
+@pytest.mark.parametrize("name", ["golden_shim_train_both.npz",
+                                  "golden_shim_train_s1_3steps.npz"])
+def test_oracle_training_equals_reference_trainer(name):
+  g, cfg, params, feeds = sg.train_case(name)
+  p, st = dict(params), oracle.adadelta_init(params)
+  for step, feed in enumerate(feeds):
+    loss, wd, pgl, p, st, grads = oracle.train_step(p, st, step, cfg, feed)
+    ref = g["loss_%d" % step]
+    assert np.allclose([loss, wd] + pgl, ref, rtol=2e-6, atol=1e-6), (loss, ref)
+    for n, gr in grads.items():
+      e_s, e_a = sg.digest_err(gr, g["grad_%d|%s" % (step, n)])
+      assert e_s < 2e-5 and e_a < 1e-4, (n, e_s, e_a)
+  for n in p:
+    e_s, e_a = sg.digest_err(p[n], g["param|%s" % n])
+    assert e_s < 1e-6 and e_a < 1e-6, (n, e_s, e_a)
+  assert int(g["global_step"][0]) == len(feeds)
+
+
+@pytest.mark.skipif(not rr.available(), reason="needs the /root/reference checkout")
+def test_live_reference_run_reproduces_the_fixture():
+  """Re-run the reference's code on the shim and compare bitwise with the
+  committed fixture (guards against a stale golden)."""
+  g, cfg, params, feed = sg.forward_case("golden_shim_beam_s1.npz")
+  cls, reg, beam = rr.forward(cfg, params, feed)
+  assert (np.asarray(cls[1]) == g["cls_1"]).all()
+  assert (np.asarray(reg[1]) == g["reg_1"]).all()
+  assert (np.asarray(beam[1]) == g["beam_ids"]).all()
+  assert (np.asarray(beam[0]) == g["beam_logits"]).all()
