@@ -170,7 +170,23 @@ def test_checkpoint_roundtrip(tmp_path):
   assert total == 21337728
 
 
-def test_trainer_fails_loudly():
+def test_trainer_rejects_unbuilt_switches():
+  """Trainer / mv_train_config: anything outside the published training wiring
+  fails loudly on the host, before any device work."""
   from multiverse_amd import _lib
-  with pytest.raises(_lib.MvError, match="not built"):
-    pred_models.Trainer(None, None)
+  cfg = synth.default_config(batch_size=2, is_train=False)
+  with pytest.raises(_lib.MvError, match="is_train"):
+    pred_models.Trainer(None, cfg)
+  for field, val, msg in (("optimizer", "adam", "adadelta"),
+                          ("train_w_onehot", False, "train_w_onehot"),
+                          ("use_teacher_forcing", True, "train_w_onehot"),
+                          ("use_soft_grid_class", True, "soft_grid"),
+                          ("keep_prob", 0.7, "keep_prob")):
+    cfg = synth.default_config(batch_size=2, is_train=True)
+    setattr(cfg, field, val)
+    with pytest.raises(_lib.MvError, match=msg):
+      _lib.make_train_config(cfg)
+  tc = _lib.make_train_config(synth.default_config(batch_size=20, is_train=True,
+                                                   train_num_examples=1000))
+  assert tc.decay_steps == int(1000 / 20 * 2.0) and tc.do_clip == 1
+  assert abs(tc.clip_gradient_norm - 10.0) < 1e-6 and abs(tc.wd - 0.001) < 1e-9
