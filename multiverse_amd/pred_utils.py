@@ -64,8 +64,7 @@ def process_args(args):
 # ------------------------------------------------------------------ weights
 
 def save_params(path, params):
-  """Checkpoint = .npz keyed by TF-1 variable name, HWIO layout (what
-  tf.train.Saver stores; a TF tensor-bundle reader is SURVEY.md section 8f N1)."""
+  """Light checkpoint = .npz keyed by TF-1 variable name, HWIO layout."""
   np.savez(path, **{k.replace("/", "__"): v for k, v in params.items()})
 
 
@@ -74,24 +73,93 @@ def load_params(path):
     return {k.replace("__", "/"): z[k] for k in z.files}
 
 
+def _find_weights(path):
+  """A weights source from a path: an .npz, a TF checkpoint prefix / .index, or
+  a directory holding either (tf.train.get_checkpoint_state semantics for TF
+  checkpoints, code/pred_utils.py:186-204; newest .npz otherwise)."""
+  if os.path.isdir(path):
+    if os.path.exists(os.path.join(path, "checkpoint")):
+      return "tf", path
+    cands = sorted(f for f in os.listdir(path) if f.endswith(".npz"))
+    if cands:
+      return "npz", os.path.join(path, cands[-1])
+    raise IOError("Model not exists: no checkpoint under %s" % path)
+  if path.endswith(".npz") and os.path.exists(path):
+    return "npz", path
+  if os.path.exists(path + ".index") or (path.endswith(".index") and os.path.exists(path)):
+    return "tf", path
+  raise IOError("Model not exists: %s" % path)
+
+
+def load_weights(path, scope="person_pred"):
+  """{TF variable name: array} under `scope`, optimizer slots and global_step
+  dropped (code/pred_utils.py:166-174, multifuture_inference.py:282-289)."""
+  from multiverse_amd import tf_checkpoint
+  kind, src = _find_weights(path)
+  if kind == "tf":
+    return tf_checkpoint.load_checkpoint(src, scope=scope)
+  return {k: v for k, v in load_params(src).items()
+          if k.split("/")[0] == scope and
+          k.split("/")[-1] not in tf_checkpoint.OPTIMIZER_SLOT_NAMES}
+
+
 def initialize(load, load_best, args, model):
   """code/pred_utils.py:149-205 role: put weights into the model.  `model`
-  plays the session's part.  Only the `person_pred` scope is consumed, like the
-  inference script (code/multifuture_inference.py:287-289)."""
+  plays the session's part.  Reads a TensorFlow checkpoint (the reference's own
+  `tf.train.Saver` files, via multiverse_amd.tf_checkpoint) or an .npz; only the
+  `person_pred` scope is consumed, like the inference script
+  (code/multifuture_inference.py:287-289)."""
   if not load:
     raise ValueError("random initialisation lives in multiverse_amd.synth.make_params")
   path = getattr(args, "load_from", None)
   if path is None:
-    path = args.save_dir_best_model if load_best else args.save_dir_model
-  if os.path.isdir(path):
-    cands = sorted(f for f in os.listdir(path) if f.endswith(".npz"))
-    if not cands:
-      raise IOError("Model not exists: no .npz under %s" % path)
-    path = os.path.join(path, cands[-1])
-  if not os.path.exists(path):
-    raise IOError("Model not exists: %s" % path)
-  params = {k: v for k, v in load_params(path).items() if k.startswith("person_pred/")}
-  model.load_params(params)
+    path = args.save_dir_best if load_best else args.save_dir
+  model.load_params(load_weights(path))
+
+
+class Saver(object):
+  """tf.train.Saver(max_to_keep=5) role (code/train.py:170-171, 222, 244):
+  `save(model, path, global_step)` writes a TensorFlow-format checkpoint with
+  the variables, the Adadelta slots under TF's slot names and global_step, so a
+  run can resume and the reference's own tools can read the weights."""
+
+  def __init__(self, max_to_keep=5):
+    self.max_to_keep = max_to_keep
+
+  def save(self, model, path, global_step=None):
+    from multiverse_amd import tf_checkpoint
+    eng = model.engine
+    variables = model.get_params()
+    try:
+      step = eng.global_step
+      for n in list(variables):
+        variables[n + "/Adadelta"] = eng.get_opt_slot(n, 0)
+        variables[n + "/Adadelta_1"] = eng.get_opt_slot(n, 1)
+    except _lib_error():
+      step = 0                       # inference-only engine: weights only
+    variables["global_step"] = np.asarray(step, dtype="int32")
+    return tf_checkpoint.save_checkpoint(path, variables, global_step=global_step,
+                                         max_to_keep=self.max_to_keep)
+
+  def restore(self, model, path, with_optimizer=True):
+    """Resume: weights + (when present) Adadelta slots and global_step."""
+    from multiverse_amd import tf_checkpoint
+    allv = tf_checkpoint.load_checkpoint(path, skip_optimizer_slots=False)
+    model.load_params({k: v for k, v in allv.items()
+                       if k.startswith("person_pred/") and
+                       k.split("/")[-1] not in tf_checkpoint.OPTIMIZER_SLOT_NAMES})
+    if with_optimizer and "global_step" in allv:
+      eng = model.engine
+      for n, _ in eng.param_specs():
+        if n + "/Adadelta" in allv:
+          eng.set_opt_slot(n, 0, allv[n + "/Adadelta"])
+          eng.set_opt_slot(n, 1, allv[n + "/Adadelta_1"])
+      eng.global_step = int(allv["global_step"])
+
+
+def _lib_error():
+  from multiverse_amd import _lib
+  return _lib.MvError
 
 
 # ------------------------------------------------------------------ data
