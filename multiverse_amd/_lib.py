@@ -128,12 +128,13 @@ def load():
   global _lib
   if _lib is not None:
     return _lib
-  if not os.path.exists(LIB_PATH):
+  path = os.environ.get("MV_LIB_PATH", LIB_PATH)   # A/B builds of the same ABI (tuning)
+  if not os.path.exists(path):
     raise MvError(
         "%s not found: the HIP extension has not been built "
         "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
         "There is no CPU fallback." % LIB_PATH)
-  lib = C.CDLL(LIB_PATH)
+  lib = C.CDLL(path)
   h = C.c_void_p
   lib.mv_last_error.restype = C.c_char_p
   lib.mv_last_error.argtypes = [h]

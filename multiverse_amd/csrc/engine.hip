@@ -57,16 +57,21 @@ struct HipError { std::string msg; };
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
+  T* base = nullptr;     // allocation start (p - pad)
   size_t n = 0;
-  void alloc(size_t count) {
+  // `pad` elements of zeroed slack before and after (operands of the wgrad
+  // kernel, whose masked lanes may read one cell outside the tensor)
+  void alloc(size_t count, size_t pad = 0) {
     if (count <= n && p) return;
     release();
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&base), (count + 2 * pad) * sizeof(T)));
+    if (pad) HIP_CHECK(hipMemset(base, 0, (count + 2 * pad) * sizeof(T)));
+    p = base + pad;
     n = count;
   }
   void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr; n = 0;
+    if (base) (void)hipFree(base);
+    p = nullptr; base = nullptr; n = 0;
   }
   ~DevBuf() { release(); }
   DevBuf() = default;
@@ -1367,7 +1372,9 @@ int mv_op_convlstm_bwd(int device, const float* x, const float* c, const float* 
     const size_t cells = (size_t)M * H * W;
     DevBuf<float> dx_, dc_, dh_, dw, db, dco, dho, dg, ddh, ddc, dwd, dxo, dho2, part, dW,
         dB, tmp;
-    ctx.up(dx_, x, cells * Cx);
+    dx_.alloc(cells * Cx ? cells * Cx : 1, mv::kWgradPad);
+    if (cells * Cx)
+      HIP_CHECK(hipMemcpy(dx_.p, x, cells * Cx * sizeof(float), hipMemcpyHostToDevice));
     ctx.up(db, biases, (size_t)4 * C);
     std::vector<float> packed(mv::convlstm_wpack_elems(Cx, C));
     mv::pack_convlstm_weights(kernel, Cx, C, packed.data());
@@ -1376,7 +1383,7 @@ int mv_op_convlstm_bwd(int device, const float* x, const float* c, const float* 
     mv::pack_convlstm_dgrad_weights(kernel, Cx, C, packedT.data());
     ctx.up(dwd, packedT.data(), packedT.size());
     const bool zero = (c == nullptr && h == nullptr);
-    dc_.alloc(cells * C); dh_.alloc(cells * C);
+    dc_.alloc(cells * C); dh_.alloc(cells * C, mv::kWgradPad);
     if (!zero) {
       MV_REQUIRE(c && h, "c and h must both be given or both be NULL");
       HIP_CHECK(hipMemcpy(dc_.p, c, cells * C * sizeof(float), hipMemcpyHostToDevice));
@@ -1385,7 +1392,7 @@ int mv_op_convlstm_bwd(int device, const float* x, const float* c, const float* 
       HIP_CHECK(hipMemset(dc_.p, 0, cells * C * sizeof(float)));
       HIP_CHECK(hipMemset(dh_.p, 0, cells * C * sizeof(float)));
     }
-    dco.alloc(cells * C); dho.alloc(cells * C); dg.alloc(cells * 4 * C);
+    dco.alloc(cells * C); dho.alloc(cells * C); dg.alloc(cells * 4 * C, mv::kWgradPad);
     ctx.up(ddh, dh_new, cells * C);
     ctx.up(ddc, dc_new, cells * C);
     // forward with saved gate activations
@@ -1411,8 +1418,7 @@ int mv_op_convlstm_bwd(int device, const float* x, const float* c, const float* 
     mv::wgrad_plan(wa, 3072);
     part.alloc(mv::wgrad_partial_elems(wa));
     wa.partial = part.p;
-    hipLaunchKernelGGL(mv::convlstm_wgrad_kernel, dim3(mv::wgrad_blocks(wa)), dim3(256), 0,
-                       ctx.stream, wa);
+    mv::launch_convlstm_wgrad(wa, ctx.stream);
     const size_t ncols = (size_t)9 * (Cx + C) * 4 * C;
     dW.alloc(ncols);
     hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv(ncols, 256)), dim3(256), 0,

@@ -97,16 +97,16 @@ void train_alloc(mv_engine* e) {
     TrainScale& R = t.sc[s];
     const size_t K = S.K, NK = N * K, slots = To + Tp + 1;
     for (int b = 0; b < 2; ++b) {
-      R.hs[b].alloc(slots * NK * C); R.cs[b].alloc(slots * NK * C);
+      R.hs[b].alloc(slots * NK * C, mv::kWgradPad); R.cs[b].alloc(slots * NK * C);
       HIP_CHECK(hipMemset(R.hs[b].p, 0, NK * C * sizeof(float)));   // slot 0: zero state
       HIP_CHECK(hipMemset(R.cs[b].p, 0, NK * C * sizeof(float)));
       R.dh_a[b].alloc(NK * C); R.dh_b[b].alloc(NK * C); R.dc[b].alloc(NK * C);
     }
     auto chain = [&](TrainChain& ch, ConvCell* cell, size_t T, bool need_dx) {
       ch.cell = cell; ch.T = (int)T; ch.Cx = cell->Cx;
-      ch.xs.alloc(T * NK * cell->Cx);
+      ch.xs.alloc(T * NK * cell->Cx, mv::kWgradPad);
       if (need_dx) ch.dxs.alloc(T * NK * cell->Cx);
-      ch.gates.alloc(T * NK * 4 * C);
+      ch.gates.alloc(T * NK * 4 * C, mv::kWgradPad);
       ch.wdpack.alloc(mv::convlstm_dgrad_wpack_elems(cell->Cx, (int)C));
       mv::WgradArgs wa{};
       wa.R = (int)(T * N); wa.H = S.H; wa.W = S.W; wa.Cx = cell->Cx; wa.C = (int)C;
@@ -118,7 +118,7 @@ void train_alloc(mv_engine* e) {
     chain(R.dec[0], &S.dec_cls, Tp, true);
     chain(R.dec[1], &S.dec_reg, Tp, true);
     if (c.use_gnn) {
-      R.hg.alloc(Tp * NK * C);
+      R.hg.alloc(Tp * NK * C, mv::kWgradPad);
       R.gnn_a.alloc(NK * 9); R.gnn_de.alloc(NK * 9); R.gnn_n.alloc(NK);
       R.dsmean.alloc(NK * D);
     }
@@ -420,8 +420,7 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
   const size_t ncols = (size_t)9 * (ch.Cx + C) * 4 * C;
   launch(e, "convlstm_wgrad", 2.0 * cells * 9 * (ch.Cx + C) * 4.0 * C,
          cells * (ch.Cx + 5.0 * C) * 4.0, [&] {
-    hipLaunchKernelGGL(mv::convlstm_wgrad_kernel, dim3(mv::wgrad_blocks(wa)), dim3(256), 0,
-                       e->stream, wa);
+    mv::launch_convlstm_wgrad(wa, e->stream);
   });
   launch(e, "wgrad_reduce", 0, 4.0 * ncols * (wa.nsplit + 1), [&] {
     hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv(ncols, 256)), dim3(256), 0,
