@@ -333,14 +333,36 @@ void convlstm_wgrad_fast_kernel(const WgradArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int N4 = 4 * a.C;
   const int nquads = N4 / (4 * kWgTile);
-  const int tiles_per_split = 9 * a.n_ciblocks * nquads;
-  const int xcd = blockIdx.x & 7;          // split -> XCD pinning, see above
-  int b = blockIdx.x >> 3;
-  const int split = xcd + 8 * (b / tiles_per_split);
-  b = b % tiles_per_split;
-  const int nq = b % nquads; b /= nquads;
-  const int cib = b % a.n_ciblocks;
-  const int tap = b / a.n_ciblocks;
+  // Block order inside one XCD (xcd = id % 8, measured 1:1 on MI355X with
+  // tools/xcc_probe.py): all FULL (h) tiles of its splits, split by split, then
+  // all partial (x) tiles.  The workgroups resident on an XCD at one time then
+  // run at the same speed over the same cell range, so they stay in phase and
+  // share the range's A / G rows through the 4 MiB L2; a partial tile does half
+  // the MFMAs per cell, runs ahead and would pull its rows through L2 a second
+  // time (measured: 9.4 GB fetched per launch for 0.7 GB of operands when the
+  // two kinds were interleaved).
+  const int xcd = blockIdx.x & 7;
+  int j = blockIdx.x >> 3;
+  const int splits_per_xcd = a.nsplit >> 3;
+  const int n_hblocks = a.n_ciblocks - a.n_xblocks;
+  const int n_h_tiles = 9 * n_hblocks * nquads;
+  const int n_x_tiles = 9 * a.n_xblocks * nquads;
+  int sl, cib, tap, nq;
+  if (j < splits_per_xcd * n_h_tiles) {
+    sl = j / n_h_tiles;
+    int t = j - sl * n_h_tiles;
+    nq = t % nquads; t /= nquads;
+    cib = a.n_xblocks + t % n_hblocks;
+    tap = t / n_hblocks;
+  } else {
+    j -= splits_per_xcd * n_h_tiles;
+    sl = j / n_x_tiles;
+    int t = j - sl * n_x_tiles;
+    nq = t % nquads; t /= nquads;
+    cib = t % a.n_xblocks;
+    tap = t / a.n_xblocks;
+  }
+  const int split = xcd + 8 * sl;
   const int n0 = (nq * 4 + wave) * kWgTile;
   if (n0 >= N4) return;
   const bool is_x = cib < a.n_xblocks;

@@ -1479,4 +1479,26 @@ int mv_op_gnn_bwd(int device, const float* h, const float* scene_mean, const flo
   });
 }
 
+// Debug probe (not part of the public header): XCC id of every workgroup of a
+// 1-D launch of `nblocks` x 256 threads -- checks the "linear id % 8 -> XCD"
+// dispatch pattern the XCD-aware block maps rely on for speed.
+__global__ void xcc_probe_kernel(int32_t* out) {
+  if (threadIdx.x == 0) {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    out[blockIdx.x] = (int32_t)(v & 0xf);
+  }
+}
+
+int mv_debug_xcc_map(int device, int32_t nblocks, int32_t* out) {
+  return guarded(nullptr, [&] {
+    OpCtx ctx(device);
+    DevBuf<int32_t> d;
+    d.alloc(nblocks);
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(nblocks), dim3(256), 0, ctx.stream, d.p);
+    HIP_CHECK(hipGetLastError());
+    ctx.down(out, d, (size_t)nblocks);
+  });
+}
+
 }  // extern "C"
