@@ -75,6 +75,10 @@ def main():
   ap.add_argument("--graph", type=int, default=None,
                   help="1: replay the forward as a captured hipGraph "
                        "(default: 0 greedy, 1 beam)")
+  ap.add_argument("--compute", choices=("f32", "f16x3"), default="f32",
+                  help="gate-convolution arithmetic of the inference forward: fp32 MFMA, "
+                       "or f16x3 (two scaled fp16 planes per operand, three fp16 MFMAs "
+                       "per product, fp32 accumulate: fp32-class error)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-batch", type=int, default=8)
   args = ap.parse_args()
@@ -119,6 +123,7 @@ def main():
   eng.set_params(params)
   eng.upload(feed)          # inputs resident in HBM before the timed region
   eng.set_graph_mode(bool(args.graph))
+  eng.set_compute_mode(args.compute)
   if train:
     from multiverse_amd import parallel
     eng.train_init()

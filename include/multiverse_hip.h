@@ -181,6 +181,13 @@ int  mv_get_opt_slot(mv_handle h, const char* tf_name, int32_t slot, float* out,
 int  mv_set_opt_slot(mv_handle h, const char* tf_name, int32_t slot,
                      const float* data, int64_t elems);
 
+/* Arithmetic of the gate convolution in the inference forward:
+ *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32), default;
+ *   1  "f16x3": every fp32 operand as two pre-scaled fp16 planes, each product as
+ *      three fp16 MFMAs accumulating in fp32 -- fp32-roundoff-class error (DESIGN.md
+ *      section 3c) at up to 5.3x the fp32 matrix rate.  Same outputs contract. */
+int  mv_set_compute_mode(mv_handle h, int32_t mode);
+
 /* Replay the forward as a captured hipGraph (one graph per (mode, T_pred, U)):
  * the reference's whole forward is ONE sess.run (pred_models.py:1779), here it
  * is one hipGraphLaunch instead of ~150 kernel launches.  Off by default. */

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "mv_forward_greedy", "mv_forward_beam",
     "mv_upload_inputs", "mv_run_greedy_resident", "mv_run_beam_resident",
     "mv_synchronize", "mv_download_outputs", "mv_download_beam_outputs",
-    "mv_set_graph_mode", "mv_set_profiling", "mv_reset_kernel_stats", "mv_num_kernel_stats",
+    "mv_set_graph_mode", "mv_set_compute_mode", "mv_set_profiling", "mv_reset_kernel_stats", "mv_num_kernel_stats",
     "mv_kernel_stat", "mv_time_greedy_resident", "mv_time_beam_resident",
     "mv_op_convlstm_step", "mv_op_gnn", "mv_op_hidden2grid", "mv_op_beam_step",
     "mv_train_init", "mv_train_step", "mv_train_forward_backward",
@@ -156,6 +156,7 @@ def load():
   lib.mv_download_beam_outputs.argtypes = [h, C.POINTER(mv_beam_outputs)]
   lib.mv_set_profiling.argtypes = [h, C.c_int32]
   lib.mv_set_graph_mode.argtypes = [h, C.c_int32]
+  lib.mv_set_compute_mode.argtypes = [h, C.c_int32]
   lib.mv_reset_kernel_stats.argtypes = [h]
   lib.mv_num_kernel_stats.argtypes = [h]
   lib.mv_kernel_stat.argtypes = [h, C.c_int32, C.c_char_p, C.c_int32,
@@ -526,6 +527,11 @@ class Engine(object):
   def global_step(self, step):
     if self.lib.mv_set_global_step(self.handle, int(step)) != 0:
       raise MvError("mv_train_init has not been called")
+
+  def set_compute_mode(self, mode):
+    """0 / "f32": fp32 MFMA; 1 / "f16x3": split-fp16 matrix pipe at fp32 accuracy."""
+    mode = {"f32": 0, "f16x3": 1}.get(mode, mode)
+    check(self.lib.mv_set_compute_mode(self.handle, int(mode)), self.handle)
 
   def set_graph_mode(self, on):
     check(self.lib.mv_set_graph_mode(self.handle, 1 if on else 0), self.handle)

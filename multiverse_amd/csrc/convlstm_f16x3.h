@@ -1,0 +1,303 @@
+// ConvLSTM step with the gate convolution on the fp16 matrix pipe at fp32
+// accuracy ("f16x3"): every fp32 operand v is carried as two fp16 planes of the
+// pre-scaled value 256 v,
+//     v0 = half(256 v),  v1 = half(256 v - v0)      (|256 v - v0 - v1| <= 2^-22 |256 v|)
+// and every product a*w is formed as  a0 w0 + a0 w1 + a1 w0  by three
+// v_mfma_f32_32x32x16_f16 accumulating in fp32 (fp16 x fp16 products are exact in
+// fp32); the dropped a1 w1 term and the plane residuals are ~2^-22 relative, i.e.
+// fp32-roundoff class.  The accumulators carry 2^16 x the pre-activation and are
+// rescaled (exactly) in the epilogue.  Measured against fp64 on the full forward
+// the error equals the fp32-MFMA path's own; the parity
+// bars (argmax bit-exact, 1e-4 on logits / offsets) are asserted for this path
+// by the same GPU tests.
+//
+// Why: the fp32 MFMA (32x32x2) peaks at 157 TFLOP/s, the fp16 MFMA (32x32x16)
+// at 2.5 PFLOP/s; three fp16 MFMAs per product put the ceiling of this
+// MFMA-bound sweep at 2.5 PF / 3 = 833 "fp32-equivalent" TFLOP/s.
+//
+// Same tile as the fp32 kernel (convlstm_mfma.h): a wave owns 32 cells x 128
+// columns = the four gates of one block of 32 channels, so the LSTM update still
+// runs in the accumulator registers; operands are register-direct.  One k-step
+// is 16 input channels of one tap: A = 2 planes x 16 B of the lane's cell,
+// B = 2 planes x 4 gates x 16 B in fragment order, 12 MFMAs.
+// The regression encoder's 2-channel pixel-offset input (|x| up to 1920, outside
+// the scaled fp16 range) keeps its single fp32 chunk on v_mfma_f32_32x32x2_f32,
+// with weights pre-scaled by 2^16 so that it lands in the same accumulators.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "convlstm_mfma.h"
+
+namespace mv {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kF16Scale = 256.0f;                 // per operand
+constexpr float kF16Unscale = 1.0f / 65536.0f;      // per product
+
+struct ConvLstm16Args {
+  ConvLstmArgs f;              // geometry, fp32 x (x_small only), c, bias, outputs, src rows
+  const _Float16* x16;         // [2 planes][rows*H*W*Cx]   (unused when f.x_small)
+  const _Float16* h16;         // [2 planes][src rows*H*W*C]
+  const _Float16* wp16;        // [cb][kstep][plane][gate][lane][8]
+  const float* wx32;           // x_small: fp32 fragment-order chunk [cb][4][4][64][4], x 2^16
+  int64_t x_plane_stride;      // elements between the two planes
+  int64_t h_plane_stride;
+  int32_t n_xk;                // f16 k-steps taken from x (9 * Cx/16; 0 when x_small)
+  int32_t n_hk;                // f16 k-steps taken from h (9 * C/16; 0 for the zero state)
+  int32_t w_ksteps;            // k-steps per channel block in wp16 (x + all h)
+};
+
+struct ConvLstm16Group {
+  ConvLstm16Args p[kMaxGroup];
+  int32_t block_end[kMaxGroup];
+  int32_t n;
+};
+
+static inline int f16x3_xksteps(int Cx) { return (Cx % 16 == 0) ? 9 * (Cx / 16) : 0; }
+static inline bool f16x3_cx_supported(int Cx) {
+  return Cx == 0 || (Cx % 16) == 0 || 9 * Cx <= kBK;
+}
+static inline size_t f16x3_wpack_elems(int Cx, int C) {   // in halves
+  return (size_t)(C / kChBlock) * (size_t)(f16x3_xksteps(Cx) + 9 * (C / 16)) * 2 * 4 * 64 * 8;
+}
+
+// Host-side pack: TF HWIO kernel [3,3,Cx+C,4C] -> wp16.  k-steps: x channel
+// groups of 16 (group-major, tap-minor), then h groups; element e of lane l is
+// k = 8*(l>>5) + e (the same (half, element) -> k map on the A side, so the
+// hardware's pairing of A and B elements is respected whatever its k labels).
+static inline void pack_f16x3_weights(const float* w, int Cx, int C, _Float16* out) {
+  const int Cin = Cx + C, N4 = 4 * C;
+  const int nxk = f16x3_xksteps(Cx), nk = nxk + 9 * (C / 16);
+  for (int cb = 0; cb < C / kChBlock; ++cb)
+    for (int s = 0; s < nk; ++s) {
+      const bool is_x = s < nxk;
+      const int q = is_x ? s : s - nxk;
+      const int cg = q / 9, tap = q % 9;
+      for (int g = 0; g < 4; ++g)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 8; ++e) {
+            const int k = 8 * (l >> 5) + e;
+            const int ci = (is_x ? 0 : Cx) + cg * 16 + k;
+            const int n = g * C + cb * kChBlock + (l & 31);
+            const float v = w[((size_t)tap * Cin + ci) * N4 + n] * kF16Scale;
+            const _Float16 v0 = (_Float16)v;
+            const _Float16 v1 = (_Float16)(v - (float)v0);
+            const size_t base = ((size_t)cb * nk + s) * 2 * 4 * 64 * 8;
+            out[base + ((size_t)(0 * 4 + g) * 64 + l) * 8 + e] = v0;
+            out[base + ((size_t)(1 * 4 + g) * 64 + l) * 8 + e] = v1;
+          }
+    }
+}
+
+// fp32 -> two scaled fp16 planes (elementwise).
+__global__ void split_planes_kernel(const float* __restrict__ in, _Float16* __restrict__ p0,
+                                    _Float16* __restrict__ p1, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(in)[i];
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 a, b;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float s = v[j] * kF16Scale;
+    const _Float16 h0 = (_Float16)s;
+    a[j] = h0;
+    b[j] = (_Float16)(s - (float)h0);
+  }
+  reinterpret_cast<f16x4*>(p0)[i] = a;
+  reinterpret_cast<f16x4*>(p1)[i] = b;
+}
+
+struct Conv16Frag {
+  f16x8 a0, a1;
+  f16x8 b0[4], b1[4];
+  uint32_t ok;
+};
+
+__device__ __forceinline__ f16x8 mask_f16x8(f16x8 v, uint32_t m) {
+  u32x4 u = __builtin_bit_cast(u32x4, v);
+  u = u & m;
+  return __builtin_bit_cast(f16x8, u);
+}
+
+__device__ __forceinline__ void convlstm16_body(const ConvLstm16Args& p, int block) {
+  const ConvLstmArgs& a = p.f;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int ncb = a.C / kChBlock;
+  const int cb = block % ncb;      // channel block = XCD (speed only)
+  const int mt = block / ncb;
+  const int H = a.H, W = a.W, HW = H * W, C = a.C, Cx = a.Cx;
+  const int M_total = a.rows * HW;
+  const int m_wave = mt * kBlockRows + wave * kWaveRows;
+  if (m_wave >= M_total) return;
+
+  int ypos, xpos, xoff, hoff;
+  {
+    const int m = m_wave + (lane & 31);
+    if (m < M_total) {
+      const int r = m / HW, cell = m - r * HW;
+      const int y = cell / W;
+      ypos = y; xpos = cell - y * W;
+      const int sr = a.src_row_h ? a.src_row_h[r] : r;
+      xoff = r * a.x_row_stride + cell * Cx;
+      hoff = (sr * HW + cell) * C;
+    } else {
+      ypos = -100000; xpos = -100000; xoff = 0; hoff = 0;
+    }
+  }
+  const int k8 = (lane >> 5) * 8;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+
+  // ---- x_small prologue: the packed fp32 chunk (all 9 taps x Cx <= 3 channels)
+  if (a.x_small) {
+    const int khalf = (lane >> 5) * 4;
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wx32 + (size_t)cb * kBN * kBK) + lane;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 b[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b[g] = wsrc[(kk * 4 + g) * 64];
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = kk * 8 + khalf + j;
+        const int tap = k / Cx, ch = k - tap * Cx;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int yy = ypos + dy, xx = xpos + dx;
+        const bool ok = (k < 9 * Cx) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+        int off = xoff + (dy * W + dx) * Cx + ch;
+        off = ok ? off : 0;
+        const float tv = a.x[off];
+        v[j] = ok ? tv : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], b[g][j], acc[g], 0, 0, 0);
+    }
+  }
+
+  // ---- f16 k-steps
+  const int nxk = p.n_xk;
+  const int nsteps = nxk + p.n_hk;
+  const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wp16) +
+                      (size_t)cb * p.w_ksteps * (2 * 4 * 64) + lane;
+  auto load_step = [&](int s, Conv16Frag& f) {
+    const bool is_x = s < nxk;
+    // weights: x k-steps first, then h k-steps (a zero-state step skips the h part,
+    // which sits AFTER the x part, so the index is simply s)
+    const f16x8* wsrc = wblk + (size_t)s * (2 * 4 * 64);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f.b0[g] = wsrc[g * 64];
+      f.b1[g] = wsrc[(4 + g) * 64];
+    }
+    const int q = is_x ? s : s - nxk;
+    const int cg = q / 9, tap = q - cg * 9;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const _Float16* base = is_x ? p.x16 : p.h16;
+    const int64_t pstr = is_x ? p.x_plane_stride : p.h_plane_stride;
+    const int cs = is_x ? Cx : C;
+    const int yy = ypos + dy, xx = xpos + dx;
+    const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+    int off = (is_x ? xoff : hoff) + (dy * W + dx) * cs + cg * 16 + k8;
+    off = ok ? off : 0;
+    f.a0 = *reinterpret_cast<const f16x8*>(base + off);
+    f.a1 = *reinterpret_cast<const f16x8*>(base + pstr + off);
+    f.ok = ok ? 0xffffffffu : 0u;
+  };
+  auto mma_step = [&](const Conv16Frag& f) {
+    const f16x8 a0 = mask_f16x8(f.a0, f.ok), a1 = mask_f16x8(f.a1, f.ok);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, f.b0[g], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, f.b1[g], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, f.b0[g], acc[g], 0, 0, 0);
+  };
+  Conv16Frag f0, f1;
+  if (nsteps > 0) load_step(0, f0);
+  for (int s = 0; s < nsteps; s += 2) {     // nsteps is a multiple of 2 (9*even or 9*16)
+    load_step(min(s + 1, nsteps - 1), f1);
+    mma_step(f0);
+    load_step(min(s + 2, nsteps - 1), f0);
+    if (s + 1 < nsteps) mma_step(f1);
+  }
+
+  // ---- epilogue (as convlstm_mfma.h), accumulators carry 2^16 x the pre-activation
+  const int ch = cb * kChBlock + (lane & 31);
+  const float bi = a.bias[ch], bj = a.bias[C + ch], bf = a.bias[2 * C + ch],
+              bo = a.bias[3 * C + ch];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    const int m = m_wave + row;
+    if (m < M_total) {
+      float cprev = 0.f;
+      if (!a.zero_state) {
+        const int r = m / HW, cell = m - r * HW;
+        const int sr = a.src_row_c ? a.src_row_c[r] : r;
+        cprev = a.c[((size_t)sr * HW + cell) * C + ch];
+      }
+      const float gi = acc[0][reg] * kF16Unscale + bi, gj = acc[1][reg] * kF16Unscale + bj,
+                  gf = acc[2][reg] * kF16Unscale + bf, go = acc[3][reg] * kF16Unscale + bo;
+      const float si = sigm_(gi), tj = tanh_(gj), sf = sigm_(gf + a.forget_bias),
+                  so = sigm_(go);
+      float cn = sf * cprev;
+      cn = cn + si * tj;
+      const float hn = tanh_(cn) * so;
+      a.c_out[(size_t)m * C + ch] = cn;
+      a.h_out[(size_t)m * C + ch] = hn;
+      if (a.gates_out) {
+        float* gp = a.gates_out + (size_t)m * 4 * C + ch;
+        gp[0] = si; gp[C] = tj; gp[2 * C] = sf; gp[3 * C] = so;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2)
+void convlstm_step_f16x3_kernel(const ConvLstm16Group g) {
+  int block = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxGroup - 1; ++i)
+    if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
+  if (pi > 0) block -= g.block_end[pi - 1];
+  switch (pi) {
+    case 0: convlstm16_body(g.p[0], block); break;
+    case 1: convlstm16_body(g.p[1], block); break;
+    case 2: convlstm16_body(g.p[2], block); break;
+    default: convlstm16_body(g.p[3], block); break;
+  }
+}
+
+static inline void launch_convlstm16_steps(const ConvLstm16Args* probs, int n,
+                                           hipStream_t stream) {
+  ConvLstm16Group g{};
+  g.n = n;
+  unsigned total = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = probs[i];
+    total += convlstm_blocks(probs[i].f);
+    g.block_end[i] = (int32_t)total;
+  }
+  for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
+  hipLaunchKernelGGL(convlstm_step_f16x3_kernel, dim3(total), dim3(256), 0, stream, g);
+}
+
+}  // namespace mv

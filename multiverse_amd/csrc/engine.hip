@@ -21,6 +21,7 @@
 
 #include "convlstm_mfma.h"
 #include "convlstm_wgrad.h"
+#include "convlstm_f16x3.h"
 #include "kernels_misc.h"
 #include "train_kernels.h"
 
@@ -96,6 +97,9 @@ struct ConvCell {           // one ConvLSTMCell: packed kernel + biases
   Param* kernel = nullptr;
   Param* biases = nullptr;
   DevBuf<float> wpack;
+  DevBuf<_Float16> wp16;    // f16x3 compute mode: two scaled fp16 planes, fragment order
+  DevBuf<float> wx32;       // f16x3, Cx <= 3: the fp32 x chunk scaled by 2^16
+  bool host_stale = false;  // device copy was updated by the optimizer
   int Cx = 0;
 };
 
@@ -154,6 +158,10 @@ struct mv_engine {
   DevBuf<int32_t> bm_trace;        // [N, B, T]
   DevBuf<float> bm_out_logits;     // [N, B, T, K]
   DevBuf<int32_t> bm_out_ids;      // [N, B, T]
+  // 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3 split on the fp16 matrix pipe
+  int compute_mode = 0;
+  bool force_f32 = false;          // the training forward always runs the fp32 kernel
+  DevBuf<_Float16> px16[mv::kMaxGroup], ph16[mv::kMaxGroup];   // operand planes per group slot
   // hipGraph replay of the forward (one graph per (mode, T_pred, U))
   bool graph_mode = false;
   std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
@@ -357,6 +365,47 @@ void ensure_packed(mv_engine* e, ConvCell& cc) {
                       hipMemcpyHostToDevice));
 }
 
+// f16x3 packs (two scaled fp16 planes in fragment order; the fp32 x chunk of the
+// 2-channel regression-encoder input scaled by 2^16), from the CURRENT weights.
+void ensure_packed16(mv_engine* e, ConvCell& cc) {
+  if (cc.wp16.p) return;
+  const int C = e->cfg.hidden_size;
+  MV_REQUIRE(mv::f16x3_cx_supported(cc.Cx), "f16x3: Cx %d unsupported", cc.Cx);
+  if (cc.host_stale) {
+    HIP_CHECK(hipMemcpy(cc.kernel->host.data(), cc.kernel->dev.p,
+                        cc.kernel->elems() * sizeof(float), hipMemcpyDeviceToHost));
+    cc.host_stale = false;
+  }
+  const bool small = cc.Cx > 0 && 9 * cc.Cx <= mv::kBK;
+  // the h part (and an x part that is a multiple of 16 channels) as fp16 planes
+  const int Cx16 = small ? 0 : cc.Cx;
+  std::vector<_Float16> p16(mv::f16x3_wpack_elems(Cx16, C));
+  if (small) {   // drop the x channels: pack a view of the kernel without them
+    const int Cin = cc.Cx + C, N4 = 4 * C;
+    std::vector<float> wh((size_t)9 * C * N4);
+    for (int t = 0; t < 9; ++t)
+      memcpy(&wh[(size_t)t * C * N4], &cc.kernel->host[((size_t)t * Cin + cc.Cx) * N4],
+             (size_t)C * N4 * sizeof(float));
+    mv::pack_f16x3_weights(wh.data(), 0, C, p16.data());
+    std::vector<float> packed(mv::convlstm_wpack_elems(cc.Cx, C));
+    mv::pack_convlstm_weights(cc.kernel->host.data(), cc.Cx, C, packed.data());
+    const int nch = mv::convlstm_xchunks(cc.Cx) + 9 * (C / mv::kBK);
+    std::vector<float> wx((size_t)(C / mv::kChBlock) * mv::kBN * mv::kBK);
+    for (int cb = 0; cb < C / mv::kChBlock; ++cb)
+      for (int i = 0; i < mv::kBN * mv::kBK; ++i)
+        wx[(size_t)cb * mv::kBN * mv::kBK + i] =
+            packed[((size_t)cb * nch + 0) * mv::kBN * mv::kBK + i] * 65536.0f;
+    cc.wx32.alloc(wx.size());
+    HIP_CHECK(hipMemcpy(cc.wx32.p, wx.data(), wx.size() * sizeof(float),
+                        hipMemcpyHostToDevice));
+  } else {
+    mv::pack_f16x3_weights(cc.kernel->host.data(), cc.Cx, C, p16.data());
+  }
+  cc.wp16.alloc(p16.size());
+  HIP_CHECK(hipMemcpy(cc.wp16.p, p16.data(), p16.size() * sizeof(_Float16),
+                      hipMemcpyHostToDevice));
+}
+
 void ensure_params(mv_engine* e) {
   for (auto& p : e->params)
     MV_REQUIRE(p->set, "parameter %s not set (mv_set_param)", p->name.c_str());
@@ -365,6 +414,9 @@ void ensure_params(mv_engine* e) {
     if (!S.use) continue;
     ensure_packed(e, S.enc_cls); ensure_packed(e, S.enc_reg);
     ensure_packed(e, S.dec_cls); ensure_packed(e, S.dec_reg);
+    if (e->compute_mode == 1)
+      for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
+        ensure_packed16(e, *cc);
   }
 }
 
@@ -393,6 +445,61 @@ ConvLstmArgs conv_problem(mv_engine* e, const ConvCell& cc, const float* x,
   return a;
 }
 
+ConvCell* cell_of_pack(mv_engine* e, const float* wpack) {
+  for (int s = 0; s < e->cfg.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
+      if (cc->wpack.p == wpack) return cc;
+  }
+  throw HipError{"internal: unknown weight pack"};
+}
+
+// f16x3 compute mode: split the fp32 operands of every problem into two scaled
+// fp16 planes (HBM-bound, ~2 % of the step), then one grouped launch of the
+// fp16-MFMA kernel.
+void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
+                          double flops, double bytes) {
+  std::vector<mv::ConvLstm16Args> p16(probs.size());
+  for (size_t i = 0; i < probs.size(); ++i) {
+    const ConvLstmArgs& a = probs[i];
+    ConvCell* cc = cell_of_pack(e, a.wpack);
+    mv::ConvLstm16Args& q = p16[i];
+    q.f = a;
+    q.wp16 = cc->wp16.p;
+    q.wx32 = cc->wx32.p;
+    const size_t cells = (size_t)a.rows * a.H * a.W;
+    q.n_xk = a.x_small ? 0 : mv::f16x3_xksteps(a.Cx);
+    q.n_hk = a.zero_state ? 0 : 9 * (a.C / 16);
+    q.w_ksteps = mv::f16x3_xksteps(a.Cx) + 9 * (a.C / 16);
+    if (a.x_small) q.w_ksteps = 9 * (a.C / 16);
+    q.x16 = nullptr; q.h16 = nullptr;
+    q.x_plane_stride = q.h_plane_stride = 0;
+    if (!a.x_small && a.Cx > 0) {
+      MV_REQUIRE((size_t)a.x_row_stride == (size_t)a.H * a.W * a.Cx,
+                 "internal: f16x3 needs a contiguous x operand");
+      const size_t n = cells * a.Cx;
+      MV_REQUIRE(e->px16[i].n >= 2 * n, "internal: f16x3 x plane scratch too small");
+      q.x16 = e->px16[i].p; q.x_plane_stride = (int64_t)n;
+      launch(e, "split_planes", 0, 8.0 * n, [&] {
+        hipLaunchKernelGGL(mv::split_planes_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0,
+                           e->stream, a.x, e->px16[i].p, e->px16[i].p + n, n / 4);
+      });
+    }
+    if (!a.zero_state) {
+      const size_t n = cells * a.C;     // source rows == rows (beam: permuted, same count)
+      MV_REQUIRE(e->ph16[i].n >= 2 * n, "internal: f16x3 h plane scratch too small");
+      q.h16 = e->ph16[i].p; q.h_plane_stride = (int64_t)n;
+      launch(e, "split_planes", 0, 8.0 * n, [&] {
+        hipLaunchKernelGGL(mv::split_planes_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0,
+                           e->stream, a.h, e->ph16[i].p, e->ph16[i].p + n, n / 4);
+      });
+    }
+  }
+  launch(e, "convlstm_step", flops, bytes, [&] {
+    mv::launch_convlstm16_steps(p16.data(), (int)p16.size(), e->stream);
+  });
+}
+
 // One launch for up to four independent ConvLSTM steps (class / regression
 // chain of each scale advance in lockstep).
 void run_conv_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs) {
@@ -403,6 +510,10 @@ void run_conv_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs) {
     // algorithmic work of the step as the reference computes it (dense)
     flops += 2.0 * M * 9.0 * (a.Cx + a.C) * 4.0 * a.C;
     bytes += M * (a.Cx + 4.0 * a.C) * 4.0;   // x,h,c in; h,c out
+  }
+  if (e->compute_mode == 1 && !e->force_f32) {
+    run_conv_group_f16x3(e, probs, flops, bytes);
+    return;
   }
   launch(e, "convlstm_step", flops, bytes, [&] {
     mv::launch_convlstm_steps(probs.data(), (int)probs.size(), e->stream);
@@ -990,7 +1101,10 @@ int mv_set_param(mv_handle h, const char* tf_name, const float* data,
     for (int s = 0; s < h->cfg.num_scales; ++s) {
       ScaleState& S = h->sc[s];
       for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
-        if (cc->kernel == p) cc->wpack.release();
+        if (cc->kernel == p) {
+          cc->wpack.release(); cc->wp16.release(); cc->wx32.release();
+          cc->host_stale = false;
+        }
     }
   });
 }
@@ -1200,6 +1314,29 @@ int mv_set_opt_slot(mv_handle h, const char* tf_name, int32_t slot, const float*
     float* dst = (slot == 0 ? TS(h).accum.p : TS(h).accum_update.p) +
                  TS(h).goff[param_index(h, p)];
     HIP_CHECK(hipMemcpy(dst, data, p->elems() * sizeof(float), hipMemcpyHostToDevice));
+  });
+}
+
+int mv_set_compute_mode(mv_handle h, int32_t mode) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(mode == 0 || mode == 1, "compute mode %d (0 = fp32 MFMA, 1 = f16x3)", mode);
+    if (mode == 1) {
+      // operand-plane scratch per group slot: even slots class-sized (N*B rows),
+      // odd slots regression-sized (N rows), largest enabled grid
+      const mv_config& c = h->cfg;
+      size_t K = 0;
+      for (int s = 0; s < c.num_scales; ++s)
+        if (h->sc[s].use) K = std::max(K, (size_t)h->sc[s].K);
+      const size_t xc = (size_t)std::max(c.scene_conv_dim, c.emb_size);
+      for (int i = 0; i < mv::kMaxGroup; ++i) {
+        const size_t rows = (size_t)c.batch_size * ((i % 2 == 0) ? c.beam_size : 1);
+        h->px16[i].alloc(2 * rows * K * xc);
+        h->ph16[i].alloc(2 * rows * K * c.hidden_size);
+      }
+    }
+    if (h->compute_mode != mode) h->drop_graphs();
+    h->compute_mode = mode;
   });
 }
 

@@ -251,7 +251,15 @@ ConvLstmArgs train_problem(mv_engine* e, TrainChain& ch, const float* x, const f
 }
 
 // ------------------------------------------------------------ forward (is_train)
+void train_forward_impl(mv_engine* e);
 void train_forward(mv_engine* e) {
+  // the training forward saves fp32 gate activations for the fp32 backward: it
+  // always runs the fp32-MFMA kernel, whatever the inference compute mode
+  e->force_f32 = true;
+  try { train_forward_impl(e); } catch (...) { e->force_f32 = false; throw; }
+  e->force_f32 = false;
+}
+void train_forward_impl(mv_engine* e) {
   const mv_config& c = e->cfg;
   TrainState& t = TS(e);
   const int N = c.batch_size, To = c.obs_len, Tp = e->pred_len, C = c.hidden_size,
@@ -713,6 +721,12 @@ void train_apply(mv_engine* e, float grad_scale) {
                        n);
   }
   train_pack_all(e);
+  for (int s = 0; s < e->cfg.num_scales; ++s) {   // f16x3 packs follow lazily
+    ScaleState& S = e->sc[s];
+    for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg}) {
+      cc->wp16.release(); cc->wx32.release(); cc->host_stale = true;
+    }
+  }
   t.global_step += 1;
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(e->stream));
