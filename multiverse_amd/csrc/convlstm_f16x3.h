@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "convlstm_mfma.h"
 
@@ -270,6 +271,212 @@ __device__ __forceinline__ void convlstm16_body(const ConvLstm16Args& p, int blo
   }
 }
 
+// ---------------------------------------------------------------- v2: B through LDS
+// v1 streams 10 KB of operands per k-step (384 MFMA cycles) per wave from L1:
+// 104 B/clk/CU at full matrix rate against an L1 of 64 B/clk/CU (measured v1:
+// 266 TF-equivalent = 32 % of the fp16 pipe).  The four waves of a workgroup
+// need the SAME weight fragments, so v2 stages them through LDS: each stage of
+// kKpb k-steps (kKpb x 8 KB) is copied global -> LDS once per workgroup
+// (coalesced 16-B loads, one quarter per wave) into a double buffer and read back
+// as fragments with conflict-free ds_read_b128; one barrier per stage.  L1
+// traffic per workgroup and k-step drops from 40 KB to 16 KB.
+#ifndef MV_F16_KPB
+#define MV_F16_KPB 3
+#endif
+constexpr int kKpb = MV_F16_KPB;                 // k-steps per LDS stage (2, 3 or 6 divide every k-step count)
+constexpr int kStageVec = kKpb * 2 * 4 * 64;     // f16x8 elements per stage (kKpb x 8 KB)
+
+__device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int block,
+                                                    f16x8* lds /* [2][kStageVec] */) {
+  const ConvLstmArgs& a = p.f;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int ncb = a.C / kChBlock;
+  const int cb = block % ncb;
+  const int mt = block / ncb;
+  const int H = a.H, W = a.W, HW = H * W, C = a.C, Cx = a.Cx;
+  const int M_total = a.rows * HW;
+  const int m_wave = mt * kBlockRows + wave * kWaveRows;
+  const bool wave_live = m_wave < M_total;     // dead waves still copy and hit barriers
+
+  int ypos, xpos, xoff, hoff;
+  {
+    const int m = m_wave + (lane & 31);
+    if (m < M_total) {
+      const int r = m / HW, cell = m - r * HW;
+      const int y = cell / W;
+      ypos = y; xpos = cell - y * W;
+      const int sr = a.src_row_h ? a.src_row_h[r] : r;
+      xoff = r * a.x_row_stride + cell * Cx;
+      hoff = (sr * HW + cell) * C;
+    } else {
+      ypos = -100000; xpos = -100000; xoff = 0; hoff = 0;
+    }
+  }
+  const int k8 = (lane >> 5) * 8;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+
+  if (a.x_small && wave_live) {
+    const int khalf = (lane >> 5) * 4;
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wx32 + (size_t)cb * kBN * kBK) + lane;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 b[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b[g] = wsrc[(kk * 4 + g) * 64];
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = kk * 8 + khalf + j;
+        const int tap = k / Cx, ch = k - tap * Cx;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int yy = ypos + dy, xx = xpos + dx;
+        const bool ok = (k < 9 * Cx) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+        int off = xoff + (dy * W + dx) * Cx + ch;
+        off = ok ? off : 0;
+        const float tv = a.x[off];
+        v[j] = ok ? tv : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], b[g][j], acc[g], 0, 0, 0);
+    }
+  }
+
+  const int nxk = p.n_xk;
+  const int nsteps = nxk + p.n_hk;
+  const int nstages = nsteps / kKpb;           // every k-step count is a multiple of 18
+  const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wp16) +
+                      (size_t)cb * p.w_ksteps * (2 * 4 * 64);
+  constexpr int kCopy = kStageVec / 256;       // 16-B vectors per thread per stage
+
+  struct AFrag { f16x8 a0, a1; uint32_t ok; };
+  auto load_a = [&](int s, AFrag& f) {
+    const bool is_x = s < nxk;
+    const int q = is_x ? s : s - nxk;
+    const int cg = q / 9, tap = q - cg * 9;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const _Float16* base = is_x ? p.x16 : p.h16;
+    const int64_t pstr = is_x ? p.x_plane_stride : p.h_plane_stride;
+    const int cs = is_x ? Cx : C;
+    const int yy = ypos + dy, xx = xpos + dx;
+    const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+    int off = (is_x ? xoff : hoff) + (dy * W + dx) * cs + cg * 16 + k8;
+    off = ok ? off : 0;
+    f.a0 = *reinterpret_cast<const f16x8*>(base + off);
+    f.a1 = *reinterpret_cast<const f16x8*>(base + pstr + off);
+    f.ok = ok ? 0xffffffffu : 0u;
+  };
+
+  if (nstages > 0) {
+    f16x8 stg[kCopy];
+#pragma unroll
+    for (int i = 0; i < kCopy; ++i) stg[i] = wblk[i * 256 + tid];
+#pragma unroll
+    for (int i = 0; i < kCopy; ++i) lds[i * 256 + tid] = stg[i];
+    AFrag fa;
+    load_a(0, fa);
+    __syncthreads();
+    for (int st = 0; st < nstages; ++st) {
+      const bool more = st + 1 < nstages;
+      const f16x8* buf = lds + (st & 1) * kStageVec;
+#pragma unroll
+      for (int kk = 0; kk < kKpb; ++kk) {
+        const int s = st * kKpb + kk;
+        AFrag fn;
+        load_a(min(s + 1, nsteps - 1), fn);
+        // the next stage's weights are requested AFTER the first k-step's operands:
+        // vmcnt retires in order, and a copy issued at the top of the stage would
+        // sit in front of the A fragment the first MFMAs are waiting for
+        if (kk == 1 && more) {
+          const f16x8* src = wblk + (size_t)(st + 1) * kStageVec;
+#pragma unroll
+          for (int i = 0; i < kCopy; ++i) stg[i] = src[i * 256 + tid];
+        }
+        f16x8 b0[4], b1[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          b0[g] = buf[((kk * 2 + 0) * 4 + g) * 64 + lane];
+          b1[g] = buf[((kk * 2 + 1) * 4 + g) * 64 + lane];
+        }
+        const f16x8 a0 = mask_f16x8(fa.a0, fa.ok), a1 = mask_f16x8(fa.a1, fa.ok);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0[g], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1[g], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[g], acc[g], 0, 0, 0);
+        fa = fn;
+      }
+      if (more) {
+        f16x8* dst = lds + ((st + 1) & 1) * kStageVec;
+#pragma unroll
+        for (int i = 0; i < kCopy; ++i) dst[i * 256 + tid] = stg[i];
+      }
+      __syncthreads();
+    }
+  }
+  if (!wave_live) return;
+
+  const int ch = cb * kChBlock + (lane & 31);
+  const float bi = a.bias[ch], bj = a.bias[C + ch], bf = a.bias[2 * C + ch],
+              bo = a.bias[3 * C + ch];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    const int m = m_wave + row;
+    if (m < M_total) {
+      float cprev = 0.f;
+      if (!a.zero_state) {
+        const int r = m / HW, cell = m - r * HW;
+        const int sr = a.src_row_c ? a.src_row_c[r] : r;
+        cprev = a.c[((size_t)sr * HW + cell) * C + ch];
+      }
+      const float gi = acc[0][reg] * kF16Unscale + bi, gj = acc[1][reg] * kF16Unscale + bj,
+                  gf = acc[2][reg] * kF16Unscale + bf, go = acc[3][reg] * kF16Unscale + bo;
+      const float si = sigm_(gi), tj = tanh_(gj), sf = sigm_(gf + a.forget_bias),
+                  so = sigm_(go);
+      float cn = sf * cprev;
+      cn = cn + si * tj;
+      const float hn = tanh_(cn) * so;
+      a.c_out[(size_t)m * C + ch] = cn;
+      a.h_out[(size_t)m * C + ch] = hn;
+      if (a.gates_out) {
+        float* gp = a.gates_out + (size_t)m * 4 * C + ch;
+        gp[0] = si; gp[C] = tj; gp[2 * C] = sf; gp[3 * C] = so;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2)
+void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
+  __shared__ f16x8 lds[2 * kStageVec];
+  int block = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxGroup - 1; ++i)
+    if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
+  if (pi > 0) block -= g.block_end[pi - 1];
+  switch (pi) {
+    case 0: convlstm16_lds_body(g.p[0], block, lds); break;
+    case 1: convlstm16_lds_body(g.p[1], block, lds); break;
+    case 2: convlstm16_lds_body(g.p[2], block, lds); break;
+    default: convlstm16_lds_body(g.p[3], block, lds); break;
+  }
+}
+
 __global__ __launch_bounds__(256, 2)
 void convlstm_step_f16x3_kernel(const ConvLstm16Group g) {
   int block = blockIdx.x;
@@ -297,7 +504,11 @@ static inline void launch_convlstm16_steps(const ConvLstm16Args* probs, int n,
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
-  hipLaunchKernelGGL(convlstm_step_f16x3_kernel, dim3(total), dim3(256), 0, stream, g);
+  static const int variant = getenv("MV_F16X3_VARIANT") ? atoi(getenv("MV_F16X3_VARIANT")) : 2;
+  if (variant == 1)
+    hipLaunchKernelGGL(convlstm_step_f16x3_kernel, dim3(total), dim3(256), 0, stream, g);
+  else
+    hipLaunchKernelGGL(convlstm_step_f16x3_lds_kernel, dim3(total), dim3(256), 0, stream, g);
 }
 
 }  // namespace mv
