@@ -35,6 +35,7 @@ namespace mv {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kPlanePad = 16;                       // zero halves in front of every operand plane
 constexpr float kF16Scale = 256.0f;                 // per operand
 constexpr float kF16Unscale = 1.0f / 65536.0f;      // per product
 
@@ -44,6 +45,8 @@ struct ConvLstm16Args {
   const _Float16* h16;         // [2 planes][src rows*H*W*C]
   const _Float16* wp16;        // [cb][kstep][plane][gate][lane][8]
   const float* wx32;           // x_small: fp32 fragment-order chunk [cb][4][4][64][4], x 2^16
+  _Float16* h16_out;           // optional: planes of h' for the next step's h operand
+  int64_t h16_out_stride;
   int64_t x_plane_stride;      // elements between the two planes
   int64_t h_plane_stride;
   int32_t n_xk;                // f16 k-steps taken from x (9 * Cx/16; 0 when x_small)
@@ -263,6 +266,12 @@ __device__ __forceinline__ void convlstm16_body(const ConvLstm16Args& p, int blo
       const float hn = tanh_(cn) * so;
       a.c_out[(size_t)m * C + ch] = cn;
       a.h_out[(size_t)m * C + ch] = hn;
+      if (p.h16_out) {
+        const float sc = hn * kF16Scale;
+        const _Float16 h0 = (_Float16)sc;
+        p.h16_out[(size_t)m * C + ch] = h0;
+        p.h16_out[p.h16_out_stride + (size_t)m * C + ch] = (_Float16)(sc - (float)h0);
+      }
       if (a.gates_out) {
         float* gp = a.gates_out + (size_t)m * 4 * C + ch;
         gp[0] = si; gp[C] = tj; gp[2 * C] = sf; gp[3 * C] = so;
@@ -351,30 +360,62 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     }
   }
 
+  // ---- f16 k-steps.  k-step s = (channel group cg, tap); a stage = the three
+  // taps of one image ROW of the stencil (tap = 3 j + kk, j = dy + 1 uniform per
+  // stage, kk = dx + 1 compile-time), so the per-k-step address is one add and
+  // the border handling one select: an out-of-image tap reads the 16 zero halves
+  // that precede every operand plane (kPlanePad) instead of being masked with
+  // eight v_and.  (The first version spent 8.4 non-MFMA instructions per MFMA --
+  // 3.7 VALU + 3.5 SALU -- against ~6 issue slots per 32-cycle MFMA: issue-bound at
+  // 49 % MFMA busy, profiles/r1_f16x3_pmc_v2.json.)
+  static_assert(kKpb == 3, "a stage is one stencil row");
   const int nxk = p.n_xk;
   const int nsteps = nxk + p.n_hk;
-  const int nstages = nsteps / kKpb;           // every k-step count is a multiple of 18
+  const int nstages = nsteps / 3;
+  const int nxst = nxk / 3;
   const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wp16) +
                       (size_t)cb * p.w_ksteps * (2 * 4 * 64);
   constexpr int kCopy = kStageVec / 256;       // 16-B vectors per thread per stage
 
-  struct AFrag { f16x8 a0, a1; uint32_t ok; };
-  auto load_a = [&](int s, AFrag& f) {
-    const bool is_x = s < nxk;
-    const int q = is_x ? s : s - nxk;
-    const int cg = q / 9, tap = q - cg * 9;
-    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-    const _Float16* base = is_x ? p.x16 : p.h16;
-    const int64_t pstr = is_x ? p.x_plane_stride : p.h_plane_stride;
-    const int cs = is_x ? Cx : C;
-    const int yy = ypos + dy, xx = xpos + dx;
-    const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-    int off = (is_x ? xoff : hoff) + (dy * W + dx) * cs + cg * 16 + k8;
-    off = ok ? off : 0;
-    f.a0 = *reinterpret_cast<const f16x8*>(base + off);
-    f.a1 = *reinterpret_cast<const f16x8*>(base + pstr + off);
-    f.ok = ok ? 0xffffffffu : 0u;
+  const bool okx0 = (xpos - 1 >= 0) & (xpos - 1 < W), okx1 = (xpos >= 0) & (xpos < W),
+             okx2 = (xpos + 1 >= 0) & (xpos + 1 < W);
+  // row validity as a bit mask (a 3-way select of captured bools went through
+  // scratch memory and a flat byte load)
+  const int okymask = (int)((ypos - 1 >= 0) & (ypos - 1 < H)) |
+                      ((int)((ypos >= 0) & (ypos < H)) << 1) |
+                      ((int)((ypos + 1 >= 0) & (ypos + 1 < H)) << 2);
+  const int xbase = xoff + k8, hbase = hoff + k8;
+
+  // per-stage address state as plain scalars (a struct of pointers here ended up
+  // in scratch memory and turned the loads into flat_load)
+  auto stage_isx = [&](int st) { return st < nxst; };
+  auto stage_rowoff = [&](int st) {
+    const bool is_x = st < nxst;
+    const int q = is_x ? st : st - nxst;
+    const int cg = q / 3, j = q - cg * 3;
+    return (is_x ? xbase : hbase) + (j - 1) * W * (is_x ? Cx : C) + cg * 16;
   };
+  auto stage_rowok = [&](int st) {
+    const int q = (st < nxst) ? st : st - nxst;
+    const int j = q - (q / 3) * 3;
+    return ((okymask >> j) & 1) != 0;
+  };
+  const _Float16* const x16 = p.x16;
+  const _Float16* const h16 = p.h16;
+  const int64_t xps = p.x_plane_stride, hps = p.h_plane_stride;
+
+#define MV_LOAD_A(ISX, ROWOFF, ROWOK, KK, A0, A1)                                      \
+  do {                                                                                  \
+    const bool ok_ = (ROWOK) & ((KK) == 0 ? okx0 : ((KK) == 1 ? okx1 : okx2));          \
+    const int off_ = ok_ ? (ROWOFF) + ((KK) - 1) * ((ISX) ? Cx : C) : -kPlanePad;       \
+    if (ISX) {                                                                          \
+      A0 = *reinterpret_cast<const f16x8*>(x16 + off_);                                 \
+      A1 = *reinterpret_cast<const f16x8*>(x16 + xps + off_);                           \
+    } else {                                                                            \
+      A0 = *reinterpret_cast<const f16x8*>(h16 + off_);                                 \
+      A1 = *reinterpret_cast<const f16x8*>(h16 + hps + off_);                           \
+    }                                                                                   \
+  } while (0)
 
   if (nstages > 0) {
     f16x8 stg[kCopy];
@@ -382,17 +423,24 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     for (int i = 0; i < kCopy; ++i) stg[i] = wblk[i * 256 + tid];
 #pragma unroll
     for (int i = 0; i < kCopy; ++i) lds[i * 256 + tid] = stg[i];
-    AFrag fa;
-    load_a(0, fa);
+    bool c_isx = stage_isx(0);
+    int c_rowoff = stage_rowoff(0);
+    bool c_rowok = stage_rowok(0);
+    f16x8 fa0, fa1;
+    MV_LOAD_A(c_isx, c_rowoff, c_rowok, 0, fa0, fa1);
     __syncthreads();
     for (int st = 0; st < nstages; ++st) {
       const bool more = st + 1 < nstages;
+      const int stn = more ? st + 1 : st;
+      const bool n_isx = stage_isx(stn);
+      const int n_rowoff = stage_rowoff(stn);
+      const bool n_rowok = stage_rowok(stn);
       const f16x8* buf = lds + (st & 1) * kStageVec;
 #pragma unroll
-      for (int kk = 0; kk < kKpb; ++kk) {
-        const int s = st * kKpb + kk;
-        AFrag fn;
-        load_a(min(s + 1, nsteps - 1), fn);
+      for (int kk = 0; kk < 3; ++kk) {
+        f16x8 fn0, fn1;
+        if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_rowok, kk + 1, fn0, fn1);
+        else MV_LOAD_A(n_isx, n_rowoff, n_rowok, 0, fn0, fn1);   // (re-read at the very end)
         // the next stage's weights are requested AFTER the first k-step's operands:
         // vmcnt retires in order, and a copy issued at the top of the stage would
         // sit in front of the A fragment the first MFMAs are waiting for
@@ -407,18 +455,18 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
           b0[g] = buf[((kk * 2 + 0) * 4 + g) * 64 + lane];
           b1[g] = buf[((kk * 2 + 1) * 4 + g) * 64 + lane];
         }
-        const f16x8 a0 = mask_f16x8(fa.a0, fa.ok), a1 = mask_f16x8(fa.a1, fa.ok);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0[g], acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, b0[g], acc[g], 0, 0, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1[g], acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b1[g], acc[g], 0, 0, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[g], acc[g], 0, 0, 0);
-        fa = fn;
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
+        fa0 = fn0; fa1 = fn1;
       }
+      c_isx = n_isx; c_rowoff = n_rowoff; c_rowok = n_rowok;
       if (more) {
         f16x8* dst = lds + ((st + 1) & 1) * kStageVec;
 #pragma unroll
@@ -427,6 +475,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       __syncthreads();
     }
   }
+#undef MV_LOAD_A
   if (!wave_live) return;
 
   const int ch = cb * kChBlock + (lane & 31);
@@ -452,6 +501,12 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       const float hn = tanh_(cn) * so;
       a.c_out[(size_t)m * C + ch] = cn;
       a.h_out[(size_t)m * C + ch] = hn;
+      if (p.h16_out) {
+        const float sc = hn * kF16Scale;
+        const _Float16 h0 = (_Float16)sc;
+        p.h16_out[(size_t)m * C + ch] = h0;
+        p.h16_out[p.h16_out_stride + (size_t)m * C + ch] = (_Float16)(sc - (float)h0);
+      }
       if (a.gates_out) {
         float* gp = a.gates_out + (size_t)m * 4 * C + ch;
         gp[0] = si; gp[C] = tj; gp[2 * C] = sf; gp[3 * C] = so;

@@ -161,7 +161,24 @@ struct mv_engine {
   // 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3 split on the fp16 matrix pipe
   int compute_mode = 0;
   bool force_f32 = false;          // the training forward always runs the fp32 kernel
-  DevBuf<_Float16> px16[mv::kMaxGroup], ph16[mv::kMaxGroup];   // operand planes per group slot
+  DevBuf<_Float16> px16[mv::kMaxGroup], ph16[mv::kMaxGroup];   // fallback plane scratch per slot
+  // planes that travel with an fp32 operand buffer: producers (conv epilogue, graph
+  // attention, embeddings) emit them, the next conv launch consumes them
+  struct PlaneBuf { _Float16* p; size_t n; bool valid; };
+  std::map<const float*, PlaneBuf> planes;
+  std::vector<std::unique_ptr<DevBuf<_Float16>>> plane_store;
+  _Float16* plane_out(const float* dst, size_t* stride) {   // producer side
+    if (compute_mode != 1 || force_f32) return nullptr;
+    auto it = planes.find(dst);
+    if (it == planes.end()) return nullptr;
+    it->second.valid = true;
+    *stride = it->second.n;
+    return it->second.p;
+  }
+  void plane_invalidate(const float* dst) {
+    auto it = planes.find(dst);
+    if (it != planes.end()) it->second.valid = false;
+  }
   // hipGraph replay of the forward (one graph per (mode, T_pred, U))
   bool graph_mode = false;
   std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
@@ -474,25 +491,45 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     if (a.x_small) q.w_ksteps = 9 * (a.C / 16);
     q.x16 = nullptr; q.h16 = nullptr;
     q.x_plane_stride = q.h_plane_stride = 0;
+    // The conv epilogue CAN emit the planes of h' (h16_out), but its 2-byte
+    // per-row stores cost more (+74 us per launch) than the separate split pass
+    // over the freshly written fp32 h' (64 us): measured, so it stays off.
+    q.h16_out = nullptr;
+    q.h16_out_stride = 0;
+    e->plane_invalidate(a.h_out);
+    auto ready = [&](const float* src) -> const mv_engine::PlaneBuf* {
+      auto it = e->planes.find(src);
+      return (it != e->planes.end() && it->second.valid) ? &it->second : nullptr;
+    };
     if (!a.x_small && a.Cx > 0) {
       MV_REQUIRE((size_t)a.x_row_stride == (size_t)a.H * a.W * a.Cx,
                  "internal: f16x3 needs a contiguous x operand");
       const size_t n = cells * a.Cx;
-      MV_REQUIRE(e->px16[i].n >= 2 * n, "internal: f16x3 x plane scratch too small");
-      q.x16 = e->px16[i].p; q.x_plane_stride = (int64_t)n;
+      if (const auto* pb = ready(a.x)) {
+        q.x16 = pb->p; q.x_plane_stride = (int64_t)pb->n;
+      } else {
+      MV_REQUIRE(e->px16[i].n >= 2 * (n + mv::kPlanePad), "internal: f16x3 x plane scratch");
+      _Float16* p0 = e->px16[i].p + mv::kPlanePad;
+      q.x16 = p0; q.x_plane_stride = (int64_t)(n + mv::kPlanePad);
       launch(e, "split_planes", 0, 8.0 * n, [&] {
         hipLaunchKernelGGL(mv::split_planes_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0,
-                           e->stream, a.x, e->px16[i].p, e->px16[i].p + n, n / 4);
+                           e->stream, a.x, p0, p0 + n + mv::kPlanePad, n / 4);
       });
+      }
     }
     if (!a.zero_state) {
       const size_t n = cells * a.C;     // source rows == rows (beam: permuted, same count)
-      MV_REQUIRE(e->ph16[i].n >= 2 * n, "internal: f16x3 h plane scratch too small");
-      q.h16 = e->ph16[i].p; q.h_plane_stride = (int64_t)n;
+      if (const auto* pb = ready(a.h)) {
+        q.h16 = pb->p; q.h_plane_stride = (int64_t)pb->n;
+      } else {
+      MV_REQUIRE(e->ph16[i].n >= 2 * (n + mv::kPlanePad), "internal: f16x3 h plane scratch");
+      _Float16* p0 = e->ph16[i].p + mv::kPlanePad;
+      q.h16 = p0; q.h_plane_stride = (int64_t)(n + mv::kPlanePad);
       launch(e, "split_planes", 0, 8.0 * n, [&] {
         hipLaunchKernelGGL(mv::split_planes_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0,
-                           e->stream, a.h, e->ph16[i].p, e->ph16[i].p + n, n / 4);
+                           e->stream, a.h, p0, p0 + n + mv::kPlanePad, n / 4);
       });
+      }
     }
   }
   launch(e, "convlstm_step", flops, bytes, [&] {
@@ -572,9 +609,12 @@ void run_encoders(mv_engine* e, Cursors& cur) {
       if (!S.use) continue;
       const size_t total = (size_t)N * S.K * D;
       launch(e, "enc_class_input", 0, 4.0 * total, [&] {
+        size_t pst = 0;
+        _Float16* p16 = e->plane_out(S.xbuf_cls.p, &pst);
         hipLaunchKernelGGL(mv::enc_class_input_kernel, dim3(cdiv(total, 256)),
                            dim3(256), 0, e->stream, e->scene_conv[s].p,
-                           e->obs_scene.p, S.labels.p, S.xbuf_cls.p, N, T, t, S.K, D);
+                           e->obs_scene.p, S.labels.p, S.xbuf_cls.p, N, T, t, S.K, D, p16,
+                           pst);
       });
       // x = grid_obs_regress[:, t] is read in place through the row stride
       const size_t row = (size_t)S.K * 2;
@@ -599,9 +639,11 @@ void run_gnn(mv_engine* e, ScaleState& S, const float* h, const int32_t* src_row
   launch(e, "gnn_attend", cells * (9.0 * 2 * 2 * (c.hidden_size + c.scene_conv_dim) +
                                    9.0 * 2 * c.hidden_size),
          4.0 * cells * (2.0 * c.hidden_size) + 4.0 * (cells / sm_div) * c.scene_conv_dim, [&] {
+    size_t pst = 0;
+    _Float16* p16 = e->plane_out(out, &pst);
     hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
                        e->stream, h, S.scene_mean.p, src_row, out, rows, S.H, S.W,
-                       c.hidden_size, c.scene_conv_dim, sm_div);
+                       c.hidden_size, c.scene_conv_dim, sm_div, p16, pst);
   });
 }
 
@@ -621,9 +663,11 @@ void run_emb_onehot(mv_engine* e, ScaleState& S, const int32_t* ids, int stride,
   const int E = e->cfg.emb_size;
   const size_t total = (size_t)rows * S.K * E;
   launch(e, "grid_emb_onehot", (double)total, 4.0 * total, [&] {
+    size_t pst = 0;
+    _Float16* p16 = e->plane_out(out, &pst);
     hipLaunchKernelGGL(mv::grid_emb_onehot_kernel, dim3(cdiv(total, 256)),
                        dim3(256), 0, e->stream, ids, stride, ids_div, S.emb_cls_W->dev.p,
-                       S.emb_cls_b->dev.p, out, rows, S.H, S.W, E);
+                       S.emb_cls_b->dev.p, out, rows, S.H, S.W, E, p16, pst);
   });
 }
 
@@ -632,9 +676,11 @@ void run_emb_dense(mv_engine* e, ScaleState& S, const float* x, size_t row_strid
   const int E = e->cfg.emb_size;
   const size_t total = (size_t)rows * S.K * E;
   launch(e, "grid_emb_dense", total * 2.0 * 18, 4.0 * total, [&] {
+    size_t pst = 0;
+    _Float16* p16 = e->plane_out(out, &pst);
     hipLaunchKernelGGL(mv::grid_emb_dense_kernel, dim3(cdiv(total, 256)), dim3(256),
                        0, e->stream, x, row_stride, S.emb_reg_W->dev.p,
-                       S.emb_reg_b->dev.p, out, rows, S.H, S.W, 2, E);
+                       S.emb_reg_b->dev.p, out, rows, S.H, S.W, 2, E, p16, pst);
   });
 }
 
@@ -771,6 +817,7 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
       hipLaunchKernelGGL(tile_rows_kernel, dim3(cdiv(total4, 256)), dim3(256), 0,
                          e->stream, S.cls_c[cc].p, S.cls_c[cc ^ 1].p, row4, B, total4);
     });
+    e->plane_invalidate(S.cls_h[cc ^ 1].p);   // fp32 copy only: planes are re-split
     cur.cls[s] ^= 1;
   }
   HIP_CHECK(hipMemsetAsync(e->bm_lp[0].p, 0, (size_t)R * sizeof(float), e->stream));
@@ -1331,10 +1378,31 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
       const size_t xc = (size_t)std::max(c.scene_conv_dim, c.emb_size);
       for (int i = 0; i < mv::kMaxGroup; ++i) {
         const size_t rows = (size_t)c.batch_size * ((i % 2 == 0) ? c.beam_size : 1);
-        h->px16[i].alloc(2 * rows * K * xc);
-        h->ph16[i].alloc(2 * rows * K * c.hidden_size);
+        // [pad | plane 0 | pad | plane 1], pads zero (out-of-image taps read them)
+        h->px16[i].alloc(2 * (rows * K * xc + mv::kPlanePad));
+        h->ph16[i].alloc(2 * (rows * K * c.hidden_size + mv::kPlanePad));
+        HIP_CHECK(hipMemset(h->px16[i].p, 0, h->px16[i].n * sizeof(_Float16)));
+        HIP_CHECK(hipMemset(h->ph16[i].p, 0, h->ph16[i].n * sizeof(_Float16)));
       }
     }
+    if (mode == 1 && h->planes.empty()) {
+      for (int s = 0; s < h->cfg.num_scales; ++s) {
+        ScaleState& S = h->sc[s];
+        if (!S.use) continue;
+        for (DevBuf<float>* b : {&S.cls_h[0], &S.cls_h[1], &S.reg_h[0], &S.reg_h[1],
+                                 &S.cls_hg, &S.xbuf_cls, &S.xbuf_reg}) {
+          if (!b->p) continue;
+          h->plane_store.emplace_back(new DevBuf<_Float16>());
+          DevBuf<_Float16>& pb = *h->plane_store.back();
+          pb.alloc(2 * (b->n + mv::kPlanePad));
+          HIP_CHECK(hipMemset(pb.p, 0, pb.n * sizeof(_Float16)));
+          // p -> first element of plane 0; plane stride n + pad puts a zero pad in
+          // front of plane 1 as well
+          h->planes[b->p] = mv_engine::PlaneBuf{pb.p + mv::kPlanePad, b->n + mv::kPlanePad, false};
+        }
+      }
+    }
+    for (auto& kv : h->planes) kv.second.valid = false;
     if (h->compute_mode != mode) h->drop_graphs();
     h->compute_mode = mode;
   });

@@ -10,6 +10,17 @@ namespace mv {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// f16x3 compute mode (convlstm_f16x3.h): a producer of a ConvLSTM operand can
+// emit the two pre-scaled fp16 planes of its output next to the fp32 value, so
+// that no separate split pass is needed.  p16 == nullptr: off.
+__device__ __forceinline__ void emit_planes(_Float16* p16, size_t stride, size_t idx, float v) {
+  if (!p16) return;
+  const float s = v * 256.0f;
+  const _Float16 h0 = (_Float16)s;
+  p16[idx] = h0;
+  p16[stride + idx] = (_Float16)(s - (float)h0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -73,7 +84,8 @@ __global__ void enc_class_input_kernel(const float* __restrict__ conv,
                                        const int32_t* __restrict__ obs_scene,
                                        const int32_t* __restrict__ labels,
                                        float* __restrict__ out, int N, int T,
-                                       int t, int K, int D) {
+                                       int t, int K, int D, _Float16* p16 = nullptr,
+                                       size_t p16_stride = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per = (size_t)K * D;
   if (idx >= (size_t)N * per) return;
@@ -84,6 +96,7 @@ __global__ void enc_class_input_kernel(const float* __restrict__ conv,
   if (cell == labels[n * T + t])
     v = conv[(size_t)obs_scene[n * T + t] * per + off];
   out[idx] = v;
+  emit_planes(p16, p16_stride, idx, v);
 }
 
 // ---------------------------------------------------------------- grid_emb
@@ -96,7 +109,8 @@ __global__ void grid_emb_dense_kernel(const float* __restrict__ x,
                                       const float* __restrict__ w,
                                       const float* __restrict__ b,
                                       float* __restrict__ out, int M, int H,
-                                      int W, int P, int E) {
+                                      int W, int P, int E, _Float16* p16 = nullptr,
+                                      size_t p16_stride = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)M * H * W * E;
   if (idx >= total) return;
@@ -117,7 +131,9 @@ __global__ void grid_emb_dense_kernel(const float* __restrict__ x,
         acc = fmaf(ip[p], w[((ky * 3 + kx) * P + p) * E + e], acc);
     }
   }
-  out[idx] = tanhf(acc + b[e]);
+  const float v = tanhf(acc + b[e]);
+  out[idx] = v;
+  emit_planes(p16, p16_stride, idx, v);
 }
 
 // One-hot input in closed form: the cell at offset (dy,dx) from the hot cell
@@ -131,7 +147,8 @@ __global__ void grid_emb_onehot_kernel(const int32_t* __restrict__ ids,
                                        const float* __restrict__ w,
                                        const float* __restrict__ b,
                                        float* __restrict__ out, int M, int H,
-                                       int W, int E) {
+                                       int W, int E, _Float16* p16 = nullptr,
+                                       size_t p16_stride = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)M * H * W * E;
   if (idx >= total) return;
@@ -146,7 +163,9 @@ __global__ void grid_emb_onehot_kernel(const int32_t* __restrict__ ids,
   float acc = 0.f;
   if (dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1)
     acc = w[((1 - dy) * 3 + (1 - dx)) * E + e];  // P == 1
-  out[idx] = tanhf(acc + b[e]);
+  const float v = tanhf(acc + b[e]);
+  out[idx] = v;
+  emit_planes(p16, p16_stride, idx, v);
 }
 
 // ---------------------------------------------------------------- graph attention
@@ -165,7 +184,7 @@ void gnn_attend_kernel(const float* __restrict__ h,
                        const float* __restrict__ scene_mean,
                        const int32_t* __restrict__ src_row,
                        float* __restrict__ out, int M, int H, int W, int C,
-                       int D, int sm_div) {
+                       int D, int sm_div, _Float16* p16 = nullptr, size_t p16_stride = 0) {
   const int lane = threadIdx.x & 63;
   const size_t cell_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int K = H * W;
@@ -225,6 +244,20 @@ void gnn_attend_kernel(const float* __restrict__ h,
   }
   f32x4_t o = {hi[0] + node[0], hi[1] + node[1], hi[2] + node[2], hi[3] + node[3]};
   *reinterpret_cast<f32x4_t*>(out + ((size_t)m * K + cell) * C + lane * 4) = o;
+  if (p16) {
+    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+    f16x4_t a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sc = o[j] * 256.0f;
+      const _Float16 h0 = (_Float16)sc;
+      a[j] = h0;
+      b[j] = (_Float16)(sc - (float)h0);
+    }
+    const size_t idx = ((size_t)m * K + cell) * C + lane * 4;
+    *reinterpret_cast<f16x4_t*>(p16 + idx) = a;
+    *reinterpret_cast<f16x4_t*>(p16 + p16_stride + idx) = b;
+  }
 }
 
 // ---------------------------------------------------------------- hidden2grid

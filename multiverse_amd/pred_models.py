@@ -85,6 +85,14 @@ class Model(object):
     self.beam_size = getattr(config, "beam_size", 1)
     self._check_config(config)
     self.engine = _lib.Engine(config, device=gpuid)
+    # gate-convolution arithmetic of the inference forward: "f16x3" (default; fp32
+    # operands as two pre-scaled fp16 planes, three fp16 MFMAs per product, fp32
+    # accumulate -- fp32-class error, same parity bars) or "f32" (fp32 MFMA);
+    # config.compute_mode or the MV_COMPUTE environment variable override it
+    import os
+    self.compute_mode = getattr(config, "compute_mode", None) or \
+        os.environ.get("MV_COMPUTE", "f16x3")
+    self.engine.set_compute_mode(self.compute_mode)
     self.global_step = 0
     # names of the fetches, kept for callers that introspect them
     self.grid_pred_decoded = ["grid_pred_decoded_%d" % i
