@@ -218,8 +218,9 @@ def main():
   # of this same command (FETCH_SIZE and WRITE_SIZE cannot share a pass on
   # gfx950); bench.py cannot collect PMCs itself, so it quotes the committed
   # profile when the workload matches, else null.
-  pmc_path = os.path.join(ROOT, "profiles", "r1_convlstm_pmc.json")
-  if args.batch == 64 and not beam and not train and not f16 and os.path.exists(pmc_path):
+  pmc_name = "r1_f16x3_pmc_convlstm_step.json" if f16 else "r1_convlstm_pmc.json"
+  pmc_path = os.path.join(ROOT, "profiles", pmc_name)
+  if args.batch == 64 and not beam and not train and os.path.exists(pmc_path):
     with open(pmc_path) as f:
       pmc = json.load(f)
     hb = pmc.get("hbm_bytes_per_launch")
@@ -227,7 +228,7 @@ def main():
       roofline["traffic"] = round(hb["total_corrected"] / 1e6, 1)
       roofline["traffic_unit"] = "MB HBM per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
       roofline["traffic_raw_MB"] = round(hb["total_raw"] / 1e6, 1)
-      roofline["traffic_source"] = "profiles/r1_convlstm_pmc.json"
+      roofline["traffic_source"] = "profiles/" + pmc_name
       roofline["alg_MB_per_launch"] = round(conv["bytes"] / conv["launches"] / 1e6, 1)
 
   if beam:
@@ -250,8 +251,11 @@ def main():
     metric = ("trajectories/sec (8-obs/12-pred, multi-scale 18x32+9x16 grid, "
               "greedy forward)")
     workload = ("BASELINE configs[1]: multi-scale 18x32+9x16 (scene 36x64x11), "
-                "batch %d/GPU, fp32 forward-only, beam 1, obs 8 / pred 12%s"
-                % (args.batch, ", hipGraph replay" if args.graph else ""))
+                "batch %d/GPU, fp32 forward-only, beam 1, obs 8 / pred 12%s; gate "
+                "convolution on %s"
+                % (args.batch, ", hipGraph replay" if args.graph else "",
+                   "the fp16 matrix pipe (f16x3 split, fp32-class error)" if
+                   args.compute == "f16x3" else "the fp32 matrix pipe"))
   out = {
       "metric": metric,
       "value": round(value, 2),
