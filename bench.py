@@ -98,11 +98,17 @@ def main():
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs an MI355X; no HIP device visible "
                      "(there is no CPU fallback)")
+  # MV_BENCH_BACKEND=gloo lets several ranks share ONE GPU (control-flow check of the
+  # multi-rank path on a single-GPU box; RCCL refuses duplicate devices)
+  backend = os.environ.get("MV_BENCH_BACKEND", "nccl")
+  if backend != "nccl":
+    local_rank = local_rank % torch.cuda.device_count()
+  red_dev = "cuda" if backend == "nccl" else "cpu"
   torch.cuda.set_device(local_rank)
   use_dist = world > 1
   if use_dist:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="nccl")  # RCCL; barrier + max only
+    dist.init_process_group(backend=backend)  # nccl == RCCL; barrier + max only
 
   beam = args.workload == "beam"
   train = args.workload == "train"
@@ -157,7 +163,7 @@ def main():
   barrier()
   elapsed = time.perf_counter() - t0
   if use_dist:
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -296,7 +302,7 @@ def main():
     barrier()
     el = time.perf_counter() - t1
     if use_dist:
-      tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+      tt = torch.tensor([el], dtype=torch.float64, device=red_dev)
       dist.all_reduce(tt, op=dist.ReduceOp.MAX)
       el = float(tt.item())
     out["fp32_mfma_reference"] = {

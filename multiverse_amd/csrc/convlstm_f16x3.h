@@ -96,6 +96,43 @@ static inline void pack_f16x3_weights(const float* w, int Cx, int C, _Float16* o
     }
 }
 
+// Device-side twin of pack_f16x3_weights (run after every optimizer step): one
+// thread per (cb, k-step, gate, lane, e); writes both planes.
+__global__ void pack_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
+                                  int Cx_total, int Cx16, int C, size_t total) {
+  // Cx_total: x channels in the HWIO kernel; Cx16: x channels packed as f16 k-steps
+  // (0 when the x part stays on the fp32 chunk)
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx & 7;
+  const int l = (idx >> 3) & 63;
+  const int g = (idx >> 9) & 3;
+  const size_t t = idx >> 11;                    // cb * nk + s
+  const int nxk = 9 * (Cx16 / 16), nk = nxk + 9 * (C / 16);
+  const int s = t % nk, cb = t / nk;
+  const bool is_x = s < nxk;
+  const int q = is_x ? s : s - nxk;
+  const int cg = q / 9, tap = q - cg * 9;
+  const int k = 8 * (l >> 5) + e;
+  const int ci = (is_x ? 0 : Cx_total) + cg * 16 + k;
+  const int n = g * C + cb * kChBlock + (l & 31);
+  const int Cin = Cx_total + C, N4 = 4 * C;
+  const float v = w[((size_t)tap * Cin + ci) * N4 + n] * kF16Scale;
+  const _Float16 v0 = (_Float16)v;
+  const size_t base = t * (2 * 4 * 64 * 8);
+  out[base + ((size_t)(0 * 4 + g) * 64 + l) * 8 + e] = v0;
+  out[base + ((size_t)(1 * 4 + g) * 64 + l) * 8 + e] = (_Float16)(v - (float)v0);
+}
+
+// x_small: the fp32 x chunk of the fp32 fragment pack, scaled by 2^16
+__global__ void scale_xchunk_kernel(const float* __restrict__ wpack, float* __restrict__ wx32,
+                                    int nch, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t cb = idx / (kBN * kBK), i = idx - cb * (kBN * kBK);
+  wx32[idx] = wpack[(cb * nch + 0) * (size_t)(kBN * kBK) + i] * 65536.0f;
+}
+
 // fp32 -> two scaled fp16 planes (elementwise).
 __global__ void split_planes_kernel(const float* __restrict__ in, _Float16* __restrict__ p0,
                                     _Float16* __restrict__ p1, size_t n4) {

@@ -209,6 +209,25 @@ void run_pack(mv_engine* e, TrainChain& ch) {
     hipLaunchKernelGGL(mv::pack_dgrad_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
                        e->stream, cc.kernel->dev.p, ch.wdpack.p, Cx, C, nch, total);
   }
+  cc.host_stale = true;     // the host copy no longer matches the device weights
+  if (e->compute_mode == 1) {   // f16x3 planes of the updated kernel, on the device
+    const bool small = Cx > 0 && 9 * Cx <= mv::kBK;
+    const int Cx16 = small ? 0 : Cx;
+    const size_t halves = mv::f16x3_wpack_elems(Cx16, C);
+    cc.wp16.alloc(halves);
+    const size_t threads = halves / 2;
+    hipLaunchKernelGGL(mv::pack_f16x3_kernel, dim3(cdiv(threads, 256)), dim3(256), 0,
+                       e->stream, cc.kernel->dev.p, cc.wp16.p, Cx, Cx16, C, threads);
+    if (small) {
+      const size_t n = (size_t)(C / mv::kChBlock) * mv::kBN * mv::kBK;
+      const int nch = mv::convlstm_xchunks(Cx) + 9 * (C / mv::kBK);
+      cc.wx32.alloc(n);
+      hipLaunchKernelGGL(mv::scale_xchunk_kernel, dim3(cdiv(n, 256)), dim3(256), 0, e->stream,
+                         cc.wpack.p, cc.wx32.p, nch, n);
+    }
+  } else {
+    cc.wp16.release(); cc.wx32.release();   // rebuilt lazily if the mode is switched on
+  }
 }
 
 void train_pack_all(mv_engine* e) {
@@ -251,15 +270,10 @@ ConvLstmArgs train_problem(mv_engine* e, TrainChain& ch, const float* x, const f
 }
 
 // ------------------------------------------------------------ forward (is_train)
-void train_forward_impl(mv_engine* e);
+// The training forward runs in the engine's compute mode (f16x3: the gate
+// convolutions on the fp16 matrix pipe, saving the same fp32 gate activations);
+// dgrad and wgrad stay on the fp32 MFMA.
 void train_forward(mv_engine* e) {
-  // the training forward saves fp32 gate activations for the fp32 backward: it
-  // always runs the fp32-MFMA kernel, whatever the inference compute mode
-  e->force_f32 = true;
-  try { train_forward_impl(e); } catch (...) { e->force_f32 = false; throw; }
-  e->force_f32 = false;
-}
-void train_forward_impl(mv_engine* e) {
   const mv_config& c = e->cfg;
   TrainState& t = TS(e);
   const int N = c.batch_size, To = c.obs_len, Tp = e->pred_len, C = c.hidden_size,
@@ -721,12 +735,6 @@ void train_apply(mv_engine* e, float grad_scale) {
                        n);
   }
   train_pack_all(e);
-  for (int s = 0; s < e->cfg.num_scales; ++s) {   // f16x3 packs follow lazily
-    ScaleState& S = e->sc[s];
-    for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg}) {
-      cc->wp16.release(); cc->wx32.release(); cc->host_stale = true;
-    }
-  }
   t.global_step += 1;
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(e->stream));

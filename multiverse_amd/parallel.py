@@ -102,7 +102,12 @@ def allreduce_engine_grads(engine, device_index=None):
   if device_index is None:
     device_index = torch.cuda.current_device()
   t = engine_grad_tensor(engine, device_index)
-  dist.all_reduce(t, op=dist.ReduceOp.SUM)
+  if dist.get_backend() == "nccl":
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)       # RCCL, in place on the engine's buffer
+  else:                                            # gloo (single-GPU control-flow checks)
+    h = t.cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+    t.copy_(h)
   torch.cuda.synchronize(device_index)
 
 

@@ -93,13 +93,18 @@ def _train_case(use_grids, N, seed, gnn=True):
   return cfg, params, feed
 
 
-@pytest.mark.parametrize("use_grids,N,gnn", [((0, 1), 3, True), ((1, 1), 2, True),
-                                               ((0, 1), 2, False)])
-def test_gradients_match_oracle(built_lib, use_grids, N, gnn):
-  """tf.gradients(loss, trainable_variables): every parameter tensor."""
+@pytest.mark.parametrize("use_grids,N,gnn,mode", [((0, 1), 3, True, "f32"),
+                                                    ((1, 1), 2, True, "f32"),
+                                                    ((0, 1), 2, False, "f32"),
+                                                    ((1, 1), 2, True, "f16x3")])
+def test_gradients_match_oracle(built_lib, use_grids, N, gnn, mode):
+  """tf.gradients(loss, trainable_variables): every parameter tensor.  mode f16x3:
+  the training forward's gate convolutions run on the fp16 matrix pipe (same
+  tolerances), the backward on the fp32 MFMA."""
   cfg, params, feed = _train_case(use_grids, N, 1, gnn)
   eng = built_lib.Engine(cfg, device=0)
   eng.set_params(params)
+  eng.set_compute_mode(mode)
   eng.train_init()
   loss, wd, pgl = eng.train_forward_backward(feed)
   oloss, owd, opgl, ograds = oracle.loss_and_grads(params, cfg, feed)
@@ -121,14 +126,17 @@ def test_gradients_match_oracle(built_lib, use_grids, N, gnn):
   assert worst < 2e-3
 
 
-def test_train_steps_match_oracle(built_lib):
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+def test_train_steps_match_oracle(built_lib, mode):
   """Three Trainer.step calls: losses, updated variables, Adadelta slots and
   global_step; then the inference forward with the trained weights (device-side
-  weight repack) against the oracle with the oracle-trained weights."""
+  weight repack, fp32 and f16x3 packs) against the oracle with the oracle-trained
+  weights."""
   cfg, params, feed = _train_case((0, 1), 2, 2)
   cfg.train_num_examples = 2      # decay_steps = 2 -> the staircase LR moves at step 2
   eng = built_lib.Engine(cfg, device=0)
   eng.set_params(params)
+  eng.set_compute_mode(mode)
   eng.train_init()
   p, st = dict(params), oracle.adadelta_init(params)
   feeds = [synth.make_feed(cfg, seed=synth.SEED_BASE + 70 + i) for i in range(3)]
