@@ -249,10 +249,13 @@ def main():
               "training step)")
     workload = ("BASELINE configs[2]: multi-scale 18x32+9x16 (scene 36x64x11), "
                 "batch %d/GPU (global %d), fp32 training step = forward + CE/Huber/wd "
-                "loss + backward + %s + clip + Adadelta" % (
+                "loss + backward + %s + clip + Adadelta; gate convolutions: %s" % (
                     args.batch, args.batch * world,
                     "RCCL all-reduce of the 21.3M-float gradient buffer" if world > 1
-                    else "no all-reduce (1 rank)"))
+                    else "no all-reduce (1 rank)",
+                    "forward and dgrad on the fp16 matrix pipe (f16x3, fp32-class error), "
+                    "wgrad on the fp32 matrix pipe" if args.compute == "f16x3"
+                    else "fp32 matrix pipe"))
   else:
     metric = ("trajectories/sec (8-obs/12-pred, multi-scale 18x32+9x16 grid, "
               "greedy forward)")
@@ -275,7 +278,9 @@ def main():
       "vs_baseline": None,
       "dtype": ("f16x3 (fp32 operands as two pre-scaled fp16 planes, 3 fp16 MFMAs per "
                 "product, fp32 accumulate and state; measured error vs fp64 <= the fp32-MFMA "
-                "path's, argmax / beam ids bit-exact)" if f16 else "f32"),
+                "path's, argmax / beam ids bit-exact)" if f16 else
+                "f16x3 forward + dgrad, f32 wgrad / state / optimizer" if
+                (train and args.compute == "f16x3") else "f32"),
       "data": "synthetic (seeded AR(1) trajectories, rectangle scene masks, "
               "random-init weights with the reference's initialisers)",
       "config": {"workload": workload,

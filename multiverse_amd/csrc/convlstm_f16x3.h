@@ -45,6 +45,7 @@ struct ConvLstm16Args {
   const _Float16* h16;         // [2 planes][src rows*H*W*C]
   const _Float16* wp16;        // [cb][kstep][plane][gate][lane][8]
   const float* wx32;           // x_small: fp32 fragment-order chunk [cb][4][4][64][4], x 2^16
+  const int32_t* g_exp;        // dgrad: exponent e of the G planes' scale 2^e
   _Float16* h16_out;           // optional: planes of h' for the next step's h operand
   int64_t h16_out_stride;
   int64_t x_plane_stride;      // elements between the two planes
@@ -332,13 +333,17 @@ __device__ __forceinline__ void convlstm16_body(const ConvLstm16Args& p, int blo
 constexpr int kKpb = MV_F16_KPB;                 // k-steps per LDS stage (2, 3 or 6 divide every k-step count)
 constexpr int kStageVec = kKpb * 2 * 4 * 64;     // f16x8 elements per stage (kKpb x 8 KB)
 
+// EPI = kEpiLstm (forward, NG = 4) or kEpiStore (dgrad: the operand "h" is the gate
+// gradient G with 4C channels, the columns are input channels; NG active 32-column
+// sub-blocks in this column block; result scaled back by 2^-(8 + *g_exp)).
+template <int EPI, int NG>
 __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int block,
                                                     f16x8* lds /* [2][kStageVec] */) {
   const ConvLstmArgs& a = p.f;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int ncb = a.C / kChBlock;
+  const int ncb = a.n_colblocks;
   const int cb = block % ncb;
   const int mt = block / ncb;
   const int H = a.H, W = a.W, HW = H * W, C = a.C, Cx = a.Cx;
@@ -362,13 +367,13 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   }
   const int k8 = (lane >> 5) * 8;
 
-  f32x16 acc[4];
+  f32x16 acc[NG];
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
 
-  if (a.x_small && wave_live) {
+  if constexpr (EPI == kEpiLstm) if (a.x_small && wave_live) {
     const int khalf = (lane >> 5) * 4;
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wx32 + (size_t)cb * kBN * kBK) + lane;
 #pragma unroll
@@ -412,7 +417,17 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   const int nxst = nxk / 3;
   const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wp16) +
                       (size_t)cb * p.w_ksteps * (2 * 4 * 64);
-  constexpr int kCopy = kStageVec / 256;       // 16-B vectors per thread per stage
+  constexpr int kSV = 3 * 2 * NG * 64;         // 16-B vectors per stage (NG sub-blocks)
+  constexpr int kCopy = (kSV + 255) / 256;     // per thread
+  // stage vector v = ((kk*2 + plane)*NG + g)*64 + lane  ->  its place in the pack,
+  // which keeps four sub-block slots per (k-step, plane)
+  auto pack_index = [&](int st, int v) -> size_t {
+    const int ln = v & 63;
+    int t = v >> 6;
+    const int g = t % NG; t /= NG;
+    const int plane = t & 1, kk = t >> 1;
+    return ((size_t)(st * 3 + kk) * 2 + plane) * 256 + g * 64 + ln;
+  };
 
   const bool okx0 = (xpos - 1 >= 0) & (xpos - 1 < W), okx1 = (xpos >= 0) & (xpos < W),
              okx2 = (xpos + 1 >= 0) & (xpos + 1 < W);
@@ -457,9 +472,11 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   if (nstages > 0) {
     f16x8 stg[kCopy];
 #pragma unroll
-    for (int i = 0; i < kCopy; ++i) stg[i] = wblk[i * 256 + tid];
+    for (int i = 0; i < kCopy; ++i)
+      if (i * 256 + tid < kSV) stg[i] = wblk[pack_index(0, i * 256 + tid)];
 #pragma unroll
-    for (int i = 0; i < kCopy; ++i) lds[i * 256 + tid] = stg[i];
+    for (int i = 0; i < kCopy; ++i)
+      if (i * 256 + tid < kSV) lds[i * 256 + tid] = stg[i];
     bool c_isx = stage_isx(0);
     int c_rowoff = stage_rowoff(0);
     bool c_rowok = stage_rowok(0);
@@ -482,24 +499,24 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         // vmcnt retires in order, and a copy issued at the top of the stage would
         // sit in front of the A fragment the first MFMAs are waiting for
         if (kk == 1 && more) {
-          const f16x8* src = wblk + (size_t)(st + 1) * kStageVec;
 #pragma unroll
-          for (int i = 0; i < kCopy; ++i) stg[i] = src[i * 256 + tid];
+          for (int i = 0; i < kCopy; ++i)
+            if (i * 256 + tid < kSV) stg[i] = wblk[pack_index(st + 1, i * 256 + tid)];
         }
-        f16x8 b0[4], b1[4];
+        f16x8 b0[NG], b1[NG];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          b0[g] = buf[((kk * 2 + 0) * 4 + g) * 64 + lane];
-          b1[g] = buf[((kk * 2 + 1) * 4 + g) * 64 + lane];
+        for (int g = 0; g < NG; ++g) {
+          b0[g] = buf[((kk * 2 + 0) * NG + g) * 64 + lane];
+          b1[g] = buf[((kk * 2 + 1) * NG + g) * 64 + lane];
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < NG; ++g)
           acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, b0[g], acc[g], 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < NG; ++g)
           acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b1[g], acc[g], 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < NG; ++g)
           acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
         fa0 = fn0; fa1 = fn1;
       }
@@ -507,7 +524,8 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       if (more) {
         f16x8* dst = lds + ((st + 1) & 1) * kStageVec;
 #pragma unroll
-        for (int i = 0; i < kCopy; ++i) dst[i * 256 + tid] = stg[i];
+        for (int i = 0; i < kCopy; ++i)
+          if (i * 256 + tid < kSV) dst[i * 256 + tid] = stg[i];
       }
       __syncthreads();
     }
@@ -515,40 +533,63 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
 #undef MV_LOAD_A
   if (!wave_live) return;
 
-  const int ch = cb * kChBlock + (lane & 31);
-  const float bi = a.bias[ch], bj = a.bias[C + ch], bf = a.bias[2 * C + ch],
-              bo = a.bias[3 * C + ch];
+  if constexpr (EPI == kEpiStore) {
+    const float scale = ldexpf(1.0f, -(8 + (p.g_exp ? p.g_exp[0] : 0)));
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    const int m = m_wave + row;
-    if (m < M_total) {
-      float cprev = 0.f;
-      if (!a.zero_state) {
-        const int r = m / HW, cell = m - r * HW;
-        const int sr = a.src_row_c ? a.src_row_c[r] : r;
-        cprev = a.c[((size_t)sr * HW + cell) * C + ch];
+    for (int g = 0; g < NG; ++g) {
+      const int col = cb * kBN + g * 32 + (lane & 31);
+      float* dst = nullptr;
+      int stride = 0, cc = col;
+      if (col < a.out0_cols) { dst = a.out0; stride = a.out0_cols; }
+      else if (col - a.out0_cols < a.out1_cols) {
+        dst = a.out1; stride = a.out1_cols; cc = col - a.out0_cols;
       }
-      const float gi = acc[0][reg] * kF16Unscale + bi, gj = acc[1][reg] * kF16Unscale + bj,
-                  gf = acc[2][reg] * kF16Unscale + bf, go = acc[3][reg] * kF16Unscale + bo;
-      const float si = sigm_(gi), tj = tanh_(gj), sf = sigm_(gf + a.forget_bias),
-                  so = sigm_(go);
-      float cn = sf * cprev;
-      cn = cn + si * tj;
-      const float hn = tanh_(cn) * so;
-      a.c_out[(size_t)m * C + ch] = cn;
-      a.h_out[(size_t)m * C + ch] = hn;
-      if (p.h16_out) {
-        const float sc = hn * kF16Scale;
-        const _Float16 h0 = (_Float16)sc;
-        p.h16_out[(size_t)m * C + ch] = h0;
-        p.h16_out[p.h16_out_stride + (size_t)m * C + ch] = (_Float16)(sc - (float)h0);
-      }
-      if (a.gates_out) {
-        float* gp = a.gates_out + (size_t)m * 4 * C + ch;
-        gp[0] = si; gp[C] = tj; gp[2 * C] = sf; gp[3 * C] = so;
+      if (dst) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+          const int m = m_wave + row;
+          if (m < M_total) dst[(size_t)m * stride + cc] = acc[g][reg] * scale;
+        }
       }
     }
+  } else {
+  const int ch = cb * kChBlock + (lane & 31);
+    const float bi = a.bias[ch], bj = a.bias[C + ch], bf = a.bias[2 * C + ch],
+                bo = a.bias[3 * C + ch];
+  #pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      const int m = m_wave + row;
+      if (m < M_total) {
+        float cprev = 0.f;
+        if (!a.zero_state) {
+          const int r = m / HW, cell = m - r * HW;
+          const int sr = a.src_row_c ? a.src_row_c[r] : r;
+          cprev = a.c[((size_t)sr * HW + cell) * C + ch];
+        }
+        const float gi = acc[0][reg] * kF16Unscale + bi, gj = acc[1][reg] * kF16Unscale + bj,
+                    gf = acc[2][reg] * kF16Unscale + bf, go = acc[3][reg] * kF16Unscale + bo;
+        const float si = sigm_(gi), tj = tanh_(gj), sf = sigm_(gf + a.forget_bias),
+                    so = sigm_(go);
+        float cn = sf * cprev;
+        cn = cn + si * tj;
+        const float hn = tanh_(cn) * so;
+        a.c_out[(size_t)m * C + ch] = cn;
+        a.h_out[(size_t)m * C + ch] = hn;
+        if (p.h16_out) {
+          const float sc = hn * kF16Scale;
+          const _Float16 h0 = (_Float16)sc;
+          p.h16_out[(size_t)m * C + ch] = h0;
+          p.h16_out[p.h16_out_stride + (size_t)m * C + ch] = (_Float16)(sc - (float)h0);
+        }
+        if (a.gates_out) {
+          float* gp = a.gates_out + (size_t)m * 4 * C + ch;
+          gp[0] = si; gp[C] = tj; gp[2 * C] = sf; gp[3 * C] = so;
+        }
+      }
+    }
+  
   }
 }
 
@@ -562,11 +603,120 @@ void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
     if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
   if (pi > 0) block -= g.block_end[pi - 1];
   switch (pi) {
-    case 0: convlstm16_lds_body(g.p[0], block, lds); break;
-    case 1: convlstm16_lds_body(g.p[1], block, lds); break;
-    case 2: convlstm16_lds_body(g.p[2], block, lds); break;
-    default: convlstm16_lds_body(g.p[3], block, lds); break;
+    case 0: convlstm16_lds_body<kEpiLstm, 4>(g.p[0], block, lds); break;
+    case 1: convlstm16_lds_body<kEpiLstm, 4>(g.p[1], block, lds); break;
+    case 2: convlstm16_lds_body<kEpiLstm, 4>(g.p[2], block, lds); break;
+    default: convlstm16_lds_body<kEpiLstm, 4>(g.p[3], block, lds); break;
   }
+}
+
+// dgrad on the fp16 matrix pipe: d[h | x] = conv3x3(G, W^T flipped) with G as two
+// fp16 planes under a per-tensor power-of-two scale (split_planes_dyn_kernel) and
+// the transposed, tap-flipped kernel as planes (pack_f16x3_dgrad_kernel).
+__device__ __forceinline__ void convlstm16_dgrad_dispatch(const ConvLstm16Args& p, int block,
+                                                          f16x8* lds) {
+  const int cb = block % p.f.n_colblocks;
+  if (cb == p.f.n_colblocks - 1 && p.f.ng_last == 1)
+    convlstm16_lds_body<kEpiStore, 1>(p, block, lds);
+  else if (cb == p.f.n_colblocks - 1 && p.f.ng_last == 2)
+    convlstm16_lds_body<kEpiStore, 2>(p, block, lds);
+  else
+    convlstm16_lds_body<kEpiStore, 4>(p, block, lds);
+}
+
+__global__ __launch_bounds__(256, 2)
+void convlstm_dgrad_f16x3_kernel(const ConvLstm16Group g) {
+  __shared__ f16x8 lds[2 * kStageVec];
+  int block = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxGroup - 1; ++i)
+    if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
+  if (pi > 0) block -= g.block_end[pi - 1];
+  switch (pi) {
+    case 0: convlstm16_dgrad_dispatch(g.p[0], block, lds); break;
+    case 1: convlstm16_dgrad_dispatch(g.p[1], block, lds); break;
+    case 2: convlstm16_dgrad_dispatch(g.p[2], block, lds); break;
+    default: convlstm16_dgrad_dispatch(g.p[3], block, lds); break;
+  }
+}
+
+static inline void launch_convlstm16_dgrads(const ConvLstm16Args* probs, int n,
+                                            hipStream_t stream) {
+  ConvLstm16Group g{};
+  g.n = n;
+  unsigned total = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = probs[i];
+    total += convlstm_blocks(probs[i].f);
+    g.block_end[i] = (int32_t)total;
+  }
+  for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
+  hipLaunchKernelGGL(convlstm_dgrad_f16x3_kernel, dim3(total), dim3(256), 0, stream, g);
+}
+
+// Pack of the transposed, tap-flipped kernel as fp16 planes (cf.
+// pack_convlstm_dgrad_weights): k-step s = (group of 16 gate columns, tap'),
+// k = 8*(l>>5) + e -> gate column n = grp*16 + k; output column
+// col = cb*128 + g*32 + (l&31): col < C -> input channel Cx + col, else col - C.
+__global__ void pack_f16x3_dgrad_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
+                                        int Cx, int C, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx & 7;
+  const int l = (idx >> 3) & 63;
+  const int g = (idx >> 9) & 3;
+  const size_t t = idx >> 11;                    // cb * nk + s
+  const int nk = 9 * (4 * C / 16);
+  const int s = t % nk, cb = t / nk;
+  const int grp = s / 9, tap = s - grp * 9;
+  const int k = 8 * (l >> 5) + e;
+  const int n = grp * 16 + k;
+  const int col = cb * kBN + g * 32 + (l & 31);
+  const int Cin = Cx + C, N4 = 4 * C;
+  int ci = -1;
+  if (col < C) ci = Cx + col;
+  else if (col - C < Cx) ci = col - C;
+  const float v = (ci < 0) ? 0.f : w[((size_t)(8 - tap) * Cin + ci) * N4 + n] * kF16Scale;
+  const _Float16 v0 = (_Float16)v;
+  const size_t base = t * (2 * 4 * 64 * 8);
+  out[base + ((size_t)(0 * 4 + g) * 64 + l) * 8 + e] = v0;
+  out[base + ((size_t)(1 * 4 + g) * 64 + l) * 8 + e] = (_Float16)(v - (float)v0);
+}
+static inline size_t f16x3_dgrad_wpack_elems(int Cx, int C) {   // in halves
+  return (size_t)convlstm_dgrad_colblocks(Cx, C) * 9 * (size_t)(4 * C / 16) * 2 * 4 * 64 * 8;
+}
+
+// fp32 -> two fp16 planes under a per-tensor power-of-two scale 2^e chosen from
+// the tensor's max |.| (tracked as int bits by lstm_gate_bwd_kernel): the largest
+// element lands in [2^13, 2^14).  e is stored for the consumer's epilogue.
+__global__ void split_planes_dyn_kernel(const float* __restrict__ in, _Float16* __restrict__ p0,
+                                        _Float16* __restrict__ p1, size_t n4,
+                                        const int32_t* __restrict__ max_bits,
+                                        int32_t* __restrict__ exp_out) {
+  int mb = 0;
+  for (int i = 0; i < 64; ++i) mb = max(mb, max_bits[i]);    // uniform: scalar loads
+  const float mx = __int_as_float(mb);
+  int e = 0;
+  if (mx > 0.f) {
+    e = 13 - ilogbf(mx);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  }
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) exp_out[0] = e;
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(in)[i];
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 a, b;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float s = ldexpf(v[j], e);
+    const _Float16 h0 = (_Float16)s;
+    a[j] = h0;
+    b[j] = (_Float16)(s - (float)h0);
+  }
+  reinterpret_cast<f16x4*>(p0)[i] = a;
+  reinterpret_cast<f16x4*>(p1)[i] = b;
 }
 
 __global__ __launch_bounds__(256, 2)

@@ -393,6 +393,12 @@ void ensure_packed16(mv_engine* e, ConvCell& cc) {
                         cc.kernel->elems() * sizeof(float), hipMemcpyDeviceToHost));
     cc.host_stale = false;
   }
+  {   // 256 w must stay inside fp16 (|w| < 255): true of any sane checkpoint, checked anyway
+    float mx = 0.f;
+    for (float v : cc.kernel->host) mx = std::max(mx, std::fabs(v));
+    MV_REQUIRE(mx * mv::kF16Scale < 60000.f, "f16x3: |%s| reaches %g, outside the scaled "
+               "fp16 range; use compute mode f32", cc.kernel->name.c_str(), mx);
+  }
   const bool small = cc.Cx > 0 && 9 * cc.Cx <= mv::kBK;
   // the h part (and an x part that is a multiple of 16 channels) as fp16 planes
   const int Cx16 = small ? 0 : cc.Cx;

@@ -22,6 +22,7 @@ struct TrainChain {               // one ConvLSTM cell over its T steps
   DevBuf<float> dxs;              // [T][N][K][Cx]   d x (then d pre-activation)
   DevBuf<float> gates;            // [T][N][K][4C]   activations -> G in place
   DevBuf<float> wdpack;           // dgrad weight pack
+  DevBuf<_Float16> wd16;          // f16x3 compute mode: the same as two fp16 planes
 };
 
 struct TrainScale {
@@ -52,6 +53,10 @@ struct TrainState {
   DevBuf<float> partial;          // split-K partials / reduction scratch
   DevBuf<float> scratch;          // second-stage scratch
   DevBuf<float> losses;           // [2*MV_MAX_SCALES + 1 + nW] device scalars
+  // f16x3 dgrad: planes of the gate gradients of the current step per group slot,
+  // max |G| bits and scale exponents per (launch slot, step)
+  DevBuf<_Float16> g16[mv::kMaxGroup];
+  DevBuf<int32_t> gmax, gexp;
   bool have_grads = false;
   bool targets_ready = false;
   mv_losses last{};
@@ -137,6 +142,17 @@ void train_alloc(mv_engine* e) {
     const size_t n = (size_t)N * To * e->conv_h[i] * e->conv_w[i] * D;
     t.dys[i].alloc(n); t.dpre_sc[i].alloc(n);
   }
+  {
+    size_t K = 0;
+    for (int s = 0; s < c.num_scales; ++s)
+      if (e->sc[s].use) K = std::max(K, (size_t)e->sc[s].K);
+    for (int i = 0; i < mv::kMaxGroup; ++i) {
+      t.g16[i].alloc(2 * (N * K * 4 * C + mv::kPlanePad));
+      HIP_CHECK(hipMemset(t.g16[i].p, 0, t.g16[i].n * sizeof(_Float16)));
+    }
+    t.gmax.alloc(mv::kMaxGroup * 64 * 64);   // [slot][64 spread addresses]
+    t.gexp.alloc(mv::kMaxGroup * 64);
+  }
   t.partial.alloc(max_partial);
   t.scratch.alloc((size_t)1 << 20);
   t.losses.alloc(64);
@@ -218,6 +234,12 @@ void run_pack(mv_engine* e, TrainChain& ch) {
     const size_t threads = halves / 2;
     hipLaunchKernelGGL(mv::pack_f16x3_kernel, dim3(cdiv(threads, 256)), dim3(256), 0,
                        e->stream, cc.kernel->dev.p, cc.wp16.p, Cx, Cx16, C, threads);
+    {
+      const size_t dh = mv::f16x3_dgrad_wpack_elems(Cx, C);
+      ch.wd16.alloc(dh);
+      hipLaunchKernelGGL(mv::pack_f16x3_dgrad_kernel, dim3(cdiv(dh / 2, 256)), dim3(256), 0,
+                         e->stream, cc.kernel->dev.p, ch.wd16.p, Cx, C, dh / 2);
+    }
     if (small) {
       const size_t n = (size_t)(C / mv::kChBlock) * mv::kBN * mv::kBK;
       const int nch = mv::convlstm_xchunks(Cx) + 9 * (C / mv::kBK);
@@ -408,21 +430,58 @@ void train_losses(mv_engine* e) {
 
 // ------------------------------------------------------------ backward
 void run_gate_bwd(mv_engine* e, float* gates, const float* c_prev, const float* c_new,
-                  const float* dh, float* dc, size_t cells, int C) {
+                  const float* dh, float* dc, size_t cells, int C,
+                  int32_t* gmax_bits = nullptr) {
   const size_t total = cells * C;
   launch(e, "lstm_gate_bwd", 30.0 * total, 4.0 * total * 13, [&] {
     hipLaunchKernelGGL(mv::lstm_gate_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
-                       e->stream, gates, c_prev, c_new, dh, dc, total, C);
+                       e->stream, gates, c_prev, c_new, dh, dc, total, C, gmax_bits);
+  });
+}
+
+// f16x3 compute mode: G of every problem -> two fp16 planes under its own
+// power-of-two scale, then the grouped dgrad launch on the fp16 matrix pipe.
+void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
+                           const std::vector<TrainChain*>& chains,
+                           const std::vector<int>& slots, double fl, double by) {
+  TrainState& t = TS(e);
+  std::vector<mv::ConvLstm16Args> p16(probs.size());
+  for (size_t i = 0; i < probs.size(); ++i) {
+    const ConvLstmArgs& a = probs[i];
+    mv::ConvLstm16Args& q = p16[i];
+    q = mv::ConvLstm16Args{};
+    q.f = a;
+    const size_t n = (size_t)a.rows * a.H * a.W * a.C;      // a.C == 4C here
+    MV_REQUIRE(t.g16[i].n >= 2 * (n + mv::kPlanePad), "internal: G plane scratch");
+    _Float16* p0 = t.g16[i].p + mv::kPlanePad;
+    launch(e, "split_planes", 0, 8.0 * n, [&] {
+      hipLaunchKernelGGL(mv::split_planes_dyn_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0,
+                         e->stream, a.h, p0, p0 + n + mv::kPlanePad, n / 4,
+                         t.gmax.p + (size_t)slots[i] * 64, t.gexp.p + slots[i]);
+    });
+    q.h16 = p0; q.h_plane_stride = (int64_t)(n + mv::kPlanePad);
+    q.x16 = nullptr; q.x_plane_stride = 0;
+    q.wp16 = chains[i]->wd16.p;
+    q.n_xk = 0; q.n_hk = 9 * (a.C / 16); q.w_ksteps = q.n_hk;
+    q.g_exp = t.gexp.p + slots[i];
+  }
+  launch(e, "convlstm_dgrad", fl, by, [&] {
+    mv::launch_convlstm16_dgrads(p16.data(), (int)p16.size(), e->stream);
   });
 }
 
 void run_dgrad_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
-                     const std::vector<double>& flops) {
+                     const std::vector<double>& flops,
+                     const std::vector<TrainChain*>& chains, const std::vector<int>& slots) {
   if (probs.empty()) return;
   double fl = 0, by = 0;
   for (size_t i = 0; i < probs.size(); ++i) {
     fl += flops[i];
     by += (double)probs[i].rows * probs[i].H * probs[i].W * (probs[i].C + 288.0) * 4.0;
+  }
+  if (e->compute_mode == 1) {
+    run_dgrad_group_f16x3(e, probs, chains, slots, fl, by);
+    return;
   }
   launch(e, "convlstm_dgrad", fl, by, [&] {
     mv::launch_convlstm_dgrads(probs.data(), (int)probs.size(), e->stream);
@@ -476,10 +535,18 @@ void train_backward(mv_engine* e) {
       HIP_CHECK(hipMemsetAsync(R.dsmean.p, 0, (size_t)N * e->sc[s].K * D * sizeof(float),
                                e->stream));
   }
+  const bool f16 = e->compute_mode == 1;
+  if (f16) {
+    MV_REQUIRE(Tp <= 32 && To <= 32, "f16x3 training: at most 32 steps per chain");
+    HIP_CHECK(hipMemsetAsync(t.gmax.p, 0, t.gmax.n * sizeof(int32_t), e->stream));
+  }
+  // gmax / gexp slot of (group position i, step): i * 64 + step (steps < 64)
   // ---- decoders, t = Tp-1 .. 0
   for (int ts = Tp - 1; ts >= 0; --ts) {
     std::vector<ConvLstmArgs> probs;
     std::vector<double> flops;
+    std::vector<TrainChain*> chains;
+    std::vector<int> slots;
     for (int s = 0; s < c.num_scales; ++s) {
       ScaleState& S = e->sc[s];
       if (!S.use) continue;
@@ -494,8 +561,11 @@ void train_backward(mv_engine* e) {
                       true);
       for (int b = 0; b < 2; ++b) {
         float* G = R.dec[b].gates.p + (size_t)ts * 4 * NKC;
+        const int gs = (int)probs.size() * 64 + ts;
         run_gate_bwd(e, G, R.cs[b].p + slot * NKC, R.cs[b].p + (slot + 1) * NKC,
-                     dh_a[s][b], R.dc[b].p, NK, C);
+                     dh_a[s][b], R.dc[b].p, NK, C, f16 ? t.gmax.p + (size_t)gs * 64 : nullptr);
+        chains.push_back(&R.dec[b]);
+        slots.push_back(gs);
         ConvLstmArgs a;
         mv::convlstm_dgrad_args(a, G, R.dec[b].wdpack.p, dh_b[s][b],
                                 R.dec[b].dxs.p + (size_t)ts * NK * E, N, S.H, S.W, E, C,
@@ -504,7 +574,7 @@ void train_backward(mv_engine* e) {
         flops.push_back(2.0 * NK * 9 * (E + C) * 4.0 * C);
       }
     }
-    run_dgrad_group(e, probs, flops);
+    run_dgrad_group(e, probs, flops, chains, slots);
     for (int s = 0; s < c.num_scales; ++s) {
       ScaleState& S = e->sc[s];
       if (!S.use) continue;
@@ -548,6 +618,8 @@ void train_backward(mv_engine* e) {
   for (int ts = To - 1; ts >= 0; --ts) {
     std::vector<ConvLstmArgs> probs;
     std::vector<double> flops;
+    std::vector<TrainChain*> chains;
+    std::vector<int> slots;
     for (int s = 0; s < c.num_scales; ++s) {
       ScaleState& S = e->sc[s];
       if (!S.use) continue;
@@ -555,10 +627,14 @@ void train_backward(mv_engine* e) {
       const size_t NK = (size_t)N * S.K, NKC = NK * C;
       for (int b = 0; b < 2; ++b) {
         float* G = R.enc[b].gates.p + (size_t)ts * 4 * NKC;
-        run_gate_bwd(e, G, R.cs[b].p + ts * NKC, R.cs[b].p + (ts + 1) * NKC, dh_a[s][b],
-                     R.dc[b].p, NK, C);
+        const int gs = (int)probs.size() * 64 + 32 + ts;    // encoder steps: 32..
         const bool need_dh = ts > 0, need_dx = (b == 0);
+        run_gate_bwd(e, G, R.cs[b].p + ts * NKC, R.cs[b].p + (ts + 1) * NKC, dh_a[s][b],
+                     R.dc[b].p, NK, C,
+                     (f16 && (need_dh || need_dx)) ? t.gmax.p + (size_t)gs * 64 : nullptr);
         if (!need_dh && !need_dx) continue;
+        chains.push_back(&R.enc[b]);
+        slots.push_back(gs);
         ConvLstmArgs a;
         mv::convlstm_dgrad_args(a, G, R.enc[b].wdpack.p, dh_b[s][b],
                                 need_dx ? R.enc[b].dxs.p + (size_t)ts * NK * D : nullptr,
@@ -567,7 +643,7 @@ void train_backward(mv_engine* e) {
         flops.push_back(2.0 * NK * 9 * ((need_dx ? R.enc[b].Cx : 0) + C) * 4.0 * C);
       }
     }
-    run_dgrad_group(e, probs, flops);
+    run_dgrad_group(e, probs, flops, chains, slots);
     for (int s = 0; s < c.num_scales; ++s) {
       if (!e->sc[s].use) continue;
       for (int b = 0; b < 2; ++b) std::swap(dh_a[s][b], dh_b[s][b]);
