@@ -42,6 +42,8 @@ struct WgradArgs {
   int32_t nsplit;
   int32_t n_xblocks;         // ceil(Cx / 64)
   int32_t n_ciblocks;        // n_xblocks + C / 64
+  int32_t only_x;            // fast path: compute the x rows only (the h rows come from
+                             // the fp16-pipe kernel, convlstm_wgrad_f16x3.h)
 };
 
 struct WFrag {
@@ -344,7 +346,7 @@ void convlstm_wgrad_fast_kernel(const WgradArgs a) {
   const int xcd = blockIdx.x & 7;
   int j = blockIdx.x >> 3;
   const int splits_per_xcd = a.nsplit >> 3;
-  const int n_hblocks = a.n_ciblocks - a.n_xblocks;
+  const int n_hblocks = a.only_x ? 0 : a.n_ciblocks - a.n_xblocks;
   const int n_h_tiles = 9 * n_hblocks * nquads;
   const int n_x_tiles = 9 * a.n_xblocks * nquads;
   int sl, cib, tap, nq;
@@ -405,7 +407,8 @@ static inline void wgrad_plan(WgradArgs& a, int target_blocks) {
 }
 
 static inline unsigned wgrad_blocks(const WgradArgs& a) {
-  return (unsigned)a.nsplit * 9u * (unsigned)a.n_ciblocks * (unsigned)((4 * a.C) / (4 * kWgTile));
+  const unsigned cib = a.only_x ? (unsigned)a.n_xblocks : (unsigned)a.n_ciblocks;
+  return (unsigned)a.nsplit * 9u * cib * (unsigned)((4 * a.C) / (4 * kWgTile));
 }
 
 static inline size_t wgrad_partial_elems(const WgradArgs& a) {

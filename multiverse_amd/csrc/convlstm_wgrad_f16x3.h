@@ -1,0 +1,375 @@
+// wgrad of the ConvLSTM gate convolution on the fp16 matrix pipe (f16x3 split,
+// see convlstm_f16x3.h), h rows of the kernel gradient:
+//
+//   dW[tap][Cx + ci][n] = sum_m  h[m + d_tap][ci] * G[m][n]
+//
+// v_mfma_f32_32x32x16_f16 wants 8 consecutive REDUCTION elements per lane, and the
+// reduction runs over cells, so both operands are first re-laid cell-contiguous
+// ("transposed") as two scaled fp16 planes:
+//   GT        [plane][4C][Mrow]            scale 2^e (chain-wide, from max |G|)
+//   AT[dx]    [plane][C][Mrow], dx=-1,0,1  AT[dx][ci][m] = h[m + dx][ci], zero where
+//                                          x(m) + dx leaves the image row; scale 2^8
+//                                          (|h| <= 1); an x operand (pixel offsets are
+//                                          not bounded) gets its own exponent from max|x|
+// With W % 16 == 0 a k-step of 16 cells lies inside one image row, so the column
+// shift of a tap is baked into the operand copy (three copies), the row shift
+// dy*W is a multiple of 16 cells = an ALIGNED offset, and a k-step whose tap row
+// is outside the image is simply skipped: no per-element masks in the GEMM.
+//
+// GEMM tile: a workgroup owns 128 (ci) x 128 (n) of one tap, four waves 2 x 2,
+// each 64 x 64 (2 x 2 accumulators); a stage = 32 cells = two k-steps; the A and
+// G tiles of a stage (2 x 20 KB) are copied global -> LDS (16-B vectors along
+// cells) into a double buffer, fragments come back with ds_read_b128; 8 reads
+// and 12 MFMAs per k-step and wave, the same ratio as the forward kernel.
+// Split-K over cell ranges pinned to XCDs, per-split partial tiles summed by the
+// common reduction pass (bitwise reproducible).  The x rows (Cx = 64 / 32 / 2
+// channels) use the same tile with rows enumerating (tap, channel) pairs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "convlstm_f16x3.h"
+
+namespace mv {
+
+// in fp32 [Mtot][Cc] -> out [2][Cc][Mrow] halves; out[c][m] = in[m+dx][c] * 2^e,
+// zero when the shifted cell leaves its image row or the tensor.  Block = 64 cells
+// x 64 channels through LDS; grid (Mrow/64, Cc/64).
+__global__ __launch_bounds__(256)
+void transpose_split_kernel(const float* __restrict__ in, _Float16* __restrict__ out,
+                            long long Mtot, int Cc, long long Mrow, int W, int dx,
+                            const int32_t* __restrict__ exp_ptr, int exp_const,
+                            float* __restrict__ colsum_out) {
+  __shared__ float tile[64][65];
+  const int e = exp_ptr ? exp_ptr[0] : exp_const;
+  const long long m0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  // load: 16 threads x float4 cover the 64 channels of a cell, 16 cells per pass
+  const int lc = (tid & 15) * 4, lj = tid >> 4;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int j = pass * 16 + lj;
+    const long long m = m0 + j;
+    const int x = (int)(m % W);
+    const long long src = m + dx;
+    const bool ok = (m < Mtot) & (x + dx >= 0) & (x + dx < W) & (src >= 0) & (src < Mtot);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) v = *reinterpret_cast<const f32x4*>(in + (size_t)src * Cc + c0 + lc);
+    tile[j][lc + 0] = v[0]; tile[j][lc + 1] = v[1];
+    tile[j][lc + 2] = v[2]; tile[j][lc + 3] = v[3];
+  }
+  __syncthreads();
+  if (colsum_out && tid < 64) {          // per-block column sums (bias gradient partials)
+    float sum = 0.f;
+#pragma unroll 8
+    for (int jj = 0; jj < 64; ++jj) sum += tile[jj][tid];
+    colsum_out[(size_t)blockIdx.x * Cc + c0 + tid] = sum;
+  }
+  // store: item = (channel, group of 8 cells): 64 x 8 = 512 items, 2 per thread
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = it * 256 + tid;
+    const int ch = item >> 3, grp = item & 7;
+    f16x8 p0, p1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float s = ldexpf(tile[grp * 8 + q][ch], e);
+      const _Float16 h0 = (_Float16)s;
+      p0[q] = h0;
+      p1[q] = (_Float16)(s - (float)h0);
+    }
+    const size_t o = (size_t)(c0 + ch) * Mrow + m0 + grp * 8;
+    *reinterpret_cast<f16x8*>(out + o) = p0;
+    *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow + o) = p1;
+  }
+}
+
+// the same for a narrow tensor (Cc < 64, any Cc): one block = 64 cells x all channels
+__global__ __launch_bounds__(256)
+void transpose_split_narrow_kernel(const float* __restrict__ in, _Float16* __restrict__ out,
+                                   long long Mtot, int Cc, long long Mrow, int W, int dx,
+                                   const int32_t* __restrict__ exp_ptr) {
+  __shared__ float tile[64][65];
+  const int exp_const = exp_ptr[0];
+  const long long m0 = (long long)blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < 64 * Cc; idx += 256) {
+    const int jj = idx / Cc, c = idx - jj * Cc;
+    const long long m = m0 + jj;
+    const int x = (int)(m % W);
+    const long long src = m + dx;
+    const bool ok = (m < Mtot) & (x + dx >= 0) & (x + dx < W) & (src >= 0) & (src < Mtot);
+    tile[jj][c] = ok ? in[(size_t)src * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int item = tid; item < Cc * 8; item += 256) {
+    const int ch = item >> 3, grp = item & 7;
+    f16x8 p0, p1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float s = ldexpf(tile[grp * 8 + q][ch], exp_const);
+      const _Float16 h0 = (_Float16)s;
+      p0[q] = h0;
+      p1[q] = (_Float16)(s - (float)h0);
+    }
+    const size_t o = (size_t)ch * Mrow + m0 + grp * 8;
+    *reinterpret_cast<f16x8*>(out + o) = p0;
+    *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow + o) = p1;
+  }
+}
+
+// max |in| as float bits (non-negative floats order like ints); *out zeroed before
+__global__ __launch_bounds__(256)
+void absmax_bits_kernel(const float* __restrict__ in, size_t n, int32_t* __restrict__ out) {
+  __shared__ int32_t red[4];
+  int32_t mb = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    mb = max(mb, __float_as_int(fabsf(in[i])));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mb = max(mb, __shfl_xor(mb, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mb;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+
+// exponent of the chain-wide G scale: e = 13 - ilogb(max over the chain's steps)
+__global__ void chain_exp_kernel(const int32_t* __restrict__ gmax, int nsteps, int step_stride,
+                                 int32_t* __restrict__ exp_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int mb = 0;
+  for (int s = 0; s < nsteps; ++s)
+    for (int i = 0; i < 64; ++i) mb = max(mb, gmax[(size_t)s * step_stride + i]);
+  const float mx = __int_as_float(mb);
+  int e = 0;
+  if (mx > 0.f) {
+    e = 13 - ilogbf(mx);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  }
+  exp_out[0] = e;
+}
+
+struct Wgrad16Args {
+  const _Float16* at[3];     // A operand planes [2][Ca][Mrow], dx = -1, 0, +1
+  const _Float16* gt;
+  float* partial;            // [nsplit][9][Cx + C][4C]
+  const int32_t* g_exp;      // scale exponents of G and of the A operand
+  const int32_t* a_exp;
+  long long Mrow;            // cells per operand row (multiple of 64)
+  int32_t ksteps_total;      // Mtot / 16
+  int32_t H, W, Cx, C;
+  int32_t Ca;                // channels of the A operand: C (h rows) or Cx (x rows)
+  int32_t ksteps_per_split;  // even
+  int32_t nsplit;            // multiple of 8
+};
+
+constexpr int kWg16Pitch = 40;                         // halves per LDS row (32 cells + pad)
+constexpr int kWg16Tile = 2 * 128 * kWg16Pitch;        // halves per operand tile (2 planes)
+
+// XROWS = false: h rows.  A workgroup's 128 tile rows are 128 channels of ONE tap,
+//   so "tap row outside the image" is uniform per k-step and its MFMAs are skipped.
+// XROWS = true: x rows (Ca = Cx channels, any width).  Tile rows enumerate
+//   (tap, channel) pairs, R = tap * Cx + ci < 9 Cx, so each row has its own operand
+//   copy / row shift and an invalid (row, k-step) is staged as zeros instead.
+template <bool XROWS>
+__global__ __launch_bounds__(256, 2)
+void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds_raw[];   // [buffer][A | G][tile]
+  _Float16 (*lds)[2][kWg16Tile] = reinterpret_cast<_Float16 (*)[2][kWg16Tile]>(lds_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, wj = wave & 1;
+  const int H = a.H, W = a.W, C = a.C, N4 = 4 * C, Ca = a.Ca;
+  const int wk = W / 16;                               // k-steps per image row
+  const int nnb = N4 / 128;
+  const int nrb = XROWS ? (9 * Ca + 127) / 128 : 9 * (C / 128);   // row blocks
+  const int tiles_per_split = nrb * nnb;
+  const int xcd = blockIdx.x & 7;                      // split -> XCD (see convlstm_wgrad.h)
+  int j = blockIdx.x >> 3;
+  const int split = xcd + 8 * (j / tiles_per_split);
+  j = j % tiles_per_split;
+  const int nb = j % nnb;
+  const int rb = j / nnb;
+  const int n0 = nb * 128;
+  // h rows: rb = tap * (C/128) + cib
+  const int tap_u = XROWS ? 0 : rb / (C / 128);
+  const int ci0_u = XROWS ? 0 : (rb - tap_u * (C / 128)) * 128;
+  const int dy_u = tap_u / 3 - 1;
+  const long long Mrow = a.Mrow;
+
+  const int ks0 = split * a.ksteps_per_split;
+  int ks1 = ks0 + a.ksteps_per_split;
+  if (ks1 > a.ksteps_total) ks1 = a.ksteps_total;
+  const int nstages = ks1 > ks0 ? (ks1 - ks0 + 1) / 2 : 0;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[x][y][i] = 0.f;
+
+  // per-thread copy slots: q -> plane q>>1, tile row (q&1)*64 + tid>>2, 8-cell vector tid&3
+  const int vec = tid & 3;
+  const _Float16* ap[4];
+  const _Float16* gp[4];
+  int dyq[4];                                          // XROWS: row shift of slot q (huge = dead row)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int plane = q >> 1, row = (q & 1) * 64 + (tid >> 2);
+    gp[q] = a.gt + ((size_t)plane * N4 + n0 + row) * Mrow + vec * 8;
+    if (XROWS) {
+      const int R = rb * 128 + row;
+      const bool live = R < 9 * Ca;
+      const int tap = live ? R / Ca : 4;
+      const int ci = live ? R - tap * Ca : 0;
+      dyq[q] = live ? tap / 3 - 1 : (1 << 20);
+      ap[q] = a.at[tap - (tap / 3) * 3] + ((size_t)plane * Ca + ci) * Mrow + vec * 8;
+    } else {
+      dyq[q] = dy_u;
+      ap[q] = a.at[tap_u - (tap_u / 3) * 3] + ((size_t)plane * Ca + ci0_u + row) * Mrow + vec * 8;
+    }
+  }
+
+  // image row of the two k-steps of the stage being LOADED (uniform, incremental)
+  int ly, lxk;
+  {
+    const int kin = ks0 % (H * wk);
+    ly = kin / wk; lxk = kin - ly * wk;
+  }
+  auto advance = [&](int& y, int& xk) { if (++xk == wk) { xk = 0; if (++y == H) y = 0; } };
+
+  f16x8 sa[4], sg[4];
+  bool cv0 = false, cv1 = false;                       // h rows: k-step validity, stage in LDS
+  bool nv0 = false, nv1 = false;                       //          ... stage in registers
+  auto stage_load = [&](int st) {
+    const int ksb = ks0 + 2 * st;
+    const int y0 = ly; advance(ly, lxk);
+    const int y1 = ly; advance(ly, lxk);
+    const bool in0 = ksb < ks1, in1 = ksb + 1 < ks1;
+    const long long m0 = (long long)ksb * 16;          // stage = 32 consecutive cells
+    const int ysel = (vec & 2) ? y1 : y0;
+    const bool insel = (vec & 2) ? in1 : in0;
+    if (!XROWS) {
+      nv0 = in0 & ((unsigned)(y0 + dy_u) < (unsigned)H);
+      nv1 = in1 & ((unsigned)(y1 + dy_u) < (unsigned)H);
+      const int sh = ((vec & 2) ? nv1 : nv0) ? dy_u * W : 0;   // skipped k-step: unshifted
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        sa[q] = *reinterpret_cast<const f16x8*>(ap[q] + m0 + sh);
+        sg[q] = *reinterpret_cast<const f16x8*>(gp[q] + m0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = insel & ((unsigned)(ysel + dyq[q]) < (unsigned)H);
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) v = *reinterpret_cast<const f16x8*>(ap[q] + m0 + dyq[q] * W);
+        sa[q] = v;
+        sg[q] = *reinterpret_cast<const f16x8*>(gp[q] + m0);
+      }
+      nv0 = in0; nv1 = in1;
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int plane = q >> 1, row = (q & 1) * 64 + (tid >> 2);
+      const int o = (plane * 128 + row) * kWg16Pitch + vec * 8;
+      *reinterpret_cast<f16x8*>(&lds[buf][0][o]) = sa[q];
+      *reinterpret_cast<f16x8*>(&lds[buf][1][o]) = sg[q];
+    }
+  };
+
+  if (nstages > 0) {
+    stage_load(0);
+    stage_store(0);
+    cv0 = nv0; cv1 = nv1;
+    __syncthreads();
+    const int li = lane & 31, k8 = (lane >> 5) * 8;
+    for (int st = 0; st < nstages; ++st) {
+      const bool more = st + 1 < nstages;
+      if (more) stage_load(st + 1);
+      const _Float16* A = &lds[st & 1][0][0];
+      const _Float16* G = &lds[st & 1][1][0];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if (kk ? cv1 : cv0) {                   // uniform
+          f16x8 fa[2][2], fg[2][2];             // [sub-block][plane]
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+              fa[s2][pl] = *reinterpret_cast<const f16x8*>(
+                  A + (pl * 128 + wi * 64 + s2 * 32 + li) * kWg16Pitch + kk * 16 + k8);
+              fg[s2][pl] = *reinterpret_cast<const f16x8*>(
+                  G + (pl * 128 + wj * 64 + s2 * 32 + li) * kWg16Pitch + kk * 16 + k8);
+            }
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][1], fg[y][0], acc[x][y], 0, 0, 0);
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][0], fg[y][1], acc[x][y], 0, 0, 0);
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][0], fg[y][0], acc[x][y], 0, 0, 0);
+        }
+      }
+      if (more) stage_store((st + 1) & 1);
+      cv0 = nv0; cv1 = nv1;
+      __syncthreads();
+    }
+  }
+
+  // D: col j = lane&31 (n), row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const float scale = ldexpf(1.0f, -(a.a_exp[0] + a.g_exp[0]));
+  const int Cin = a.Cx + C;
+  float* ps = a.partial + (size_t)split * 9 * Cin * N4;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int r = wi * 64 + x * 32 + i;
+        const int n = n0 + wj * 64 + y * 32 + (lane & 31);
+        if (XROWS) {
+          const int R = rb * 128 + r;
+          if (R < 9 * Ca) {
+            const int tap = R / Ca, ci = R - tap * Ca;
+            ps[((size_t)tap * Cin + ci) * N4 + n] = acc[x][y][reg] * scale;
+          }
+        } else {
+          ps[((size_t)tap_u * Cin + a.Cx + ci0_u + r) * N4 + n] = acc[x][y][reg] * scale;
+        }
+      }
+}
+
+constexpr size_t kWg16LdsBytes = (size_t)2 * 2 * kWg16Tile * sizeof(_Float16);   // 80 KB
+
+static inline bool wgrad16_ok(int W, int C) { return (W % 16) == 0 && (C % 128) == 0; }
+
+static inline void wgrad16_plan(Wgrad16Args& a, long long Mtot, int nsplit) {
+  a.ksteps_total = (int32_t)(Mtot / 16);
+  int per = (a.ksteps_total + nsplit - 1) / nsplit;
+  per = (per + 1) & ~1;
+  a.ksteps_per_split = per;
+  a.nsplit = nsplit;
+}
+
+static inline unsigned wgrad16_blocks(const Wgrad16Args& a, bool xrows) {
+  const unsigned nrb = xrows ? (unsigned)((9 * a.Ca + 127) / 128) : 9u * (unsigned)(a.C / 128);
+  return (unsigned)a.nsplit * nrb * (unsigned)(4 * a.C / 128);
+}
+
+}  // namespace mv

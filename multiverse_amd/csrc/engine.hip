@@ -22,6 +22,7 @@
 #include "convlstm_mfma.h"
 #include "convlstm_wgrad.h"
 #include "convlstm_f16x3.h"
+#include "convlstm_wgrad_f16x3.h"
 #include "kernels_misc.h"
 #include "train_kernels.h"
 

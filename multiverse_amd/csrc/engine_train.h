@@ -57,6 +57,12 @@ struct TrainState {
   // max |G| bits and scale exponents per (launch slot, step)
   DevBuf<_Float16> g16[mv::kMaxGroup];
   DevBuf<int32_t> gmax, gexp;
+  // f16x3 wgrad: cell-contiguous operand planes of one chain at a time
+  DevBuf<_Float16> gt16, at16[3], xt16[3];
+  DevBuf<float> bias_part;        // [Mrow / 64][4C] per-block column sums of G
+  DevBuf<int32_t> chain_exp;
+  size_t mrow_max = 0;
+  bool wgrad16_attr = false;
   bool have_grads = false;
   bool targets_ready = false;
   mv_losses last{};
@@ -151,6 +157,10 @@ void train_alloc(mv_engine* e) {
       HIP_CHECK(hipMemset(t.g16[i].p, 0, t.g16[i].n * sizeof(_Float16)));
     }
     t.gmax.alloc(mv::kMaxGroup * 64 * 64);   // [slot][64 spread addresses]
+    t.chain_exp.alloc(256);   // [0] G exp, [1] h exp (8), [2] x exp, [64..127] max|x| bits
+    { const int32_t eight = 8;
+      HIP_CHECK(hipMemcpy(t.chain_exp.p + 1, &eight, sizeof(eight), hipMemcpyHostToDevice)); }
+    t.mrow_max = ((size_t)std::max(To, Tp) * N * K + 63) / 64 * 64;
     t.gexp.alloc(mv::kMaxGroup * 64);
   }
   t.partial.alloc(max_partial);
@@ -488,7 +498,9 @@ void run_dgrad_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
   });
 }
 
-void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H, int W) {
+// gslot: first gmax slot of the chain's steps (f16x3 mode), see train_backward
+void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H, int W,
+               int gslot) {
   TrainState& t = TS(e);
   const int N = e->cfg.batch_size, C = e->cfg.hidden_size;
   mv::WgradArgs wa{};
@@ -499,10 +511,85 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
   MV_REQUIRE(mv::wgrad_partial_elems(wa) <= t.partial.n, "internal: wgrad partial buffer");
   const double cells = (double)wa.R * H * W;
   const size_t ncols = (size_t)9 * (ch.Cx + C) * 4 * C;
+  const bool f16 = e->compute_mode == 1 && mv::wgrad16_ok(W, C);
+  if (f16) {
+    // both operands as cell-contiguous fp16 plane pairs, then the f16x3 GEMMs
+    // (convlstm_wgrad_f16x3.h): h rows, x rows; bias partials fall out of the G pass
+    const long long Mtot = (long long)wa.R * H * W;
+    const long long Mrow = (Mtot + 63) / 64 * 64;
+    const int Cx = ch.Cx;
+    MV_REQUIRE((size_t)Mrow <= t.mrow_max, "internal: wgrad plane scratch");
+    t.gt16.alloc((size_t)2 * 4 * C * t.mrow_max);
+    t.bias_part.alloc(t.mrow_max / 64 * 4 * C);
+    for (int d = 0; d < 3; ++d) t.at16[d].alloc((size_t)2 * C * t.mrow_max);
+    if (Cx)
+      for (int d = 0; d < 3; ++d) t.xt16[d].alloc((size_t)2 * 64 * t.mrow_max);
+    MV_REQUIRE(Cx <= 64, "internal: f16x3 wgrad x operand wider than 64 channels");
+    if (!t.wgrad16_attr) {
+      HIP_CHECK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(mv::convlstm_wgrad_f16x3_kernel<false>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)mv::kWg16LdsBytes));
+      HIP_CHECK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(mv::convlstm_wgrad_f16x3_kernel<true>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)mv::kWg16LdsBytes));
+      t.wgrad16_attr = true;
+    }
+    launch(e, "wgrad_transpose", 0, cells * (4.0 * C * 8 + (C + Cx) * 8.0 * 3), [&] {
+      hipLaunchKernelGGL(mv::chain_exp_kernel, dim3(1), dim3(64), 0, e->stream,
+                         t.gmax.p + (size_t)gslot * 64, Tsteps, 64, t.chain_exp.p);
+      hipLaunchKernelGGL(mv::transpose_split_kernel, dim3((unsigned)(Mrow / 64), 4 * C / 64),
+                         dim3(256), 0, e->stream, ch.gates.p, t.gt16.p, Mtot, 4 * C, Mrow, W,
+                         0, t.chain_exp.p, 0, t.bias_part.p);
+      for (int d = 0; d < 3; ++d)
+        hipLaunchKernelGGL(mv::transpose_split_kernel, dim3((unsigned)(Mrow / 64), C / 64),
+                           dim3(256), 0, e->stream, hin, t.at16[d].p, Mtot, C, Mrow, W,
+                           d - 1, (const int32_t*)nullptr, 8, (float*)nullptr);
+      if (Cx) {   // x operand: exponent from max |x| of the chain
+        HIP_CHECK(hipMemsetAsync(t.chain_exp.p + 64, 0, 64 * sizeof(int32_t), e->stream));
+        hipLaunchKernelGGL(mv::absmax_bits_kernel, dim3(256), dim3(256), 0, e->stream,
+                           ch.xs.p, (size_t)Mtot * Cx, t.chain_exp.p + 64);
+        hipLaunchKernelGGL(mv::chain_exp_kernel, dim3(1), dim3(64), 0, e->stream,
+                           t.chain_exp.p + 64, 1, 64, t.chain_exp.p + 2);
+      }
+      for (int d = 0; d < 3 && Cx; ++d) {
+        if (Cx == 64)
+          hipLaunchKernelGGL(mv::transpose_split_kernel, dim3((unsigned)(Mrow / 64), 1),
+                             dim3(256), 0, e->stream, ch.xs.p, t.xt16[d].p, Mtot, Cx, Mrow, W,
+                             d - 1, t.chain_exp.p + 2, 0, (float*)nullptr);
+        else
+          hipLaunchKernelGGL(mv::transpose_split_narrow_kernel, dim3((unsigned)(Mrow / 64)),
+                             dim3(256), 0, e->stream, ch.xs.p, t.xt16[d].p, Mtot, Cx, Mrow, W,
+                             d - 1, t.chain_exp.p + 2);
+      }
+    });
+    mv::Wgrad16Args q{};
+    for (int d = 0; d < 3; ++d) q.at[d] = t.at16[d].p;
+    q.gt = t.gt16.p; q.partial = t.partial.p; q.g_exp = t.chain_exp.p;
+    q.a_exp = t.chain_exp.p + 1;
+    q.Mrow = Mrow; q.H = H; q.W = W; q.Cx = Cx; q.C = C; q.Ca = C;
+    mv::wgrad16_plan(q, Mtot, wa.nsplit);
+    launch(e, "convlstm_wgrad", 2.0 * cells * 9 * C * 4.0 * C, cells * 5.0 * C * 4.0, [&] {
+      hipLaunchKernelGGL(mv::convlstm_wgrad_f16x3_kernel<false>,
+                         dim3(mv::wgrad16_blocks(q, false)), dim3(256), mv::kWg16LdsBytes,
+                         e->stream, q);
+    });
+    if (Cx > 0) {
+      mv::Wgrad16Args qx = q;
+      for (int d = 0; d < 3; ++d) qx.at[d] = t.xt16[d].p;
+      qx.Ca = Cx; qx.a_exp = t.chain_exp.p + 2;
+      launch(e, "convlstm_wgrad_x", 2.0 * cells * 9 * Cx * 4.0 * C,
+             cells * (Cx + 4.0 * C) * 4.0, [&] {
+        hipLaunchKernelGGL(mv::convlstm_wgrad_f16x3_kernel<true>,
+                           dim3(mv::wgrad16_blocks(qx, true)), dim3(256), mv::kWg16LdsBytes,
+                           e->stream, qx);
+      });
+    }
+  } else {
   launch(e, "convlstm_wgrad", 2.0 * cells * 9 * (ch.Cx + C) * 4.0 * C,
          cells * (ch.Cx + 5.0 * C) * 4.0, [&] {
     mv::launch_convlstm_wgrad(wa, e->stream);
   });
+  }
   launch(e, "wgrad_reduce", 0, 4.0 * ncols * (wa.nsplit + 1), [&] {
     hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv(ncols, 256)), dim3(256), 0,
                        e->stream, t.partial.p, grad_of(e, ch.cell->kernel),
@@ -510,8 +597,12 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
   });
   // biases: column sums of G
   launch(e, "bias_colsum", 0, cells * 4.0 * C * 4.0, [&] {
-    run_colsum(e, ch.gates.p, (size_t)cells, (size_t)4 * C, grad_of(e, ch.cell->biases),
-               t.partial.p);
+    if (f16)
+      run_colsum(e, t.bias_part.p, (size_t)(((long long)cells + 63) / 64), (size_t)4 * C,
+                 grad_of(e, ch.cell->biases), t.partial.p);
+    else
+      run_colsum(e, ch.gates.p, (size_t)cells, (size_t)4 * C, grad_of(e, ch.cell->biases),
+                 t.partial.p);
   });
 }
 
@@ -540,7 +631,7 @@ void train_backward(mv_engine* e) {
     MV_REQUIRE(Tp <= 32 && To <= 32, "f16x3 training: at most 32 steps per chain");
     HIP_CHECK(hipMemsetAsync(t.gmax.p, 0, t.gmax.n * sizeof(int32_t), e->stream));
   }
-  // gmax / gexp slot of (group position i, step): i * 64 + step (steps < 64)
+  // gmax / gexp slot of (scale s, branch b, step): (2 s + b) * 64 + step (+32: encoder)
   // ---- decoders, t = Tp-1 .. 0
   for (int ts = Tp - 1; ts >= 0; --ts) {
     std::vector<ConvLstmArgs> probs;
@@ -561,7 +652,7 @@ void train_backward(mv_engine* e) {
                       true);
       for (int b = 0; b < 2; ++b) {
         float* G = R.dec[b].gates.p + (size_t)ts * 4 * NKC;
-        const int gs = (int)probs.size() * 64 + ts;
+        const int gs = (2 * s + b) * 64 + ts;
         run_gate_bwd(e, G, R.cs[b].p + slot * NKC, R.cs[b].p + (slot + 1) * NKC,
                      dh_a[s][b], R.dc[b].p, NK, C, f16 ? t.gmax.p + (size_t)gs * 64 : nullptr);
         chains.push_back(&R.dec[b]);
@@ -627,11 +718,11 @@ void train_backward(mv_engine* e) {
       const size_t NK = (size_t)N * S.K, NKC = NK * C;
       for (int b = 0; b < 2; ++b) {
         float* G = R.enc[b].gates.p + (size_t)ts * 4 * NKC;
-        const int gs = (int)probs.size() * 64 + 32 + ts;    // encoder steps: 32..
+        const int gs = (2 * s + b) * 64 + 32 + ts;    // encoder steps: 32..
         const bool need_dh = ts > 0, need_dx = (b == 0);
         run_gate_bwd(e, G, R.cs[b].p + ts * NKC, R.cs[b].p + (ts + 1) * NKC, dh_a[s][b],
                      R.dc[b].p, NK, C,
-                     (f16 && (need_dh || need_dx)) ? t.gmax.p + (size_t)gs * 64 : nullptr);
+                     f16 ? t.gmax.p + (size_t)gs * 64 : nullptr);
         if (!need_dh && !need_dx) continue;
         chains.push_back(&R.enc[b]);
         slots.push_back(gs);
@@ -656,9 +747,9 @@ void train_backward(mv_engine* e) {
     TrainScale& R = t.sc[s];
     const size_t NK = (size_t)N * S.K, NKC = NK * C;
     for (int b = 0; b < 2; ++b) {
-      run_wgrad(e, R.enc[b], R.hs[b].p, To, S.H, S.W);
+      run_wgrad(e, R.enc[b], R.hs[b].p, To, S.H, S.W, (2 * s + b) * 64 + 32);
       const float* hin = (b == 0 && c.use_gnn) ? R.hg.p : R.hs[b].p + (size_t)To * NKC;
-      run_wgrad(e, R.dec[b], hin, Tp, S.H, S.W);
+      run_wgrad(e, R.dec[b], hin, Tp, S.H, S.W, (2 * s + b) * 64);
     }
     // class-decoder grid_emb on one-hot maps
     hipLaunchKernelGGL(mv::onehot_map_kernel, dim3(cdiv(NK, 256)), dim3(256), 0, e->stream,

@@ -164,6 +164,37 @@ def test_train_steps_match_oracle(built_lib, mode):
   eng.close()
 
 
+@pytest.mark.parametrize("use_grids", [(0, 1), (1, 0)])
+def test_f16x3_gradients_match_f32_mode(built_lib, use_grids):
+  """The f16x3 backward (dgrad and wgrad on the fp16 matrix pipe, operands split into
+  two scaled fp16 planes) against the fp32-MFMA backward of the same engine, per
+  tensor and, for the gate kernels, x rows (pixel offsets are NOT bounded by 1: the
+  x operand carries its own scale exponent) and h rows apart."""
+  cfg, params, _ = _train_case(use_grids, 2, 2)
+  fd = synth.make_feed(cfg, seed=synth.SEED_BASE + 70)
+  gr = {}
+  for mode in ("f32", "f16x3"):
+    eng = built_lib.Engine(cfg, device=0)
+    eng.set_params(params)
+    eng.set_compute_mode(mode)
+    eng.train_init()
+    eng.train_forward_backward(fd)
+    gr[mode] = {n: eng.get_grad(n) for n, _ in eng.param_specs()}
+    eng.close()
+  C = cfg.enc_hidden_size
+  for n, a in gr["f32"].items():
+    b = gr["f16x3"][n]
+    assert np.isfinite(b).all(), n
+    parts = [("all", a, b)]
+    if n.endswith("/kernel") and a.ndim == 4 and a.shape[3] == 4 * C:
+      Cx = a.shape[2] - C
+      parts = [("x rows", a[:, :, :Cx], b[:, :, :Cx]), ("h rows", a[:, :, Cx:], b[:, :, Cx:])]
+    for what, u, v in parts:
+      err = np.abs(u - v).max() / max(np.abs(u).max(), 1e-30)
+      print("%-75s %-7s rel %.2e max %.3g" % (n, what, err, np.abs(u).max()))
+      assert err < 5e-5, (n, what)
+
+
 def test_train_is_deterministic_and_split_apply_equals_step(built_lib):
   """Bitwise run-to-run determinism of the gradients (no atomics), and
   forward_backward + apply(1.0) == train_step."""
