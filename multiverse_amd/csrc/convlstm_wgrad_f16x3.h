@@ -6,11 +6,14 @@
 // v_mfma_f32_32x32x16_f16 wants 8 consecutive REDUCTION elements per lane, and the
 // reduction runs over cells, so both operands are first re-laid cell-contiguous
 // ("transposed") as two scaled fp16 planes:
-//   GT        [plane][4C][Mrow]            scale 2^e (chain-wide, from max |G|)
-//   AT[dx]    [plane][C][Mrow], dx=-1,0,1  AT[dx][ci][m] = h[m + dx][ci], zero where
+//   GT        [plane][Mrow/32][4C][32]     scale 2^e (chain-wide, from max |G|)
+//   AT[dx]    [plane][Mrow/32][C][32]      dx=-1,0,1: AT[dx][ci][m] = h[m + dx][ci], zero where
 //                                          x(m) + dx leaves the image row; scale 2^8
 //                                          (|h| <= 1); an x operand (pixel offsets are
 //                                          not bounded) gets its own exponent from max|x|
+// (cells blocked by 32 = one pipeline stage, so the tile rows a workgroup stages are
+// ONE contiguous 8 KB run per plane instead of 64-byte pieces at a row stride of
+// hundreds of KB -- DRAM-page and TLB friendly.)
 // With W % 16 == 0 a k-step of 16 cells lies inside one image row, so the column
 // shift of a tap is baked into the operand copy (three copies), the row shift
 // dy*W is a multiple of 16 cells = an ALIGNED offset, and a k-step whose tap row
@@ -32,7 +35,12 @@
 
 namespace mv {
 
-// in fp32 [Mtot][Cc] -> out [2][Cc][Mrow] halves; out[c][m] = in[m+dx][c] * 2^e,
+// element (cell m, row r) of a plane with R rows: cells blocked by 32
+__device__ __forceinline__ size_t wg16_plane_index(long long m, int r, int R) {
+  return ((size_t)(m >> 5) * R + r) * 32 + (size_t)(m & 31);
+}
+
+// in fp32 [Mtot][Cc] -> out [2][Mrow/32][Cc][32] halves; out[c][m] = in[m+dx][c] * 2^e,
 // zero when the shifted cell leaves its image row or the tensor.  Block = 64 cells
 // x 64 channels through LDS; grid (Mrow/64, Cc/64).
 __global__ __launch_bounds__(256)
@@ -79,7 +87,7 @@ void transpose_split_kernel(const float* __restrict__ in, _Float16* __restrict__
       p0[q] = h0;
       p1[q] = (_Float16)(s - (float)h0);
     }
-    const size_t o = (size_t)(c0 + ch) * Mrow + m0 + grp * 8;
+    const size_t o = wg16_plane_index(m0 + grp * 8, c0 + ch, Cc);
     *reinterpret_cast<f16x8*>(out + o) = p0;
     *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow + o) = p1;
   }
@@ -113,7 +121,7 @@ void transpose_split_narrow_kernel(const float* __restrict__ in, _Float16* __res
       p0[q] = h0;
       p1[q] = (_Float16)(s - (float)h0);
     }
-    const size_t o = (size_t)ch * Mrow + m0 + grp * 8;
+    const size_t o = wg16_plane_index(m0 + grp * 8, ch, Cc);
     *reinterpret_cast<f16x8*>(out + o) = p0;
     *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow + o) = p1;
   }
@@ -219,17 +227,17 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int plane = q >> 1, row = (q & 1) * 64 + (tid >> 2);
-    gp[q] = a.gt + ((size_t)plane * N4 + n0 + row) * Mrow + vec * 8;
+    gp[q] = a.gt + (size_t)plane * N4 * Mrow + (size_t)(n0 + row) * 32 + vec * 8;
     if (XROWS) {
       const int R = rb * 128 + row;
       const bool live = R < 9 * Ca;
       const int tap = live ? R / Ca : 4;
       const int ci = live ? R - tap * Ca : 0;
       dyq[q] = live ? tap / 3 - 1 : (1 << 20);
-      ap[q] = a.at[tap - (tap / 3) * 3] + ((size_t)plane * Ca + ci) * Mrow + vec * 8;
+      ap[q] = a.at[tap - (tap / 3) * 3] + (size_t)plane * Ca * Mrow + (size_t)ci * 32;
     } else {
       dyq[q] = dy_u;
-      ap[q] = a.at[tap_u - (tap_u / 3) * 3] + ((size_t)plane * Ca + ci0_u + row) * Mrow + vec * 8;
+      ap[q] = a.at[tap_u - (tap_u / 3) * 3] + (size_t)plane * Ca * Mrow + (size_t)(ci0_u + row) * 32;
     }
   }
 
@@ -249,7 +257,11 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
     const int y0 = ly; advance(ly, lxk);
     const int y1 = ly; advance(ly, lxk);
     const bool in0 = ksb < ks1, in1 = ksb + 1 < ks1;
-    const long long m0 = (long long)ksb * 16;          // stage = 32 consecutive cells
+    const int m0 = ksb * 16;                           // stage = one 32-cell block
+    const size_t gofs = (size_t)m0 * N4;
+    auto aofs = [&](int cell) -> size_t {              // cell is a multiple of 8
+      return (size_t)(cell >> 5) * ((size_t)Ca * 32) + (size_t)(cell & 31);
+    };
     const int ysel = (vec & 2) ? y1 : y0;
     const bool insel = (vec & 2) ? in1 : in0;
     if (!XROWS) {
@@ -258,17 +270,17 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
       const int sh = ((vec & 2) ? nv1 : nv0) ? dy_u * W : 0;   // skipped k-step: unshifted
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        sa[q] = *reinterpret_cast<const f16x8*>(ap[q] + m0 + sh);
-        sg[q] = *reinterpret_cast<const f16x8*>(gp[q] + m0);
+        sa[q] = *reinterpret_cast<const f16x8*>(ap[q] + aofs(m0 + vec * 8 + sh));
+        sg[q] = *reinterpret_cast<const f16x8*>(gp[q] + gofs);
       }
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const bool ok = insel & ((unsigned)(ysel + dyq[q]) < (unsigned)H);
         f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok) v = *reinterpret_cast<const f16x8*>(ap[q] + m0 + dyq[q] * W);
+        if (ok) v = *reinterpret_cast<const f16x8*>(ap[q] + aofs(m0 + vec * 8 + dyq[q] * W));
         sa[q] = v;
-        sg[q] = *reinterpret_cast<const f16x8*>(gp[q] + m0);
+        sg[q] = *reinterpret_cast<const f16x8*>(gp[q] + gofs);
       }
       nv0 = in0; nv1 = in1;
     }
