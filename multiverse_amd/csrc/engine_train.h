@@ -139,7 +139,8 @@ void train_alloc(mv_engine* e) {
     R.loss_row.alloc(Tp * N); R.loss_elem.alloc(Tp * NK * 2);
     R.pred_labels.alloc(N * Tp); R.pred_reg.alloc(N * Tp * K * 2);
     // small-conv wgrad partials: blocks x 9 x Ci*Co (<= 512)
-    max_partial = std::max(max_partial, (size_t)1024 * 9 * 512);
+    max_partial = std::max(max_partial, (size_t)4096 * 9 * 512);
+    max_partial = std::max(max_partial, (size_t)64 * c.scene_conv_kernel * c.scene_conv_kernel * std::max<size_t>(D, c.scene_class) * D);
     // bias column sums: slabs x 4C
     max_partial = std::max(max_partial, (size_t)1024 * 4 * C);
     (void)E;
@@ -191,10 +192,21 @@ void run_small_dgrad(mv_engine* e, const float* dout, size_t dout_rs, const floa
                      float* din, size_t din_rs, int M, int H, int W, int Ci, int Co,
                      bool accumulate) {
   const size_t total = (size_t)M * H * W * Ci;
+  const bool vec4 = (Ci % 4 == 0) && (Co == 1 || Co == 2) && (din_rs % 4 == 0) &&
+                    total / 4 < 0xffffffffull;
   launch(e, "conv3x3_small_dgrad", 2.0 * total * 9 * Co, 4.0 * total * 2, [&] {
-    hipLaunchKernelGGL(mv::conv3x3_small_dgrad_kernel, dim3(cdiv(total, 256)), dim3(256),
-                       0, e->stream, dout, dout_rs, w, din, din_rs, M, H, W, Ci, Co,
-                       accumulate ? 1 : 0);
+    if (vec4 && Co == 1)
+      hipLaunchKernelGGL(mv::conv3x3_small_dgrad4_kernel<1>, dim3(cdiv(total / 4, 256)),
+                         dim3(256), 0, e->stream, dout, dout_rs, w, din, din_rs, M, H, W, Ci,
+                         accumulate ? 1 : 0);
+    else if (vec4)
+      hipLaunchKernelGGL(mv::conv3x3_small_dgrad4_kernel<2>, dim3(cdiv(total / 4, 256)),
+                         dim3(256), 0, e->stream, dout, dout_rs, w, din, din_rs, M, H, W, Ci,
+                         accumulate ? 1 : 0);
+    else
+      hipLaunchKernelGGL(mv::conv3x3_small_dgrad_kernel, dim3(cdiv(total, 256)), dim3(256),
+                         0, e->stream, dout, dout_rs, w, din, din_rs, M, H, W, Ci, Co,
+                         accumulate ? 1 : 0);
   });
 }
 
@@ -204,17 +216,32 @@ void run_small_wgrad(mv_engine* e, const float* in, const float* dout, float* dw
   TrainState& t = TS(e);
   MV_REQUIRE(Ci * Co <= 512, "small wgrad: Ci*Co %d > 512", Ci * Co);
   const long long cells = (long long)R * H * W;
-  long long nblk = std::min<long long>(1024, (cells + 255) / 256);
+  const int P = Ci * Co;
+  const int G = std::max(1, 256 / P);                 // cell groups per workgroup
+  long long nblk = std::min<long long>(4096, (cells + 63) / 64);
   const int cpb = (int)((cells + nblk - 1) / nblk);
   nblk = (cells + cpb - 1) / cpb;
-  const int threads = ((Ci * Co + 63) / 64) * 64;
-  const size_t ncols = (size_t)9 * Ci * Co;
+  const int threads = ((P * G + 63) / 64) * 64;
+  const size_t ncols = (size_t)9 * P;
+  const size_t lds = G > 1 ? (size_t)G * 9 * P * sizeof(float) : 0;
+  MV_REQUIRE((size_t)nblk * ncols <= t.partial.n && 64 * ncols <= t.scratch.n,
+             "internal: small wgrad partial buffer");
   launch(e, "conv3x3_small_wgrad", 2.0 * cells * 9 * Ci * Co,
          4.0 * cells * (9.0 * Ci + Co), [&] {
-    hipLaunchKernelGGL(mv::conv3x3_small_wgrad_kernel, dim3((unsigned)nblk), dim3(threads),
-                       0, e->stream, in, dout, t.partial.p, R, H, W, Ci, Co, cpb);
+    if (Ci > Co)
+      hipLaunchKernelGGL(mv::conv3x3_small_wgrad_kernel<true>, dim3((unsigned)nblk),
+                         dim3(threads), lds, e->stream, in, dout, t.partial.p, R, H, W, Ci,
+                         Co, cpb, G);
+    else
+      hipLaunchKernelGGL(mv::conv3x3_small_wgrad_kernel<false>, dim3((unsigned)nblk),
+                         dim3(threads), lds, e->stream, in, dout, t.partial.p, R, H, W, Ci,
+                         Co, cpb, G);
+    // two-level fold of the nblk partial rows (fixed order)
+    const size_t rps = ((size_t)nblk + 63) / 64, nslab = ((size_t)nblk + rps - 1) / rps;
+    hipLaunchKernelGGL(mv::colsum_kernel, dim3((unsigned)nslab, cdiv(ncols, 256)), dim3(256),
+                       0, e->stream, t.partial.p, t.scratch.p, (size_t)nblk, ncols, rps);
     hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv(ncols, 256)), dim3(256), 0,
-                       e->stream, t.partial.p, dw, (size_t)nblk, ncols, (size_t)nblk);
+                       e->stream, t.scratch.p, dw, nslab, ncols, nslab);
   });
 }
 
@@ -804,9 +831,15 @@ void train_backward(mv_engine* e) {
     const size_t nw = (size_t)k * k * Ci * D;
     const float* in = i == 0 ? e->scene_feat.p : e->scene_conv[i - 1].p;
     launch(e, "scene_conv_wgrad", 2.0 * n * k * k * Ci, 4.0 * nw, [&] {
-      hipLaunchKernelGGL(mv::conv_s2_wgrad_kernel, dim3(cdiv(nw, 256)), dim3(256), 0,
-                         e->stream, in, t.dpre_sc[i].p, grad_of(e, e->scene_W[i]), U, Hi,
-                         Wi, Ci, Ho, Wo, D, k, ph / 2, pw / 2);
+      // output rows (u, oy) in <= 64 slabs, partials folded in slab order
+      const int rows = U * Ho, rps = (rows + 63) / 64, nslab = (rows + rps - 1) / rps;
+      MV_REQUIRE((size_t)nslab * nw <= t.partial.n, "internal: scene wgrad partial buffer");
+      hipLaunchKernelGGL(mv::conv_s2_wgrad_kernel, dim3(cdiv(nw, 256), nslab), dim3(256), 0,
+                         e->stream, in, t.dpre_sc[i].p, t.partial.p, U, Hi, Wi, Ci, Ho, Wo,
+                         D, k, ph / 2, pw / 2, rps);
+      hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv(nw, 256)), dim3(256), 0, e->stream,
+                         t.partial.p, grad_of(e, e->scene_W[i]), (size_t)nslab, nw,
+                         (size_t)nslab);
     });
     run_colsum(e, t.dpre_sc[i].p, (size_t)U * Ho * Wo, D, grad_of(e, e->scene_b[i]),
                t.partial.p);

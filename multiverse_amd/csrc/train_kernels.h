@@ -233,17 +233,81 @@ __global__ void conv3x3_small_dgrad_kernel(const float* __restrict__ dout,
   *o = accumulate ? *o + acc : acc;
 }
 
+// The same for Ci % 4 == 0 and Co <= 2 (hidden2grid): one thread per (cell, 4 input
+// channels), 16-byte accesses of din / W, 32-bit index arithmetic.
+template <int CO>
+__global__ void conv3x3_small_dgrad4_kernel(const float* __restrict__ dout,
+                                            size_t dout_row_stride,
+                                            const float* __restrict__ w,
+                                            float* __restrict__ din, size_t din_row_stride,
+                                            int M, int H, int W, int Ci, int accumulate) {
+  const int q = Ci >> 2;
+  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned total = (unsigned)M * H * W * q;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % (unsigned)q) * 4;
+  unsigned r = idx / (unsigned)q;
+  const int xx = r % (unsigned)W; r /= (unsigned)W;
+  const int yy = r % (unsigned)H;
+  const int m = r / (unsigned)H;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  const float* dbase = dout + (size_t)m * dout_row_stride;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int sy = yy - (t / 3 - 1), sx = xx - (t % 3 - 1);
+    if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+    const float* dp = dbase + (size_t)(sy * W + sx) * CO;
+    const float* wp = w + ((size_t)t * Ci + c4) * CO;       // [ci][co], 4 * CO floats
+    if (CO == 1) {
+      const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(wp);
+      const float d = dp[0];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = fmaf(d, wv[i], acc[i]);
+    } else {
+      const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wp);
+      const f32x4_t w1 = *reinterpret_cast<const f32x4_t*>(wp + 4);
+      const float d0 = dp[0], d1 = dp[1];
+      // same order as the scalar kernel: co = 0 then co = 1 per channel
+      acc[0] = fmaf(d1, w0[1], fmaf(d0, w0[0], acc[0]));
+      acc[1] = fmaf(d1, w0[3], fmaf(d0, w0[2], acc[1]));
+      acc[2] = fmaf(d1, w1[1], fmaf(d0, w1[0], acc[2]));
+      acc[3] = fmaf(d1, w1[3], fmaf(d0, w1[2], acc[3]));
+    }
+  }
+  f32x4_t* o = reinterpret_cast<f32x4_t*>(din + (size_t)m * din_row_stride +
+                                          (size_t)(yy * W + xx) * Ci + c4);
+  if (accumulate) {
+    const f32x4_t old = *o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = old[i] + acc[i];
+  }
+  *o = acc;
+}
+
 // wgrad of a 3x3 SAME conv with Ci*Co <= 512 (hidden2grid, grid_emb):
-//   partial[blk][tap][ci][co] = sum_{m in slab} in[m + d_tap][ci] * dout[m][co]
+//   partial[blk][tap][ci][co] = sum_m in[m + d_tap][ci] * dout[m][co]
 // in [R, HW, Ci], dout [R, HW, Co] contiguous; one thread per (ci, co), one
 // workgroup per slab of cells; reduce with colsum_kernel afterwards.
-__global__ void conv3x3_small_wgrad_kernel(const float* __restrict__ in,
-                                           const float* __restrict__ dout,
-                                           float* __restrict__ partial, int R, int H,
-                                           int W, int Ci, int Co, int cells_per_block) {
+// The wide operand is read ONCE per cell and the narrow one nine times (broadcast
+// loads): WIDE_IN = false walks the output cells m of the slab (grid_emb: Co = 32
+// wide, Ci <= 2), WIDE_IN = true walks the INPUT cells m' = m + d_tap (hidden2grid:
+// Ci = 256 wide, Co <= 2), i.e. acc[tap] += in[m'] * dout[m' - d_tap].
+// A workgroup = G cell groups x (Ci*Co) threads: group g takes the cells m0 + g,
+// m0 + g + G, ... of the slab (narrow convs would otherwise run one wave per
+// workgroup with a 200-cell serial loop); the groups' sums are folded through LDS
+// in group order, so the result does not depend on timing.
+template <bool WIDE_IN>
+__global__ __launch_bounds__(512)
+void conv3x3_small_wgrad_kernel(const float* __restrict__ in,
+                                const float* __restrict__ dout,
+                                float* __restrict__ partial, int R, int H,
+                                int W, int Ci, int Co, int cells_per_block, int G) {
+  extern __shared__ float wred[];          // [G][9][Ci*Co] when G > 1
+  const int P = Ci * Co;
   const int tid = threadIdx.x;
-  if (tid >= Ci * Co) return;
-  const int ci = tid / Co, co = tid - ci * Co;
+  const int g = tid / P, pq = tid - g * P;
+  const bool live = g < G;
+  const int ci = pq / Co, co = pq - ci * Co;
   const long long total = (long long)R * H * W;
   const long long m0 = (long long)blockIdx.x * cells_per_block;
   long long m1 = m0 + cells_per_block;
@@ -252,20 +316,50 @@ __global__ void conv3x3_small_wgrad_kernel(const float* __restrict__ in,
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-  for (long long m = m0; m < m1; ++m) {
-    const int cell = (int)(m % HW);
-    const int y = cell / W, x = cell - y * W;
-    const float d = dout[(size_t)m * Co + co];
+  if (live) {
+    int cell = (int)((m0 + g) % HW);
+    for (long long m = m0 + g; m < m1; m += G) {
+      const int y = cell / W, x = cell - y * W;
+      if (WIDE_IN) {
+        const float v = in[(size_t)m * Ci + ci];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-        acc[t] = fmaf(in[(size_t)(m + (t / 3 - 1) * W + (t % 3 - 1)) * Ci + ci], d, acc[t]);
+        for (int t = 0; t < 9; ++t) {
+          const int dy = t / 3 - 1, dx = t % 3 - 1;
+          const int yy = y - dy, xx = x - dx;          // the output cell this input feeds
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+            acc[t] = fmaf(v, dout[(size_t)(m - dy * W - dx) * Co + co], acc[t]);
+        }
+      } else {
+        const float d = dout[(size_t)m * Co + co];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+            acc[t] = fmaf(in[(size_t)(m + (t / 3 - 1) * W + (t % 3 - 1)) * Ci + ci], d, acc[t]);
+        }
+      }
+      cell += G;
+      while (cell >= HW) cell -= HW;
     }
   }
-  float* p = partial + (size_t)blockIdx.x * 9 * Ci * Co;
+  float* p = partial + (size_t)blockIdx.x * 9 * P;
+  if (G == 1) {
+    if (live) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t) p[((size_t)t * Ci + ci) * Co + co] = acc[t];
+      for (int t = 0; t < 9; ++t) p[(size_t)t * P + pq] = acc[t];
+    }
+    return;
+  }
+  if (live) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wred[(g * 9 + t) * P + pq] = acc[t];
+  }
+  __syncthreads();
+  for (int i = tid; i < 9 * P; i += blockDim.x) {
+    float sum = 0.f;
+    for (int gg = 0; gg < G; ++gg) sum += wred[gg * 9 * P + i];
+    p[i] = sum;
+  }
 }
 
 // dpre = dy * (1 - y^2)   (backward of tanh); in place over dy allowed.
@@ -427,12 +521,14 @@ __global__ void conv_s2_dgrad_kernel(const float* __restrict__ dpre,
   din[idx] = accumulate ? din[idx] + acc : acc;
 }
 
-// wgrad of conv k x k, stride 2, SAME; one thread per (ky,kx,ci,co), direct sum.
+// wgrad of conv k x k, stride 2, SAME; one thread per (ky,kx,ci,co), direct sum over
+// the output rows [blockIdx.y * rows_per_slab, ...) of the flattened (u, oy) index;
+// dw is [gridDim.y][k*k*Ci*Co] partials, folded by colsum_kernel.
 __global__ void conv_s2_wgrad_kernel(const float* __restrict__ in,
                                      const float* __restrict__ dpre,
                                      float* __restrict__ dw, int U, int Hi, int Wi,
                                      int Ci, int Ho, int Wo, int Co, int k, int pad_t,
-                                     int pad_l) {
+                                     int pad_l, int rows_per_slab) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)k * k * Ci * Co;
   if (idx >= total) return;
@@ -442,18 +538,20 @@ __global__ void conv_s2_wgrad_kernel(const float* __restrict__ in,
   const int kx = r % k;
   const int ky = r / k;
   float acc = 0.f;
-  for (int u = 0; u < U; ++u)
-    for (int oy = 0; oy < Ho; ++oy) {
-      const int iy = oy * 2 + ky - pad_t;
-      if (iy < 0 || iy >= Hi) continue;
-      for (int ox = 0; ox < Wo; ++ox) {
-        const int ix = ox * 2 + kx - pad_l;
-        if (ix < 0 || ix >= Wi) continue;
-        acc = fmaf(in[(((size_t)u * Hi + iy) * Wi + ix) * Ci + ci],
-                   dpre[(((size_t)u * Ho + oy) * Wo + ox) * Co + co], acc);
-      }
+  const int r0 = blockIdx.y * rows_per_slab;
+  const int r1 = min(r0 + rows_per_slab, U * Ho);
+  for (int row = r0; row < r1; ++row) {
+    const int u = row / Ho, oy = row - u * Ho;
+    const int iy = oy * 2 + ky - pad_t;
+    if (iy < 0 || iy >= Hi) continue;
+    for (int ox = 0; ox < Wo; ++ox) {
+      const int ix = ox * 2 + kx - pad_l;
+      if (ix < 0 || ix >= Wi) continue;
+      acc = fmaf(in[(((size_t)u * Hi + iy) * Wi + ix) * Ci + ci],
+                 dpre[(((size_t)u * Ho + oy) * Wo + ox) * Co + co], acc);
     }
-  dw[idx] = acc;
+  }
+  dw[(size_t)blockIdx.y * total + idx] = acc;
 }
 
 // ------------------------------------------------------------ optimizer
