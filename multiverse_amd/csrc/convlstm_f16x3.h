@@ -53,6 +53,12 @@ struct ConvLstm16Args {
   int32_t n_xk;                // f16 k-steps taken from x (9 * Cx/16; 0 when x_small)
   int32_t n_hk;                // f16 k-steps taken from h (9 * C/16; 0 for the zero state)
   int32_t w_ksteps;            // k-steps per channel block in wp16 (x + all h)
+  // dgrad split-K: the channel groups of G are cut into n_kslice ranges, each range
+  // of each column block a workgroup of its own; slice s stores its partial sums to
+  // part0/part1 + s * rows*H*W*cols, summed afterwards by sum_slices_kernel
+  int32_t n_kslice;            // 0/1 = off
+  float* part0;
+  float* part1;
 };
 
 struct ConvLstm16Group {
@@ -337,15 +343,13 @@ constexpr int kStageVec = kKpb * 2 * 4 * 64;     // f16x8 elements per stage (kK
 // gradient G with 4C channels, the columns are input channels; NG active 32-column
 // sub-blocks in this column block; result scaled back by 2^-(8 + *g_exp)).
 template <int EPI, int NG>
-__device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int block,
+__device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int cb, int mt,
+                                                    int kslice, int n_kslice,
                                                     f16x8* lds /* [2][kStageVec] */) {
   const ConvLstmArgs& a = p.f;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int ncb = a.n_colblocks;
-  const int cb = block % ncb;
-  const int mt = block / ncb;
   const int H = a.H, W = a.W, HW = H * W, C = a.C, Cx = a.Cx;
   const int M_total = a.rows * HW;
   const int m_wave = mt * kBlockRows + wave * kWaveRows;
@@ -469,22 +473,28 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     }                                                                                   \
   } while (0)
 
-  if (nstages > 0) {
+  // stage range of this workgroup (split-K: n_kslice equal ranges)
+  const int st_lo = (nstages / n_kslice) * kslice;
+  const int st_hi = n_kslice > 1 ? st_lo + nstages / n_kslice : nstages;
+  if (st_hi > st_lo) {
     f16x8 stg[kCopy];
 #pragma unroll
     for (int i = 0; i < kCopy; ++i)
-      if (i * 256 + tid < kSV) stg[i] = wblk[pack_index(0, i * 256 + tid)];
+      if (i * 256 + tid < kSV) stg[i] = wblk[pack_index(st_lo, i * 256 + tid)];
+    {
+      f16x8* dst0 = lds + (st_lo & 1) * kStageVec;
 #pragma unroll
-    for (int i = 0; i < kCopy; ++i)
-      if (i * 256 + tid < kSV) lds[i * 256 + tid] = stg[i];
-    bool c_isx = stage_isx(0);
-    int c_rowoff = stage_rowoff(0);
-    bool c_rowok = stage_rowok(0);
+      for (int i = 0; i < kCopy; ++i)
+        if (i * 256 + tid < kSV) dst0[i * 256 + tid] = stg[i];
+    }
+    bool c_isx = stage_isx(st_lo);
+    int c_rowoff = stage_rowoff(st_lo);
+    bool c_rowok = stage_rowok(st_lo);
     f16x8 fa0, fa1;
     MV_LOAD_A(c_isx, c_rowoff, c_rowok, 0, fa0, fa1);
     __syncthreads();
-    for (int st = 0; st < nstages; ++st) {
-      const bool more = st + 1 < nstages;
+    for (int st = st_lo; st < st_hi; ++st) {
+      const bool more = st + 1 < st_hi;
       const int stn = more ? st + 1 : st;
       const bool n_isx = stage_isx(stn);
       const int n_rowoff = stage_rowoff(stn);
@@ -540,9 +550,14 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       const int col = cb * kBN + g * 32 + (lane & 31);
       float* dst = nullptr;
       int stride = 0, cc = col;
-      if (col < a.out0_cols) { dst = a.out0; stride = a.out0_cols; }
-      else if (col - a.out0_cols < a.out1_cols) {
-        dst = a.out1; stride = a.out1_cols; cc = col - a.out0_cols;
+      if (col < a.out0_cols) {
+        stride = a.out0_cols;
+        dst = n_kslice > 1 ? (a.out0 ? p.part0 + (size_t)kslice * M_total * stride : nullptr)
+                           : a.out0;
+      } else if (col - a.out0_cols < a.out1_cols) {
+        stride = a.out1_cols; cc = col - a.out0_cols;
+        dst = n_kslice > 1 ? (a.out1 ? p.part1 + (size_t)kslice * M_total * stride : nullptr)
+                           : a.out1;
       }
       if (dst) {
 #pragma unroll
@@ -603,10 +618,10 @@ void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
     if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
   if (pi > 0) block -= g.block_end[pi - 1];
   switch (pi) {
-    case 0: convlstm16_lds_body<kEpiLstm, 4>(g.p[0], block, lds); break;
-    case 1: convlstm16_lds_body<kEpiLstm, 4>(g.p[1], block, lds); break;
-    case 2: convlstm16_lds_body<kEpiLstm, 4>(g.p[2], block, lds); break;
-    default: convlstm16_lds_body<kEpiLstm, 4>(g.p[3], block, lds); break;
+    case 0: convlstm16_lds_body<kEpiLstm, 4>(g.p[0], block % g.p[0].f.n_colblocks, block / g.p[0].f.n_colblocks, 0, 1, lds); break;
+    case 1: convlstm16_lds_body<kEpiLstm, 4>(g.p[1], block % g.p[1].f.n_colblocks, block / g.p[1].f.n_colblocks, 0, 1, lds); break;
+    case 2: convlstm16_lds_body<kEpiLstm, 4>(g.p[2], block % g.p[2].f.n_colblocks, block / g.p[2].f.n_colblocks, 0, 1, lds); break;
+    default: convlstm16_lds_body<kEpiLstm, 4>(g.p[3], block % g.p[3].f.n_colblocks, block / g.p[3].f.n_colblocks, 0, 1, lds); break;
   }
 }
 
@@ -615,13 +630,33 @@ void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
 // the transposed, tap-flipped kernel as planes (pack_f16x3_dgrad_kernel).
 __device__ __forceinline__ void convlstm16_dgrad_dispatch(const ConvLstm16Args& p, int block,
                                                           f16x8* lds) {
-  const int cb = block % p.f.n_colblocks;
-  if (cb == p.f.n_colblocks - 1 && p.f.ng_last == 1)
-    convlstm16_lds_body<kEpiStore, 1>(p, block, lds);
-  else if (cb == p.f.n_colblocks - 1 && p.f.ng_last == 2)
-    convlstm16_lds_body<kEpiStore, 2>(p, block, lds);
+  // block -> (column block, k slice, row tile).  Full-width column blocks first,
+  // combo = block % (n_main * nks) = (k slice, column block): with 2 x 4 combos a
+  // combo is an XCD (blockIdx % 8), whose L2 then keeps that combo's 1.2 MB of
+  // kernel planes while the G planes stream through; the narrow last block (d x
+  // columns) follows as its own region.
+  const int ncb = p.f.n_colblocks;
+  const int nks = p.n_kslice > 1 ? p.n_kslice : 1;
+  const bool narrow = p.f.ng_last != 4;
+  const int n_main = narrow ? ncb - 1 : ncb;
+  const int M_total = p.f.rows * p.f.H * p.f.W;
+  const int mtiles = (M_total + kBlockRows - 1) / kBlockRows;
+  const int main_blocks = mtiles * n_main * nks;
+  int cb, ks, mt;
+  if (block < main_blocks) {
+    const int combo = block % (n_main * nks);
+    mt = block / (n_main * nks);
+    cb = combo % n_main; ks = combo / n_main;
+  } else {
+    const int b2 = block - main_blocks;
+    cb = ncb - 1; ks = b2 % nks; mt = b2 / nks;
+  }
+  if (cb == ncb - 1 && p.f.ng_last == 1)
+    convlstm16_lds_body<kEpiStore, 1>(p, cb, mt, ks, nks, lds);
+  else if (cb == ncb - 1 && p.f.ng_last == 2)
+    convlstm16_lds_body<kEpiStore, 2>(p, cb, mt, ks, nks, lds);
   else
-    convlstm16_lds_body<kEpiStore, 4>(p, block, lds);
+    convlstm16_lds_body<kEpiStore, 4>(p, cb, mt, ks, nks, lds);
 }
 
 __global__ __launch_bounds__(256, 2)
@@ -648,11 +683,38 @@ static inline void launch_convlstm16_dgrads(const ConvLstm16Args* probs, int n,
   unsigned total = 0;
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
-    total += convlstm_blocks(probs[i].f);
+    total += convlstm_blocks(probs[i].f) * (unsigned)(probs[i].n_kslice > 1 ? probs[i].n_kslice : 1);
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
   hipLaunchKernelGGL(convlstm_dgrad_f16x3_kernel, dim3(total), dim3(256), 0, stream, g);
+}
+
+// out[seg][i] = sum over the k slices (in slice order) of part[seg][s][i]
+struct SumSlicesArgs {
+  const float* part[2 * kMaxGroup];
+  float* out[2 * kMaxGroup];
+  unsigned long long n[2 * kMaxGroup];     // elements per slice (multiple of 4)
+  unsigned block_end[2 * kMaxGroup];
+  int nseg, nslice;
+};
+__global__ __launch_bounds__(256)
+void sum_slices_kernel(const SumSlicesArgs a) {
+  int seg = 0;
+#pragma unroll
+  for (int i = 0; i < 2 * kMaxGroup - 1; ++i)
+    if (i + 1 < a.nseg && blockIdx.x >= a.block_end[i]) seg = i + 1;
+  const unsigned b = blockIdx.x - (seg ? a.block_end[seg - 1] : 0u);
+  const size_t i4 = (size_t)b * 256 + threadIdx.x;
+  const size_t n4 = a.n[seg] / 4;
+  if (i4 >= n4) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(a.part[seg]);
+  f32x4 v = src[i4];
+  for (int s2 = 1; s2 < a.nslice; ++s2) {
+    const f32x4 w = src[(size_t)s2 * n4 + i4];
+    v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+  }
+  reinterpret_cast<f32x4*>(a.out[seg])[i4] = v;
 }
 
 // Pack of the transposed, tap-flipped kernel as fp16 planes (cf.

@@ -56,6 +56,7 @@ struct TrainState {
   // f16x3 dgrad: planes of the gate gradients of the current step per group slot,
   // max |G| bits and scale exponents per (launch slot, step)
   DevBuf<_Float16> g16[mv::kMaxGroup];
+  DevBuf<float> dpart0[mv::kMaxGroup], dpart1[mv::kMaxGroup];   // dgrad split-K partials
   DevBuf<int32_t> gmax, gexp;
   // f16x3 wgrad: cell-contiguous operand planes of one chain at a time
   DevBuf<_Float16> gt16, at16[3], xt16[3];
@@ -501,10 +502,49 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     q.wp16 = chains[i]->wd16.p;
     q.n_xk = 0; q.n_hk = 9 * (a.C / 16); q.w_ksteps = q.n_hk;
     q.g_exp = t.gexp.p + slots[i];
+    // split-K over four channel-group ranges (see convlstm16_dgrad_dispatch)
+    const int nstages = q.n_hk / 3;
+    static const int ks_env = getenv("MV_DGRAD_KSLICES") ? atoi(getenv("MV_DGRAD_KSLICES")) : 4;
+    if (ks_env > 1 && nstages % (2 * ks_env) == 0) {
+      const size_t M = (size_t)a.rows * a.H * a.W;
+      q.n_kslice = ks_env;
+      t.dpart0[i].alloc((size_t)ks_env * M * a.out0_cols);
+      q.part0 = t.dpart0[i].p;
+      if (a.out1_cols > 0) {
+        t.dpart1[i].alloc((size_t)ks_env * M * ((a.out1_cols + 3) / 4 * 4));
+        q.part1 = t.dpart1[i].p;
+      }
+    }
   }
   launch(e, "convlstm_dgrad", fl, by, [&] {
     mv::launch_convlstm16_dgrads(p16.data(), (int)p16.size(), e->stream);
   });
+  mv::SumSlicesArgs sa{};
+  unsigned blocks = 0;
+  double sbytes = 0;
+  for (size_t i = 0; i < p16.size(); ++i) {
+    const mv::ConvLstm16Args& q = p16[i];
+    if (q.n_kslice <= 1) continue;
+    const size_t M = (size_t)q.f.rows * q.f.H * q.f.W;
+    sa.nslice = q.n_kslice;
+    for (int o = 0; o < 2; ++o) {
+      float* out = o ? q.f.out1 : q.f.out0;
+      const size_t n = M * (size_t)(o ? q.f.out1_cols : q.f.out0_cols);
+      if (!out || n == 0) continue;
+      MV_REQUIRE(n % 4 == 0, "internal: dgrad slice sum needs a multiple of 4 elements");
+      sa.part[sa.nseg] = o ? q.part1 : q.part0;
+      sa.out[sa.nseg] = out;
+      sa.n[sa.nseg] = n;
+      blocks += cdiv(n / 4, 256);
+      sa.block_end[sa.nseg] = blocks;
+      sbytes += 4.0 * n * (q.n_kslice + 1);
+      ++sa.nseg;
+    }
+  }
+  if (sa.nseg > 0)
+    launch(e, "dgrad_slice_sum", 0, sbytes, [&] {
+      hipLaunchKernelGGL(mv::sum_slices_kernel, dim3(blocks), dim3(256), 0, e->stream, sa);
+    });
 }
 
 void run_dgrad_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
