@@ -146,6 +146,37 @@ int  mv_forward_beam(mv_handle h, const mv_inputs* in, mv_beam_outputs* out);
 
 /* -- resident-input variants (bench: inputs already in HBM) -------------- */
 int  mv_upload_inputs(mv_handle h, const mv_inputs* in);   /* H2D + sync */
+
+/* Device-side batch assembly.  The dense regression maps the graph
+ * consumes are a pure function of one (x, y) per trajectory step,
+ *   map[n, t, h, w, :] = (float)((double)xy[n, t, :] - centre[h, w, :])
+ * (code/preprocess.py:463-475: float32 trajectory minus float64 grid centres, stored
+ * as float32), and the scene masks are 0/1 bytes in data_*.npz (preprocess.py:831).
+ * The compact forms hand over 16 bytes per step instead of 2*H*W*4 per scale and
+ * uint8 masks; the engine expands both in HBM, bit-identical to the dense upload.
+ * Rows n >= num_rows (the batcher's padding, code/pred_models.py:1070-1191) get zero
+ * maps.  mv_set_grid_centers once per scale (data["grid_center_<s>"], float64
+ * [H, W, 2]); then mv_upload_inputs_compact (+ mv_upload_targets_compact when
+ * training) and the resident calls (mv_run_*_resident, mv_train_step(h, NULL, NULL, ..)). */
+typedef struct mv_inputs_compact {
+  const int32_t* obs_scene;        /* [N, T_o] row index into scene_feat_u8 */
+  const uint8_t* scene_feat_u8;    /* [U, SH, SW, SC] 0/1 masks */
+  int32_t        num_scene_frames; /* U */
+  int32_t        pred_len;         /* run-time T_pred (<= max_pred_len) */
+  const int32_t* grid_obs_labels[MV_MAX_SCALES];   /* [N, T_o] */
+  const double*  obs_xy;           /* [N, T_o, 2] pixel coordinates */
+  int32_t        num_rows;         /* rows that carry data (<= N) */
+} mv_inputs_compact;
+
+typedef struct mv_targets_compact {
+  const int32_t* grid_pred_labels[MV_MAX_SCALES];  /* [N, T_p] */
+  const double*  pred_xy;          /* [N, T_p, 2] */
+  int32_t        num_rows;
+} mv_targets_compact;
+
+int  mv_set_grid_centers(mv_handle h, int32_t scale, const double* centers /* [H, W, 2] */);
+int  mv_upload_inputs_compact(mv_handle h, const mv_inputs_compact* in);
+int  mv_upload_targets_compact(mv_handle h, const mv_targets_compact* tg);
 int  mv_run_greedy_resident(mv_handle h);   /* enqueue on the handle's stream */
 int  mv_run_beam_resident(mv_handle h);
 int  mv_synchronize(mv_handle h);

@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "mv_upload_targets", "mv_grad_buffer", "mv_train_apply", "mv_get_grad", "mv_get_global_step",
     "mv_set_global_step", "mv_get_opt_slot", "mv_set_opt_slot",
     "mv_op_convlstm_bwd", "mv_op_gnn_bwd",
+    "mv_set_grid_centers", "mv_upload_inputs_compact", "mv_upload_targets_compact",
 ]
 
 
@@ -75,6 +76,30 @@ class mv_inputs(C.Structure):
       ("pred_len", C.c_int32),
       ("grid_obs_labels", _ip * MV_MAX_SCALES),
       ("grid_obs_regress", _fp * MV_MAX_SCALES),
+  ]
+
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class mv_inputs_compact(C.Structure):
+  _fields_ = [
+      ("obs_scene", _ip),
+      ("scene_feat_u8", _u8p),
+      ("num_scene_frames", C.c_int32),
+      ("pred_len", C.c_int32),
+      ("grid_obs_labels", _ip * MV_MAX_SCALES),
+      ("obs_xy", _dp),
+      ("num_rows", C.c_int32),
+  ]
+
+
+class mv_targets_compact(C.Structure):
+  _fields_ = [
+      ("grid_pred_labels", _ip * MV_MAX_SCALES),
+      ("pred_xy", _dp),
+      ("num_rows", C.c_int32),
   ]
 
 
@@ -149,6 +174,9 @@ def load():
   lib.mv_forward_beam.argtypes = [h, C.POINTER(mv_inputs),
                                   C.POINTER(mv_beam_outputs)]
   lib.mv_upload_inputs.argtypes = [h, C.POINTER(mv_inputs)]
+  lib.mv_set_grid_centers.argtypes = [h, C.c_int32, _dp]
+  lib.mv_upload_inputs_compact.argtypes = [h, C.POINTER(mv_inputs_compact)]
+  lib.mv_upload_targets_compact.argtypes = [h, C.POINTER(mv_targets_compact)]
   lib.mv_run_greedy_resident.argtypes = [h]
   lib.mv_run_beam_resident.argtypes = [h]
   lib.mv_synchronize.argtypes = [h]
@@ -412,6 +440,75 @@ class Engine(object):
     inp = self._inputs(feed)
     self._pred_len = inp.pred_len
     check(self.lib.mv_upload_inputs(self.handle, C.byref(inp)), self.handle)
+
+  # ---- compact inputs (device-side batch assembly)
+  def set_grid_centers(self, centers):
+    """centers: list over scales of float64 [H, W, 2] (data["grid_center_<s>"])."""
+    for s, (h, w) in enumerate(self.cfg.scene_grids):
+      if not self.cfg.use_grids[s]:
+        continue
+      c = np.ascontiguousarray(np.asarray(centers[s], dtype=np.float64).reshape(h, w, 2))
+      check(self.lib.mv_set_grid_centers(self.handle, s, c.ctypes.data_as(_dp)),
+            self.handle)
+    self._centers_set = True
+
+  def upload_compact(self, feed):
+    """feed: obs_scene, scene_feat (0/1, any dtype), grid_obs_labels, obs_xy
+    [N, T_o, 2], optional num_rows, pred_length; with grid_pred_labels + pred_xy
+    also the training targets (after train_init)."""
+    cfg = self.cfg
+    N, T = cfg.batch_size, cfg.obs_len
+    if not getattr(self, "_centers_set", False):
+      self.set_grid_centers(feed["grid_centers"])
+    inp = mv_inputs_compact()
+    obs_scene = i32(feed["obs_scene"]).reshape(N, T)
+    scene = np.ascontiguousarray(np.asarray(feed["scene_feat"]).astype(np.uint8, copy=False))
+    xy = np.ascontiguousarray(np.asarray(feed["obs_xy"], dtype=np.float64).reshape(N, T, 2))
+    keep = [obs_scene, scene, xy]
+    inp.obs_scene = iptr(obs_scene)
+    inp.scene_feat_u8 = scene.ctypes.data_as(_u8p)
+    inp.num_scene_frames = int(scene.shape[0])
+    inp.pred_len = int(feed.get("pred_length", cfg.pred_len))
+    inp.obs_xy = xy.ctypes.data_as(_dp)
+    inp.num_rows = int(feed.get("num_rows", N))
+    for s in range(len(cfg.scene_grids)):
+      if not cfg.use_grids[s]:
+        continue
+      lab = i32(feed["grid_obs_labels"][s]).reshape(N, T)
+      keep.append(lab)
+      inp.grid_obs_labels[s] = iptr(lab)
+    self._pred_len = inp.pred_len
+    check(self.lib.mv_upload_inputs_compact(self.handle, C.byref(inp)), self.handle)
+    if feed.get("pred_xy") is not None and getattr(self, "_tc", None) is not None:
+      Tp = inp.pred_len
+      tg = mv_targets_compact()
+      pxy = np.ascontiguousarray(
+          np.asarray(feed["pred_xy"], dtype=np.float64).reshape(N, -1, 2)[:, :Tp])
+      keep.append(pxy)
+      tg.pred_xy = pxy.ctypes.data_as(_dp)
+      tg.num_rows = inp.num_rows
+      for s in range(len(cfg.scene_grids)):
+        if not cfg.use_grids[s]:
+          continue
+        lab = i32(feed["grid_pred_labels"][s]).reshape(N, Tp)
+        keep.append(lab)
+        tg.grid_pred_labels[s] = iptr(lab)
+      check(self.lib.mv_upload_targets_compact(self.handle, C.byref(tg)), self.handle)
+    del keep      # both calls copy synchronously
+
+  def forward_greedy_compact(self, feed):
+    self.upload_compact(feed)
+    self.run_resident(False)
+    return self.download()
+
+  def forward_beam_compact(self, feed):
+    self.upload_compact(feed)
+    self.run_resident(True)
+    return self.download_beam()
+
+  def train_step_compact(self, feed):
+    self.upload_compact(feed)
+    return self.train_step(None)
 
   def run_resident(self, beam=False):
     fn = self.lib.mv_run_beam_resident if beam else self.lib.mv_run_greedy_resident

@@ -124,6 +124,7 @@ struct ScaleState {
   DevBuf<float> scene_mean;                 // [N, K, D]
   DevBuf<int32_t> labels;                   // [N, T_o]
   DevBuf<float> obs_reg;                    // [N, T_o, K, 2]
+  DevBuf<double> centers;                   // [K, 2] cell centres (compact inputs)
   DevBuf<float> cls_c[2], cls_h[2], cls_hg; // class chain state [R, K, C]
   DevBuf<float> reg_c[2], reg_h[2];         // regression chain state [N, K, C]
   DevBuf<float> xbuf_cls, xbuf_reg;         // ConvLSTM x operand
@@ -146,6 +147,8 @@ struct mv_engine {
   // inputs
   DevBuf<int32_t> obs_scene;       // [N, T_o]
   DevBuf<float> scene_feat;        // [U, SH, SW, SC]
+  DevBuf<uint8_t> scene_u8;        // compact inputs: the masks as uploaded
+  DevBuf<double> xy_dev;           // compact inputs: [N, T, 2] coordinates
   DevBuf<float> scene_conv[MV_MAX_SCALES];  // per level [U, h*w, D]
   std::vector<int> conv_h, conv_w;
   int num_frames = 0;
@@ -970,6 +973,54 @@ void upload_inputs(mv_engine* e, const mv_inputs* in) {
   e->inputs_ready = true;
 }
 
+// compact inputs: labels / scene indices as before, maps and masks expanded in HBM
+void upload_inputs_compact(mv_engine* e, const mv_inputs_compact* in) {
+  const mv_config& c = e->cfg;
+  const size_t N = c.batch_size, T = c.obs_len;
+  MV_REQUIRE(in->obs_scene && in->scene_feat_u8 && in->obs_xy,
+             "obs_scene / scene_feat_u8 / obs_xy is NULL");
+  MV_REQUIRE(in->num_scene_frames >= 1 && (size_t)in->num_scene_frames <= N * T,
+             "num_scene_frames %d not in [1, N*T_o=%zu]", in->num_scene_frames, N * T);
+  MV_REQUIRE(in->pred_len >= 1 && in->pred_len <= c.max_pred_len,
+             "pred_len %d not in [1, max_pred_len=%d]", in->pred_len, c.max_pred_len);
+  MV_REQUIRE(in->num_rows >= 0 && (size_t)in->num_rows <= N, "num_rows %d not in [0, N=%zu]",
+             in->num_rows, N);
+  for (size_t i = 0; i < N * T; ++i)
+    MV_REQUIRE(in->obs_scene[i] >= 0 && in->obs_scene[i] < in->num_scene_frames,
+               "obs_scene[%zu] = %d out of range [0,%d)", i, in->obs_scene[i],
+               in->num_scene_frames);
+  e->num_frames = in->num_scene_frames;
+  e->pred_len = in->pred_len;
+  HIP_CHECK(hipMemcpyAsync(e->obs_scene.p, in->obs_scene, N * T * sizeof(int32_t),
+                           hipMemcpyHostToDevice, e->stream));
+  const size_t nscene = (size_t)e->num_frames * c.scene_h * c.scene_w * c.scene_class;
+  e->scene_u8.alloc(N * T * c.scene_h * c.scene_w * c.scene_class);
+  HIP_CHECK(hipMemcpyAsync(e->scene_u8.p, in->scene_feat_u8, nscene, hipMemcpyHostToDevice,
+                           e->stream));
+  hipLaunchKernelGGL(mv::u8_to_f32_kernel, dim3(cdiv(nscene, 256)), dim3(256), 0, e->stream,
+                     e->scene_u8.p, e->scene_feat.p, nscene);
+  e->xy_dev.alloc(2 * N * std::max<size_t>(T, c.max_pred_len));
+  HIP_CHECK(hipMemcpyAsync(e->xy_dev.p, in->obs_xy, 2 * N * T * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    MV_REQUIRE(in->grid_obs_labels[s], "grid_obs_labels[%d] is NULL for an enabled scale", s);
+    MV_REQUIRE(S.centers.p, "mv_set_grid_centers(%d) has not been called", s);
+    for (size_t i = 0; i < N * T; ++i)
+      MV_REQUIRE(in->grid_obs_labels[s][i] >= 0 && in->grid_obs_labels[s][i] < S.K,
+                 "grid_obs_labels[%d][%zu] = %d out of range [0,%d)", s, i,
+                 in->grid_obs_labels[s][i], S.K);
+    HIP_CHECK(hipMemcpyAsync(S.labels.p, in->grid_obs_labels[s],
+                             N * T * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(mv::regress_from_xy_kernel, dim3(cdiv(N * T * S.K, 256)), dim3(256), 0,
+                       e->stream, e->xy_dev.p, S.centers.p, S.obs_reg.p, (int)(N * T), (int)T,
+                       S.K, in->num_rows);
+  }
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+  e->inputs_ready = true;
+}
+
 void download_outputs(mv_engine* e, mv_outputs* out) {
   const mv_config& c = e->cfg;
   const size_t N = c.batch_size, Tp = e->pred_len;
@@ -1184,6 +1235,27 @@ int mv_upload_inputs(mv_handle h, const mv_inputs* in) {
   });
 }
 
+int mv_set_grid_centers(mv_handle h, int32_t scale, const double* centers) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(scale >= 0 && scale < h->cfg.num_scales && h->sc[scale].use,
+               "mv_set_grid_centers: scale %d is not an enabled scale", scale);
+    MV_REQUIRE(centers, "mv_set_grid_centers: NULL centers");
+    ScaleState& S = h->sc[scale];
+    S.centers.alloc((size_t)S.K * 2);
+    HIP_CHECK(hipMemcpy(S.centers.p, centers, (size_t)S.K * 2 * sizeof(double),
+                        hipMemcpyHostToDevice));
+  });
+}
+
+int mv_upload_inputs_compact(mv_handle h, const mv_inputs_compact* in) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(in, "mv_upload_inputs_compact: NULL inputs");
+    upload_inputs_compact(h, in);
+  });
+}
+
 int mv_run_greedy_resident(mv_handle h) {
   if (!h) return 1;
   return guarded(h, [&] {
@@ -1284,6 +1356,17 @@ int mv_upload_targets(mv_handle h, const mv_targets* tg) {
     MV_REQUIRE(tg, "mv_upload_targets: NULL targets");
     MV_REQUIRE(h->inputs_ready, "mv_upload_inputs first (it fixes T_pred)");
     upload_targets(h, tg);
+    TS(h).targets_ready = true;
+  });
+}
+
+int mv_upload_targets_compact(mv_handle h, const mv_targets_compact* tg) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train, "mv_train_init has not been called");
+    MV_REQUIRE(tg, "mv_upload_targets_compact: NULL targets");
+    MV_REQUIRE(h->inputs_ready, "mv_upload_inputs first (it fixes T_pred)");
+    upload_targets_compact(h, tg);
     TS(h).targets_ready = true;
   });
 }

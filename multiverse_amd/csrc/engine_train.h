@@ -320,6 +320,34 @@ void upload_targets(mv_engine* e, const mv_targets* tg) {
   HIP_CHECK(hipStreamSynchronize(e->stream));
 }
 
+void upload_targets_compact(mv_engine* e, const mv_targets_compact* tg) {
+  const mv_config& c = e->cfg;
+  const size_t N = c.batch_size, Tp = e->pred_len;
+  MV_REQUIRE(tg->pred_xy, "pred_xy is NULL");
+  MV_REQUIRE(tg->num_rows >= 0 && (size_t)tg->num_rows <= N, "num_rows %d not in [0, N=%zu]",
+             tg->num_rows, N);
+  e->xy_dev.alloc(2 * N * std::max<size_t>(c.obs_len, c.max_pred_len));
+  HIP_CHECK(hipMemcpyAsync(e->xy_dev.p, tg->pred_xy, 2 * N * Tp * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    MV_REQUIRE(tg->grid_pred_labels[s], "grid_pred_labels[%d] is NULL for an enabled scale", s);
+    MV_REQUIRE(S.centers.p, "mv_set_grid_centers(%d) has not been called", s);
+    for (size_t i = 0; i < N * Tp; ++i)
+      MV_REQUIRE(tg->grid_pred_labels[s][i] >= 0 && tg->grid_pred_labels[s][i] < S.K,
+                 "grid_pred_labels[%d][%zu] = %d out of range [0,%d)", s, i,
+                 tg->grid_pred_labels[s][i], S.K);
+    TrainScale& R = TS(e).sc[s];
+    HIP_CHECK(hipMemcpyAsync(R.pred_labels.p, tg->grid_pred_labels[s],
+                             N * Tp * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(mv::regress_from_xy_kernel, dim3(cdiv(N * Tp * S.K, 256)), dim3(256),
+                       0, e->stream, e->xy_dev.p, S.centers.p, R.pred_reg.p, (int)(N * Tp),
+                       (int)Tp, S.K, tg->num_rows);
+  }
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+}
+
 ConvLstmArgs train_problem(mv_engine* e, TrainChain& ch, const float* x, const float* h,
                            const float* c, float* h_out, float* c_out, float* gates,
                            int H, int W, bool zero_state) {

@@ -423,4 +423,29 @@ void beam_step_kernel(const float* __restrict__ logits,
   }
 }
 
+// ------------------------------------------------------------ batch assembly
+// Dense regression maps from one (x, y) per row-step: out[r, cell, :] =
+// (float)(xy[r, :] - centre[cell, :]) in double, the rounding of
+// code/preprocess.py:463-475; rows of samples n >= num_rows are zero.
+__global__ void regress_from_xy_kernel(const double* __restrict__ xy,
+                                       const double* __restrict__ centers,
+                                       float* __restrict__ out, int rows, int T, int K,
+                                       int num_rows) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (row-step, cell)
+  if (idx >= (size_t)rows * K) return;
+  const int r = (int)(idx / K), cell = (int)(idx - (size_t)r * K);
+  float2 v = {0.f, 0.f};
+  if (r / T < num_rows) {
+    v.x = (float)(xy[2 * (size_t)r] - centers[2 * cell]);
+    v.y = (float)(xy[2 * (size_t)r + 1] - centers[2 * cell + 1]);
+  }
+  reinterpret_cast<float2*>(out)[idx] = v;
+}
+
+__global__ void u8_to_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                 size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+
 }  // namespace mv

@@ -223,13 +223,20 @@ def make_scene_feat(rng, F, cfg):
   return out
 
 
-def make_npz_data(cfg, num_examples, seed=SEED_BASE, frames_per_group=4):
+def make_npz_data(cfg, num_examples, seed=SEED_BASE, frames_per_group=4,
+                  float32_traj=False):
   """The dict `np.savez(data_{split}.npz)` would hold
   (`code/preprocess.py:670-866`), restricted to the keys the hot path and
-  `pred_utils.evaluate` read."""
+  `pred_utils.evaluate` read.  float32_traj: round the walk to float32 BEFORE the
+  grid classes / regression maps are derived, as the reference does
+  (`preprocess.py:308` reads the trajectory file into float32), so that
+  `*_grid_target_all` == float32(float64(obs_traj) - grid_center) exactly; the
+  default keeps the float64 walk the committed golden fixtures were made from."""
   rng = np.random.default_rng(seed)
   T = cfg.obs_len + cfg.pred_len
   traj = make_trajectories(rng, num_examples, T, cfg)
+  if float32_traj:
+    traj = traj.astype("float32").astype("float64")
   classes, targets = grid_class_and_targets(cfg, traj)
   F = int(math.ceil(num_examples / float(frames_per_group)))
   scene_feat = make_scene_feat(rng, F, cfg)
@@ -250,6 +257,7 @@ def make_npz_data(cfg, num_examples, seed=SEED_BASE, frames_per_group=4):
       "video_wh": (cfg.video_w, cfg.video_h),
       "scene_grid_strides": list(cfg.scene_grid_strides),
   }
+  data["_traj64"] = traj       # the unrounded walk the maps below were derived from
   for i, c in enumerate(grid_centers(cfg)):
     data["grid_center_%d" % i] = c
     data["obs_grid_target_all_%d" % i] = targets[i][:, :cfg.obs_len]
@@ -281,4 +289,9 @@ def make_feed(cfg, seed=SEED_BASE, frames_per_group=4, pred_len=None):
         np.ascontiguousarray(data["pred_grid_class"][:, s, :], dtype="int32"))
     feed["grid_pred_regress"].append(
         np.ascontiguousarray(data["pred_grid_target_all_%d" % s], dtype="float32"))
+  # compact form of the same batch (Engine.upload_compact): coordinates + centres
+  feed["obs_xy"] = np.ascontiguousarray(data["_traj64"][:, :cfg.obs_len])
+  feed["pred_xy"] = np.ascontiguousarray(data["_traj64"][:, cfg.obs_len:])
+  feed["grid_centers"] = [data["grid_center_%d" % s] for s in range(len(cfg.scene_grids))]
+  feed["scene_feat_u8"] = data["scene_feat"]
   return feed

@@ -110,3 +110,70 @@ def test_full_size_properties_batch64(built_lib):
   for s in (0, 1):
     assert (c4[s] == cls[s][lo:lo + 4]).all()      # same kernels, same order: bitwise
     assert (r4[s] == reg[s][lo:lo + 4]).all()
+
+
+def test_compact_inputs_are_bit_identical(built_lib):
+  """SURVEY 8f N3 (device-side batch assembly): labels + one (x, y) per step +
+  uint8 masks, expanded in HBM, against the dense upload of the same batch --
+  greedy outputs, beam outputs and one training step, bit for bit; then the same
+  through Tester.step with config.compact_inputs on a reference-style npz."""
+  cfg = synth.default_config(batch_size=3, use_grids=(1, 1))
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 4)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 31)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  cls, reg = eng.forward_greedy(feed)
+  ccls, creg = eng.forward_greedy_compact(dict(feed, num_rows=3))
+  for s in range(2):
+    assert (cls[s] == ccls[s]).all() and (reg[s] == creg[s]).all()
+  # padded rows: maps zero, as rows beyond len(data) in the reference feed
+  dense2 = dict(feed)
+  dense2["grid_obs_regress"] = [a.copy() for a in feed["grid_obs_regress"]]
+  for a in dense2["grid_obs_regress"]:
+    a[2:] = 0.0
+  cls2, reg2 = eng.forward_greedy(dense2)
+  ccls2, creg2 = eng.forward_greedy_compact(dict(feed, num_rows=2))
+  for s in range(2):
+    assert (cls2[s] == ccls2[s]).all() and (reg2[s] == creg2[s]).all()
+  eng.close()
+
+  bcfg = synth.default_config(batch_size=2, use_grids=(1, 0), use_beam_search=True,
+                              beam_size=5, diverse_beam=True)
+  beng = built_lib.Engine(bcfg, device=0)
+  beng.set_params(synth.make_params(bcfg, seed=synth.SEED_BASE + 4))
+  bfeed = synth.make_feed(bcfg, seed=synth.SEED_BASE + 32)
+  a, _ = beng.forward_beam(bfeed)
+  b, _ = beng.forward_beam_compact(bfeed)
+  for k in a:
+    assert (a[k] == b[k]).all(), k
+  beng.close()
+
+  tcfg = synth.default_config(batch_size=2, use_grids=(1, 1), is_train=True)
+  tparams = synth.make_params(tcfg, seed=synth.SEED_BASE + 4)
+  tfeed = synth.make_feed(tcfg, seed=synth.SEED_BASE + 33)
+  out = []
+  for compact in (False, True):
+    e = built_lib.Engine(tcfg, device=0)
+    e.set_params(tparams)
+    e.train_init()
+    out.append((e.train_step_compact(tfeed) if compact else e.train_step(tfeed),
+                e.get_param("person_pred/scene_conv1/W")))
+    e.close()
+  assert out[0][0] == out[1][0]
+  assert (out[0][1] == out[1][1]).all()
+
+  # through the host mirror: Tester.step on a reference-style dataset
+  cfg4 = synth.default_config(batch_size=4, use_grids=(1, 1))
+  data = synth.make_npz_data(cfg4, 6, seed=9, float32_traj=True)
+  ds = pred_utils.dataset_from_npz_dict(data, "test", cfg4)
+  model = pred_models.get_model(cfg4, 0)
+  model.load_params(synth.make_params(cfg4, seed=synth.SEED_BASE + 4))
+  tester = pred_models.Tester(model, cfg4)
+  res = []
+  for compact in (False, True):
+    cfg4.compact_inputs = compact
+    res.append([tester.step(None, bt) for bt in ds.get_batches(4, full=True, shuffle=False)])
+  for (c0, r0, _), (c1, r1, _) in zip(*res):
+    for s in range(2):
+      assert (c0[s] == c1[s]).all() and (r0[s] == r1[s]).all()
+  model.close()

@@ -108,6 +108,34 @@ def test_feed_dict_contents():
   assert tr["grid_pred_labels"][0].shape == (4, 12)
 
 
+def test_compact_feed_dict_expands_to_the_dense_one():
+  """labels + one (x, y) per step carry the same batch as the dense
+  feed when the npz is built the reference's way (float32 trajectory, float64
+  centres): float32(float64(xy) - centre) == *_grid_target_all bit for bit, padded
+  rows zero; the masks travel as uint8."""
+  cfg = synth.default_config(batch_size=4, use_grids=(1, 1), is_train=True)
+  data = synth.make_npz_data(cfg, 3, seed=5, float32_traj=True)
+  ds = pred_utils.dataset_from_npz_dict(data, "train", cfg)
+  (_, b), = list(ds.get_batches(4, full=True, shuffle=False))
+  dense = pred_models.build_feed_dict(cfg, b, is_train=True)
+  comp = pred_models.build_compact_feed_dict(cfg, b, is_train=True)
+  assert comp["compact"]
+  n = len(b.data["obs_grid_class"])
+  assert comp["scene_feat"].dtype == np.uint8
+  assert (comp["scene_feat"] == dense["scene_feat"]).all()
+  assert (comp["obs_scene"] == dense["obs_scene"]).all()
+  for j in range(2):
+    c = np.asarray(comp["grid_centers"][j], dtype="float64")
+    assert (comp["grid_obs_labels"][j] == dense["grid_obs_labels"][j]).all()
+    assert (comp["grid_pred_labels"][j] == dense["grid_pred_labels"][j]).all()
+    for key_xy, key_map in (("obs_xy", "grid_obs_regress"), ("pred_xy", "grid_pred_regress")):
+      m = (comp[key_xy][:, :, None, None, :] - c[None, None]).astype("float32")
+      m[comp["num_rows"]:] = 0.0
+      assert m.shape == dense[key_map][j].shape
+      assert (m == dense[key_map][j]).all(), (j, key_map)
+  assert comp["num_rows"] == n
+
+
 class _PerfectTester(object):
   """Emits one-hot GT logits and the GT offsets: ADE/FDE must be ~0."""
 
