@@ -178,6 +178,8 @@ def main():
   stats = eng.kernel_stats()
   eng.set_profiling(False)
   mfma_kernels = ["convlstm_step"] + (["convlstm_dgrad", "convlstm_wgrad"] if train else [])
+  if train and "convlstm_wgrad_x" in stats:      # f16x3: the x rows are a launch of their own
+    mfma_kernels.append("convlstm_wgrad_x")
   conv = {k: sum(stats[n][k] for n in mfma_kernels)
           for k in ("launches", "total_ms", "flops", "bytes")}
   conv_s = conv["total_ms"] * 1e-3
@@ -185,7 +187,7 @@ def main():
   flops_traj, bytes_traj = algorithmic_counts(cfg, args.beam if beam else 1)
   if train:
     flops_traj *= 3.0   # forward + dgrad + wgrad of every gate convolution
-  f16 = args.compute == "f16x3" and not train
+  f16 = args.compute == "f16x3"
   peak = PEAK_FP16_MFMA_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS
   roofline = {
       "kernel": "+".join(mfma_kernels),
@@ -253,8 +255,8 @@ def main():
                     args.batch, args.batch * world,
                     "RCCL all-reduce of the 21.3M-float gradient buffer" if world > 1
                     else "no all-reduce (1 rank)",
-                    "forward and dgrad on the fp16 matrix pipe (f16x3, fp32-class error), "
-                    "wgrad on the fp32 matrix pipe" if args.compute == "f16x3"
+                    "forward, dgrad and wgrad on the fp16 matrix pipe (f16x3 split, "
+                    "fp32-class error)" if args.compute == "f16x3"
                     else "fp32 matrix pipe"))
   else:
     metric = ("trajectories/sec (8-obs/12-pred, multi-scale 18x32+9x16 grid, "
@@ -278,9 +280,10 @@ def main():
       "vs_baseline": None,
       "dtype": ("f16x3 (fp32 operands as two pre-scaled fp16 planes, 3 fp16 MFMAs per "
                 "product, fp32 accumulate and state; measured error vs fp64 <= the fp32-MFMA "
-                "path's, argmax / beam ids bit-exact)" if f16 else
-                "f16x3 forward + dgrad, f32 wgrad / state / optimizer" if
-                (train and args.compute == "f16x3") else "f32"),
+                "path's, argmax / beam ids bit-exact)" if (f16 and not train) else
+                "f16x3 gate convolutions (forward, dgrad, wgrad: fp32 operands as two "
+                "pre-scaled fp16 planes, 3 fp16 MFMAs per product, fp32 accumulate); fp32 "
+                "state, losses, gradients and optimizer" if f16 else "f32"),
       "data": "synthetic (seeded AR(1) trajectories, rectangle scene masks, "
               "random-init weights with the reference's initialisers)",
       "config": {"workload": workload,
@@ -294,7 +297,7 @@ def main():
       "roofline": roofline,
   }
 
-  if f16:
+  if f16 and not train:
     # the same workload on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), for reference
     eng.set_compute_mode("f32")
     one_step()
@@ -317,8 +320,9 @@ def main():
                                         / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
     eng.set_compute_mode("f16x3")
 
-  if rank == 0 and world == 1 and not args.no_cpu_baseline and not beam and not train:
-    out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and not beam:
+    out["cpu_baseline"] = (cpu_baseline_train(min(args.cpu_batch, 4)) if train
+                           else cpu_baseline(args.cpu_batch))
 
   eng.close()
   if use_dist:
@@ -368,6 +372,33 @@ def cpu_baseline(batch):
           "sample": "%d passes of %d trajectories (both scales, greedy), torch-CPU "
                     "fp32 oracle restatement of the reference graph -- NOT TF1"
                     % (passes, batch)}
+
+
+def cpu_baseline_train(batch):
+  """The CPU oracle's training step (forward, loss, autograd backward, clip,
+  Adadelta) on a bounded sample: 1 warm-up + timed steps of `batch` trajectories
+  until ~15 s of CPU work."""
+  import torch
+  from multiverse_amd import synth
+  from oracle import multiverse_oracle as oracle
+  cores = effective_cores()
+  torch.set_num_threads(cores)
+  cfg = synth.default_config(batch_size=batch, use_grids=(1, 1), is_train=True)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 2)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 2)
+  p, st = dict(params), oracle.adadelta_init(params)
+  _, _, _, p, st, _ = oracle.train_step(p, st, 0, cfg, feed)   # warm-up
+  t0 = time.perf_counter()
+  steps = 0
+  while steps < 1 or (time.perf_counter() - t0 < 15.0 and steps < 12):
+    _, _, _, p, st, _ = oracle.train_step(p, st, steps + 1, cfg, feed)
+    steps += 1
+  dt = time.perf_counter() - t0
+  return {"value": round(batch * steps / dt, 3), "unit": "trajectories/sec",
+          "cores": torch.get_num_threads(), "kind": "port",
+          "sample": "%d training steps of %d trajectories (both scales), torch-CPU "
+                    "fp32 oracle restatement of the reference graph + Trainer -- NOT TF1"
+                    % (steps, batch)}
 
 
 if __name__ == "__main__":
