@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "convlstm_mfma.h"
+#include "plane_layout.h"
 
 namespace mv {
 
@@ -140,188 +141,36 @@ __global__ void scale_xchunk_kernel(const float* __restrict__ wpack, float* __re
   wx32[idx] = wpack[(cb * nch + 0) * (size_t)(kBN * kBK) + i] * 65536.0f;
 }
 
-// fp32 -> two scaled fp16 planes (elementwise).
+// fp32 [M][C] -> two scaled fp16 planes in the operand layout (plane_index,
+// kernels_misc.h): tiles of 32 cells x 16 channels in MFMA A-fragment order.  One
+// thread per (cell, 8 channels), cells fastest inside a tile: 16-byte stores,
+// contiguous over the 32 cells of a tile half.
 __global__ void split_planes_kernel(const float* __restrict__ in, _Float16* __restrict__ p0,
-                                    _Float16* __restrict__ p1, size_t n4) {
+                                    _Float16* __restrict__ p1, int M, int C) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  const f32x4 v = reinterpret_cast<const f32x4*>(in)[i];
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  f16x4 a, b;
+  const int c8n = C >> 3;
+  const size_t per_tile = (size_t)32 * c8n;
+  const size_t mb = i / per_tile;
+  const int r = (int)(i - mb * per_tile);
+  const int c8 = r >> 5, cell = r & 31;
+  const long long m = (long long)mb * 32 + cell;
+  if (m >= M) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(in + (size_t)m * C + c8 * 8);
+  const f32x4 v0 = src[0], v1 = src[1];
+  f16x8 a, b;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float s = v[j] * kF16Scale;
-    const _Float16 h0 = (_Float16)s;
+  for (int j = 0; j < 8; ++j) {
+    const float sv = (j < 4 ? v0[j] : v1[j - 4]) * kF16Scale;
+    const _Float16 h0 = (_Float16)sv;
     a[j] = h0;
-    b[j] = (_Float16)(s - (float)h0);
+    b[j] = (_Float16)(sv - (float)h0);
   }
-  reinterpret_cast<f16x4*>(p0)[i] = a;
-  reinterpret_cast<f16x4*>(p1)[i] = b;
+  const size_t o = plane_index(m, c8 * 8, C);
+  *reinterpret_cast<f16x8*>(p0 + o) = a;
+  *reinterpret_cast<f16x8*>(p1 + o) = b;
 }
-
-struct Conv16Frag {
-  f16x8 a0, a1;
-  f16x8 b0[4], b1[4];
-  uint32_t ok;
-};
-
-__device__ __forceinline__ f16x8 mask_f16x8(f16x8 v, uint32_t m) {
-  u32x4 u = __builtin_bit_cast(u32x4, v);
-  u = u & m;
-  return __builtin_bit_cast(f16x8, u);
-}
-
-__device__ __forceinline__ void convlstm16_body(const ConvLstm16Args& p, int block) {
-  const ConvLstmArgs& a = p.f;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int ncb = a.C / kChBlock;
-  const int cb = block % ncb;      // channel block = XCD (speed only)
-  const int mt = block / ncb;
-  const int H = a.H, W = a.W, HW = H * W, C = a.C, Cx = a.Cx;
-  const int M_total = a.rows * HW;
-  const int m_wave = mt * kBlockRows + wave * kWaveRows;
-  if (m_wave >= M_total) return;
-
-  int ypos, xpos, xoff, hoff;
-  {
-    const int m = m_wave + (lane & 31);
-    if (m < M_total) {
-      const int r = m / HW, cell = m - r * HW;
-      const int y = cell / W;
-      ypos = y; xpos = cell - y * W;
-      const int sr = a.src_row_h ? a.src_row_h[r] : r;
-      xoff = r * a.x_row_stride + cell * Cx;
-      hoff = (sr * HW + cell) * C;
-    } else {
-      ypos = -100000; xpos = -100000; xoff = 0; hoff = 0;
-    }
-  }
-  const int k8 = (lane >> 5) * 8;
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
-
-  // ---- x_small prologue: the packed fp32 chunk (all 9 taps x Cx <= 3 channels)
-  if (a.x_small) {
-    const int khalf = (lane >> 5) * 4;
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wx32 + (size_t)cb * kBN * kBK) + lane;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      f32x4 b[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) b[g] = wsrc[(kk * 4 + g) * 64];
-      f32x4 v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = kk * 8 + khalf + j;
-        const int tap = k / Cx, ch = k - tap * Cx;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int yy = ypos + dy, xx = xpos + dx;
-        const bool ok = (k < 9 * Cx) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-        int off = xoff + (dy * W + dx) * Cx + ch;
-        off = ok ? off : 0;
-        const float tv = a.x[off];
-        v[j] = ok ? tv : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], b[g][j], acc[g], 0, 0, 0);
-    }
-  }
-
-  // ---- f16 k-steps
-  const int nxk = p.n_xk;
-  const int nsteps = nxk + p.n_hk;
-  const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wp16) +
-                      (size_t)cb * p.w_ksteps * (2 * 4 * 64) + lane;
-  auto load_step = [&](int s, Conv16Frag& f) {
-    const bool is_x = s < nxk;
-    // weights: x k-steps first, then h k-steps (a zero-state step skips the h part,
-    // which sits AFTER the x part, so the index is simply s)
-    const f16x8* wsrc = wblk + (size_t)s * (2 * 4 * 64);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f.b0[g] = wsrc[g * 64];
-      f.b1[g] = wsrc[(4 + g) * 64];
-    }
-    const int q = is_x ? s : s - nxk;
-    const int cg = q / 9, tap = q - cg * 9;
-    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-    const _Float16* base = is_x ? p.x16 : p.h16;
-    const int64_t pstr = is_x ? p.x_plane_stride : p.h_plane_stride;
-    const int cs = is_x ? Cx : C;
-    const int yy = ypos + dy, xx = xpos + dx;
-    const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-    int off = (is_x ? xoff : hoff) + (dy * W + dx) * cs + cg * 16 + k8;
-    off = ok ? off : 0;
-    f.a0 = *reinterpret_cast<const f16x8*>(base + off);
-    f.a1 = *reinterpret_cast<const f16x8*>(base + pstr + off);
-    f.ok = ok ? 0xffffffffu : 0u;
-  };
-  auto mma_step = [&](const Conv16Frag& f) {
-    const f16x8 a0 = mask_f16x8(f.a0, f.ok), a1 = mask_f16x8(f.a1, f.ok);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, f.b0[g], acc[g], 0, 0, 0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, f.b1[g], acc[g], 0, 0, 0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, f.b0[g], acc[g], 0, 0, 0);
-  };
-  Conv16Frag f0, f1;
-  if (nsteps > 0) load_step(0, f0);
-  for (int s = 0; s < nsteps; s += 2) {     // nsteps is a multiple of 2 (9*even or 9*16)
-    load_step(min(s + 1, nsteps - 1), f1);
-    mma_step(f0);
-    load_step(min(s + 2, nsteps - 1), f0);
-    if (s + 1 < nsteps) mma_step(f1);
-  }
-
-  // ---- epilogue (as convlstm_mfma.h), accumulators carry 2^16 x the pre-activation
-  const int ch = cb * kChBlock + (lane & 31);
-  const float bi = a.bias[ch], bj = a.bias[C + ch], bf = a.bias[2 * C + ch],
-              bo = a.bias[3 * C + ch];
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    const int m = m_wave + row;
-    if (m < M_total) {
-      float cprev = 0.f;
-      if (!a.zero_state) {
-        const int r = m / HW, cell = m - r * HW;
-        const int sr = a.src_row_c ? a.src_row_c[r] : r;
-        cprev = a.c[((size_t)sr * HW + cell) * C + ch];
-      }
-      const float gi = acc[0][reg] * kF16Unscale + bi, gj = acc[1][reg] * kF16Unscale + bj,
-                  gf = acc[2][reg] * kF16Unscale + bf, go = acc[3][reg] * kF16Unscale + bo;
-      const float si = sigm_(gi), tj = tanh_(gj), sf = sigm_(gf + a.forget_bias),
-                  so = sigm_(go);
-      float cn = sf * cprev;
-      cn = cn + si * tj;
-      const float hn = tanh_(cn) * so;
-      a.c_out[(size_t)m * C + ch] = cn;
-      a.h_out[(size_t)m * C + ch] = hn;
-      if (p.h16_out) {
-        const float sc = hn * kF16Scale;
-        const _Float16 h0 = (_Float16)sc;
-        p.h16_out[(size_t)m * C + ch] = h0;
-        p.h16_out[p.h16_out_stride + (size_t)m * C + ch] = (_Float16)(sc - (float)h0);
-      }
-      if (a.gates_out) {
-        float* gp = a.gates_out + (size_t)m * 4 * C + ch;
-        gp[0] = si; gp[C] = tj; gp[2 * C] = sf; gp[3 * C] = so;
-      }
-    }
-  }
+static inline unsigned split_planes_blocks(size_t M, int C) {
+  return (unsigned)((((M + 31) / 32) * 32 * (size_t)(C >> 3) + 255) / 256);
 }
 
 // ---------------------------------------------------------------- v2: B through LDS
@@ -355,7 +204,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   const int m_wave = mt * kBlockRows + wave * kWaveRows;
   const bool wave_live = m_wave < M_total;     // dead waves still copy and hit barriers
 
-  int ypos, xpos, xoff, hoff;
+  int ypos, xpos, xoff, xcell, hcell;    // xcell / hcell: flat cell index in the operand planes
   {
     const int m = m_wave + (lane & 31);
     if (m < M_total) {
@@ -364,12 +213,13 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       ypos = y; xpos = cell - y * W;
       const int sr = a.src_row_h ? a.src_row_h[r] : r;
       xoff = r * a.x_row_stride + cell * Cx;
-      hoff = (sr * HW + cell) * C;
+      xcell = m;
+      hcell = sr * HW + cell;
     } else {
-      ypos = -100000; xpos = -100000; xoff = 0; hoff = 0;
+      ypos = -100000; xpos = -100000; xoff = 0; xcell = 0; hcell = 0;
     }
   }
-  const int k8 = (lane >> 5) * 8;
+  const int khalf = (lane >> 5) * 256;   // second k half of a 32 x 16 operand tile
 
   f32x16 acc[NG];
 #pragma unroll
@@ -378,7 +228,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
 
   if constexpr (EPI == kEpiLstm) if (a.x_small && wave_live) {
-    const int khalf = (lane >> 5) * 4;
+    const int khalf4 = (lane >> 5) * 4;
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wx32 + (size_t)cb * kBN * kBK) + lane;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -388,7 +238,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       f32x4 v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int k = kk * 8 + khalf + j;
+        const int k = kk * 8 + khalf4 + j;
         const int tap = k / Cx, ch = k - tap * Cx;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const int yy = ypos + dy, xx = xpos + dx;
@@ -440,16 +290,23 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   const int okymask = (int)((ypos - 1 >= 0) & (ypos - 1 < H)) |
                       ((int)((ypos >= 0) & (ypos < H)) << 1) |
                       ((int)((ypos + 1 >= 0) & (ypos + 1 < H)) << 2);
-  const int xbase = xoff + k8, hbase = hoff + k8;
-
   // per-stage address state as plain scalars (a struct of pointers here ended up
-  // in scratch memory and turned the loads into flat_load)
+  // in scratch memory and turned the loads into flat_load).  The operand planes
+  // are tiled (plane_index): cell m', channel group cg, k half -> one 16-byte
+  // vector at ((m' >> 5) * KG + cg) * 512 + khalf + (m' & 31) * 8, so a wave's
+  // load of 32 consecutive cells is two contiguous 512-byte runs instead of 32
+  // separate cache lines.
+  const int KGx = Cx >> 4, KGh = C >> 4;
   auto stage_isx = [&](int st) { return st < nxst; };
-  auto stage_rowoff = [&](int st) {
+  auto stage_rowoff = [&](int st) {       // (stencil row - 1) * W + first cell of the lane
     const bool is_x = st < nxst;
     const int q = is_x ? st : st - nxst;
-    const int cg = q / 3, j = q - cg * 3;
-    return (is_x ? xbase : hbase) + (j - 1) * W * (is_x ? Cx : C) + cg * 16;
+    const int j = q - (q / 3) * 3;
+    return (is_x ? xcell : hcell) + (j - 1) * W;
+  };
+  auto stage_cg = [&](int st) {
+    const int q = (st < nxst) ? st : st - nxst;
+    return q / 3;
   };
   auto stage_rowok = [&](int st) {
     const int q = (st < nxst) ? st : st - nxst;
@@ -460,10 +317,13 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   const _Float16* const h16 = p.h16;
   const int64_t xps = p.x_plane_stride, hps = p.h_plane_stride;
 
-#define MV_LOAD_A(ISX, ROWOFF, ROWOK, KK, A0, A1)                                      \
+#define MV_LOAD_A(ISX, ROWOFF, CG, ROWOK, KK, A0, A1)                                  \
   do {                                                                                  \
     const bool ok_ = (ROWOK) & ((KK) == 0 ? okx0 : ((KK) == 1 ? okx1 : okx2));          \
-    const int off_ = ok_ ? (ROWOFF) + ((KK) - 1) * ((ISX) ? Cx : C) : -kPlanePad;       \
+    const int mm_ = (ROWOFF) + ((KK) - 1);                                              \
+    const int off_ = ok_ ? ((mm_ >> 5) * ((ISX) ? KGx : KGh) + (CG)) * 512 + khalf +    \
+                               (mm_ & 31) * 8                                           \
+                         : -kPlanePad;                                                  \
     if (ISX) {                                                                          \
       A0 = *reinterpret_cast<const f16x8*>(x16 + off_);                                 \
       A1 = *reinterpret_cast<const f16x8*>(x16 + xps + off_);                           \
@@ -488,23 +348,23 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         if (i * 256 + tid < kSV) dst0[i * 256 + tid] = stg[i];
     }
     bool c_isx = stage_isx(st_lo);
-    int c_rowoff = stage_rowoff(st_lo);
+    int c_rowoff = stage_rowoff(st_lo), c_cg = stage_cg(st_lo);
     bool c_rowok = stage_rowok(st_lo);
     f16x8 fa0, fa1;
-    MV_LOAD_A(c_isx, c_rowoff, c_rowok, 0, fa0, fa1);
+    MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 0, fa0, fa1);
     __syncthreads();
     for (int st = st_lo; st < st_hi; ++st) {
       const bool more = st + 1 < st_hi;
       const int stn = more ? st + 1 : st;
       const bool n_isx = stage_isx(stn);
-      const int n_rowoff = stage_rowoff(stn);
+      const int n_rowoff = stage_rowoff(stn), n_cg = stage_cg(stn);
       const bool n_rowok = stage_rowok(stn);
       const f16x8* buf = lds + (st & 1) * kStageVec;
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
         f16x8 fn0, fn1;
-        if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_rowok, kk + 1, fn0, fn1);
-        else MV_LOAD_A(n_isx, n_rowoff, n_rowok, 0, fn0, fn1);   // (re-read at the very end)
+        if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, fn0, fn1);
+        else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 0, fn0, fn1);   // (re-read at the very end)
         // the next stage's weights are requested AFTER the first k-step's operands:
         // vmcnt retires in order, and a copy issued at the top of the stage would
         // sit in front of the A fragment the first MFMAs are waiting for
@@ -530,7 +390,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
           acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
         fa0 = fn0; fa1 = fn1;
       }
-      c_isx = n_isx; c_rowoff = n_rowoff; c_rowok = n_rowok;
+      c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
       if (more) {
         f16x8* dst = lds + ((st + 1) & 1) * kStageVec;
 #pragma unroll
@@ -595,8 +455,9 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         if (p.h16_out) {
           const float sc = hn * kF16Scale;
           const _Float16 h0 = (_Float16)sc;
-          p.h16_out[(size_t)m * C + ch] = h0;
-          p.h16_out[p.h16_out_stride + (size_t)m * C + ch] = (_Float16)(sc - (float)h0);
+          const size_t po = plane_index(m, ch, C);
+          p.h16_out[po] = h0;
+          p.h16_out[p.h16_out_stride + po] = (_Float16)(sc - (float)h0);
         }
         if (a.gates_out) {
           float* gp = a.gates_out + (size_t)m * 4 * C + ch;
@@ -753,7 +614,7 @@ static inline size_t f16x3_dgrad_wpack_elems(int Cx, int C) {   // in halves
 // the tensor's max |.| (tracked as int bits by lstm_gate_bwd_kernel): the largest
 // element lands in [2^13, 2^14).  e is stored for the consumer's epilogue.
 __global__ void split_planes_dyn_kernel(const float* __restrict__ in, _Float16* __restrict__ p0,
-                                        _Float16* __restrict__ p1, size_t n4,
+                                        _Float16* __restrict__ p1, int M, int C,
                                         const int32_t* __restrict__ max_bits,
                                         int32_t* __restrict__ exp_out) {
   int mb = 0;
@@ -766,35 +627,26 @@ __global__ void split_planes_dyn_kernel(const float* __restrict__ in, _Float16* 
   }
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) exp_out[0] = e;
-  if (i >= n4) return;
-  const f32x4 v = reinterpret_cast<const f32x4*>(in)[i];
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  f16x4 a, b;
+  const int c8n = C >> 3;
+  const size_t per_tile = (size_t)32 * c8n;
+  const size_t tb = i / per_tile;
+  const int r = (int)(i - tb * per_tile);
+  const int c8 = r >> 5, cell = r & 31;
+  const long long m = (long long)tb * 32 + cell;
+  if (m >= M) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(in + (size_t)m * C + c8 * 8);
+  const f32x4 v0 = src[0], v1 = src[1];
+  f16x8 a, b;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float s = ldexpf(v[j], e);
-    const _Float16 h0 = (_Float16)s;
+  for (int j = 0; j < 8; ++j) {
+    const float sv = ldexpf(j < 4 ? v0[j] : v1[j - 4], e);
+    const _Float16 h0 = (_Float16)sv;
     a[j] = h0;
-    b[j] = (_Float16)(s - (float)h0);
+    b[j] = (_Float16)(sv - (float)h0);
   }
-  reinterpret_cast<f16x4*>(p0)[i] = a;
-  reinterpret_cast<f16x4*>(p1)[i] = b;
-}
-
-__global__ __launch_bounds__(256, 2)
-void convlstm_step_f16x3_kernel(const ConvLstm16Group g) {
-  int block = blockIdx.x;
-  int pi = 0;
-#pragma unroll
-  for (int i = 0; i < kMaxGroup - 1; ++i)
-    if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
-  if (pi > 0) block -= g.block_end[pi - 1];
-  switch (pi) {
-    case 0: convlstm16_body(g.p[0], block); break;
-    case 1: convlstm16_body(g.p[1], block); break;
-    case 2: convlstm16_body(g.p[2], block); break;
-    default: convlstm16_body(g.p[3], block); break;
-  }
+  const size_t o = plane_index(m, c8 * 8, C);
+  *reinterpret_cast<f16x8*>(p0 + o) = a;
+  *reinterpret_cast<f16x8*>(p1 + o) = b;
 }
 
 static inline void launch_convlstm16_steps(const ConvLstm16Args* probs, int n,
@@ -808,11 +660,7 @@ static inline void launch_convlstm16_steps(const ConvLstm16Args* probs, int n,
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
-  static const int variant = getenv("MV_F16X3_VARIANT") ? atoi(getenv("MV_F16X3_VARIANT")) : 2;
-  if (variant == 1)
-    hipLaunchKernelGGL(convlstm_step_f16x3_kernel, dim3(total), dim3(256), 0, stream, g);
-  else
-    hipLaunchKernelGGL(convlstm_step_f16x3_lds_kernel, dim3(total), dim3(256), 0, stream, g);
+  hipLaunchKernelGGL(convlstm_step_f16x3_lds_kernel, dim3(total), dim3(256), 0, stream, g);
 }
 
 }  // namespace mv

@@ -518,12 +518,13 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       if (const auto* pb = ready(a.x)) {
         q.x16 = pb->p; q.x_plane_stride = (int64_t)pb->n;
       } else {
-      MV_REQUIRE(e->px16[i].n >= 2 * (n + mv::kPlanePad), "internal: f16x3 x plane scratch");
+      const size_t pst = n + mv::kPlaneSlack + mv::kPlanePad;
+      MV_REQUIRE(e->px16[i].n >= 2 * pst, "internal: f16x3 x plane scratch");
       _Float16* p0 = e->px16[i].p + mv::kPlanePad;
-      q.x16 = p0; q.x_plane_stride = (int64_t)(n + mv::kPlanePad);
+      q.x16 = p0; q.x_plane_stride = (int64_t)pst;
       launch(e, "split_planes", 0, 8.0 * n, [&] {
-        hipLaunchKernelGGL(mv::split_planes_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0,
-                           e->stream, a.x, p0, p0 + n + mv::kPlanePad, n / 4);
+        hipLaunchKernelGGL(mv::split_planes_kernel, dim3(mv::split_planes_blocks(cells, a.Cx)),
+                           dim3(256), 0, e->stream, a.x, p0, p0 + pst, (int)cells, a.Cx);
       });
       }
     }
@@ -532,12 +533,13 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       if (const auto* pb = ready(a.h)) {
         q.h16 = pb->p; q.h_plane_stride = (int64_t)pb->n;
       } else {
-      MV_REQUIRE(e->ph16[i].n >= 2 * (n + mv::kPlanePad), "internal: f16x3 h plane scratch");
+      const size_t pst = n + mv::kPlaneSlack + mv::kPlanePad;
+      MV_REQUIRE(e->ph16[i].n >= 2 * pst, "internal: f16x3 h plane scratch");
       _Float16* p0 = e->ph16[i].p + mv::kPlanePad;
-      q.h16 = p0; q.h_plane_stride = (int64_t)(n + mv::kPlanePad);
+      q.h16 = p0; q.h_plane_stride = (int64_t)pst;
       launch(e, "split_planes", 0, 8.0 * n, [&] {
-        hipLaunchKernelGGL(mv::split_planes_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0,
-                           e->stream, a.h, p0, p0 + n + mv::kPlanePad, n / 4);
+        hipLaunchKernelGGL(mv::split_planes_kernel, dim3(mv::split_planes_blocks(cells, a.C)),
+                           dim3(256), 0, e->stream, a.h, p0, p0 + pst, (int)cells, a.C);
       });
       }
     }
@@ -1469,8 +1471,8 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
       for (int i = 0; i < mv::kMaxGroup; ++i) {
         const size_t rows = (size_t)c.batch_size * ((i % 2 == 0) ? c.beam_size : 1);
         // [pad | plane 0 | pad | plane 1], pads zero (out-of-image taps read them)
-        h->px16[i].alloc(2 * (rows * K * xc + mv::kPlanePad));
-        h->ph16[i].alloc(2 * (rows * K * c.hidden_size + mv::kPlanePad));
+        h->px16[i].alloc(2 * (rows * K * xc + mv::kPlaneSlack + mv::kPlanePad));
+        h->ph16[i].alloc(2 * (rows * K * c.hidden_size + mv::kPlaneSlack + mv::kPlanePad));
         HIP_CHECK(hipMemset(h->px16[i].p, 0, h->px16[i].n * sizeof(_Float16)));
         HIP_CHECK(hipMemset(h->ph16[i].p, 0, h->ph16[i].n * sizeof(_Float16)));
       }
@@ -1484,11 +1486,12 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
           if (!b->p) continue;
           h->plane_store.emplace_back(new DevBuf<_Float16>());
           DevBuf<_Float16>& pb = *h->plane_store.back();
-          pb.alloc(2 * (b->n + mv::kPlanePad));
+          pb.alloc(2 * (b->n + mv::kPlaneSlack + mv::kPlanePad));
           HIP_CHECK(hipMemset(pb.p, 0, pb.n * sizeof(_Float16)));
-          // p -> first element of plane 0; plane stride n + pad puts a zero pad in
-          // front of plane 1 as well
-          h->planes[b->p] = mv_engine::PlaneBuf{pb.p + mv::kPlanePad, b->n + mv::kPlanePad, false};
+          // p -> first element of plane 0; plane stride n + slack + pad puts a zero
+          // pad in front of plane 1 as well (slack: the last partial 32-cell tile row)
+          h->planes[b->p] = mv_engine::PlaneBuf{pb.p + mv::kPlanePad,
+                                                b->n + mv::kPlaneSlack + mv::kPlanePad, false};
         }
       }
     }

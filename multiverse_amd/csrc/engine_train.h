@@ -155,7 +155,7 @@ void train_alloc(mv_engine* e) {
     for (int s = 0; s < c.num_scales; ++s)
       if (e->sc[s].use) K = std::max(K, (size_t)e->sc[s].K);
     for (int i = 0; i < mv::kMaxGroup; ++i) {
-      t.g16[i].alloc(2 * (N * K * 4 * C + mv::kPlanePad));
+      t.g16[i].alloc(2 * (N * K * 4 * C + mv::kPlaneSlack + mv::kPlanePad));
       HIP_CHECK(hipMemset(t.g16[i].p, 0, t.g16[i].n * sizeof(_Float16)));
     }
     t.gmax.alloc(mv::kMaxGroup * 64 * 64);   // [slot][64 spread addresses]
@@ -518,14 +518,16 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     q = mv::ConvLstm16Args{};
     q.f = a;
     const size_t n = (size_t)a.rows * a.H * a.W * a.C;      // a.C == 4C here
-    MV_REQUIRE(t.g16[i].n >= 2 * (n + mv::kPlanePad), "internal: G plane scratch");
+    const size_t pst = n + mv::kPlaneSlack + mv::kPlanePad;
+    const size_t gcells = (size_t)a.rows * a.H * a.W;
+    MV_REQUIRE(t.g16[i].n >= 2 * pst, "internal: G plane scratch");
     _Float16* p0 = t.g16[i].p + mv::kPlanePad;
     launch(e, "split_planes", 0, 8.0 * n, [&] {
-      hipLaunchKernelGGL(mv::split_planes_dyn_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0,
-                         e->stream, a.h, p0, p0 + n + mv::kPlanePad, n / 4,
+      hipLaunchKernelGGL(mv::split_planes_dyn_kernel, dim3(mv::split_planes_blocks(gcells, a.C)),
+                         dim3(256), 0, e->stream, a.h, p0, p0 + pst, (int)gcells, a.C,
                          t.gmax.p + (size_t)slots[i] * 64, t.gexp.p + slots[i]);
     });
-    q.h16 = p0; q.h_plane_stride = (int64_t)(n + mv::kPlanePad);
+    q.h16 = p0; q.h_plane_stride = (int64_t)pst;
     q.x16 = nullptr; q.x_plane_stride = 0;
     q.wp16 = chains[i]->wd16.p;
     q.n_xk = 0; q.n_hk = 9 * (a.C / 16); q.w_ksteps = q.n_hk;

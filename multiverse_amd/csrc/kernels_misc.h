@@ -3,6 +3,7 @@
 // Every kernel cites the reference lines it replaces.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "plane_layout.h"
 #include <stdint.h>
 #include <math.h>
 
@@ -13,12 +14,15 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // f16x3 compute mode (convlstm_f16x3.h): a producer of a ConvLSTM operand can
 // emit the two pre-scaled fp16 planes of its output next to the fp32 value, so
 // that no separate split pass is needed.  p16 == nullptr: off.
-__device__ __forceinline__ void emit_planes(_Float16* p16, size_t stride, size_t idx, float v) {
+__device__ __forceinline__ void emit_planes(_Float16* p16, size_t stride, size_t idx, int C,
+                                            float v) {
   if (!p16) return;
   const float s = v * 256.0f;
   const _Float16 h0 = (_Float16)s;
-  p16[idx] = h0;
-  p16[stride + idx] = (_Float16)(s - (float)h0);
+  const size_t m = idx / (size_t)C;
+  const size_t o = plane_index((long long)m, (int)(idx - m * C), C);
+  p16[o] = h0;
+  p16[stride + o] = (_Float16)(s - (float)h0);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -96,7 +100,7 @@ __global__ void enc_class_input_kernel(const float* __restrict__ conv,
   if (cell == labels[n * T + t])
     v = conv[(size_t)obs_scene[n * T + t] * per + off];
   out[idx] = v;
-  emit_planes(p16, p16_stride, idx, v);
+  emit_planes(p16, p16_stride, idx, D, v);
 }
 
 // ---------------------------------------------------------------- grid_emb
@@ -133,7 +137,7 @@ __global__ void grid_emb_dense_kernel(const float* __restrict__ x,
   }
   const float v = tanhf(acc + b[e]);
   out[idx] = v;
-  emit_planes(p16, p16_stride, idx, v);
+  emit_planes(p16, p16_stride, idx, E, v);
 }
 
 // One-hot input in closed form: the cell at offset (dy,dx) from the hot cell
@@ -165,7 +169,7 @@ __global__ void grid_emb_onehot_kernel(const int32_t* __restrict__ ids,
     acc = w[((1 - dy) * 3 + (1 - dx)) * E + e];  // P == 1
   const float v = tanhf(acc + b[e]);
   out[idx] = v;
-  emit_planes(p16, p16_stride, idx, v);
+  emit_planes(p16, p16_stride, idx, E, v);
 }
 
 // ---------------------------------------------------------------- graph attention
@@ -254,7 +258,7 @@ void gnn_attend_kernel(const float* __restrict__ h,
       a[j] = h0;
       b[j] = (_Float16)(sc - (float)h0);
     }
-    const size_t idx = ((size_t)m * K + cell) * C + lane * 4;
+    const size_t idx = plane_index((long long)m * K + cell, lane * 4, C);   // 4 of one 8-group
     *reinterpret_cast<f16x4_t*>(p16 + idx) = a;
     *reinterpret_cast<f16x4_t*>(p16 + p16_stride + idx) = b;
   }
