@@ -164,7 +164,6 @@ struct mv_engine {
   DevBuf<int32_t> bm_out_ids;      // [N, B, T]
   // 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3 split on the fp16 matrix pipe
   int compute_mode = 0;
-  bool force_f32 = false;          // the training forward always runs the fp32 kernel
   DevBuf<_Float16> px16[mv::kMaxGroup], ph16[mv::kMaxGroup];   // fallback plane scratch per slot
   // planes that travel with an fp32 operand buffer: producers (conv epilogue, graph
   // attention, embeddings) emit them, the next conv launch consumes them
@@ -172,7 +171,7 @@ struct mv_engine {
   std::map<const float*, PlaneBuf> planes;
   std::vector<std::unique_ptr<DevBuf<_Float16>>> plane_store;
   _Float16* plane_out(const float* dst, size_t* stride) {   // producer side
-    if (compute_mode != 1 || force_f32) return nullptr;
+    if (compute_mode != 1) return nullptr;
     auto it = planes.find(dst);
     if (it == planes.end()) return nullptr;
     it->second.valid = true;
@@ -560,7 +559,7 @@ void run_conv_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs) {
     flops += 2.0 * M * 9.0 * (a.Cx + a.C) * 4.0 * a.C;
     bytes += M * (a.Cx + 4.0 * a.C) * 4.0;   // x,h,c in; h,c out
   }
-  if (e->compute_mode == 1 && !e->force_f32) {
+  if (e->compute_mode == 1) {
     run_conv_group_f16x3(e, probs, flops, bytes);
     return;
   }
