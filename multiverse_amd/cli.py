@@ -60,6 +60,8 @@ _FLAGS = [
     ("--learning_rate_decay", float, 0.95, 0.95, "tT"),
     ("--num_epoch_per_decay", float, 2.0, 2.0, "tT"),
     ("--init_lr", float, 0.2, 0.2, "tT"), ("--emb_lr", float, 1.0, 1.0, "tT"),
+    # not a reference flag: device-side batch assembly (pred_models.compact_inputs_enabled)
+    ("--compact_inputs", B, None, None, "tT"),
 ]
 
 

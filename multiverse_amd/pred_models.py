@@ -33,10 +33,8 @@ def compact_inputs_enabled(cfg):
   """Device-side batch assembly: config.compact_inputs or
   MV_COMPACT_INPUTS=1."""
   import os
-  v = getattr(cfg, "compact_inputs", None)
-  if v is None:
-    v = os.environ.get("MV_COMPACT_INPUTS", "0") not in ("", "0")
-  return bool(v)
+  return bool(getattr(cfg, "compact_inputs", False)) or \
+      os.environ.get("MV_COMPACT_INPUTS", "0") not in ("", "0")
 
 
 def build_compact_feed_dict(cfg, batch, is_train=False):
