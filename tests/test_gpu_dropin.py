@@ -177,3 +177,20 @@ def test_compact_inputs_are_bit_identical(built_lib):
     for s in range(2):
       assert (c0[s] == c1[s]).all() and (r0[s] == r1[s]).all()
   model.close()
+
+  # and Trainer.step: two steps over the same batches, dense vs compact feeds
+  tr = []
+  for compact in (False, True):
+    cfg5 = synth.default_config(batch_size=4, use_grids=(1, 1), is_train=True)
+    cfg5.compact_inputs = compact
+    cfg5.train_num_examples = 6
+    ds5 = pred_utils.dataset_from_npz_dict(data, "train", cfg5)
+    m5 = pred_models.get_model(cfg5, 0)
+    m5.load_params(synth.make_params(cfg5, seed=synth.SEED_BASE + 4))
+    trainer = pred_models.Trainer(m5, cfg5)
+    losses = [trainer.step(None, bt)
+              for bt in ds5.get_batches(4, num_steps=2, full=True, shuffle=False)]
+    tr.append((losses, m5.get_params()["person_pred/scene_conv2/W"]))
+    m5.close()
+  assert [l[0] for l in tr[0][0]] == [l[0] for l in tr[1][0]]
+  assert (tr[0][1] == tr[1][1]).all()
