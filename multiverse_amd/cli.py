@@ -212,9 +212,8 @@ _MF_FLAGS = [
 ]
 
 
-def multifuture_inference_main(argv=None):
-  """code/multifuture_inference.py:387-530."""
-  from multiverse_amd import multifuture as mf, pred_models, pred_utils
+def multifuture_inference_parser():
+  """The argument table of code/multifuture_inference.py:22-76 (+ --batch_size)."""
   p = argparse.ArgumentParser()
   for pos in ("traj_path", "multifuture_path", "model_path"):
     p.add_argument(pos)
@@ -224,7 +223,13 @@ def multifuture_inference_main(argv=None):
       p.add_argument(flag, action="store_true")
     else:
       p.add_argument(flag, type=typ, default=default)
-  args = p.parse_args(argv)
+  return p
+
+
+def multifuture_inference_main(argv=None):
+  """code/multifuture_inference.py:387-530."""
+  from multiverse_amd import multifuture as mf, pred_models, pred_utils
+  args = multifuture_inference_parser().parse_args(argv)
   mf.add_grid(args)
   assert sum(args.use_grids) == 1
   traj_files = glob(os.path.join(args.traj_path, "*.txt"))
