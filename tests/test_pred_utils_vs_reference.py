@@ -1,0 +1,114 @@
+"""The host side of test.py -- `read_data`, the batcher (`Dataset.get_batches`: padding,
+scene-table compaction) and `evaluate` (grid accuracy, ADE/FDE from class + offset) --
+against the reference's own `code/pred_utils.py`, imported UNMODIFIED (its `import
+tensorflow` resolves to the eager shim, which this path never calls).  The same
+deterministic fake Tester feeds both.  Needs /root/reference; skipped elsewhere."""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from multiverse_amd import pred_utils, synth
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                "oracle", "tf1_shim"))
+import run_reference as rr  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not rr.available(), reason="needs the /root/reference checkout")
+
+
+def _reference_pred_utils():
+  rr.import_reference()                      # puts the TF shim in place
+  sys.path.insert(0, rr.REFERENCE_CODE)
+  try:
+    sys.modules.pop("pred_utils", None)
+    mod = importlib.import_module("pred_utils")
+  finally:
+    sys.path.remove(rr.REFERENCE_CODE)
+  assert os.path.abspath(mod.__file__).startswith(os.path.abspath(rr.REFERENCE_CODE))
+  return mod
+
+
+class _NoisyGtTester(object):
+  """Logits = one-hot of the GT cell + seeded noise (so some argmaxes are wrong),
+  offsets = GT offsets + noise; depends only on the batch CONTENT, so the reference's
+  batcher and ours must have produced the same batches for the results to agree."""
+
+  def __init__(self, cfg):
+    self.cfg = cfg
+
+  def step(self, sess, batch):
+    cfg = self.cfg
+    idxs, b = batch
+    N, T = cfg.batch_size, cfg.pred_len
+    cls, reg = [], []
+    for j, (h, w) in enumerate(cfg.scene_grids):
+      if not cfg.use_grids[j]:
+        cls.append([])
+        reg.append([])
+        continue
+      rng = np.random.default_rng(1000 + j)
+      noise = rng.normal(0, 1.0, (64, T, h * w)).astype("float32")
+      rnoise = rng.normal(0, 3.0, (64, T, h, w, 2)).astype("float32")
+      lg = np.zeros((N, T, h * w), dtype="float32")
+      rg = np.zeros((N, T, h, w, 2), dtype="float32")
+      for i in range(len(b.data["pred_grid_class"])):
+        key = int(round(float(np.asarray(b.data["obs_traj"][i])[0, 0]) * 7)) % 64
+        gt = np.asarray(b.data["pred_grid_class"][i])[j]
+        lg[i, np.arange(T), gt] = 2.0
+        lg[i] += noise[key]
+        rg[i] = np.asarray(b.data["pred_grid_target_all_%d" % j][i]) + rnoise[key]
+      cls.append(lg.reshape(N, T, h, w, 1))
+      reg.append(rg)
+    return cls, reg, None
+
+
+def _config(tmp_path, use_grids, batch_size):
+  cfg = synth.default_config(batch_size=batch_size, use_grids=use_grids)
+  cfg.prepropath = str(tmp_path)
+  cfg.per_scene_eval = False
+  cfg.save_output = None
+  cfg.use_beam_search = False
+  cfg.use_gt_grid = False
+  cfg.show_center_only = False
+  cfg.show_grid_acc_at_T = False
+  return cfg
+
+
+@pytest.mark.parametrize("use_grids", [(1, 1), (1, 0)])
+def test_read_data_batcher_and_evaluate_match_the_reference(tmp_path, use_grids):
+  ref_pu = _reference_pred_utils()
+  cfg = _config(tmp_path, use_grids, batch_size=4)
+  data = synth.make_npz_data(cfg, 10, seed=21, float32_traj=True)
+  np.savez(os.path.join(str(tmp_path), "data_test.npz"), **data)
+
+  ref_ds = ref_pu.read_data(cfg, "test")
+  my_ds = pred_utils.read_data(cfg, "test")
+  assert ref_ds.num_examples == my_ds.num_examples == 10
+
+  # the batcher: same indices, same padded content, same compacted scene table
+  rb = list(ref_ds.get_batches(4, full=True, shuffle=False))
+  mb = list(my_ds.get_batches(4, full=True, shuffle=False))
+  assert len(rb) == len(mb) == 3
+  for (ri, r), (mi, m) in zip(rb, mb):
+    assert tuple(ri) == tuple(mi)
+    assert r.data["original_batch_size"] == m.data["original_batch_size"]
+    assert (np.asarray(r.data["batch_obs_scene"]) == np.asarray(m.data["batch_obs_scene"])).all()
+    assert (np.asarray(r.data["batch_scene_feat"]) == np.asarray(m.data["batch_scene_feat"])).all()
+    for key in ("obs_traj", "pred_traj", "obs_grid_class", "pred_grid_class",
+                "obs_grid_target_all_0"):
+      assert (np.asarray(r.data[key]) == np.asarray(m.data[key])).all(), key
+
+  tester = _NoisyGtTester(cfg)
+  ref_p = ref_pu.evaluate(ref_ds, cfg, None, tester)
+  my_p = pred_utils.evaluate(my_ds, cfg, None, tester)
+  assert sorted(ref_p) == sorted(my_p)
+  assert len(ref_p) >= 3
+  for k in ref_p:
+    print("%-28s reference %.10g  here %.10g" % (k, ref_p[k], my_p[k]))
+    assert my_p[k] == pytest.approx(ref_p[k], rel=1e-6, abs=1e-9), k
+  acc = [v for k, v in ref_p.items() if k.endswith("_acc")]
+  assert acc and all(0.05 < a < 1.0 for a in acc)      # the noise made it non-trivial
