@@ -981,6 +981,27 @@ class Session(object):
     return out
 
 
+class _Logging(object):
+  """tf.compat.v1.logging: the scripts only silence TensorFlow's own logger."""
+  DEBUG, INFO, WARN, ERROR, FATAL = 10, 20, 30, 40, 50
+
+  @staticmethod
+  def set_verbosity(level):
+    return None
+
+
+class _CompatV1(object):
+  logging = _Logging()
+
+
+class _Compat(object):
+  v1 = _CompatV1()
+
+
+compat = _Compat()
+logging = _Logging()
+
+
 def truncated_normal(*a, **k):
   raise NotImplementedError("truncated_normal (unreachable `linear` helper)")
 
