@@ -218,3 +218,36 @@ def test_trainer_rejects_unbuilt_switches():
                                                    train_num_examples=1000))
   assert tc.decay_steps == int(1000 / 20 * 2.0) and tc.do_clip == 1
   assert abs(tc.clip_gradient_norm - 10.0) < 1e-6 and abs(tc.wd - 0.001) < 1e-9
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path, built_lib):
+  """sizeof / offsetof of every struct of include/multiverse_hip.h, as gcc lays them
+  out from the header itself, against the ctypes mirror in multiverse_amd/_lib.py
+  (the header must compile as plain C: it is what a foreign binding would include)."""
+  import shutil
+  import subprocess
+  gcc = shutil.which("gcc")
+  if gcc is None:
+    pytest.skip("no gcc")
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  names = ["mv_config", "mv_inputs", "mv_outputs", "mv_beam_outputs", "mv_train_config",
+           "mv_targets", "mv_losses", "mv_inputs_compact", "mv_targets_compact"]
+  lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "multiverse_hip.h"',
+           'int main(void) {']
+  for n in names:
+    st = getattr(built_lib, n)
+    lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (n, n))
+    for f in st._fields_:
+      lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (n, f[0], n, f[0]))
+  lines += ['  return 0;', '}']
+  src = tmp_path / "layout.c"
+  src.write_text("\n".join(lines))
+  exe = str(tmp_path / "layout")
+  subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                         str(src), "-o", exe])
+  got = dict(l.split() for l in subprocess.check_output([exe]).decode().splitlines())
+  for n in names:
+    st = getattr(built_lib, n)
+    assert int(got[n]) == ctypes.sizeof(st), n
+    for f in st._fields_:
+      assert int(got["%s.%s" % (n, f[0])]) == getattr(st, f[0]).offset, (n, f[0])
