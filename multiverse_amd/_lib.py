@@ -163,6 +163,7 @@ def load():
   h = C.c_void_p
   lib.mv_last_error.restype = C.c_char_p
   lib.mv_last_error.argtypes = [h]
+  lib.mv_abi_version.argtypes = []
   lib.mv_create.argtypes = [C.POINTER(mv_config), C.c_int, C.POINTER(h)]
   lib.mv_destroy.argtypes = [h]
   lib.mv_set_param.argtypes = [h, C.c_char_p, _fp, C.POINTER(C.c_int64), C.c_int32]

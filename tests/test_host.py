@@ -251,3 +251,26 @@ def test_ctypes_structs_match_the_c_header(tmp_path, built_lib):
     assert int(got[n]) == ctypes.sizeof(st), n
     for f in st._fields_:
       assert int(got["%s.%s" % (n, f[0])]) == getattr(st, f[0]).offset, (n, f[0])
+
+
+def test_ctypes_prototypes_match_the_c_header(built_lib):
+  """Every function the header declares has ctypes argtypes of the same arity, and
+  pointer / scalar positions agree."""
+  import re
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  text = open(os.path.join(root, "include", "multiverse_hip.h")).read()
+  text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+  lib = built_lib.load()
+  protos = re.findall(r"\b(?:int|const char\*)\s+(mv_\w+)\s*\(([^;{]*?)\)\s*;", text)
+  assert len(protos) == len(built_lib.EXPORTED_SYMBOLS)
+  for name, params in protos:
+    params = params.strip()
+    plist = [] if params in ("", "void") else [p.strip() for p in params.split(",")]
+    fn = getattr(lib, name)
+    assert fn.argtypes is not None, "%s has no ctypes argtypes" % name
+    assert len(fn.argtypes) == len(plist), (name, plist, fn.argtypes)
+    for p, t in zip(plist, fn.argtypes):
+      is_ptr_c = "*" in p or p.startswith("mv_handle")
+      is_ptr_py = hasattr(t, "contents") or t in (ctypes.c_char_p, ctypes.c_void_p) or \
+          getattr(t, "_type_", None) == "P"
+      assert is_ptr_c == is_ptr_py, (name, p, t)
