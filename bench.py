@@ -239,6 +239,32 @@ def main():
       roofline["traffic_source"] = "profiles/" + pmc_name
       roofline["alg_MB_per_launch"] = round(conv["bytes"] / conv["launches"] / 1e6, 1)
 
+  if train and f16 and args.batch == 32:
+    # the three matrix kernels of the training step, launch-weighted
+    names = {"convlstm_step": "r1_train_pmc_convlstm_step_f16x3_lds.json",
+             "convlstm_dgrad": "r1_train_pmc_convlstm_dgrad.json",
+             "convlstm_wgrad": "r1_train_pmc_convlstm_wgrad_f16x3.json"}
+    tot, raw, n, ok = 0.0, 0.0, 0, True
+    for k, fn in names.items():
+      pth = os.path.join(ROOT, "profiles", fn)
+      if not os.path.exists(pth):
+        ok = False
+        break
+      with open(pth) as f:
+        hb = json.load(f).get("hbm_bytes_per_launch")
+      if not hb:
+        ok = False
+        break
+      tot += hb["total_corrected"] * stats[k]["launches"]
+      raw += hb["total_raw"] * stats[k]["launches"]
+      n += stats[k]["launches"]
+    if ok and n:
+      roofline["traffic"] = round(tot / n / 1e6, 1)
+      roofline["traffic_unit"] = ("MB HBM per launch, launch-weighted over step / dgrad / wgrad "
+                                  "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)")
+      roofline["traffic_raw_MB"] = round(raw / n / 1e6, 1)
+      roofline["traffic_source"] = "profiles/r1_train_pmc_*.json"
+
   if beam:
     metric = ("trajectories/sec (8-obs/12-pred, 18x32 grid, diverse beam-%d "
               "multi-future decode)" % args.beam)
