@@ -42,10 +42,11 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 (v_mfma_f3
 PEAK_HBM_GBS = 8000.0
 
 
-def algorithmic_counts(cfg, beam=1):
-  """FLOPs / state bytes per trajectory as the reference computes the sweep
-  (dense): 2*K*9*(Cx+C)*4C per ConvLSTM step; each step
-  reads x,h,c and writes h,c once."""
+def algorithmic_counts(cfg, beam=1, executed=False):
+  """FLOPs / state bytes per trajectory of the ConvLSTM sweep:
+  2*K*9*(Cx+C)*4C per step; each step reads x,h,c and writes h,c once.  Dense = as the
+  reference computes it; executed = the first encoder step starts from the zero state
+  and never multiplies (or reads) the h half -- those FLOPs are NOT counted as achieved."""
   C, D, E = cfg.enc_hidden_size, cfg.scene_conv_dim, cfg.emb_size
   To, Tp = cfg.obs_len, cfg.pred_len
   flops = 0.0
@@ -54,9 +55,13 @@ def algorithmic_counts(cfg, beam=1):
     if not cfg.use_grids[s]:
       continue
     K = h * w
-    for cx, steps, rows in ((D, To, 1), (2, To, 1), (E, Tp, beam), (E, Tp, 1)):
+    for cx, steps, rows, enc in ((D, To, 1, True), (2, To, 1, True), (E, Tp, beam, False),
+                                 (E, Tp, 1, False)):
       flops += rows * steps * 2.0 * K * 9 * (cx + C) * 4 * C
       nbytes += rows * steps * K * (cx + 4 * C) * 4.0
+      if executed and enc:
+        flops -= rows * 2.0 * K * 9 * C * 4 * C
+        nbytes -= rows * K * 2 * C * 4.0
   return flops, nbytes
 
 
@@ -133,7 +138,7 @@ def main():
   eng.set_compute_mode(args.compute)
   if train:
     from multiverse_amd import parallel
-    eng.train_init()
+    eng.train_init(world=world)
     eng.upload_targets(feed)
 
   def one_step():
@@ -181,12 +186,15 @@ def main():
   if train and "convlstm_wgrad_x" in stats:      # f16x3: the x rows are a launch of their own
     mfma_kernels.append("convlstm_wgrad_x")
   conv = {k: sum(stats[n][k] for n in mfma_kernels)
-          for k in ("launches", "total_ms", "flops", "bytes")}
+          for k in ("launches", "total_ms", "flops", "bytes", "flops_dense")}
   conv_s = conv["total_ms"] * 1e-3
+  # achieved = algorithmic FLOPs the launches EXECUTED (zero-state steps skip the h half)
   achieved_tf = conv["flops"] / conv_s / 1e12
   flops_traj, bytes_traj = algorithmic_counts(cfg, args.beam if beam else 1)
+  flops_traj_exec, _ = algorithmic_counts(cfg, args.beam if beam else 1, executed=True)
   if train:
     flops_traj *= 3.0   # forward + dgrad + wgrad of every gate convolution
+    flops_traj_exec *= 3.0
   f16 = args.compute == "f16x3"
   peak = PEAK_FP16_MFMA_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS
   roofline = {
@@ -200,12 +208,31 @@ def main():
       "launches": conv["launches"],
       "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
       "alg_gflop_per_launch_avg": round(conv["flops"] / conv["launches"] / 1e9, 2),
+      # the same launches counted densely, as the reference computes them (the t = 0
+      # encoder step multiplies an all-zero h there); NOT what achieved / frac use
+      "alg_dense": {"gflop_per_launch_avg": round(conv["flops_dense"] / conv["launches"] / 1e9, 2),
+                    "TFLOPs": round(conv["flops_dense"] / conv_s / 1e12, 2)},
       # the same sweep against the HBM roofline, as north_star phrases it
       "hbm_achieved_GBs": round(conv["bytes"] / conv_s / 1e9, 1),
       "hbm_frac": round(conv["bytes"] / conv_s / 1e9 / PEAK_HBM_GBS, 4),
-      "whole_forward_mfma_frac": round(value / world * flops_traj / 1e12 / peak, 4),
+      "whole_forward_mfma_frac": round(value / world * flops_traj_exec / 1e12 / peak, 4),
       "other_kernels_ms": {k: round(v["total_ms"], 3) for k, v in stats.items()
                            if k not in mfma_kernels},
+      "other_kernels_ms_total": round(sum(v["total_ms"] for k, v in stats.items()
+                                          if k not in mfma_kernels), 3),
+      # the HBM-bound members of the path: algorithmic bytes / hipEvent
+      # time of their launches against the 8 TB/s HBM roofline
+      "hbm_kernels": {
+          k: {"launches": v["launches"], "ms": round(v["total_ms"], 3),
+              "alg_MB_per_launch": round(v["bytes"] / v["launches"] / 1e6, 2),
+              "GBs": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1),
+              "frac": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+          for k, v in stats.items()
+          if k not in mfma_kernels and v["bytes"] > 0 and v["total_ms"] > 0 and
+          k in ("gnn_attend", "hidden2grid", "decode_tail", "split_planes", "lstm_gate_bwd",
+                "gnn_bwd", "grid_emb_dense", "grid_emb_onehot", "wgrad_transpose",
+                "beam_tile_state", "dgrad_slice_sum", "tanh_bwd", "conv3x3_small_dgrad",
+                "conv3x3_small_wgrad")},
   }
   if f16:
     # achieved / frac count ALGORITHMIC fp32 FLOPs against the dense fp16 MFMA peak;
@@ -319,6 +346,7 @@ def main():
                                  if train else
                                  "batch-sharded x%d, no data-path collective" % world),
                  "alg_gflop_per_trajectory": round(flops_traj / 1e9, 2),
+                 "alg_gflop_per_trajectory_executed": round(flops_traj_exec / 1e9, 2),
                  "alg_state_MB_per_trajectory": round(bytes_traj / 1e6, 2)},
       "roofline": roofline,
   }
@@ -342,8 +370,8 @@ def main():
     out["fp32_mfma_reference"] = {
         "value": round(world * args.batch * nref / el, 2), "unit": "trajectories/sec",
         "ms_per_step": round(1e3 * el / nref, 3), "steps": nref,
-        "mfma_frac_of_fp32_peak": round(world * args.batch * nref / el / world * flops_traj
-                                        / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        "mfma_frac_of_fp32_peak": round(world * args.batch * nref / el / world *
+                                        flops_traj_exec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
     eng.set_compute_mode("f16x3")
 
   if rank == 0 and world == 1 and not args.no_cpu_baseline and not beam:

@@ -233,6 +233,11 @@ int  mv_num_kernel_stats(mv_handle h);
 int  mv_kernel_stat(mv_handle h, int32_t i, char* name_out, int32_t name_cap,
                     int64_t* launches, double* total_ms, double* flops,
                     double* bytes);
+/* `flops` above are the algorithmic FLOPs the launches EXECUTED (the zero-state first
+ * encoder step skips the h half of the gate convolution, SURVEY.md 8d: "do not count
+ * them as achieved FLOPs"); this returns the same steps counted densely, as the
+ * reference computes them: 2 M 9 (Cx + C) 4C per ConvLSTM step. */
+int  mv_kernel_stat_dense_flops(mv_handle h, int32_t i, double* flops_dense);
 /* elapsed ms between two events recorded around fn on the engine's stream */
 int  mv_time_greedy_resident(mv_handle h, int32_t iters, float* ms_out);
 int  mv_time_beam_resident(mv_handle h, int32_t iters, float* ms_out);

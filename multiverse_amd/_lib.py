@@ -27,7 +27,8 @@ EXPORTED_SYMBOLS = [
     "mv_upload_inputs", "mv_run_greedy_resident", "mv_run_beam_resident",
     "mv_synchronize", "mv_download_outputs", "mv_download_beam_outputs",
     "mv_set_graph_mode", "mv_set_compute_mode", "mv_set_profiling", "mv_reset_kernel_stats", "mv_num_kernel_stats",
-    "mv_kernel_stat", "mv_time_greedy_resident", "mv_time_beam_resident",
+    "mv_kernel_stat", "mv_kernel_stat_dense_flops", "mv_time_greedy_resident",
+    "mv_time_beam_resident",
     "mv_op_convlstm_step", "mv_op_gnn", "mv_op_hidden2grid", "mv_op_beam_step",
     "mv_train_init", "mv_train_step", "mv_train_forward_backward",
     "mv_upload_targets", "mv_grad_buffer", "mv_train_apply", "mv_get_grad", "mv_get_global_step",
@@ -191,6 +192,7 @@ def load():
   lib.mv_kernel_stat.argtypes = [h, C.c_int32, C.c_char_p, C.c_int32,
                                  C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]
+  lib.mv_kernel_stat_dense_flops.argtypes = [h, C.c_int32, C.POINTER(C.c_double)]
   lib.mv_time_greedy_resident.argtypes = [h, C.c_int32, _fp]
   lib.mv_time_beam_resident.argtypes = [h, C.c_int32, _fp]
   lib.mv_op_convlstm_step.argtypes = [C.c_int, _fp, _fp, _fp, _fp, _fp] + \
@@ -273,9 +275,12 @@ def make_config(cfg):
   return c
 
 
-def make_train_config(cfg):
+def make_train_config(cfg, world=1):
   """Trainer.__init__ / Model.build_loss fields of the config
-  (reference code/pred_models.py:1636-1717, 961-1040) -> mv_train_config."""
+  (reference code/pred_models.py:1636-1717, 961-1040) -> mv_train_config.
+  `world`: data-parallel ranks.  cfg.batch_size is the PER-RANK batch; the schedules
+  count optimizer steps over the global batch (batch_size * world), as a single-GPU
+  run of the reference with that batch size would."""
   if cfg.optimizer != "adadelta":
     raise MvError("optimizer %r is not implemented (adadelta only, the published "
                   "configuration)" % (cfg.optimizer,))
@@ -294,9 +299,9 @@ def make_train_config(cfg):
   t.use_cosine_lr = 1 if getattr(cfg, "use_cosine_lr", False) else 0
   t.has_decay = 0 if cfg.learning_rate_decay is None else 1
   t.learning_rate_decay = float(cfg.learning_rate_decay or 1.0)
-  t.decay_steps = int(cfg.train_num_examples / cfg.batch_size *
-                      cfg.num_epoch_per_decay)
-  t.max_steps = int(cfg.train_num_examples / cfg.batch_size * cfg.num_epochs)
+  gbatch = cfg.batch_size * max(1, int(world))
+  t.decay_steps = int(cfg.train_num_examples / gbatch * cfg.num_epoch_per_decay)
+  t.max_steps = int(cfg.train_num_examples / gbatch * cfg.num_epochs)
   t.do_clip = 0 if cfg.clip_gradient_norm is None else 1
   t.clip_gradient_norm = float(cfg.clip_gradient_norm or 0.0)
   t.wd = float(cfg.wd or 0.0)
@@ -445,13 +450,30 @@ class Engine(object):
   # ---- compact inputs (device-side batch assembly)
   def set_grid_centers(self, centers):
     """centers: list over scales of float64 [H, W, 2] (data["grid_center_<s>"])."""
+    sent = []
     for s, (h, w) in enumerate(self.cfg.scene_grids):
       if not self.cfg.use_grids[s]:
+        sent.append(None)
         continue
       c = np.ascontiguousarray(np.asarray(centers[s], dtype=np.float64).reshape(h, w, 2))
       check(self.lib.mv_set_grid_centers(self.handle, s, c.ctypes.data_as(_dp)),
             self.handle)
-    self._centers_set = True
+      sent.append(c.copy())
+    self._centers_sent = sent
+
+  def _centers_current(self, centers):
+    """Are the centres resident in the engine the ones of this feed?  (A second
+    dataset -- val after train -- may carry different grid centres.)"""
+    sent = getattr(self, "_centers_sent", None)
+    if sent is None:
+      return False
+    for s, (h, w) in enumerate(self.cfg.scene_grids):
+      if not self.cfg.use_grids[s]:
+        continue
+      c = np.asarray(centers[s], dtype=np.float64).reshape(h, w, 2)
+      if sent[s] is None or not np.array_equal(sent[s], c):
+        return False
+    return True
 
   def upload_compact(self, feed):
     """feed: obs_scene, scene_feat (0/1, any dtype), grid_obs_labels, obs_xy
@@ -459,8 +481,12 @@ class Engine(object):
     also the training targets (after train_init)."""
     cfg = self.cfg
     N, T = cfg.batch_size, cfg.obs_len
-    if not getattr(self, "_centers_set", False):
+    if not self._centers_current(feed["grid_centers"]):
       self.set_grid_centers(feed["grid_centers"])
+    scene_any = np.asarray(feed["scene_feat"])
+    if scene_any.dtype != np.uint8 and not ((scene_any == 0) | (scene_any == 1)).all():
+      raise MvError("upload_compact: scene_feat must be 0/1 masks (it is handed over as "
+                    "uint8); use the dense upload for real-valued scene features")
     inp = mv_inputs_compact()
     obs_scene = i32(feed["obs_scene"]).reshape(N, T)
     scene = np.ascontiguousarray(np.asarray(feed["scene_feat"]).astype(np.uint8, copy=False))
@@ -535,8 +561,8 @@ class Engine(object):
     return arrs, s
 
   # ---- training (Trainer.step)
-  def train_init(self, cfg=None):
-    self._tc = make_train_config(cfg or self.cfg)
+  def train_init(self, cfg=None, world=1):
+    self._tc = make_train_config(cfg or self.cfg, world=world)
     check(self.lib.mv_train_init(self.handle, C.byref(self._tc)), self.handle)
 
   def _targets(self, feed):
@@ -644,12 +670,16 @@ class Engine(object):
   def kernel_stats(self):
     out = {}
     name = C.create_string_buffer(256)
-    n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+    n, ms, fl, by, dn = C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
     for i in range(self.lib.mv_num_kernel_stats(self.handle)):
       self.lib.mv_kernel_stat(self.handle, i, name, 256, C.byref(n), C.byref(ms),
                               C.byref(fl), C.byref(by))
+      self.lib.mv_kernel_stat_dense_flops(self.handle, i, C.byref(dn))
+      # flops: algorithmic FLOPs the launches executed; flops_dense: the same steps as
+      # the reference computes them (a zero-state encoder step still multiplies h = 0)
       out[name.value.decode()] = {"launches": int(n.value), "total_ms": ms.value,
-                                  "flops": fl.value, "bytes": by.value}
+                                  "flops": fl.value, "bytes": by.value,
+                                  "flops_dense": dn.value}
     return out
 
 

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -107,7 +108,10 @@ struct ConvCell {           // one ConvLSTMCell: packed kernel + biases
 struct KernelStat {
   std::string name;
   int64_t launches = 0;
-  double total_ms = 0, flops = 0, bytes = 0;
+  // flops: algorithmic FLOPs the launches EXECUTED (a zero-state step skips the h
+  // half of the gate convolution); flops_dense: the same steps as the reference
+  // computes them (dense 2*M*9*(Cx+C)*4C).  bytes: algorithmic HBM bytes.
+  double total_ms = 0, flops = 0, bytes = 0, flops_dense = 0;
 };
 
 struct PendingEvent {
@@ -217,9 +221,26 @@ namespace {
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PROCESS-wide property of the kernel
+// (per device): it is only ever raised, so a second engine / mv_op_beam_step with a
+// smaller beam_size * K cannot lower the limit under a live engine.
+void ensure_beam_step_lds(int device, size_t lds) {
+  static std::mutex mu;
+  static std::map<int, size_t> granted;
+  std::lock_guard<std::mutex> lk(mu);
+  MV_REQUIRE(lds <= 160 * 1024, "beam_size*K too large for the LDS beam step (%zu B)", lds);
+  size_t& cur = granted[device];
+  if (lds > cur) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mv::beam_step_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    cur = lds;
+  }
+}
+
 // Launch wrapper: optional hipEvent bracket per launch for the roofline figure.
 template <typename F>
-void launch(mv_engine* e, const char* name, double flops, double bytes, F&& fn) {
+void launch(mv_engine* e, const char* name, double flops, double bytes, F&& fn,
+            double flops_dense = -1.0) {
   if (!e->profiling) {
     fn();
     return;
@@ -233,6 +254,7 @@ void launch(mv_engine* e, const char* name, double flops, double bytes, F&& fn) 
   HIP_CHECK(hipEventRecord(pe.b, e->stream));
   e->stats[si].launches += 1;
   e->stats[si].flops += flops;
+  e->stats[si].flops_dense += flops_dense >= 0 ? flops_dense : flops;
   e->stats[si].bytes += bytes;
   e->pending.push_back(pe);
 }
@@ -484,7 +506,7 @@ ConvCell* cell_of_pack(mv_engine* e, const float* wpack) {
 // fp16 planes (HBM-bound, ~2 % of the step), then one grouped launch of the
 // fp16-MFMA kernel.
 void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
-                          double flops, double bytes) {
+                          double flops, double bytes, double dense) {
   std::vector<mv::ConvLstm16Args> p16(probs.size());
   for (size_t i = 0; i < probs.size(); ++i) {
     const ConvLstmArgs& a = probs[i];
@@ -545,27 +567,29 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
   }
   launch(e, "convlstm_step", flops, bytes, [&] {
     mv::launch_convlstm16_steps(p16.data(), (int)p16.size(), e->stream);
-  });
+  }, dense);
 }
 
 // One launch for up to four independent ConvLSTM steps (class / regression
 // chain of each scale advance in lockstep).
 void run_conv_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs) {
   if (probs.empty()) return;
-  double flops = 0, bytes = 0;
+  double flops = 0, bytes = 0, dense = 0;
   for (const auto& a : probs) {
     const double M = (double)a.rows * a.H * a.W;
-    // algorithmic work of the step as the reference computes it (dense)
-    flops += 2.0 * M * 9.0 * (a.Cx + a.C) * 4.0 * a.C;
-    bytes += M * (a.Cx + 4.0 * a.C) * 4.0;   // x,h,c in; h,c out
+    // dense: the step as the reference computes it; executed: a zero-state step
+    // (first encoder step) never multiplies the h half and never reads h, c
+    dense += 2.0 * M * 9.0 * (a.Cx + a.C) * 4.0 * a.C;
+    flops += 2.0 * M * 9.0 * (a.Cx + (a.zero_state ? 0 : a.C)) * 4.0 * a.C;
+    bytes += M * (a.Cx + (a.zero_state ? 2.0 : 4.0) * a.C) * 4.0;   // x,(h,c) in; h,c out
   }
-  if (e->compute_mode == 1) {
-    run_conv_group_f16x3(e, probs, flops, bytes);
+  if (e->compute_mode != 0) {
+    run_conv_group_f16x3(e, probs, flops, bytes, dense);
     return;
   }
   launch(e, "convlstm_step", flops, bytes, [&] {
     mv::launch_convlstm_steps(probs.data(), (int)probs.size(), e->stream);
-  });
+  }, dense);
 }
 
 void run_scene(mv_engine* e) {
@@ -859,6 +883,7 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
                            e->stream, logits, e->bm_lp[lpi].p, B, K, time,
                            c.diverse_beam, logf(c.diverse_gamma), c.fix_num_timestep,
                            e->bm_lp[lpi ^ 1].p, ids, parents, e->bm_src_row.p);
+        HIP_CHECK(hipGetLastError());   // a refused LDS size must not pass silently
       });
       lpi ^= 1;
       src = e->bm_src_row.p;
@@ -1146,10 +1171,7 @@ int mv_create(const mv_config* cfg, int device, mv_handle* out) {
       size_t K = 0;
       for (int s = 0; s < cfg->num_scales; ++s)
         if (e->sc[s].use) K = e->sc[s].K;
-      const size_t lds = ((size_t)2 * cfg->beam_size * K + 512) * sizeof(float);
-      MV_REQUIRE(lds <= 160 * 1024, "beam_size*K too large for the LDS beam step");
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mv::beam_step_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      ensure_beam_step_lds(device, ((size_t)2 * cfg->beam_size * K + 512) * sizeof(float));
     }
   });
   if (rc != 0) { delete e; return rc; }
@@ -1517,6 +1539,12 @@ int mv_reset_kernel_stats(mv_handle h) {
 
 int mv_num_kernel_stats(mv_handle h) { return h ? (int)h->stats.size() : -1; }
 
+int mv_kernel_stat_dense_flops(mv_handle h, int32_t i, double* flops_dense) {
+  if (!h || i < 0 || i >= (int)h->stats.size() || !flops_dense) return 1;
+  *flops_dense = h->stats[i].flops_dense;
+  return 0;
+}
+
 int mv_kernel_stat(mv_handle h, int32_t i, char* name_out, int32_t name_cap,
                    int64_t* launches, double* total_ms, double* flops, double* bytes) {
   if (!h || i < 0 || i >= (int)h->stats.size()) return 1;
@@ -1639,9 +1667,7 @@ int mv_op_beam_step(int device, const float* logits, const float* prev_logprob,
   return guarded(nullptr, [&] {
     OpCtx ctx(device);
     const size_t lds = ((size_t)2 * B * K + 512) * sizeof(float);
-    MV_REQUIRE(lds <= 160 * 1024, "B*K too large for the LDS beam step");
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mv::beam_step_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ensure_beam_step_lds(device, lds);
     DevBuf<float> dl, dp, dn;
     DevBuf<int32_t> di, dpa;
     ctx.up(dl, logits, (size_t)N * B * K);

@@ -37,6 +37,48 @@ def compact_inputs_enabled(cfg):
       os.environ.get("MV_COMPACT_INPUTS", "0") not in ("", "0")
 
 
+_compact_warned = set()
+
+
+def compact_inputs_consistent(cfg, batch):
+  """Is the compact hand-over bit-identical to the dense feed for THIS batch?
+
+  The engine rebuilds `*_grid_target_all_<s>` as float32(float64(xy) - centre).  That
+  holds when the npz was written from `obs_traj` in pixel coordinates
+  (code/preprocess.py:463-475), NOT when preprocess ran with `--traj_pixel_lst`
+  (:428-475: the maps come from the alternate pixel trajectory while `obs_traj` stays
+  in world coordinates), and the uint8 hand-over of the scene table needs 0/1 masks
+  (:831).  Checked per batch on its first and last row wherever the dense maps are
+  present; a mismatch falls back to the dense feed (once-per-reason warning).
+  -> (ok, reason)"""
+  data = batch.data
+  sf = np.asarray(data["batch_scene_feat"])
+  if sf.dtype != np.uint8 and not ((sf == 0) | (sf == 1)).all():
+    return False, "scene_feat is not a 0/1 mask"
+  n_have = len(data["obs_grid_class"])
+  if not n_have:
+    return True, ""
+  with_targets = getattr(cfg, "is_train", False) or getattr(cfg, "use_gt_grid", False)
+  for j in range(len(cfg.scene_grids)):
+    if not cfg.use_grids[j]:
+      continue
+    centre = np.asarray(batch.shared["grid_center_%d" % j], dtype=np.float64)
+    for key, traj in (("obs_grid_target_all_%d" % j, "obs_traj"),
+                      ("pred_grid_target_all_%d" % j, "pred_traj")):
+      if key not in data or traj not in data:
+        continue
+      if traj == "pred_traj" and not with_targets:
+        continue
+      for i in sorted({0, n_have - 1}):
+        xy = np.asarray(data[traj][i], dtype=np.float64)                 # [T, 2]
+        want = (xy[:, None, None, :] - centre[None]).astype(np.float32)  # [T, H, W, 2]
+        have = np.asarray(data[key][i], dtype=np.float32)
+        if have.shape != want.shape or not (have == want).all():
+          return False, ("%s is not float32(%s - grid_center_%d) (an npz written with "
+                         "--traj_pixel_lst?)" % (key, traj, j))
+  return True, ""
+
+
 def build_compact_feed_dict(cfg, batch, is_train=False):
   """The same batch as `build_feed_dict`, handed over as labels + one (x, y) per
   step + the uint8 scene masks; the engine derives the dense regression maps in HBM
@@ -192,7 +234,13 @@ class Model(object):
     if compact_inputs_enabled(self.config) and "obs_traj" in batch.data and \
         all(("grid_center_%d" % j) in batch.shared
             for j in range(len(self.config.scene_grids))):
-      return build_compact_feed_dict(self.config, batch, is_train=is_train)
+      ok, why = compact_inputs_consistent(self.config, batch)
+      if ok:
+        return build_compact_feed_dict(self.config, batch, is_train=is_train)
+      if why not in _compact_warned:
+        _compact_warned.add(why)
+        import sys
+        sys.stderr.write("compact_inputs: falling back to the dense feed: %s\n" % why)
     return build_feed_dict(self.config, batch, is_train=is_train)
 
   # -- one sess.run ----------------------------------------------------------
@@ -250,7 +298,8 @@ class Trainer(object):
     self.model = model
     if not getattr(config, "is_train", False):
       raise _lib.MvError("Trainer needs a config with is_train=True")
-    model.engine.train_init(config)
+    from multiverse_amd import parallel
+    model.engine.train_init(config, world=parallel.world_size())
 
   @property
   def global_step(self):

@@ -125,6 +125,7 @@ class Saver(object):
 
   def __init__(self, max_to_keep=5):
     self.max_to_keep = max_to_keep
+    self._last_checkpoints = []    # only what THIS saver wrote is ever deleted
 
   def save(self, model, path, global_step=None):
     from multiverse_amd import tf_checkpoint
@@ -139,7 +140,8 @@ class Saver(object):
       step = 0                       # inference-only engine: weights only
     variables["global_step"] = np.asarray(step, dtype="int32")
     return tf_checkpoint.save_checkpoint(path, variables, global_step=global_step,
-                                         max_to_keep=self.max_to_keep)
+                                         max_to_keep=self.max_to_keep,
+                                         written=self._last_checkpoints)
 
   def restore(self, model, path, with_optimizer=True):
     """Resume: weights + (when present) Adadelta slots and global_step."""

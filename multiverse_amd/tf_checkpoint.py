@@ -531,11 +531,18 @@ def load_checkpoint(path, scope=None, skip_optimizer_slots=True, verify_crc=Fals
   return out
 
 
+_WRITTEN_BY_PROCESS = {}     # directory -> basenames written by module-level saves
+
+
 def save_checkpoint(prefix, variables, global_step=None, update_state=True,
-                    max_to_keep=5):
+                    max_to_keep=5, written=None):
   """`saver.save(sess, prefix, global_step)`: writes
   `<prefix>-<step>.index/.data-00000-of-00001` and updates the directory's
-  `checkpoint` state file (keeping the newest `max_to_keep` entries).
+  `checkpoint` state file.  Like `tf.train.Saver` (its `_last_checkpoints` list),
+  only checkpoints written through the same `written` list -- one per Saver
+  instance; the process-wide default for bare calls -- count against
+  `max_to_keep` and are ever deleted: resuming into a directory never removes the
+  checkpoints of the previous run (they stay listed in the state file).
   Returns the checkpoint prefix written."""
   if global_step is not None:
     prefix = "%s-%d" % (prefix, int(global_step))
@@ -558,11 +565,14 @@ def save_checkpoint(prefix, variables, global_step=None, update_state=True,
       offset += len(raw)
   write_table(prefix + ".index", items)
   if update_state:
-    _update_state(prefix, max_to_keep)
+    if written is None:
+      written = _WRITTEN_BY_PROCESS.setdefault(
+          os.path.abspath(os.path.dirname(prefix) or "."), [])
+    _update_state(prefix, max_to_keep, written)
   return prefix
 
 
-def _update_state(prefix, max_to_keep):
+def _update_state(prefix, max_to_keep, written):
   d = os.path.dirname(prefix) or "."
   state = os.path.join(d, "checkpoint")
   base = os.path.basename(prefix)
@@ -573,8 +583,13 @@ def _update_state(prefix, max_to_keep):
         if line.startswith("all_model_checkpoint_paths:"):
           allp.append(line.split(":", 1)[1].strip().strip('"'))
   allp = [p for p in allp if p != base] + [base]
-  while max_to_keep and len(allp) > max_to_keep:
-    old = allp.pop(0)
+  if base in written:
+    written.remove(base)
+  written.append(base)
+  while max_to_keep and len(written) > max_to_keep:
+    old = written.pop(0)
+    if old in allp:
+      allp.remove(old)
     for suffix in (".index", ".data-00000-of-00001"):
       try:
         os.remove(os.path.join(d, old + suffix))

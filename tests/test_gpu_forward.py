@@ -29,6 +29,7 @@ def _check_greedy(built_lib, cfg, params, feed):
   eng.close()
   ocls, oreg, _ = oracle.forward(params, cfg, feed)
   N, Tp = cfg.batch_size, int(feed["pred_length"])
+  tolerated = 0
   for s in range(len(cfg.scene_grids)):
     if not cfg.use_grids[s]:
       assert cls[s] == [] and reg[s] == []
@@ -45,11 +46,17 @@ def _check_greedy(built_lib, cfg, params, feed):
         assert margins[n, t] < TOL, (
             "argmax differs at n=%d t=%d with oracle margin %g" % (n, t, margins[n, t]))
         upto = t + 1
+        tolerated += 1
       else:
         upto = Tp
       assert np.abs(cls[s][n, :upto] - ocls[s][n, :upto]).max() < TOL
     assert (gi == oi).mean() > 0.99
     assert np.abs(reg[s] - oreg[s]).max() < TOL
+  # every tolerated flip sits on an oracle top-1/top-2 margin below TOL; a regression
+  # that flips more than one row of these small batches must not pass silently
+  print("greedy parity: %d rows with an argmax flip on an oracle margin < %g (of %d)"
+        % (tolerated, TOL, N * sum(bool(u) for u in cfg.use_grids)))
+  assert tolerated <= 1
   return cls, reg
 
 

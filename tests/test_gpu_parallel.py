@@ -1,0 +1,127 @@
+# coding=utf-8
+"""GPU: the multi-rank path with the ENGINE on every rank.
+
+Two processes share the one GPU of the test box (RCCL refuses duplicate devices, so the
+process group is gloo -- the same `parallel.allreduce_engine_grads` call the RCCL job
+makes, with the reduction staged through the host); each rank owns one batch shard:
+
+  training   mv_train_forward_backward(shard) -> all-reduce(SUM) of the flat gradient
+             buffer -> mv_train_apply(1/world)   ==   one process, mv_train_step on the
+             global batch: parameters after two steps (incl. the LR staircase, which
+             counts GLOBAL batches), Adadelta slots and global_step;
+  inference  the shards' outputs concatenate BITWISE to the single-process forward.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_GLOBAL, STEPS = 4, 2
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def _cfg(batch, synth, is_train):
+  cfg = synth.default_config(batch_size=batch, use_grids=(1, 1), is_train=is_train)
+  cfg.train_num_examples = N_GLOBAL       # decay_steps = 2 global batches: LR moves at step 2
+  cfg.num_epoch_per_decay = 2.0
+  return cfg
+
+
+def _worker(rank, world, port, outdir):
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  import torch
+  import torch.distributed as dist
+  torch.cuda.set_device(0)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  from multiverse_amd import _lib, parallel, synth
+  gcfg = _cfg(N_GLOBAL, synth, True)
+  params = synth.make_params(gcfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0,
+                             bias_scale=0.1)
+  lo, hi = parallel.shard_range(N_GLOBAL, rank, world)
+  scfg = _cfg(hi - lo, synth, True)
+  eng = _lib.Engine(scfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode("f16x3")
+  eng.train_init(world=world)
+  losses = []
+  for step in range(STEPS):
+    feed = synth.make_feed(gcfg, seed=synth.SEED_BASE + 200 + step)
+    shard, _ = parallel.shard_feed(feed, rank, world, N_GLOBAL)
+    loss, wd, pgl = eng.train_forward_backward(shard)
+    parallel.allreduce_engine_grads(eng, 0)
+    eng.train_apply(1.0 / world)
+    loss, pgl = parallel.mean_over_ranks(loss, pgl)
+    losses.append([loss, wd] + list(pgl))
+  assert eng.global_step == STEPS
+  out = {n: eng.get_param(n) for n, _ in eng.param_specs()}
+  out.update({"slot0|" + n: eng.get_opt_slot(n, 0) for n, _ in eng.param_specs()})
+  # inference on the trained weights: this rank's shard of a fresh batch
+  feed = synth.make_feed(gcfg, seed=synth.SEED_BASE + 300)
+  shard, _ = parallel.shard_feed(feed, rank, world, N_GLOBAL)
+  cls, reg = eng.forward_greedy(shard)
+  eng.close()
+  full = [parallel.gather_to_rank0(a) for a in (cls[0], cls[1], reg[0], reg[1])]
+  if rank == 0:
+    out["losses"] = np.asarray(losses)
+    for k, a in zip(("cls0", "cls1", "reg0", "reg1"), full):
+      out[k] = a
+    np.savez(os.path.join(outdir, "dp.npz"), **out)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_engine_equals_single_process(built_lib, tmp_path):
+  from multiverse_amd import synth
+  world = 2
+  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  dp = np.load(os.path.join(str(tmp_path), "dp.npz"))
+  gcfg = _cfg(N_GLOBAL, synth, True)
+  params = synth.make_params(gcfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0,
+                             bias_scale=0.1)
+  eng = built_lib.Engine(gcfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode("f16x3")
+  eng.train_init()
+  for step in range(STEPS):
+    feed = synth.make_feed(gcfg, seed=synth.SEED_BASE + 200 + step)
+    loss, wd, pgl = eng.train_step(feed)
+    ref = np.asarray([loss, wd] + list(pgl))
+    print("step %d: single-process %s | 2 ranks (mean) %s" % (step, ref, dp["losses"][step]))
+    assert np.allclose(dp["losses"][step], ref, rtol=2e-6, atol=1e-7)
+  worst = 0.0
+  for n, _ in eng.param_specs():
+    ref = eng.get_param(n)
+    upd = max(float(np.abs(ref - params[n]).max()), 1e-12)
+    d = float(np.abs(dp[n] - ref).max())
+    worst = max(worst, d / max(1.0, float(np.abs(ref).max())))
+    assert d <= 1e-6 * max(1.0, float(np.abs(ref).max())) and d <= 2e-3 * upd, (n, d, upd)
+    s_ref = eng.get_opt_slot(n, 0)
+    assert np.abs(dp["slot0|" + n] - s_ref).max() <= 1e-4 * max(np.abs(s_ref).max(), 1e-30)
+  print("parameters after %d data-parallel steps: max |2 ranks - 1 process| = %.2e"
+        % (STEPS, worst))
+  # inference: shards concatenate bitwise (same kernels, same per-row order)
+  trained = {n: dp[n] for n, _ in eng.param_specs()}
+  eng.close()
+  icfg = _cfg(N_GLOBAL, synth, False)
+  ieng = built_lib.Engine(icfg, device=0)
+  ieng.set_params(trained)
+  ieng.set_compute_mode("f16x3")
+  cls, reg = ieng.forward_greedy(synth.make_feed(icfg, seed=synth.SEED_BASE + 300))
+  ieng.close()
+  assert (cls[0] == dp["cls0"]).all() and (cls[1] == dp["cls1"]).all()
+  assert (reg[0] == dp["reg0"]).all() and (reg[1] == dp["reg1"]).all()

@@ -274,3 +274,29 @@ def test_ctypes_prototypes_match_the_c_header(built_lib):
       is_ptr_py = hasattr(t, "contents") or t in (ctypes.c_char_p, ctypes.c_void_p) or \
           getattr(t, "_type_", None) == "P"
       assert is_ptr_c == is_ptr_py, (name, p, t)
+
+
+def test_compact_inputs_consistency_gate():
+  """the compact hand-over (labels + xy + uint8 masks) is only taken when
+  it reproduces the dense maps of the npz bit for bit; otherwise the dense feed."""
+  import copy
+  from multiverse_amd import pred_models, pred_utils
+  cfg = synth.default_config(batch_size=4, use_grids=(1, 1))
+  good = synth.make_npz_data(cfg, 6, seed=9, float32_traj=True)
+  ds = pred_utils.dataset_from_npz_dict(good, "test", cfg)
+  batch = next(ds.get_batches(4, full=True, shuffle=False))[1]
+  ok, why = pred_models.compact_inputs_consistent(cfg, batch)
+  assert ok, why
+  # maps derived from a DIFFERENT trajectory than obs_traj (preprocess --traj_pixel_lst)
+  bad = copy.deepcopy(good)
+  bad["obs_traj"] = (bad["obs_traj"] * 0.01).astype("float32")     # "world" coordinates
+  ds2 = pred_utils.dataset_from_npz_dict(bad, "test", cfg)
+  batch2 = next(ds2.get_batches(4, full=True, shuffle=False))[1]
+  ok, why = pred_models.compact_inputs_consistent(cfg, batch2)
+  assert not ok and "obs_grid_target_all_0" in why
+  # real-valued scene features cannot travel as uint8
+  batch3 = next(ds.get_batches(4, full=True, shuffle=False))[1]
+  batch3.data["batch_scene_feat"] = np.asarray(batch3.data["batch_scene_feat"],
+                                               dtype="float32") * 0.5
+  ok, why = pred_models.compact_inputs_consistent(cfg, batch3)
+  assert not ok and "0/1" in why

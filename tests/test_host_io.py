@@ -101,6 +101,28 @@ def test_max_to_keep_and_state_file(tmp_path):
   assert 'model_checkpoint_path: "save-4"' in open(os.path.join(d, "checkpoint")).read()
 
 
+def test_resumed_run_never_deletes_the_previous_runs_checkpoints(tmp_path):
+  """tf.train.Saver deletes only what it wrote itself (`_last_checkpoints`): a run
+  resumed with --load into the same save_dir keeps the restored checkpoint."""
+  d = str(tmp_path)
+  v = {"person_pred/x/W": np.ones((2, 2), "f4")}
+  first = []
+  for step in (10, 20):
+    tc.save_checkpoint(os.path.join(d, "save"), v, global_step=step, max_to_keep=2,
+                       written=first)
+  second = []                         # a new Saver instance: the resumed run
+  for step in (30, 40, 50):
+    tc.save_checkpoint(os.path.join(d, "save"), v, global_step=step, max_to_keep=2,
+                       written=second)
+  idx = sorted(n for n in os.listdir(d) if n.endswith(".index"))
+  assert idx == ["save-10.index", "save-20.index", "save-40.index", "save-50.index"]
+  state = open(os.path.join(d, "checkpoint")).read()
+  assert 'model_checkpoint_path: "save-50"' in state
+  for keep in ("save-10", "save-20", "save-40", "save-50"):
+    assert 'all_model_checkpoint_paths: "%s"' % keep in state
+  assert "save-30" not in state
+
+
 def test_snappy_decoder():
   # literal + copy elements: "abcdabcdabcdX"
   comp = bytes([13, (4 - 1) << 2]) + b"abcd" + bytes([((8 - 4) << 2) | 1, 4]) + \
