@@ -432,10 +432,12 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   const int ch = cb * kChBlock + (lane & 31);
     const float bi = a.bias[ch], bj = a.bias[C + ch], bf = a.bias[2 * C + ch],
                 bo = a.bias[3 * C + ch];
+    _Float16* const tl = reinterpret_cast<_Float16*>(lds) + wave * 2048;
   #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
       const int m = m_wave + row;
+      float hn_keep = 0.f;                 // cells past the end: zero planes
       if (m < M_total) {
         float cprev = 0.f;
         if (!a.zero_state) {
@@ -452,20 +454,38 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         const float hn = tanh_(cn) * so;
         a.c_out[(size_t)m * C + ch] = cn;
         a.h_out[(size_t)m * C + ch] = hn;
-        if (p.h16_out) {
-          const float sc = hn * kF16Scale;
-          const _Float16 h0 = (_Float16)sc;
-          const size_t po = plane_index(m, ch, C);
-          p.h16_out[po] = h0;
-          p.h16_out[p.h16_out_stride + po] = (_Float16)(sc - (float)h0);
-        }
+        hn_keep = hn;
         if (a.gates_out) {
           float* gp = a.gates_out + (size_t)m * 4 * C + ch;
           gp[0] = si; gp[C] = tj; gp[2 * C] = sf; gp[3 * C] = so;
         }
       }
+      if (p.h16_out) {
+        // operand planes of h' for the next step: the wave's 32 cells x 32 channels are
+        // two plane tiles (32 cells x 16 channels, [k half][cell][8 ch]); a lane holds
+        // ONE channel of 16 cells, so the tile is assembled in LDS (the weight stage
+        // buffers are free after the last barrier; 4 KB per wave, wave-private) and
+        // goes out as 16-byte vectors, 1 KB contiguous per tile and plane.  (Stored
+        // straight from the accumulator layout these were 2-byte stores at a 16-byte
+        // stride: slower than a separate split pass)
+        const float sc = hn_keep * kF16Scale;
+        const _Float16 h0 = (_Float16)sc;
+        const int chl = lane & 31;
+        const int tofs = (chl >> 4) * 512 + ((chl >> 3) & 1) * 256 + (chl & 7) + row * 8;
+        tl[tofs] = h0;
+        tl[1024 + tofs] = (_Float16)(sc - (float)h0);
+      }
     }
-  
+    if (p.h16_out) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS ops of a wave retire in order
+      const size_t tile0 = ((size_t)(m_wave >> 5) * (size_t)(C >> 4) + (size_t)cb * 2) * 512;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {        // q = plane * 2 + tile
+        const f16x8 v = *reinterpret_cast<const f16x8*>(tl + q * 512 + lane * 8);
+        *reinterpret_cast<f16x8*>(p.h16_out + (size_t)(q >> 1) * p.h16_out_stride + tile0 +
+                                  (size_t)(q & 1) * 512 + lane * 8) = v;
+      }
+    }
   }
 }
 

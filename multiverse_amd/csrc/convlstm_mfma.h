@@ -79,6 +79,8 @@ struct ConvLstmArgs {
   int32_t x_small;      // 1: 9*Cx <= 32, all taps of x packed in ONE chunk
   int32_t zero_state;   // 1: h == c == 0 (first encoder step): skip h, c reads
   float forget_bias;
+  int32_t want_h16;     // host-side hint (f16x3 mode): the next consumer of h' is a gate
+                        // convolution, emit its operand planes from the epilogue
 };
 
 struct ConvLstmGroup {

@@ -476,7 +476,7 @@ ConvLstmArgs conv_problem(mv_engine* e, const ConvCell& cc, const float* x,
                           const float* h, const float* c, const int32_t* src_row_h,
                           const int32_t* src_row_c, float* h_out, float* c_out,
                           int rows, int H, int W, bool zero_state,
-                          size_t x_row_stride = 0) {
+                          size_t x_row_stride = 0, bool want_h16 = true) {
   ConvLstmArgs a{};
   // the kernel forms element offsets in 32-bit registers
   const size_t xrs = x_row_stride ? x_row_stride : (size_t)H * W * cc.Cx;
@@ -490,6 +490,7 @@ ConvLstmArgs conv_problem(mv_engine* e, const ConvCell& cc, const float* x,
   a.h_out = h_out; a.c_out = c_out;
   a.rows = rows; a.H = H; a.W = W; a.Cx = cc.Cx; a.C = e->cfg.hidden_size;
   mv::convlstm_finish_args(a, zero_state);
+  a.want_h16 = want_h16 ? 1 : 0;
   return a;
 }
 
@@ -522,12 +523,20 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     if (a.x_small) q.w_ksteps = 9 * (a.C / 16);
     q.x16 = nullptr; q.h16 = nullptr;
     q.x_plane_stride = q.h_plane_stride = 0;
-    // The conv epilogue CAN emit the planes of h' (h16_out), but its 2-byte
-    // per-row stores cost more (+74 us per launch) than the separate split pass
-    // over the freshly written fp32 h' (64 us): measured, so it stays off.
+    // The conv epilogue emits the operand planes of h' (assembled per wave in LDS,
+    // 16-byte stores) when the next consumer of h' is a gate convolution; MV_EPI_PLANES=0
+    // falls back to the separate split pass over the fp32 h'.
+    static const bool epi = !(getenv("MV_EPI_PLANES") && atoi(getenv("MV_EPI_PLANES")) == 0);
     q.h16_out = nullptr;
     q.h16_out_stride = 0;
     e->plane_invalidate(a.h_out);
+    if (epi && a.want_h16 && !a.gates_out) {
+      size_t pst = 0;
+      if (_Float16* po = e->plane_out(a.h_out, &pst)) {   // marks the planes valid
+        q.h16_out = po;
+        q.h16_out_stride = (int64_t)pst;
+      }
+    }
     auto ready = [&](const float* src) -> const mv_engine::PlaneBuf* {
       auto it = e->planes.find(src);
       return (it != e->planes.end() && it->second.valid) ? &it->second : nullptr;
@@ -656,7 +665,8 @@ void run_encoders(mv_engine* e, Cursors& cur) {
       const int cc = cur.cls[s], cr = cur.reg[s];
       probs.push_back(conv_problem(e, S.enc_cls, S.xbuf_cls.p, S.cls_h[cc].p,
                                    S.cls_c[cc].p, nullptr, nullptr, S.cls_h[cc ^ 1].p,
-                                   S.cls_c[cc ^ 1].p, N, S.H, S.W, t == 0));
+                                   S.cls_c[cc ^ 1].p, N, S.H, S.W, t == 0, 0,
+                                   /*want_h16=*/t + 1 < T || !c.use_gnn));
       probs.push_back(conv_problem(e, S.enc_reg, S.obs_reg.p + (size_t)t * row,
                                    S.reg_h[cr].p, S.reg_c[cr].p, nullptr, nullptr,
                                    S.reg_h[cr ^ 1].p, S.reg_c[cr ^ 1].p, N, S.H, S.W,
@@ -768,7 +778,8 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
         run_emb_onehot(e, S, S.ids.p, 1, S.xbuf_cls.p, N);
       probs.push_back(conv_problem(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cc].p,
                                    nullptr, nullptr, S.cls_h[cc ^ 1].p,
-                                   S.cls_c[cc ^ 1].p, N, S.H, S.W, false));
+                                   S.cls_c[cc ^ 1].p, N, S.H, S.W, false, 0,
+                                   /*want_h16=*/!c.use_gnn));
       cur.cls[s] ^= 1;
       probs.push_back(reg_decoder_problem(e, s, cur, t, Tp));
     }
@@ -868,7 +879,8 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
       std::vector<ConvLstmArgs> probs;
       probs.push_back(conv_problem(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cc].p,
                                    c.use_gnn ? nullptr : src, src, S.cls_h[cc ^ 1].p,
-                                   S.cls_c[cc ^ 1].p, R, S.H, S.W, false));
+                                   S.cls_c[cc ^ 1].p, R, S.H, S.W, false, 0,
+                                   /*want_h16=*/!c.use_gnn));
       cur.cls[s] ^= 1;
       probs.push_back(reg_decoder_problem(e, s, cur, time - 1, Tp));
       run_conv_group(e, probs);

@@ -11,8 +11,12 @@ def compare_beams(arrs, oreg, ologits, oids, olp, topv, otrace):
   selected candidate scores at that step are tied to within TIE_TOL (float32
   ulps of exp/log decide the order of such beams; the reference's back-trace
   gathers logits by the new beam index, code/pred_models.py:738, so a swap of
-  two tied beams moves their logits rows at that one step).  Every tolerated
-  position is counted and printed."""
+  two tied beams moves their logits rows at that one step).  The row of the
+  per-step logits tensor that index names was itself placed by the selection of
+  the step BEFORE (the rows of step t are the beams as ordered at step t-1), so
+  a tie at either of the two selections explains a swapped logits row; near the
+  end of a 12-step decode the scores are ~ -60 and one float32 ulp is 7.6e-6.
+  Every tolerated position is counted and printed."""
   N, B, T = oids.shape
   topv = np.asarray(topv)                                   # [N, B, T]
   gap = np.full((N, B, T), np.inf, dtype=np.float64)
@@ -43,7 +47,7 @@ def compare_beams(arrs, oreg, ologits, oids, olp, topv, otrace):
         err = np.abs(arrs["logits"][n, b, t] - ologits[n, match, t]).max()
         if err >= TOL:
           j = otrace[n, match, t]
-          assert amb[n, j, t], (
+          assert amb[n, j, t] or (t > 0 and amb[n, j, t - 1]), (
               "logits differ by %g at n=%d b=%d t=%d with untied scores" % (err, n, b, t))
           tolerated += 1
   print("beam parity: %d of %d (n,b,t) logits rows differ at oracle-tied steps"
