@@ -185,6 +185,17 @@ static inline unsigned split_planes_blocks(size_t M, int C) {
 #ifndef MV_F16_KPB
 #define MV_F16_KPB 3
 #endif
+// Waves per workgroup.  Eight waves (256 cells) share one LDS weight stage: with the
+// LDS-DMA copy the kernel needs 120 VGPRs, so 2 workgroups x 8 waves = 4 waves per SIMD
+// fit (4 waves per workgroup: 3 workgroups of 48 KB LDS = 3 waves per SIMD), and every
+// staged weight byte feeds twice the MFMAs: 1.185 -> 1.137 ms per grouped launch
+// (greedy), 12.82 -> 12.08 ms (beam 20).
+#ifndef MV_CONV_WAVES
+#define MV_CONV_WAVES 8
+#endif
+constexpr int kWaves16 = MV_CONV_WAVES;           // waves per workgroup of the f16x3 kernels
+constexpr int kThreads16 = kWaves16 * 64;
+constexpr int kBlockRows16 = kWaves16 * kWaveRows; // cells per workgroup
 constexpr int kKpb = MV_F16_KPB;                 // k-steps per LDS stage (2, 3 or 6 divide every k-step count)
 constexpr int kStageVec = kKpb * 2 * 4 * 64;     // f16x8 elements per stage (kKpb x 8 KB)
 
@@ -201,7 +212,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   const int wave = tid >> 6;
   const int H = a.H, W = a.W, HW = H * W, C = a.C, Cx = a.Cx;
   const int M_total = a.rows * HW;
-  const int m_wave = mt * kBlockRows + wave * kWaveRows;
+  const int m_wave = mt * kBlockRows16 + wave * kWaveRows;
   const bool wave_live = m_wave < M_total;     // dead waves still copy and hit barriers
 
   int ypos, xpos, xoff, xcell, hcell;    // xcell / hcell: flat cell index in the operand planes
@@ -272,7 +283,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wp16) +
                       (size_t)cb * p.w_ksteps * (2 * 4 * 64);
   constexpr int kSV = 3 * 2 * NG * 64;         // 16-B vectors per stage (NG sub-blocks)
-  constexpr int kCopy = (kSV + 255) / 256;     // per thread
+  constexpr int kCopy = (kSV + kThreads16 - 1) / kThreads16;     // per thread
   // stage vector v = ((kk*2 + plane)*NG + g)*64 + lane  ->  its place in the pack,
   // which keeps four sub-block slots per (k-step, plane)
   auto pack_index = [&](int st, int v) -> size_t {
@@ -336,16 +347,22 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   // stage range of this workgroup (split-K: n_kslice equal ranges)
   const int st_lo = (nstages / n_kslice) * kslice;
   const int st_hi = n_kslice > 1 ? st_lo + nstages / n_kslice : nstages;
+#ifndef MV_CONV_VARIANT
+#define MV_CONV_VARIANT 1
+#endif
+#if MV_CONV_VARIANT == 0
+  // ---- variant 0 (round 1): weights staged global -> VGPR -> LDS, B fragments read
+  // from LDS right before their MFMAs
   if (st_hi > st_lo) {
     f16x8 stg[kCopy];
 #pragma unroll
     for (int i = 0; i < kCopy; ++i)
-      if (i * 256 + tid < kSV) stg[i] = wblk[pack_index(st_lo, i * 256 + tid)];
+      if (i * kThreads16 + tid < kSV) stg[i] = wblk[pack_index(st_lo, i * kThreads16 + tid)];
     {
       f16x8* dst0 = lds + (st_lo & 1) * kStageVec;
 #pragma unroll
       for (int i = 0; i < kCopy; ++i)
-        if (i * 256 + tid < kSV) dst0[i * 256 + tid] = stg[i];
+        if (i * kThreads16 + tid < kSV) dst0[i * kThreads16 + tid] = stg[i];
     }
     bool c_isx = stage_isx(st_lo);
     int c_rowoff = stage_rowoff(st_lo), c_cg = stage_cg(st_lo);
@@ -371,7 +388,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         if (kk == 1 && more) {
 #pragma unroll
           for (int i = 0; i < kCopy; ++i)
-            if (i * 256 + tid < kSV) stg[i] = wblk[pack_index(st + 1, i * 256 + tid)];
+            if (i * kThreads16 + tid < kSV) stg[i] = wblk[pack_index(st + 1, i * kThreads16 + tid)];
         }
         f16x8 b0[NG], b1[NG];
 #pragma unroll
@@ -395,11 +412,76 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         f16x8* dst = lds + ((st + 1) & 1) * kStageVec;
 #pragma unroll
         for (int i = 0; i < kCopy; ++i)
-          if (i * 256 + tid < kSV) dst[i * 256 + tid] = stg[i];
+          if (i * kThreads16 + tid < kSV) dst[i * kThreads16 + tid] = stg[i];
       }
       __syncthreads();
     }
   }
+#else
+  // ---- variant 1 (default): the stage copy is an LDS-DMA (global_load_lds, 16 B per
+  // lane: the pack IS the LDS image, lane-linear, so a wave's piece is one 1 KB run on
+  // both sides): no staging VGPRs (154 -> 126), no ds_write pass; 1.226 -> 1.207 ms per
+  // grouped launch.  Tried on top of it and dropped: a second
+  // register set of B fragments read one k-step ahead (180 VGPRs, 2 waves per SIMD:
+  // 1.317 ms; capped at 168 registers it spills: 1.380 ms) and A fragments requested
+  // two k-steps ahead (140 VGPRs: 1.192 vs 1.184 ms on the same box) -- neither the
+  // LDS nor the L2 latency of a single wave is what limits the matrix pipe here.
+  if (st_hi > st_lo) {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto stage_dma = [&](int st, f16x8* dstbuf) {
+#pragma unroll
+      for (int i = 0; i < kCopy; ++i) {
+        const int v0 = (i * kWaves16 + wave_u) * 64;              // wave-uniform piece of 64 vectors
+        if (v0 < kSV)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(wblk + pack_index(st, v0 + lane)),
+              (__attribute__((address_space(3))) void*)(dstbuf + v0), 16, 0, 0);
+      }
+    };
+    stage_dma(st_lo, lds + (st_lo & 1) * kStageVec);
+    bool c_isx = stage_isx(st_lo);
+    int c_rowoff = stage_rowoff(st_lo), c_cg = stage_cg(st_lo);
+    bool c_rowok = stage_rowok(st_lo);
+    f16x8 fa0, fa1;
+    MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 0, fa0, fa1);
+    __syncthreads();                       // carries the vmcnt(0) of the pending LDS-DMA
+    for (int st = st_lo; st < st_hi; ++st) {
+      const bool more = st + 1 < st_hi;
+      const int stn = more ? st + 1 : st;
+      const bool n_isx = stage_isx(stn);
+      const int n_rowoff = stage_rowoff(stn), n_cg = stage_cg(stn);
+      const bool n_rowok = stage_rowok(stn);
+      const f16x8* buf = lds + (st & 1) * kStageVec;
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        f16x8 fn0, fn1;
+        if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, fn0, fn1);
+        else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 0, fn0, fn1);   // (re-read at the very end)
+        // the DMA of the next stage goes out behind the first k-step's operands (vmcnt
+        // retires in order); its target buffer was last read before the previous barrier
+        if (kk == 1 && more) stage_dma(st + 1, lds + ((st + 1) & 1) * kStageVec);
+        f16x8 b0[NG], b1[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          b0[g] = buf[((kk * 2 + 0) * NG + g) * 64 + lane];
+          b1[g] = buf[((kk * 2 + 1) * NG + g) * 64 + lane];
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, b0[g], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b1[g], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
+        fa0 = fn0; fa1 = fn1;
+      }
+      c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
+      __syncthreads();
+    }
+  }
+#endif
 #undef MV_LOAD_A
   if (!wave_live) return;
 
@@ -489,7 +571,10 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   }
 }
 
-__global__ __launch_bounds__(256, 2)
+#ifndef MV_CONV_MINWAVES
+#define MV_CONV_MINWAVES (MV_CONV_WAVES == 8 ? 4 : 2)
+#endif
+__global__ __launch_bounds__(kThreads16, MV_CONV_MINWAVES)
 void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
   __shared__ f16x8 lds[2 * kStageVec];
   int block = blockIdx.x;
@@ -521,7 +606,7 @@ __device__ __forceinline__ void convlstm16_dgrad_dispatch(const ConvLstm16Args& 
   const bool narrow = p.f.ng_last != 4;
   const int n_main = narrow ? ncb - 1 : ncb;
   const int M_total = p.f.rows * p.f.H * p.f.W;
-  const int mtiles = (M_total + kBlockRows - 1) / kBlockRows;
+  const int mtiles = (M_total + kBlockRows16 - 1) / kBlockRows16;
   const int main_blocks = mtiles * n_main * nks;
   int cb, ks, mt;
   if (block < main_blocks) {
@@ -540,7 +625,7 @@ __device__ __forceinline__ void convlstm16_dgrad_dispatch(const ConvLstm16Args& 
     convlstm16_lds_body<kEpiStore, 4>(p, cb, mt, ks, nks, lds);
 }
 
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(kThreads16, MV_CONV_MINWAVES)
 void convlstm_dgrad_f16x3_kernel(const ConvLstm16Group g) {
   __shared__ f16x8 lds[2 * kStageVec];
   int block = blockIdx.x;
@@ -557,6 +642,11 @@ void convlstm_dgrad_f16x3_kernel(const ConvLstm16Group g) {
   }
 }
 
+static inline unsigned convlstm16_blocks(const ConvLstmArgs& a) {
+  const size_t M = (size_t)a.rows * a.H * a.W;
+  return (unsigned)((M + kBlockRows16 - 1) / kBlockRows16) * (unsigned)a.n_colblocks;
+}
+
 static inline void launch_convlstm16_dgrads(const ConvLstm16Args* probs, int n,
                                             hipStream_t stream) {
   ConvLstm16Group g{};
@@ -564,11 +654,11 @@ static inline void launch_convlstm16_dgrads(const ConvLstm16Args* probs, int n,
   unsigned total = 0;
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
-    total += convlstm_blocks(probs[i].f) * (unsigned)(probs[i].n_kslice > 1 ? probs[i].n_kslice : 1);
+    total += convlstm16_blocks(probs[i].f) * (unsigned)(probs[i].n_kslice > 1 ? probs[i].n_kslice : 1);
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
-  hipLaunchKernelGGL(convlstm_dgrad_f16x3_kernel, dim3(total), dim3(256), 0, stream, g);
+  hipLaunchKernelGGL(convlstm_dgrad_f16x3_kernel, dim3(total), dim3(kThreads16), 0, stream, g);
 }
 
 // out[seg][i] = sum over the k slices (in slice order) of part[seg][s][i]
@@ -676,11 +766,11 @@ static inline void launch_convlstm16_steps(const ConvLstm16Args* probs, int n,
   unsigned total = 0;
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
-    total += convlstm_blocks(probs[i].f);
+    total += convlstm16_blocks(probs[i].f);
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
-  hipLaunchKernelGGL(convlstm_step_f16x3_lds_kernel, dim3(total), dim3(256), 0, stream, g);
+  hipLaunchKernelGGL(convlstm_step_f16x3_lds_kernel, dim3(total), dim3(kThreads16), 0, stream, g);
 }
 
 }  // namespace mv

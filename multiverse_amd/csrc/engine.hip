@@ -25,6 +25,7 @@
 #include "convlstm_f16x3.h"
 #include "convlstm_wgrad_f16x3.h"
 #include "kernels_misc.h"
+#include "decode_tail.h"
 #include "train_kernels.h"
 
 struct mv_train_holder;
@@ -135,6 +136,10 @@ struct ScaleState {
   DevBuf<float> out_cls;                    // [N, T_p, K, 1]
   DevBuf<float> out_reg;                    // [N, T_p, K, 2]
   DevBuf<int32_t> ids;                      // [N] greedy argmax
+  // decoder tail (decode_tail.h): per-cell tap products of hidden2grid and its packs
+  DevBuf<float> q_cls, q_reg;               // [R, K, 9], [N, K, 18]
+  DevBuf<float> wq_cls, wq_reg;             // pack_h2g_kernel of out_cls_W / out_reg_W
+  bool wq_valid = false;
 };
 
 }  // namespace
@@ -382,6 +387,8 @@ void alloc_buffers(mv_engine* e) {
     S.out_cls.alloc(N * Tp * K);
     S.out_reg.alloc(N * Tp * K * 2);
     S.ids.alloc(R);
+    S.q_cls.alloc(R * K * 9); S.q_reg.alloc(N * K * 18);
+    S.wq_cls.alloc(C * 32); S.wq_reg.alloc(C * 32);
     if (B > 1) {
       e->bm_logits.alloc(Tp * R * K);
       e->bm_ids.alloc(Tp * R);
@@ -465,6 +472,14 @@ void ensure_params(mv_engine* e) {
     if (e->compute_mode == 1)
       for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
         ensure_packed16(e, *cc);
+    if (!S.wq_valid) {     // hidden2grid tap packs, from the CURRENT device weights
+      const int C = e->cfg.hidden_size;
+      hipLaunchKernelGGL(mv::pack_h2g_kernel, dim3(cdiv((size_t)C * 32, 256)), dim3(256), 0,
+                         e->stream, S.out_cls_W->dev.p, S.wq_cls.p, C, 1);
+      hipLaunchKernelGGL(mv::pack_h2g_kernel, dim3(cdiv((size_t)C * 32, 256)), dim3(256), 0,
+                         e->stream, S.out_reg_W->dev.p, S.wq_reg.p, C, 2);
+      S.wq_valid = true;
+    }
   }
 }
 
@@ -681,14 +696,27 @@ void run_gnn(mv_engine* e, ScaleState& S, const float* h, const int32_t* src_row
              float* out, int rows, int sm_div) {
   const mv_config& c = e->cfg;
   const size_t cells = (size_t)rows * S.K;
+  static const bool v2 = !(getenv("MV_GNN") && strcmp(getenv("MV_GNN"), "v1") == 0);
+  size_t pst = 0;
+  _Float16* p16 = e->plane_out(out, &pst);
+  // f16x3 inference: the only consumer of h + GNN(h) is the gate convolution, which
+  // reads the operand planes -- the fp32 copy is not written at all
+  const bool need_f32 = !(v2 && p16 && !e->train && e->compute_mode == 1);
   launch(e, "gnn_attend", cells * (9.0 * 2 * 2 * (c.hidden_size + c.scene_conv_dim) +
                                    9.0 * 2 * c.hidden_size),
-         4.0 * cells * (2.0 * c.hidden_size) + 4.0 * (cells / sm_div) * c.scene_conv_dim, [&] {
-    size_t pst = 0;
-    _Float16* p16 = e->plane_out(out, &pst);
-    hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
-                       e->stream, h, S.scene_mean.p, src_row, out, rows, S.H, S.W,
-                       c.hidden_size, c.scene_conv_dim, sm_div, p16, pst);
+         4.0 * cells * c.hidden_size * (1.0 + (need_f32 ? 1.0 : 0.0) + (p16 ? 1.0 : 0.0)) +
+             4.0 * (cells / sm_div) * c.scene_conv_dim, [&] {
+    if (v2 && S.W <= 32 && c.hidden_size == 256 && c.scene_conv_dim <= 64) {
+      int ng = 0;
+      const unsigned nb = mv::gnn_v2_blocks(cells, &ng);
+      hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nb), dim3(256), 0, e->stream, h,
+                         S.scene_mean.p, src_row, need_f32 ? out : (float*)nullptr, rows, S.H,
+                         S.W, c.hidden_size, c.scene_conv_dim, sm_div, p16, pst, ng);
+    } else {
+      hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
+                         e->stream, h, S.scene_mean.p, src_row, out, rows, S.H, S.W,
+                         c.hidden_size, c.scene_conv_dim, sm_div, p16, pst);
+    }
   });
 }
 
@@ -703,6 +731,13 @@ void run_hidden2grid(mv_engine* e, ScaleState& S, const float* h, const float* w
   });
 }
 
+// MV_TAIL=v1 selects the first-round decoder tail (hidden2grid convolved in place,
+// separate argmax / embedding launches) for A/B runs
+static bool tail_v2() {
+  static const bool on = !(getenv("MV_TAIL") && strcmp(getenv("MV_TAIL"), "v1") == 0);
+  return on;
+}
+
 void run_emb_onehot(mv_engine* e, ScaleState& S, const int32_t* ids, int stride,
                     float* out, int rows, int ids_div = 1) {
   const int E = e->cfg.emb_size;
@@ -710,9 +745,14 @@ void run_emb_onehot(mv_engine* e, ScaleState& S, const int32_t* ids, int stride,
   launch(e, "grid_emb_onehot", (double)total, 4.0 * total, [&] {
     size_t pst = 0;
     _Float16* p16 = e->plane_out(out, &pst);
-    hipLaunchKernelGGL(mv::grid_emb_onehot_kernel, dim3(cdiv(total, 256)),
-                       dim3(256), 0, e->stream, ids, stride, ids_div, S.emb_cls_W->dev.p,
-                       S.emb_cls_b->dev.p, out, rows, S.H, S.W, E, p16, pst);
+    if (tail_v2() && E % 8 == 0)
+      hipLaunchKernelGGL(mv::grid_emb_onehot8_kernel, dim3(cdiv(total / 8, 256)), dim3(256), 0,
+                         e->stream, ids, stride, ids_div, S.emb_cls_W->dev.p,
+                         S.emb_cls_b->dev.p, out, rows, S.H, S.W, E, p16, pst);
+    else
+      hipLaunchKernelGGL(mv::grid_emb_onehot_kernel, dim3(cdiv(total, 256)),
+                         dim3(256), 0, e->stream, ids, stride, ids_div, S.emb_cls_W->dev.p,
+                         S.emb_cls_b->dev.p, out, rows, S.H, S.W, E, p16, pst);
   });
 }
 
@@ -732,7 +772,8 @@ void run_emb_dense(mv_engine* e, ScaleState& S, const float* x, size_t row_strid
 // Regression decoder step t, always greedy and un-beamed
 // (code/pred_models.py:298-305 -> grid_decoder :311-471 with input_onehot=False,
 // use_gnn=False): input embedding + the conv problem; the caller launches it.
-ConvLstmArgs reg_decoder_problem(mv_engine* e, int s, Cursors& cur, int t, int Tp) {
+ConvLstmArgs reg_decoder_problem(mv_engine* e, int s, Cursors& cur, int t, int Tp,
+                                 bool embed = true) {
   const mv_config& c = e->cfg;
   ScaleState& S = e->sc[s];
   const int N = c.batch_size, T = c.obs_len;
@@ -740,7 +781,7 @@ ConvLstmArgs reg_decoder_problem(mv_engine* e, int s, Cursors& cur, int t, int T
   if (t == 0)  // first_input = obs_grid_reg[:, -1]
     run_emb_dense(e, S, S.obs_reg.p + (size_t)(T - 1) * S.K * 2, (size_t)T * S.K * 2,
                   S.xbuf_reg.p, N);
-  else         // hidden2grid output of the previous step
+  else if (embed)   // hidden2grid output of the previous step (else: the tail embedded it)
     run_emb_dense(e, S, S.out_reg.p + (size_t)(t - 1) * S.K * 2, orow, S.xbuf_reg.p, N);
   const int cr = cur.reg[s];
   cur.reg[s] ^= 1;
@@ -755,12 +796,74 @@ void reg_decoder_output(mv_engine* e, int s, const Cursors& cur, int t, int Tp) 
                      S.out_reg.p + (size_t)t * S.K * 2, orow, e->cfg.batch_size);
 }
 
+// The decoder tail of step t for all chains (decode_tail.h): hidden2grid as one
+// grouped GEMM launch reading every h' once, then one workgroup per (chain, row) for
+// the 9-tap gather, the output row, the greedy argmax and the NEXT step's embedding.
+// cls_rows / cls_out / cls_stride describe the class chain's logits destination
+// (greedy: out_cls step t; beam: bm_logits of this time step, no argmax / embedding).
+struct TailPlan {
+  int s;
+  const float* cls_h; int cls_rows; float* cls_out; int64_t cls_stride;
+  bool cls_next;       // class chain: argmax + embedding of step t+1 (greedy only)
+  const float* reg_h; float* reg_out; int64_t reg_stride; bool reg_next;
+};
+
+void run_tail(mv_engine* e, const std::vector<TailPlan>& plans) {
+  const mv_config& c = e->cfg;
+  const int C = c.hidden_size, E = c.emb_size, N = c.batch_size;
+  std::vector<mv::H2gQProblem> qp;
+  std::vector<mv::TailProblem> tp;
+  double qbytes = 0, qflops = 0, tbytes = 0;
+  for (const TailPlan& pl : plans) {
+    ScaleState& S = e->sc[pl.s];
+    MV_REQUIRE((size_t)S.K * 2 <= 2048 && E == 32, "decode tail: K %d / emb_size %d", S.K, E);
+    const size_t cc = (size_t)pl.cls_rows * S.K, cr = (size_t)N * S.K;
+    qp.push_back(mv::H2gQProblem{pl.cls_h, S.wq_cls.p, S.q_cls.p, (int32_t)cc, 1});
+    qp.push_back(mv::H2gQProblem{pl.reg_h, S.wq_reg.p, S.q_reg.p, (int32_t)cr, 2});
+    qbytes += 4.0 * (cc * (C + 9.0) + cr * (C + 18.0));
+    qflops += 2.0 * 9 * C * (cc + 2.0 * cr);
+    mv::TailProblem a{};
+    a.q = S.q_cls.p; a.out = pl.cls_out; a.out_row_stride = pl.cls_stride;
+    a.rows = pl.cls_rows; a.H = S.H; a.W = S.W; a.P = 1; a.E = E; a.onehot = 1;
+    tbytes += 4.0 * cc * (9 + 1);
+    if (pl.cls_next) {
+      size_t pst = 0;
+      a.ids_out = S.ids.p;
+      a.emb_w = S.emb_cls_W->dev.p; a.emb_b = S.emb_cls_b->dev.p;
+      a.x_out = S.xbuf_cls.p;
+      a.x16 = e->plane_out(S.xbuf_cls.p, &pst); a.x16_stride = (int64_t)pst;
+      tbytes += 4.0 * cc * E * (a.x16 ? 2 : 1);
+    }
+    tp.push_back(a);
+    mv::TailProblem b{};
+    b.q = S.q_reg.p; b.out = pl.reg_out; b.out_row_stride = pl.reg_stride;
+    b.rows = N; b.H = S.H; b.W = S.W; b.P = 2; b.E = E; b.onehot = 0;
+    tbytes += 4.0 * cr * (18 + 2);
+    if (pl.reg_next) {
+      size_t pst = 0;
+      b.emb_w = S.emb_reg_W->dev.p; b.emb_b = S.emb_reg_b->dev.p;
+      b.x_out = S.xbuf_reg.p;
+      b.x16 = e->plane_out(S.xbuf_reg.p, &pst); b.x16_stride = (int64_t)pst;
+      tbytes += 4.0 * cr * E * (b.x16 ? 2 : 1);
+    }
+    tp.push_back(b);
+  }
+  MV_REQUIRE(qp.size() <= (size_t)mv::kTailMax, "decode tail: too many chains");
+  launch(e, "hidden2grid", qflops, qbytes, [&] {
+    mv::launch_h2g_q(qp.data(), (int)qp.size(), C, e->stream);
+  });
+  launch(e, "decode_tail", 0, tbytes, [&] {
+    mv::launch_decode_tail(tp.data(), (int)tp.size(), e->stream);
+  });
+}
+
 // Greedy decoders of every enabled scale in lockstep: class decoder
 // (grid_decoder with input_onehot, use_gnn; code/pred_models.py:311-471) and
 // regression decoder.
 void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
   const mv_config& c = e->cfg;
   const int N = c.batch_size, T = c.obs_len;
+  const bool v2 = tail_v2();
   for (int t = 0; t < Tp; ++t) {
     std::vector<ConvLstmArgs> probs;
     for (int s = 0; s < c.num_scales; ++s) {
@@ -774,16 +877,34 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
       }
       if (t == 0)  // one_hot(last observed cell)
         run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, N);
-      else
+      else if (!v2)
         run_emb_onehot(e, S, S.ids.p, 1, S.xbuf_cls.p, N);
       probs.push_back(conv_problem(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cc].p,
                                    nullptr, nullptr, S.cls_h[cc ^ 1].p,
                                    S.cls_c[cc ^ 1].p, N, S.H, S.W, false, 0,
                                    /*want_h16=*/!c.use_gnn));
       cur.cls[s] ^= 1;
-      probs.push_back(reg_decoder_problem(e, s, cur, t, Tp));
+      probs.push_back(reg_decoder_problem(e, s, cur, t, Tp, !v2));
     }
     run_conv_group(e, probs);
+    if (v2) {
+      std::vector<TailPlan> plans;
+      for (int s = 0; s < c.num_scales; ++s) {
+        ScaleState& S = e->sc[s];
+        if (!S.use) continue;
+        TailPlan pl{};
+        pl.s = s;
+        pl.cls_h = S.cls_h[cur.cls[s]].p; pl.cls_rows = N;
+        pl.cls_out = S.out_cls.p + (size_t)t * S.K; pl.cls_stride = (int64_t)Tp * S.K;
+        pl.cls_next = t + 1 < Tp;
+        pl.reg_h = S.reg_h[cur.reg[s]].p;
+        pl.reg_out = S.out_reg.p + (size_t)t * S.K * 2; pl.reg_stride = (int64_t)Tp * S.K * 2;
+        pl.reg_next = t + 1 < Tp;
+        plans.push_back(pl);
+      }
+      run_tail(e, plans);
+      continue;
+    }
     for (int s = 0; s < c.num_scales; ++s) {
       ScaleState& S = e->sc[s];
       if (!S.use) continue;
@@ -882,12 +1003,24 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
                                    S.cls_c[cc ^ 1].p, R, S.H, S.W, false, 0,
                                    /*want_h16=*/!c.use_gnn));
       cur.cls[s] ^= 1;
-      probs.push_back(reg_decoder_problem(e, s, cur, time - 1, Tp));
+      const bool v2 = tail_v2();
+      probs.push_back(reg_decoder_problem(e, s, cur, time - 1, Tp, !v2));
       run_conv_group(e, probs);
-      reg_decoder_output(e, s, cur, time - 1, Tp);
       float* logits = e->bm_logits.p + (size_t)(time - 1) * R * K;
-      run_hidden2grid<1>(e, S, S.cls_h[cur.cls[s]].p, S.out_cls_W->dev.p, logits,
-                         (size_t)K, R);
+      if (v2) {
+        TailPlan pl{};
+        pl.s = s;
+        pl.cls_h = S.cls_h[cur.cls[s]].p; pl.cls_rows = R;
+        pl.cls_out = logits; pl.cls_stride = K; pl.cls_next = false;   // beam_step selects
+        pl.reg_h = S.reg_h[cur.reg[s]].p;
+        pl.reg_out = S.out_reg.p + (size_t)(time - 1) * K * 2;
+        pl.reg_stride = (int64_t)Tp * K * 2; pl.reg_next = time < Tp;
+        run_tail(e, {pl});
+      } else {
+        reg_decoder_output(e, s, cur, time - 1, Tp);
+        run_hidden2grid<1>(e, S, S.cls_h[cur.cls[s]].p, S.out_cls_W->dev.p, logits,
+                           (size_t)K, R);
+      }
       int32_t* ids = e->bm_ids.p + (size_t)(time - 1) * R;
       int32_t* parents = e->bm_parents.p + (size_t)(time - 1) * R;
       launch(e, "beam_step", 0, 4.0 * R * K, [&] {
@@ -1237,6 +1370,7 @@ int mv_set_param(mv_handle h, const char* tf_name, const float* data,
     p->set = true;
     h->drop_graphs();   // captured launches hold the old device pointers
     h->train_packs_valid = false;
+    for (int s = 0; s < h->cfg.num_scales; ++s) h->sc[s].wq_valid = false;
     // invalidate the packed copy of a ConvLSTM kernel
     for (int s = 0; s < h->cfg.num_scales; ++s) {
       ScaleState& S = h->sc[s];
@@ -1643,9 +1777,17 @@ int mv_op_gnn(int device, const float* h, const float* scene_mean, int32_t M,
     ctx.up(dh, h, cells * C);
     ctx.up(ds, scene_mean, cells * D);
     dout.alloc(cells * C);
-    hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
-                       ctx.stream, dh.p, ds.p, (const int32_t*)nullptr, dout.p, M, H,
-                       W, C, D, 1);
+    if (!(getenv("MV_GNN") && strcmp(getenv("MV_GNN"), "v1") == 0) && W <= 32) {
+      int ng = 0;
+      const unsigned nb = mv::gnn_v2_blocks(cells, &ng);
+      hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nb), dim3(256), 0, ctx.stream, dh.p,
+                         ds.p, (const int32_t*)nullptr, dout.p, M, H, W, C, D, 1,
+                         (_Float16*)nullptr, (size_t)0, ng);
+    } else {
+      hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
+                         ctx.stream, dh.p, ds.p, (const int32_t*)nullptr, dout.p, M, H,
+                         W, C, D, 1);
+    }
     HIP_CHECK(hipGetLastError());
     ctx.down(out, dout, cells * C);
   });

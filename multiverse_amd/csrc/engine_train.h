@@ -1005,6 +1005,7 @@ void train_apply(mv_engine* e, float grad_scale) {
                        n);
   }
   train_pack_all(e);
+  for (int s = 0; s < e->cfg.num_scales; ++s) e->sc[s].wq_valid = false;
   t.global_step += 1;
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(e->stream));

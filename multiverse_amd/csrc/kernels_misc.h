@@ -264,6 +264,236 @@ void gnn_attend_kernel(const float* __restrict__ h,
   }
 }
 
+// ---- graph attention, second version: LDS-tiled.
+// The first version (above) gives one wave to a cell: it gathers the nine neighbours'
+// 1.25 KB feature vectors from global memory (9x the L1/L2 traffic of the tensor) and
+// spends most of its instructions in 19 wave-wide reductions per cell; measured 1.2 TB/s
+// of algorithmic bytes (profiles/r2_*).  Here a workgroup owns 32 consecutive cells of
+// the flat [rows*K] index (= one operand-plane tile row) and stages the contiguous range
+// of cells that holds every in-image neighbour (32 + 2W + 2 <= 98 cells) through LDS in
+// chunks of 64 channels:
+//   pass 1  (4 chunks of h + 1 of scene_mean)  partial dot products: thread = (cell,
+//           8-channel slice) accumulates its 9 dots over the chunks; |u|^2 of every staged
+//           cell the same way; 8-lane shuffles at the end -> e_ij, softmax weights in LDS;
+//   pass 2  (4 chunks of h again, an L2 hit)   out = h_i + sum_j a_ij h_j: thread = (cell,
+//           8 channels), results leave as 16-byte operand-plane vectors (1 KB contiguous
+//           per wave) and, when a consumer needs them, fp32 rows.
+// Consecutive 32-cell groups are mapped to the same XCD (block % 8 -> contiguous range of
+// groups) so that a group's halo cells are its neighbours' own cells in that L2.
+constexpr int kGnnPitch = 68;        // floats per staged cell and chunk (64 + 4: bank spread)
+constexpr int kGnnStage = 98;        // 32 + 2*32 + 2 cells for W <= 32
+
+__global__ __launch_bounds__(256)
+void gnn_attend_v2_kernel(const float* __restrict__ h, const float* __restrict__ scene_mean,
+                          const int32_t* __restrict__ src_row, float* __restrict__ out,
+                          int M, int H, int W, int C, int D, int sm_div,
+                          _Float16* p16, size_t p16_stride, int ngroups) {
+  __shared__ __attribute__((aligned(16))) float buf[kGnnStage * kGnnPitch];
+  __shared__ float ssq[kGnnStage];
+  __shared__ float edot[32 * 9];
+  __shared__ float alpha[32 * 9];
+  __shared__ int hsrc[kGnnStage], ssrc[kGnnStage];
+  const int per = (ngroups + 7) >> 3;
+  const int g = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (g >= ngroups) return;
+  const int tid = threadIdx.x;
+  const int K = H * W;
+  const long long Mtot = (long long)M * K;
+  const long long m0 = (long long)g * 32;
+  const long long s0 = m0 - W - 1 > 0 ? m0 - W - 1 : 0;
+  const long long s1 = m0 + 32 + W + 1 < Mtot ? m0 + 32 + W + 1 : Mtot;
+  const int NS = (int)(s1 - s0);
+  if (tid < NS) {
+    const long long m = s0 + tid;
+    const int r = (int)(m / K), c = (int)(m - (long long)r * K);
+    hsrc[tid] = (src_row ? src_row[r] : r) * K + c;
+    ssrc[tid] = (r / sm_div) * K + c;
+    ssq[tid] = 0.f;
+  }
+  // pass-1 role: own cell i1 = tid >> 3, channel slice sl = tid & 7
+  const int i1 = tid >> 3, sl = tid & 7;
+  // pass-2 role: own cell i2 = tid & 31, channel group c8 = tid >> 5
+  const int i2 = tid & 31, c8 = tid >> 5;
+  auto cell_info = [&](int i, int& li, int& mask) {
+    const long long m = m0 + i;
+    li = (int)(m - s0);
+    mask = 0;
+    if (m < Mtot) {
+      const int c = (int)(m % K);
+      const int y = c / W, x = c - y * W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) mask |= 1 << t;
+      }
+    }
+  };
+  int li1, mask1, li2, mask2;
+  cell_info(i1, li1, mask1);
+  cell_info(i2, li2, mask2);
+
+  // all of a thread's loads of a chunk are issued before the first LDS store (a load ->
+  // wait -> store loop over a run-time trip count serialised seven HBM round trips per
+  // chunk: 48 us per workgroup)
+  constexpr int kIt = (kGnnStage * 16 + 255) / 256;     // 7
+  auto stage = [&](int q) {          // q < 4: channels q*64.. of h; q == 4: scene_mean
+    f32x4_t val[kIt];
+#pragma unroll
+    for (int k = 0; k < kIt; ++k) {
+      const int v = tid + k * 256;
+      const int ls = v >> 4, part = v & 15;
+      val[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (v < NS * 16) {
+        if (q < 4) {
+          val[k] = *reinterpret_cast<const f32x4_t*>(h + (size_t)hsrc[ls] * C + q * 64 + part * 4);
+        } else if (D == 64) {
+          val[k] = *reinterpret_cast<const f32x4_t*>(scene_mean + (size_t)ssrc[ls] * 64 + part * 4);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            val[k][j] = (part * 4 + j < D) ? scene_mean[(size_t)ssrc[ls] * D + part * 4 + j] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kIt; ++k) {
+      const int v = tid + k * 256;
+      if (v < NS * 16)
+        *reinterpret_cast<f32x4_t*>(&buf[(v >> 4) * kGnnPitch + (v & 15) * 4]) = val[k];
+    }
+  };
+  auto dot8 = [&](const float* a, const float* b) {
+    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(a), a1 = *reinterpret_cast<const f32x4_t*>(a + 4);
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(b), b1 = *reinterpret_cast<const f32x4_t*>(b + 4);
+    float d = a0[0] * b0[0];
+    d = fmaf(a0[1], b0[1], d); d = fmaf(a0[2], b0[2], d); d = fmaf(a0[3], b0[3], d);
+    d = fmaf(a1[0], b1[0], d); d = fmaf(a1[1], b1[1], d); d = fmaf(a1[2], b1[2], d);
+    d = fmaf(a1[3], b1[3], d);
+    return d;
+  };
+
+  float pd[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) pd[t] = 0.f;
+  __syncthreads();                    // hsrc / ssrc / ssq visible
+  const int nchunk = D > 0 ? 5 : 4;
+  for (int q = 0; q < nchunk; ++q) {
+    stage(q);
+    __syncthreads();
+    if (mask1) {
+      const float* fi = &buf[li1 * kGnnPitch + sl * 8];
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if ((mask1 >> t) & 1)
+          pd[t] += dot8(fi, &buf[(li1 + (t / 3 - 1) * W + (t % 3 - 1)) * kGnnPitch + sl * 8]);
+    }
+    for (int base = 0; base < NS * 8; base += 256) {     // |u|^2 of every staged cell
+      const int idx = base + tid;
+      const int ls = idx >> 3;
+      float pp = 0.f;
+      if (idx < NS * 8) {
+        const float* f = &buf[ls * kGnnPitch + sl * 8];
+        pp = dot8(f, f);
+      }
+      pp += __shfl_xor(pp, 1, 64);
+      pp += __shfl_xor(pp, 2, 64);
+      pp += __shfl_xor(pp, 4, 64);
+      if (idx < NS * 8 && sl == 0) ssq[ls] += pp;        // one writer per staged cell
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float v = pd[t];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    if (sl == 0) edot[i1 * 9 + t] = v;
+  }
+  __syncthreads();
+  if (tid < 32) {                     // softmax over the in-image neighbours of cell tid
+    int li, mask;
+    cell_info(tid, li, mask);
+    float e[9];
+    float emax = -INFINITY;
+    const float invi = mask ? rsqrtf(fmaxf(ssq[li], 1e-12f)) : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      e[t] = 0.f;
+      if ((mask >> t) & 1) {
+        const int lj = li + (t / 3 - 1) * W + (t % 3 - 1);
+        e[t] = edot[tid * 9 + t] * invi * rsqrtf(fmaxf(ssq[lj], 1e-12f));
+        emax = fmaxf(emax, e[t]);
+      }
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      e[t] = ((mask >> t) & 1) ? expf(e[t] - emax) : 0.f;
+      den += e[t];
+    }
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) alpha[tid * 9 + t] = e[t] * inv;
+  }
+  __syncthreads();
+  const long long m2 = m0 + i2;
+  for (int q = 0; q < 4; ++q) {
+    stage(q);
+    __syncthreads();
+    if (mask2) {
+      const float* hi = &buf[li2 * kGnnPitch + c8 * 8];
+      float node[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) node[j] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if ((mask2 >> t) & 1) {
+          const float a = alpha[i2 * 9 + t];
+          const float* hj = &buf[(li2 + (t / 3 - 1) * W + (t % 3 - 1)) * kGnnPitch + c8 * 8];
+          const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(hj);
+          const f32x4_t h1 = *reinterpret_cast<const f32x4_t*>(hj + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            node[j] = fmaf(a, h0[j], node[j]);
+            node[4 + j] = fmaf(a, h1[j], node[4 + j]);
+          }
+        }
+      const f32x4_t s0v = *reinterpret_cast<const f32x4_t*>(hi);
+      const f32x4_t s1v = *reinterpret_cast<const f32x4_t*>(hi + 4);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j] = s0v[j] + node[j]; o[4 + j] = s1v[j] + node[4 + j]; }
+      const int ch = q * 64 + c8 * 8;
+      if (out) {
+        f32x4_t* dst = reinterpret_cast<f32x4_t*>(out + (size_t)m2 * C + ch);
+        dst[0] = f32x4_t{o[0], o[1], o[2], o[3]};
+        dst[1] = f32x4_t{o[4], o[5], o[6], o[7]};
+      }
+      if (p16) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 pa, pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float sc = o[j] * 256.0f;
+          const _Float16 h0h = (_Float16)sc;
+          pa[j] = h0h;
+          pb[j] = (_Float16)(sc - (float)h0h);
+        }
+        const size_t idx = plane_index(m2, ch, C);
+        *reinterpret_cast<h8*>(p16 + idx) = pa;
+        *reinterpret_cast<h8*>(p16 + p16_stride + idx) = pb;
+      }
+    }
+    __syncthreads();
+  }
+}
+static inline unsigned gnn_v2_blocks(size_t cells, int* ngroups) {
+  const size_t g = (cells + 31) / 32;
+  *ngroups = (int)g;
+  return (unsigned)(((g + 7) / 8) * 8);
+}
+
 // ---------------------------------------------------------------- hidden2grid
 // conv3x3 SAME, no bias, identity, C -> P (P in {1,2}); hidden2grid,
 // code/pred_models.py:925-959.  One wave per cell, lane l holds channels
