@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define MV_MAX_SCALES 2
-#define MV_ABI_VERSION 1
+#define MV_ABI_VERSION 2
 
 typedef struct mv_engine* mv_handle;
 
@@ -61,6 +61,11 @@ typedef struct mv_config {
   int32_t diverse_beam;      /* --diverse_beam */
   float   diverse_gamma;     /* --diverse_gamma */
   int32_t fix_num_timestep;  /* --fix_num_timestep */
+  /* --use_teacher_forcing at TEST time: decoder_loop_fn takes its teacher_forcing branch
+   * (code/pred_models.py:388-406), whose not-training arm feeds hidden2grid(h') itself --
+   * raw logits, no argmax / one-hot -- to the class decoder's grid_emb.  0 = the
+   * published one-hot feedback. */
+  int32_t class_feedback_dense;
 } mv_config;
 
 /* The feed_dict of Model.get_feed_dict (pred_models.py:1042-1194), minus the
@@ -95,7 +100,9 @@ typedef struct mv_beam_outputs {
 /* The optimizer / loss fields Trainer.__init__ and Model.build_loss read from
  * the config (train.py:25-138 after process_args). */
 typedef struct mv_train_config {
-  int32_t optimizer;          /* 0 = adadelta (the published configuration) */
+  /* --optimizer (code/pred_models.py:1667-1681): 0 adadelta (published), 1 momentum
+   * (0.9), 2 adam, 3 rmsprop; TF-1.15 defaults and ApplyXxx kernel arithmetic */
+  int32_t optimizer;
   float   init_lr, emb_lr;
   int32_t use_cosine_lr;      /* --use_cosine_lr */
   int32_t has_decay;          /* learning_rate_decay is not None */
@@ -106,6 +113,21 @@ typedef struct mv_train_config {
   float   clip_gradient_norm; /* ELEMENT-WISE clip_by_value bound (pred_models.py:1700-1705) */
   float   wd;                 /* weight decay on every variable named .../W */
   float   grid_loss_weight, grid_reg_loss_weight;
+  /* --- switches of Model.build_forward / build_loss beyond the published run --- */
+  /* class-decoder next input while training (decoder_loop_fn, :388-436):
+   *   0  one_hot(argmax(hidden2grid(h')))   --train_w_onehot (published; no gradient)
+   *   1  hidden2grid(h') itself             neither flag (differentiable feedback)
+   *   2  the ground-truth map of the step   --use_teacher_forcing (pred_gt.read(time)) */
+  int32_t class_feedback;
+  int32_t reg_teacher_forcing;   /* regression decoder: 0 own output, 1 ground truth */
+  /* --use_soft_grid_class (:974-990, 1077-1124): labels = the one-hot map stamped with
+   * the --soft_grid kernel (soft_kernel_size 3 or 5, row-major soft_kernel); the loss is
+   * softmax_cross_entropy_with_logits with TF's registered gradient softmax - labels */
+  int32_t use_soft_grid_class;
+  int32_t soft_kernel_size;
+  float   soft_kernel[25];
+  int32_t mask_grid_regression;  /* --mask_grid_regression (:999-1018) */
+  float   keep_prob;             /* DropoutWrapper input keep probability (:130-132) */
 } mv_train_config;
 
 /* Training-only placeholders of Model.get_feed_dict(is_train=True)
@@ -114,6 +136,8 @@ typedef struct mv_targets {
   const int32_t* grid_pred_labels[MV_MAX_SCALES];   /* [N, T_p] */
   const float*   grid_pred_regress[MV_MAX_SCALES];  /* [N, T_p, H, W, 2] */
 } mv_targets;
+/* (soft labels, the teacher-forcing inputs and the foreground mask of the masked
+ * regression loss are all functions of grid_pred_labels: the engine builds them in HBM) */
 
 /* Fetches of Trainer.step: loss, wd_loss, pred_grid_loss = [cls_s, reg_s, ...]
  * over the enabled scales (pred_models.py:1029, 1719-1742). */
@@ -205,8 +229,19 @@ int  mv_train_apply(mv_handle h, float grad_scale);
 int  mv_get_grad(mv_handle h, const char* tf_name, float* out, int64_t capacity_elems);
 int  mv_get_global_step(mv_handle h, int64_t* step);
 int  mv_set_global_step(mv_handle h, int64_t step);
-/* optimizer slots for checkpoint save / restore: slot 0 = accum ("Adadelta"),
- * 1 = accum_update ("Adadelta_1") */
+/* keep_prob < 1: seed of the NEXT step's dropout masks.  TensorFlow's dropout is
+ * unseeded; the engine's masks come from a counter-based hash of (seed, draw number,
+ * element) -- oracle/multiverse_oracle.py dropout_keep_mask restates it -- with draws
+ * numbered in the reference's cell-call order. */
+int  mv_set_dropout_seed(mv_handle h, uint32_t seed);
+/* Adam's beta1_power / beta2_power (float32 non-slot variables of the checkpoint) */
+int  mv_get_opt_scalars(mv_handle h, float* beta1_power, float* beta2_power);
+int  mv_set_opt_scalars(mv_handle h, float beta1_power, float beta2_power);
+/* optimizer slots for checkpoint save / restore, TF slot names by optimizer:
+ *   adadelta  0 "Adadelta" (accum)   1 "Adadelta_1" (accum_update)
+ *   momentum  0 "Momentum"
+ *   adam      0 "Adam" (m)           1 "Adam_1" (v)
+ *   rmsprop   0 "RMSProp" (ms, initialised to ones)   1 "RMSProp_1" (momentum) */
 int  mv_get_opt_slot(mv_handle h, const char* tf_name, int32_t slot, float* out,
                      int64_t capacity_elems);
 int  mv_set_opt_slot(mv_handle h, const char* tf_name, int32_t slot,

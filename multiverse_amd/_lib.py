@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 MV_MAX_SCALES = 2
-MV_ABI_VERSION = 1
+MV_ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmultiverse_hip.so")
@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "mv_train_init", "mv_train_step", "mv_train_forward_backward",
     "mv_upload_targets", "mv_grad_buffer", "mv_train_apply", "mv_get_grad", "mv_get_global_step",
     "mv_set_global_step", "mv_get_opt_slot", "mv_set_opt_slot",
+    "mv_set_dropout_seed", "mv_get_opt_scalars", "mv_set_opt_scalars",
     "mv_op_convlstm_bwd", "mv_op_gnn_bwd",
     "mv_set_grid_centers", "mv_upload_inputs_compact", "mv_upload_targets_compact",
 ]
@@ -62,6 +63,7 @@ class mv_config(C.Structure):
       ("diverse_beam", C.c_int32),
       ("diverse_gamma", C.c_float),
       ("fix_num_timestep", C.c_int32),
+      ("class_feedback_dense", C.c_int32),
   ]
 
 
@@ -128,6 +130,10 @@ class mv_train_config(C.Structure):
       ("do_clip", C.c_int32), ("clip_gradient_norm", C.c_float),
       ("wd", C.c_float),
       ("grid_loss_weight", C.c_float), ("grid_reg_loss_weight", C.c_float),
+      ("class_feedback", C.c_int32), ("reg_teacher_forcing", C.c_int32),
+      ("use_soft_grid_class", C.c_int32), ("soft_kernel_size", C.c_int32),
+      ("soft_kernel", C.c_float * 25),
+      ("mask_grid_regression", C.c_int32), ("keep_prob", C.c_float),
   ]
 
 
@@ -212,6 +218,9 @@ def load():
   lib.mv_get_grad.argtypes = [h, C.c_char_p, _fp, C.c_int64]
   lib.mv_get_global_step.argtypes = [h, C.POINTER(C.c_int64)]
   lib.mv_set_global_step.argtypes = [h, C.c_int64]
+  lib.mv_set_dropout_seed.argtypes = [h, C.c_uint32]
+  lib.mv_get_opt_scalars.argtypes = [h, _fp, _fp]
+  lib.mv_set_opt_scalars.argtypes = [h, C.c_float, C.c_float]
   lib.mv_get_opt_slot.argtypes = [h, C.c_char_p, C.c_int32, _fp, C.c_int64]
   lib.mv_set_opt_slot.argtypes = [h, C.c_char_p, C.c_int32, _fp, C.c_int64]
   lib.mv_op_convlstm_bwd.argtypes = [C.c_int] + [_fp] * 7 + [C.c_int32] * 5 + [_fp] * 5
@@ -272,7 +281,28 @@ def make_config(cfg):
   c.diverse_beam = 1 if getattr(cfg, "diverse_beam", False) else 0
   c.diverse_gamma = float(getattr(cfg, "diverse_gamma", 1.0))
   c.fix_num_timestep = int(getattr(cfg, "fix_num_timestep", 0))
+  # --use_teacher_forcing at test time: the class decoder is fed its raw logits
+  # (code/pred_models.py:388-406, the not-training arm of the teacher_forcing branch)
+  c.class_feedback_dense = 1 if (getattr(cfg, "use_teacher_forcing", False) and
+                                 not getattr(cfg, "is_train", False)) else 0
   return c
+
+
+def soft_grid_kernel(soft_grid):
+  """The `--soft_grid` stamp of Model.get_feed_dict (code/pred_models.py:1084-1120)."""
+  table = {1: (0.1, 1.0), 2: (0.01, 1.0), 3: (0.05, 1.0), 4: (0.0125, 0.9),
+           5: (0.05, 0.6), 6: (0.1, 0.2)}
+  if soft_grid == 7:
+    k = np.full((5, 5), 0.0625)
+    k[1:4, 1:4] = 0.0125
+    k[2, 2] = 0.8
+    return k
+  if soft_grid not in table:
+    raise MvError("soft_grid %r not in 1..7" % (soft_grid,))
+  ring, centre = table[soft_grid]
+  k = np.full((3, 3), ring)
+  k[1, 1] = centre
+  return k
 
 
 def make_train_config(cfg, world=1):
@@ -281,19 +311,26 @@ def make_train_config(cfg, world=1):
   `world`: data-parallel ranks.  cfg.batch_size is the PER-RANK batch; the schedules
   count optimizer steps over the global batch (batch_size * world), as a single-GPU
   run of the reference with that batch size would."""
-  if cfg.optimizer != "adadelta":
-    raise MvError("optimizer %r is not implemented (adadelta only, the published "
-                  "configuration)" % (cfg.optimizer,))
-  if getattr(cfg, "use_soft_grid_class", False) or \
-      getattr(cfg, "mask_grid_regression", False):
-    raise MvError("use_soft_grid_class / mask_grid_regression are not implemented")
-  if not cfg.train_w_onehot or getattr(cfg, "use_teacher_forcing", False):
-    raise MvError("training is implemented for the published wiring only: "
-                  "--train_w_onehot without --use_teacher_forcing")
-  if cfg.keep_prob != 1.0:
-    raise MvError("keep_prob != 1.0 is not implemented")
+  kinds = {"adadelta": 0, "momentum": 1, "adam": 2, "rmsprop": 3}
+  if cfg.optimizer not in kinds:
+    raise MvError("Optimizer not implemented: %r" % (cfg.optimizer,))   # pred_models.py:1681
+  if not (0.0 < float(cfg.keep_prob) <= 1.0):
+    raise MvError("keep_prob %r not in (0, 1]" % (cfg.keep_prob,))
   t = mv_train_config()
-  t.optimizer = 0
+  t.optimizer = kinds[cfg.optimizer]
+  tf_mode = bool(getattr(cfg, "use_teacher_forcing", False))
+  # decoder_loop_fn (code/pred_models.py:388-436): teacher forcing wins over
+  # input_onehot = not is_train or train_w_onehot (:285)
+  t.class_feedback = 2 if tf_mode else (0 if cfg.train_w_onehot else 1)
+  t.reg_teacher_forcing = 1 if tf_mode else 0
+  t.use_soft_grid_class = 1 if getattr(cfg, "use_soft_grid_class", False) else 0
+  k = soft_grid_kernel(int(getattr(cfg, "soft_grid", 1))) if t.use_soft_grid_class \
+      else np.zeros((3, 3))
+  t.soft_kernel_size = int(k.shape[0])
+  for i, v in enumerate(np.asarray(k, dtype=np.float64).reshape(-1)):
+    t.soft_kernel[i] = float(v)
+  t.mask_grid_regression = 1 if getattr(cfg, "mask_grid_regression", False) else 0
+  t.keep_prob = float(cfg.keep_prob)
   t.init_lr = float(cfg.init_lr)
   t.emb_lr = float(cfg.emb_lr)
   t.use_cosine_lr = 1 if getattr(cfg, "use_cosine_lr", False) else 0
@@ -639,6 +676,17 @@ class Engine(object):
     a = f32(value)
     check(self.lib.mv_set_opt_slot(self.handle, name.encode(), int(slot), fptr(a),
                                    a.size), self.handle)
+
+  def set_dropout_seed(self, seed):
+    check(self.lib.mv_set_dropout_seed(self.handle, int(seed) & 0xFFFFFFFF), self.handle)
+
+  def opt_scalars(self):
+    a, b = C.c_float(), C.c_float()
+    check(self.lib.mv_get_opt_scalars(self.handle, C.byref(a), C.byref(b)), self.handle)
+    return float(a.value), float(b.value)
+
+  def set_opt_scalars(self, b1p, b2p):
+    check(self.lib.mv_set_opt_scalars(self.handle, float(b1p), float(b2p)), self.handle)
 
   @property
   def global_step(self):

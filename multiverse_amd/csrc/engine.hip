@@ -339,6 +339,8 @@ void validate_config(const mv_config& c) {
              "scene_conv_dim %d unsupported", c.scene_conv_dim);
   MV_REQUIRE(mv::convlstm_cx_supported(c.emb_size), "emb_size %d unsupported", c.emb_size);
   MV_REQUIRE(c.beam_size >= 1, "beam_size must be >= 1");
+  MV_REQUIRE(!(c.class_feedback_dense && c.beam_size > 1), "class_feedback_dense: greedy only "
+             "(grid_decoder_beam_search always feeds one-hot ids)");
   int hh = c.scene_h, ww = c.scene_w, used = 0;
   for (int s = 0; s < c.num_scales; ++s) {
     hh = (hh + 1) / 2; ww = (ww + 1) / 2;   // stride-2 SAME conv chain
@@ -756,16 +758,20 @@ void run_emb_onehot(mv_engine* e, ScaleState& S, const int32_t* ids, int stride,
   });
 }
 
+// grid_emb on a dense P-channel map: the regression decoder's (dx, dy) maps (default
+// weights), or -- class decoder fed its own logits / the ground-truth map (training
+// without --train_w_onehot, teacher forcing) -- a 1-channel map with the class weights
 void run_emb_dense(mv_engine* e, ScaleState& S, const float* x, size_t row_stride,
-                   float* out, int rows) {
+                   float* out, int rows, Param* W = nullptr, Param* b = nullptr, int P = 2) {
   const int E = e->cfg.emb_size;
   const size_t total = (size_t)rows * S.K * E;
-  launch(e, "grid_emb_dense", total * 2.0 * 18, 4.0 * total, [&] {
+  if (!W) { W = S.emb_reg_W; b = S.emb_reg_b; }
+  launch(e, "grid_emb_dense", total * 2.0 * 9 * P, 4.0 * total, [&] {
     size_t pst = 0;
     _Float16* p16 = e->plane_out(out, &pst);
     hipLaunchKernelGGL(mv::grid_emb_dense_kernel, dim3(cdiv(total, 256)), dim3(256),
-                       0, e->stream, x, row_stride, S.emb_reg_W->dev.p,
-                       S.emb_reg_b->dev.p, out, rows, S.H, S.W, 2, E, p16, pst);
+                       0, e->stream, x, row_stride, W->dev.p, b->dev.p, out, rows, S.H, S.W,
+                       P, E, p16, pst);
   });
 }
 
@@ -877,6 +883,9 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
       }
       if (t == 0)  // one_hot(last observed cell)
         run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, N);
+      else if (c.class_feedback_dense)   // raw logits of the previous step (:388-406)
+        run_emb_dense(e, S, S.out_cls.p + (size_t)(t - 1) * S.K, (size_t)Tp * S.K,
+                      S.xbuf_cls.p, N, S.emb_cls_W, S.emb_cls_b, 1);
       else if (!v2)
         run_emb_onehot(e, S, S.ids.p, 1, S.xbuf_cls.p, N);
       probs.push_back(conv_problem(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cc].p,
@@ -896,7 +905,7 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
         pl.s = s;
         pl.cls_h = S.cls_h[cur.cls[s]].p; pl.cls_rows = N;
         pl.cls_out = S.out_cls.p + (size_t)t * S.K; pl.cls_stride = (int64_t)Tp * S.K;
-        pl.cls_next = t + 1 < Tp;
+        pl.cls_next = t + 1 < Tp && !c.class_feedback_dense;
         pl.reg_h = S.reg_h[cur.reg[s]].p;
         pl.reg_out = S.out_reg.p + (size_t)t * S.K * 2; pl.reg_stride = (int64_t)Tp * S.K * 2;
         pl.reg_next = t + 1 < Tp;
@@ -911,7 +920,7 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
       const size_t orow = (size_t)Tp * S.K;
       float* logits = S.out_cls.p + (size_t)t * S.K;
       run_hidden2grid<1>(e, S, S.cls_h[cur.cls[s]].p, S.out_cls_W->dev.p, logits, orow, N);
-      if (t + 1 < Tp) {
+      if (t + 1 < Tp && !c.class_feedback_dense) {
         launch(e, "argmax_rows", 0, 4.0 * N * S.K, [&] {
           hipLaunchKernelGGL(mv::argmax_rows_kernel, dim3(N), dim3(64), 0, e->stream,
                              logits, orow, S.ids.p, N, S.K);
@@ -1495,15 +1504,35 @@ int mv_train_init(mv_handle h, const mv_train_config* tc) {
   if (!h) return 1;
   return guarded(h, [&] {
     MV_REQUIRE(tc, "mv_train_init: NULL config");
-    MV_REQUIRE(tc->optimizer == 0, "optimizer %d unsupported (0 = adadelta, the "
-               "published configuration)", tc->optimizer);
+    MV_REQUIRE(tc->optimizer >= 0 && tc->optimizer <= 3, "Optimizer not implemented: %d "
+               "(0 adadelta, 1 momentum, 2 adam, 3 rmsprop; reference pred_models.py:1667-1681)",
+               tc->optimizer);
+    MV_REQUIRE(tc->class_feedback >= 0 && tc->class_feedback <= 2, "class_feedback %d",
+               tc->class_feedback);
+    MV_REQUIRE(tc->keep_prob > 0.f && tc->keep_prob <= 1.f, "keep_prob %g not in (0, 1]",
+               tc->keep_prob);
+    if (tc->use_soft_grid_class)
+      MV_REQUIRE(tc->soft_kernel_size == 3 || tc->soft_kernel_size == 5,
+                 "soft_kernel_size %d (3 or 5)", tc->soft_kernel_size);
     MV_REQUIRE(h->cfg.beam_size == 1, "training needs a greedy (beam_size 1) engine "
                "(reference pred_models.py:261)");
     if (!h->train) {
       h->train = new mv_train_holder();
       train_alloc(h);
     }
-    h->train->st.tc = *tc;
+    TrainState& t = h->train->st;
+    t.tc = *tc;
+    if (t.slots_for != tc->optimizer) {
+      // slot initial values as TF creates them: zeros, except RMSProp's `rms` = ones
+      HIP_CHECK(hipMemsetAsync(t.accum.p, 0, t.total_elems * sizeof(float), h->stream));
+      HIP_CHECK(hipMemsetAsync(t.accum_update.p, 0, t.total_elems * sizeof(float), h->stream));
+      if (tc->optimizer == 3)
+        hipLaunchKernelGGL(mv::fill_kernel, dim3(cdiv(t.total_elems, 256)), dim3(256), 0,
+                           h->stream, t.accum.p, 1.0f, t.total_elems);
+      t.beta1_power = 0.9f; t.beta2_power = 0.999f;
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      t.slots_for = tc->optimizer;
+    }
   });
 }
 
@@ -1595,12 +1624,32 @@ int mv_set_global_step(mv_handle h, int64_t step) {
   return 0;
 }
 
+int mv_set_dropout_seed(mv_handle h, uint32_t seed) {
+  if (!h || !h->train) return 1;
+  h->train->st.dropout_seed = seed;
+  return 0;
+}
+
+int mv_get_opt_scalars(mv_handle h, float* beta1_power, float* beta2_power) {
+  if (!h || !h->train || !beta1_power || !beta2_power) return 1;
+  *beta1_power = h->train->st.beta1_power;
+  *beta2_power = h->train->st.beta2_power;
+  return 0;
+}
+
+int mv_set_opt_scalars(mv_handle h, float beta1_power, float beta2_power) {
+  if (!h || !h->train) return 1;
+  h->train->st.beta1_power = beta1_power;
+  h->train->st.beta2_power = beta2_power;
+  return 0;
+}
+
 int mv_get_opt_slot(mv_handle h, const char* tf_name, int32_t slot, float* out,
                     int64_t capacity) {
   if (!h) return 1;
   return guarded(h, [&] {
     MV_REQUIRE(h->train, "mv_train_init has not been called");
-    MV_REQUIRE(slot == 0 || slot == 1, "slot must be 0 (accum) or 1 (accum_update)");
+    MV_REQUIRE(slot == 0 || slot == 1, "slot must be 0 or 1 (see multiverse_hip.h)");
     Param* p = find_param(h, tf_name);
     MV_REQUIRE(out && (size_t)capacity >= p->elems(), "buffer too small for %s", tf_name);
     const float* src = (slot == 0 ? TS(h).accum.p : TS(h).accum_update.p) +
@@ -1614,7 +1663,7 @@ int mv_set_opt_slot(mv_handle h, const char* tf_name, int32_t slot, const float*
   if (!h) return 1;
   return guarded(h, [&] {
     MV_REQUIRE(h->train, "mv_train_init has not been called");
-    MV_REQUIRE(slot == 0 || slot == 1, "slot must be 0 (accum) or 1 (accum_update)");
+    MV_REQUIRE(slot == 0 || slot == 1, "slot must be 0 or 1 (see multiverse_hip.h)");
     Param* p = find_param(h, tf_name);
     MV_REQUIRE(data && (size_t)elems == p->elems(), "size mismatch for %s", tf_name);
     float* dst = (slot == 0 ? TS(h).accum.p : TS(h).accum_update.p) +

@@ -40,6 +40,10 @@ struct TrainScale {
   DevBuf<float> dsmean;           // [N][K][D]
   DevBuf<int32_t> pred_labels;    // [N][Tp]
   DevBuf<float> pred_reg;         // [N][Tp][K][2]
+  // switches beyond the published run (soft labels, teacher forcing, masked regression)
+  DevBuf<float> gt_cls;           // [Tp][N][K] one-hot / soft ground-truth class maps
+  DevBuf<float> reg_in;           // [Tp][N][K][2] teacher forcing: regression-decoder inputs
+  DevBuf<int32_t> fg_count;       // [1] cells with gt_cls > 0
 };
 
 struct TrainState {
@@ -67,6 +71,12 @@ struct TrainState {
   bool have_grads = false;
   bool targets_ready = false;
   mv_losses last{};
+  uint32_t dropout_seed = 0;      // keep_prob < 1: seed of the next step's masks
+  float beta1_power = 0.9f, beta2_power = 0.999f;   // Adam (TF non-slot variables)
+  int slots_for = -1;             // optimizer the slot buffers were initialised for
+  bool needs_gt() const {
+    return tc.use_soft_grid_class || tc.mask_grid_regression || tc.class_feedback == 2;
+  }
 };
 
 }  // namespace
@@ -139,6 +149,7 @@ void train_alloc(mv_engine* e) {
     R.dlogits.alloc(Tp * NK); R.dreg.alloc(Tp * NK * 2);
     R.loss_row.alloc(Tp * N); R.loss_elem.alloc(Tp * NK * 2);
     R.pred_labels.alloc(N * Tp); R.pred_reg.alloc(N * Tp * K * 2);
+    R.gt_cls.alloc(Tp * NK); R.reg_in.alloc(Tp * NK * 2); R.fg_count.alloc(1);
     // small-conv wgrad partials: blocks x 9 x Ci*Co (<= 512)
     max_partial = std::max(max_partial, (size_t)4096 * 9 * 512);
     max_partial = std::max(max_partial, (size_t)64 * c.scene_conv_kernel * c.scene_conv_kernel * std::max<size_t>(D, c.scene_class) * D);
@@ -361,11 +372,67 @@ ConvLstmArgs train_problem(mv_engine* e, TrainChain& ch, const float* x, const f
 // The training forward runs in the engine's compute mode (f16x3: the gate
 // convolutions on the fp16 matrix pipe, saving the same fp32 gate activations);
 // dgrad and wgrad stay on the fp32 MFMA.
+// keep_prob < 1: input dropout of one cell call, in place on its x operand (forward) or
+// on d x (backward); draw = chain offset + step, numbered in the reference's call order
+// (per used scale: class encoder, regression encoder, class decoder, regression decoder)
+int dropout_stream(mv_engine* e, int s, int chain, int step) {
+  const int To = e->cfg.obs_len, Tp = e->pred_len;
+  int used = 0;
+  for (int i = 0; i < s; ++i) used += e->sc[i].use ? 1 : 0;
+  const int base = used * (2 * To + 2 * Tp);
+  const int off[4] = {0, To, 2 * To, 2 * To + Tp};
+  return base + off[chain] + step;
+}
+void run_dropout(mv_engine* e, float* x, size_t n, int s, int chain, int step) {
+  TrainState& t = TS(e);
+  if (!(t.tc.keep_prob < 1.0f) || n == 0) return;
+  MV_REQUIRE(n < ((size_t)1 << 32), "dropout: tensor of %zu elements", n);
+  const uint32_t thr = (uint32_t)lrintf(t.tc.keep_prob * 16777216.0f);
+  launch(e, "dropout", 0, 8.0 * n, [&] {
+    hipLaunchKernelGGL(mv::dropout_kernel, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, x, n,
+                       t.dropout_seed, (uint32_t)dropout_stream(e, s, chain, step), thr,
+                       1.0f / t.tc.keep_prob);
+  });
+}
+
+// ground-truth class maps / teacher-forcing inputs / fg count of this batch's targets
+void train_prepare_targets(mv_engine* e) {
+  const mv_config& c = e->cfg;
+  TrainState& t = TS(e);
+  const int N = c.batch_size, Tp = e->pred_len;
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    TrainScale& R = t.sc[s];
+    const size_t NK = (size_t)N * S.K;
+    if (t.needs_gt()) {
+      mv::SoftKernel sk{};
+      const int ks = t.tc.use_soft_grid_class ? t.tc.soft_kernel_size : 0;
+      for (int i = 0; i < ks * ks; ++i) sk.k[i] = t.tc.soft_kernel[i];
+      hipLaunchKernelGGL(mv::gt_class_maps_kernel, dim3(cdiv((size_t)Tp * NK, 256)), dim3(256),
+                         0, e->stream, R.pred_labels.p, R.gt_cls.p, Tp, N, S.H, S.W, ks, sk);
+    }
+    if (t.tc.mask_grid_regression) {
+      HIP_CHECK(hipMemsetAsync(R.fg_count.p, 0, sizeof(int32_t), e->stream));
+      hipLaunchKernelGGL(mv::count_positive_kernel, dim3(256), dim3(256), 0, e->stream,
+                         R.gt_cls.p, (size_t)Tp * NK, R.fg_count.p);
+    }
+    if (t.tc.reg_teacher_forcing) {       // [N][Tp][K][2] -> time-major
+      const size_t tot = (size_t)N * Tp * S.K * 2;
+      hipLaunchKernelGGL(mv::transpose_nt_kernel, dim3(cdiv(tot, 256)), dim3(256), 0,
+                         e->stream, R.pred_reg.p, R.reg_in.p, N, Tp, (size_t)S.K * 2);
+    }
+  }
+}
+
 void train_forward(mv_engine* e) {
   const mv_config& c = e->cfg;
   TrainState& t = TS(e);
   const int N = c.batch_size, To = c.obs_len, Tp = e->pred_len, C = c.hidden_size,
             D = c.scene_conv_dim, E = c.emb_size;
+  const int cls_fb = t.tc.class_feedback;        // 0 one-hot, 1 dense logits, 2 ground truth
+  const bool reg_tf = t.tc.reg_teacher_forcing != 0;
+  train_prepare_targets(e);
   run_scene(e);
   for (int s = 0; s < c.num_scales; ++s) {
     ScaleState& S = e->sc[s];
@@ -391,6 +458,8 @@ void train_forward(mv_engine* e) {
                            0, e->stream, e->scene_conv[s].p, e->obs_scene.p, S.labels.p,
                            xc, N, To, ts, S.K, D);
       });
+      run_dropout(e, xc, total, s, 0, ts);
+      run_dropout(e, R.enc[1].xs.p + (size_t)ts * N * S.K * 2, (size_t)N * S.K * 2, s, 1, ts);
       for (int b = 0; b < 2; ++b) {
         const float* x = b == 0 ? xc : R.enc[1].xs.p + (size_t)ts * N * S.K * 2;
         probs.push_back(train_problem(
@@ -418,7 +487,12 @@ void train_forward(mv_engine* e) {
       }
       float* xc = R.dec[0].xs.p + (size_t)ts * NK * E;
       if (ts == 0) run_emb_onehot(e, S, S.labels.p + (To - 1), To, xc, N);
-      else run_emb_onehot(e, S, R.ids.p + (size_t)ts * N, 1, xc, N);
+      else if (cls_fb == 0) run_emb_onehot(e, S, R.ids.p + (size_t)ts * N, 1, xc, N);
+      else   // dense input map: the previous step's logits, or the step's ground truth
+        run_emb_dense(e, S, cls_fb == 1 ? R.logits.p + (size_t)(ts - 1) * NK
+                                        : R.gt_cls.p + (size_t)ts * NK,
+                      (size_t)S.K, xc, N, S.emb_cls_W, S.emb_cls_b, 1);
+      run_dropout(e, xc, NK * E, s, 2, ts);
       probs.push_back(train_problem(e, R.dec[0], xc, hin, R.cs[0].p + slot * NKC,
                                     R.hs[0].p + (slot + 1) * NKC,
                                     R.cs[0].p + (slot + 1) * NKC,
@@ -433,7 +507,11 @@ void train_forward(mv_engine* e) {
                                    (size_t)To * row * sizeof(float), row * sizeof(float),
                                    N, hipMemcpyDeviceToDevice, e->stream));
       }
-      run_emb_dense(e, S, R.regio.p + (size_t)ts * NK * 2, (size_t)S.K * 2, xr, N);
+      if (reg_tf && ts > 0)       // teacher forcing: grid_pred_regress[:, ts] (:398)
+        run_emb_dense(e, S, R.reg_in.p + (size_t)ts * NK * 2, (size_t)S.K * 2, xr, N);
+      else
+        run_emb_dense(e, S, R.regio.p + (size_t)ts * NK * 2, (size_t)S.K * 2, xr, N);
+      run_dropout(e, xr, NK * E, s, 3, ts);
       probs.push_back(train_problem(e, R.dec[1], xr, R.hs[1].p + slot * NKC,
                                     R.cs[1].p + slot * NKC, R.hs[1].p + (slot + 1) * NKC,
                                     R.cs[1].p + (slot + 1) * NKC,
@@ -450,7 +528,7 @@ void train_forward(mv_engine* e) {
       float* lg = R.logits.p + (size_t)ts * NK;
       run_hidden2grid<1>(e, S, R.hs[0].p + slot * NKC, S.out_cls_W->dev.p, lg,
                          (size_t)S.K, N);
-      if (ts + 1 < Tp) {
+      if (ts + 1 < Tp && cls_fb == 0) {
         launch(e, "argmax_rows", 0, 4.0 * NK, [&] {
           hipLaunchKernelGGL(mv::argmax_rows_kernel, dim3(N), dim3(64), 0, e->stream, lg,
                              (size_t)S.K, R.ids.p + (size_t)(ts + 1) * N, N, S.K);
@@ -475,20 +553,36 @@ void train_losses(mv_engine* e) {
     const size_t NK = (size_t)N * S.K;
     const float cs = t.tc.grid_loss_weight / (float)((size_t)N * Tp);
     launch(e, "ce_loss", 0, 8.0 * Tp * NK, [&] {
-      hipLaunchKernelGGL(mv::ce_loss_kernel, dim3(Tp * N), dim3(64), 0, e->stream,
-                         R.logits.p, R.pred_labels.p, R.loss_row.p, R.dlogits.p, Tp, N,
-                         S.K, cs);
+      if (t.tc.use_soft_grid_class)
+        hipLaunchKernelGGL(mv::ce_soft_loss_kernel, dim3(Tp * N), dim3(64), 0, e->stream,
+                           R.logits.p, R.gt_cls.p, R.loss_row.p, R.dlogits.p, S.K, cs);
+      else
+        hipLaunchKernelGGL(mv::ce_loss_kernel, dim3(Tp * N), dim3(64), 0, e->stream,
+                           R.logits.p, R.pred_labels.p, R.loss_row.p, R.dlogits.p, Tp, N,
+                           S.K, cs);
       hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream,
                          R.loss_row.p, (size_t)Tp * N, t.losses.p + li, cs, 0);
     });
     const size_t nel = (size_t)Tp * NK * 2;
     const float rs = t.tc.grid_reg_loss_weight / (float)nel;
     launch(e, "huber_loss", 0, 16.0 * nel, [&] {
-      hipLaunchKernelGGL(mv::huber_loss_kernel, dim3(cdiv(nel, 256)), dim3(256), 0,
-                         e->stream, R.regio.p + NK * 2, R.pred_reg.p, R.loss_elem.p,
-                         R.dreg.p, Tp, N, S.K * 2, rs);
-      hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream,
-                         R.loss_elem.p, nel, t.losses.p + li + 1, rs, 0);
+      if (t.tc.mask_grid_regression) {
+        hipLaunchKernelGGL(mv::huber_masked_loss_kernel, dim3(cdiv(nel, 256)), dim3(256), 0,
+                           e->stream, R.regio.p + NK * 2, R.pred_reg.p, R.gt_cls.p,
+                           R.fg_count.p, R.loss_elem.p, R.dreg.p, Tp, N, S.K,
+                           t.tc.grid_reg_loss_weight);
+        hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream,
+                           R.loss_elem.p, nel, t.scratch.p, 1.0f, 0);
+        hipLaunchKernelGGL(mv::masked_mean_kernel, dim3(1), dim3(64), 0, e->stream,
+                           t.scratch.p, R.fg_count.p, t.losses.p + li + 1,
+                           t.tc.grid_reg_loss_weight);
+      } else {
+        hipLaunchKernelGGL(mv::huber_loss_kernel, dim3(cdiv(nel, 256)), dim3(256), 0,
+                           e->stream, R.regio.p + NK * 2, R.pred_reg.p, R.loss_elem.p,
+                           R.dreg.p, Tp, N, S.K * 2, rs);
+        hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream,
+                           R.loss_elem.p, nel, t.losses.p + li + 1, rs, 0);
+      }
     });
     li += 2;
   }
@@ -790,16 +884,31 @@ void train_backward(mv_engine* e) {
       for (int b = 0; b < 2; ++b) {
         float* dx = R.dec[b].dxs.p + (size_t)ts * NK * E;
         const size_t total = NK * E;
+        run_dropout(e, dx, total, s, 2 + b, ts);       // backward of the input dropout
         launch(e, "tanh_bwd", 3.0 * total, 12.0 * total, [&] {
-          hipLaunchKernelGGL(mv::tanh_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
-                             e->stream, dx, R.dec[b].xs.p + (size_t)ts * NK * E, dx, total);
+          // xs holds the DROPPED input; where the mask is zero d x is zero too, elsewhere
+          // y = xs * keep_prob recovers the embedding output for 1 - y^2
+          if (t.tc.keep_prob < 1.0f)
+            hipLaunchKernelGGL(mv::tanh_bwd_scaled_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                               e->stream, dx, R.dec[b].xs.p + (size_t)ts * NK * E, dx, total,
+                               t.tc.keep_prob);
+          else
+            hipLaunchKernelGGL(mv::tanh_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                               e->stream, dx, R.dec[b].xs.p + (size_t)ts * NK * E, dx, total);
         });
       }
       // regression decoder: the step's input was grid_emb(out_reg[t-1]) -> d out_reg[t-1]
-      if (ts > 0)
+      // (teacher forcing feeds the ground truth instead: no gradient path)
+      if (ts > 0 && !t.tc.reg_teacher_forcing)
         run_small_dgrad(e, R.dec[1].dxs.p + (size_t)ts * NK * E, (size_t)S.K * E,
                         S.emb_reg_W->dev.p, R.dreg.p + (size_t)(ts - 1) * NK * 2,
                         (size_t)S.K * 2, N, S.H, S.W, 2, E, true);
+      // class decoder fed its own logits (training without --train_w_onehot): the same
+      // path into d logits[t-1]
+      if (ts > 0 && t.tc.class_feedback == 1)
+        run_small_dgrad(e, R.dec[0].dxs.p + (size_t)ts * NK * E, (size_t)S.K * E,
+                        S.emb_cls_W->dev.p, R.dlogits.p + (size_t)(ts - 1) * NK,
+                        (size_t)S.K, N, S.H, S.W, 1, E, true);
     }
   }
   // ---- encoders, t = To-1 .. 0
@@ -835,6 +944,8 @@ void train_backward(mv_engine* e) {
     for (int s = 0; s < c.num_scales; ++s) {
       if (!e->sc[s].use) continue;
       for (int b = 0; b < 2; ++b) std::swap(dh_a[s][b], dh_b[s][b]);
+      run_dropout(e, t.sc[s].enc[0].dxs.p + (size_t)ts * N * e->sc[s].K * D,
+                  (size_t)N * e->sc[s].K * D, s, 0, ts);
     }
   }
   // ---- parameter gradients
@@ -848,17 +959,29 @@ void train_backward(mv_engine* e) {
       const float* hin = (b == 0 && c.use_gnn) ? R.hg.p : R.hs[b].p + (size_t)To * NKC;
       run_wgrad(e, R.dec[b], hin, Tp, S.H, S.W, (2 * s + b) * 64);
     }
-    // class-decoder grid_emb on one-hot maps
+    // class-decoder grid_emb: its input maps of all steps, [Tp][N][K] -- slot 0 the
+    // one-hot of the last observed cell, slot t the one-hot argmax / the logits of step
+    // t-1 / the ground-truth map of step t, by feedback mode
     hipLaunchKernelGGL(mv::onehot_map_kernel, dim3(cdiv(NK, 256)), dim3(256), 0, e->stream,
                        S.labels.p + (To - 1), To, R.onehot.p, N, S.K);
-    if (Tp > 1)
-      hipLaunchKernelGGL(mv::onehot_map_kernel, dim3(cdiv((size_t)(Tp - 1) * NK, 256)),
-                         dim3(256), 0, e->stream, R.ids.p + N, 1, R.onehot.p + NK,
-                         (Tp - 1) * N, S.K);
+    if (Tp > 1) {
+      const size_t rest = (size_t)(Tp - 1) * NK;
+      if (t.tc.class_feedback == 0)
+        hipLaunchKernelGGL(mv::onehot_map_kernel, dim3(cdiv(rest, 256)), dim3(256), 0,
+                           e->stream, R.ids.p + N, 1, R.onehot.p + NK, (Tp - 1) * N, S.K);
+      else
+        HIP_CHECK(hipMemcpyAsync(R.onehot.p + NK,
+                                 t.tc.class_feedback == 1 ? R.logits.p : R.gt_cls.p + NK,
+                                 rest * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    }
     run_small_wgrad(e, R.onehot.p, R.dec[0].dxs.p, grad_of(e, S.emb_cls_W), Tp * N, S.H,
                     S.W, 1, E);
     run_colsum(e, R.dec[0].dxs.p, (size_t)Tp * NK, E, grad_of(e, S.emb_cls_b), t.partial.p);
-    run_small_wgrad(e, R.regio.p, R.dec[1].dxs.p, grad_of(e, S.emb_reg_W), Tp * N, S.H,
+    if (t.tc.reg_teacher_forcing)     // slot 0 of reg_in: obs_grid_reg[:, -1], as regio's
+      HIP_CHECK(hipMemcpyAsync(R.reg_in.p, R.regio.p, NK * 2 * sizeof(float),
+                               hipMemcpyDeviceToDevice, e->stream));
+    run_small_wgrad(e, t.tc.reg_teacher_forcing ? R.reg_in.p : R.regio.p, R.dec[1].dxs.p,
+                    grad_of(e, S.emb_reg_W), Tp * N, S.H,
                     S.W, 2, E);
     run_colsum(e, R.dec[1].dxs.p, (size_t)Tp * NK, E, grad_of(e, S.emb_reg_b), t.partial.p);
     // hidden2grid
@@ -996,14 +1119,37 @@ void train_apply(mv_engine* e, float grad_scale) {
   TrainState& t = TS(e);
   MV_REQUIRE(t.have_grads, "mv_train_apply before mv_train_forward_backward");
   const float lr = train_learning_rate(t);
+  const float clip = t.tc.clip_gradient_norm;
+  const int do_clip = t.tc.do_clip;
+  // Adam: alpha = lr sqrt(1 - beta2_power) / (1 - beta1_power), float32 like the TF kernel
+  const float alpha = lr * sqrtf(1.0f - t.beta2_power) / (1.0f - t.beta1_power);
   for (size_t i = 0; i < e->params.size(); ++i) {
     Param* p = e->params[i].get();
     const size_t n = p->elems(), o = t.goff[i];
-    hipLaunchKernelGGL(mv::adadelta_kernel, dim3(cdiv(n, 256)), dim3(256), 0, e->stream,
-                       p->dev.p, t.accum.p + o, t.accum_update.p + o, t.grad.p + o,
-                       grad_scale, t.tc.clip_gradient_norm, t.tc.do_clip, lr, 0.95f, 1e-8f,
-                       n);
+    float *s0 = t.accum.p + o, *s1 = t.accum_update.p + o;
+    const float* g = t.grad.p + o;
+    const dim3 grid(cdiv(n, 256)), blk(256);
+    switch (t.tc.optimizer) {
+      case 0:
+        hipLaunchKernelGGL(mv::adadelta_kernel, grid, blk, 0, e->stream, p->dev.p, s0, s1, g,
+                           grad_scale, clip, do_clip, lr, 0.95f, 1e-8f, n);
+        break;
+      case 1:
+        hipLaunchKernelGGL(mv::momentum_kernel, grid, blk, 0, e->stream, p->dev.p, s0, g,
+                           grad_scale, clip, do_clip, lr, 0.9f, n);
+        break;
+      case 2:
+        hipLaunchKernelGGL(mv::adam_kernel, grid, blk, 0, e->stream, p->dev.p, s0, s1, g,
+                           grad_scale, clip, do_clip, alpha, 1.0f - 0.9f, 1.0f - 0.999f, 1e-8f,
+                           n);
+        break;
+      default:
+        hipLaunchKernelGGL(mv::rmsprop_kernel, grid, blk, 0, e->stream, p->dev.p, s0, s1, g,
+                           grad_scale, clip, do_clip, lr, 1.0f - 0.9f, 0.0f, 1e-10f, n);
+        break;
+    }
   }
+  if (t.tc.optimizer == 2) { t.beta1_power *= 0.9f; t.beta2_power *= 0.999f; }
   train_pack_all(e);
   for (int s = 0; s < e->cfg.num_scales; ++s) e->sc[s].wq_valid = false;
   t.global_step += 1;

@@ -332,12 +332,13 @@ void gnn_attend_v2_kernel(const float* __restrict__ h, const float* __restrict__
   cell_info(i1, li1, mask1);
   cell_info(i2, li2, mask2);
 
-  // all of a thread's loads of a chunk are issued before the first LDS store (a load ->
-  // wait -> store loop over a run-time trip count serialised seven HBM round trips per
-  // chunk: 48 us per workgroup)
+  // A chunk travels global -> registers -> LDS; the loads of chunk q+1 are issued
+  // before chunk q is computed on, so their HBM / L2 latency runs under the compute
+  // phase.  (First version: load -> wait -> store inside a run-time loop: seven
+  // serialised round trips per chunk, 48 us per workgroup.)
   constexpr int kIt = (kGnnStage * 16 + 255) / 256;     // 7
-  auto stage = [&](int q) {          // q < 4: channels q*64.. of h; q == 4: scene_mean
-    f32x4_t val[kIt];
+  f32x4_t val[kIt];
+  auto stage_load = [&](int q) {     // q < 4: channels q*64.. of h; q == 4: scene_mean
 #pragma unroll
     for (int k = 0; k < kIt; ++k) {
       const int v = tid + k * 256;
@@ -355,6 +356,8 @@ void gnn_attend_v2_kernel(const float* __restrict__ h, const float* __restrict__
         }
       }
     }
+  };
+  auto stage_store = [&]() {
 #pragma unroll
     for (int k = 0; k < kIt; ++k) {
       const int v = tid + k * 256;
@@ -377,9 +380,11 @@ void gnn_attend_v2_kernel(const float* __restrict__ h, const float* __restrict__
   for (int t = 0; t < 9; ++t) pd[t] = 0.f;
   __syncthreads();                    // hsrc / ssrc / ssq visible
   const int nchunk = D > 0 ? 5 : 4;
+  stage_load(0);
   for (int q = 0; q < nchunk; ++q) {
-    stage(q);
+    stage_store();
     __syncthreads();
+    stage_load(q + 1 < nchunk ? q + 1 : 0);   // next chunk; after the last: pass 2's first
     if (mask1) {
       const float* fi = &buf[li1 * kGnnPitch + sl * 8];
 #pragma unroll
@@ -439,8 +444,9 @@ void gnn_attend_v2_kernel(const float* __restrict__ h, const float* __restrict__
   __syncthreads();
   const long long m2 = m0 + i2;
   for (int q = 0; q < 4; ++q) {
-    stage(q);
+    stage_store();
     __syncthreads();
+    if (q < 3) stage_load(q + 1);
     if (mask2) {
       const float* hi = &buf[li2 * kGnnPitch + c8 * 8];
       float node[8];

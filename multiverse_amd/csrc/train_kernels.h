@@ -371,6 +371,16 @@ __global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __res
   dpre[idx] = dy[idx] * (1.f - v * v);
 }
 
+// the same when y was stored scaled by 1 / keep_prob (dropped input of a cell):
+// dpre = dy * (1 - (y * keep)^2)
+__global__ void tanh_bwd_scaled_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                       float* __restrict__ dpre, size_t total, float keep) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const float v = y[idx] * keep;
+  dpre[idx] = dy[idx] * (1.f - v * v);
+}
+
 // out[s][col] = sum over the rows of slab s of in[row][col]; grid (nslab,
 // ceil(ncols/256)).  Used twice for a deterministic column sum (bias
 // gradients) and once with one slab to fold split-K partials.
@@ -457,6 +467,127 @@ __global__ void huber_loss_kernel(const float* __restrict__ pred,
   const float q = fminf(ab, 1.f);
   loss_elem[idx] = 0.5f * q * q + (ab - q);
   dpred[idx] = fminf(fmaxf(e, -1.f), 1.f) * scale;
+}
+
+// ------------------------------------------------------------ label maps
+// Class ground-truth maps, time-major [T][N][K], from the labels [N][T]:
+//   ks == 0  tf.one_hot(label)                       (code/pred_models.py:259-262)
+//   ks > 0   the one-hot map stamped with the --soft_grid kernel (ks x ks, row-major;
+//            scipy.ndimage.convolve(mode='constant') of a symmetric kernel, :1077-1124)
+// Used as soft labels (:988-990), as teacher-forcing inputs (:398) and as the
+// foreground mask of --mask_grid_regression (:1004-1010).
+struct SoftKernel { float k[25]; };
+__global__ void gt_class_maps_kernel(const int32_t* __restrict__ labels,
+                                     float* __restrict__ out, int T, int N, int H, int W,
+                                     int ks, const SoftKernel sk) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = H * W;
+  if (idx >= (size_t)T * N * K) return;
+  const int cell = (int)(idx % K);
+  const size_t r = idx / K;
+  const int n = (int)(r % N), t = (int)(r / N);
+  const int lab = labels[(size_t)n * T + t];
+  const int y = cell / W, x = cell - y * W, py = lab / W, px = lab - py * W;
+  float v;
+  if (ks == 0) {
+    v = (cell == lab) ? 1.f : 0.f;
+  } else {
+    const int rad = ks >> 1, dy = y - py, dx = x - px;
+    v = (dy >= -rad && dy <= rad && dx >= -rad && dx <= rad)
+            ? sk.k[(dy + rad) * ks + (dx + rad)] : 0.f;
+  }
+  out[idx] = v;
+}
+
+// number of elements > 0 (the fg cells of --mask_grid_regression); *count zeroed before;
+// integer atomics: exact and order-independent
+__global__ void count_positive_kernel(const float* __restrict__ in, size_t n,
+                                      int32_t* __restrict__ count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int c = 0;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) c += in[i] > 0.f;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+// softmax_cross_entropy_with_logits on soft labels (code/pred_models.py:988-990):
+// loss_row = -sum_k lab_k log_softmax(logits)_k; dlogits = (softmax - lab) * scale -- TF's
+// REGISTERED gradient (xent_op backprop), exact only for labels that sum to one; the
+// reference trains on it with un-normalised labels.  logits, labels time-major [T*N, K].
+__global__ __launch_bounds__(64)
+void ce_soft_loss_kernel(const float* __restrict__ logits, const float* __restrict__ soft,
+                         float* __restrict__ loss_row, float* __restrict__ dlogits, int K,
+                         float scale) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float* p = logits + (size_t)r * K;
+  const float* q = soft + (size_t)r * K;
+  float mx = -INFINITY;
+  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, p[k]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += expf(p[k] - mx);
+  s = wave_sum(s);
+  const float ls = logf(s);
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += q[k] * ((p[k] - mx) - ls);
+  acc = wave_sum(acc);
+  if (lane == 0) loss_row[r] = -acc;
+  const float inv = 1.0f / s;
+  float* d = dlogits + (size_t)r * K;
+  for (int k = lane; k < K; k += 64) d[k] = (expf(p[k] - mx) * inv - q[k]) * scale;
+}
+
+// Huber over the foreground cells only (--mask_grid_regression, :999-1014): the mean runs
+// over count[0] * 2 elements; pred / fg time-major [T, N, K(, 2)], target [N, T, K, 2].
+__global__ void huber_masked_loss_kernel(const float* __restrict__ pred,
+                                         const float* __restrict__ target,
+                                         const float* __restrict__ fg,
+                                         const int32_t* __restrict__ count,
+                                         float* __restrict__ loss_elem,
+                                         float* __restrict__ dpred, int T, int N, int K,
+                                         float weight) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)T * N * K * 2;
+  if (idx >= total) return;
+  const int kp = (int)(idx % ((size_t)K * 2));
+  const size_t r = idx / ((size_t)K * 2);
+  const int n = (int)(r % N), t = (int)(r / N);
+  const int cnt = count[0];
+  const float scale = cnt > 0 ? weight / (2.0f * (float)cnt) : 0.f;
+  const bool on = fg[idx >> 1] > 0.f;
+  const float e = pred[idx] - target[((size_t)n * T + t) * K * 2 + kp];
+  const float ab = fabsf(e);
+  const float q = fminf(ab, 1.f);
+  loss_elem[idx] = on ? 0.5f * q * q + (ab - q) : 0.f;
+  dpred[idx] = on ? fminf(fmaxf(e, -1.f), 1.f) * scale : 0.f;
+}
+// loss = weight * sum(loss_elem) / (2 count)
+__global__ void masked_mean_kernel(const float* __restrict__ sum, const int32_t* __restrict__ count,
+                                   float* __restrict__ out, float weight) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int cnt = count[0];
+    out[0] = cnt > 0 ? sum[0] / (2.0f * (float)cnt) * weight : 0.f;
+  }
+}
+
+// ------------------------------------------------------------ dropout
+// x *= keep_mask / keep_prob in place (tf.nn.rnn_cell.DropoutWrapper input dropout,
+// code/pred_models.py:194-202, 241-249; also its backward on d x).  Element i of draw
+// `stream` is kept iff the top 24 bits of hash32(i, seed, stream) < keep_prob * 2^24 --
+// the generator oracle/multiverse_oracle.py dropout_keep_mask restates.
+__device__ __forceinline__ bool dropout_keep(uint32_t i, uint32_t seed, uint32_t stream,
+                                             uint32_t thr) {
+  uint32_t x = i * 0x9E3779B1u + seed * 0x85EBCA77u + stream * 0xC2B2AE3Du;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return (x >> 8) < thr;
+}
+__global__ void dropout_kernel(float* __restrict__ x, size_t n, uint32_t seed, uint32_t stream,
+                               uint32_t thr, float inv_keep) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  x[i] = dropout_keep((uint32_t)i, seed, stream, thr) ? x[i] * inv_keep : 0.f;
 }
 
 // ------------------------------------------------------------ scene stack
@@ -580,6 +711,59 @@ __global__ void adadelta_kernel(float* __restrict__ var, float* __restrict__ acc
   var[i] = var[i] - upd * lr;
   accum_update[i] = accum_update[i] * rho + upd * upd * (1.f - rho);
   accum[i] = a;
+}
+
+// clip_by_value + TF ApplyMomentum (MomentumOptimizer(lr, 0.9), no Nesterov, :1668):
+//   accum = accum * momentum + g;  var -= lr * accum
+__global__ void momentum_kernel(float* __restrict__ var, float* __restrict__ accum,
+                                const float* __restrict__ grad, float gscale, float clip,
+                                int do_clip, float lr, float momentum, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float g = grad[i] * gscale;
+  if (do_clip) g = fminf(fmaxf(g, -clip), clip);
+  const float a = accum[i] * momentum + g;
+  var[i] = var[i] - a * lr;
+  accum[i] = a;
+}
+
+// clip_by_value + TF ApplyAdam (AdamOptimizer(lr): beta 0.9 / 0.999, eps 1e-8, :1674):
+//   m += (g - m)(1 - beta1);  v += (g^2 - v)(1 - beta2);  var -= m * alpha / (sqrt(v) + eps)
+// alpha = lr sqrt(1 - beta2_power) / (1 - beta1_power), computed on the host in float32
+__global__ void adam_kernel(float* __restrict__ var, float* __restrict__ m,
+                            float* __restrict__ v, const float* __restrict__ grad,
+                            float gscale, float clip, int do_clip, float alpha, float omb1,
+                            float omb2, float eps, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float g = grad[i] * gscale;
+  if (do_clip) g = fminf(fmaxf(g, -clip), clip);
+  const float mm = m[i] + (g - m[i]) * omb1;
+  const float vv = v[i] + (g * g - v[i]) * omb2;
+  var[i] = var[i] - (mm * alpha) / (sqrtf(vv) + eps);
+  m[i] = mm; v[i] = vv;
+}
+
+// clip_by_value + TF ApplyRMSProp (RMSPropOptimizer(lr): decay 0.9, momentum 0,
+// eps 1e-10, :1677):  ms += (g^2 - ms)(1 - decay);  mom = mom * momentum +
+// (g * lr) * rsqrt(ms + eps);  var -= mom     (ms starts at ONE)
+__global__ void rmsprop_kernel(float* __restrict__ var, float* __restrict__ ms,
+                               float* __restrict__ mom, const float* __restrict__ grad,
+                               float gscale, float clip, int do_clip, float lr, float omd,
+                               float momentum, float eps, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float g = grad[i] * gscale;
+  if (do_clip) g = fminf(fmaxf(g, -clip), clip);
+  const float s2 = ms[i] + (g * g - ms[i]) * omd;
+  const float mo = mom[i] * momentum + (g * lr) * (1.0f / sqrtf(s2 + eps));
+  var[i] = var[i] - mo;
+  ms[i] = s2; mom[i] = mo;
+}
+
+__global__ void fill_kernel(float* __restrict__ x, float v, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = v;
 }
 
 // ------------------------------------------------------------ layout helpers

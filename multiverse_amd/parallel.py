@@ -74,6 +74,13 @@ def world_size():
   return 1
 
 
+def rank():
+  import torch.distributed as dist
+  if dist.is_available() and dist.is_initialized():
+    return dist.get_rank()
+  return 0
+
+
 class _DeviceArray(object):
   """A raw device pointer as a 1-D float32 `__cuda_array_interface__` object."""
 

@@ -213,8 +213,6 @@ class Model(object):
     if getattr(config, "use_beam_search", False):
       assert not getattr(config, "is_train", False)
       assert sum(config.use_grids) == 1, "only one scale test at a time"
-    if getattr(config, "is_train", False) and config.keep_prob != 1.0:
-      raise _lib.MvError("keep_prob != 1.0 is not built (published runs use 1.0)")
 
   # -- weights (tf.train.Saver role) --------------------------------------
   def param_specs(self):
@@ -312,6 +310,14 @@ class Trainer(object):
     feed = self.model.get_feed_dict(batch_data, is_train=True)
     eng = self.model.engine
     world = parallel.world_size()
+    if self.config.keep_prob < 1.0:
+      # DropoutWrapper masks: TF draws them unseeded; here one seed per step from
+      # config.dropout_seed (default 0) and the step count -- every rank of a
+      # data-parallel job draws different masks for its own rows
+      base = int(getattr(self.config, "dropout_seed", 0))
+      rank = parallel.rank()
+      eng.set_dropout_seed((base * 1000003 + eng.global_step * 8191 + rank * 131071)
+                           & 0xFFFFFFFF)
     if feed.get("compact", False):      # batch assembled in HBM, then the resident calls
       eng.upload_compact(feed)
       feed = None

@@ -117,11 +117,17 @@ def initialize(load, load_best, args, model):
   model.load_params(load_weights(path))
 
 
+OPT_SLOT_NAMES = {        # TF-1.15 slot variable suffixes by --optimizer
+    "adadelta": ("Adadelta", "Adadelta_1"), "momentum": ("Momentum",),
+    "adam": ("Adam", "Adam_1"), "rmsprop": ("RMSProp", "RMSProp_1")}
+
+
 class Saver(object):
   """tf.train.Saver(max_to_keep=5) role (code/train.py:170-171, 222, 244):
   `save(model, path, global_step)` writes a TensorFlow-format checkpoint with
-  the variables, the Adadelta slots under TF's slot names and global_step, so a
-  run can resume and the reference's own tools can read the weights."""
+  the variables, the optimizer slots under TF's slot names (and Adam's beta powers)
+  and global_step, so a run can resume and the reference's own tools can read the
+  weights."""
 
   def __init__(self, max_to_keep=5):
     self.max_to_keep = max_to_keep
@@ -133,9 +139,14 @@ class Saver(object):
     variables = model.get_params()
     try:
       step = eng.global_step
+      slots = OPT_SLOT_NAMES[getattr(model.config, "optimizer", "adadelta")]
       for n in list(variables):
-        variables[n + "/Adadelta"] = eng.get_opt_slot(n, 0)
-        variables[n + "/Adadelta_1"] = eng.get_opt_slot(n, 1)
+        for i, suffix in enumerate(slots):
+          variables[n + "/" + suffix] = eng.get_opt_slot(n, i)
+      if slots[0] == "Adam":
+        b1p, b2p = eng.opt_scalars()
+        variables["beta1_power"] = np.asarray(b1p, dtype="float32")
+        variables["beta2_power"] = np.asarray(b2p, dtype="float32")
     except _lib_error():
       step = 0                       # inference-only engine: weights only
     variables["global_step"] = np.asarray(step, dtype="int32")
@@ -144,7 +155,7 @@ class Saver(object):
                                          written=self._last_checkpoints)
 
   def restore(self, model, path, with_optimizer=True):
-    """Resume: weights + (when present) Adadelta slots and global_step."""
+    """Resume: weights + (when present) optimizer slots and global_step."""
     from multiverse_amd import tf_checkpoint
     allv = tf_checkpoint.load_checkpoint(path, skip_optimizer_slots=False)
     model.load_params({k: v for k, v in allv.items()
@@ -152,10 +163,13 @@ class Saver(object):
                        k.split("/")[-1] not in tf_checkpoint.OPTIMIZER_SLOT_NAMES})
     if with_optimizer and "global_step" in allv:
       eng = model.engine
+      slots = OPT_SLOT_NAMES[getattr(model.config, "optimizer", "adadelta")]
       for n, _ in eng.param_specs():
-        if n + "/Adadelta" in allv:
-          eng.set_opt_slot(n, 0, allv[n + "/Adadelta"])
-          eng.set_opt_slot(n, 1, allv[n + "/Adadelta_1"])
+        for i, suffix in enumerate(slots):
+          if n + "/" + suffix in allv:
+            eng.set_opt_slot(n, i, allv[n + "/" + suffix])
+      if slots[0] == "Adam" and "beta1_power" in allv:
+        eng.set_opt_scalars(float(allv["beta1_power"]), float(allv["beta2_power"]))
       eng.global_step = int(allv["global_step"])
 
 

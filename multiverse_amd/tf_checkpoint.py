@@ -52,7 +52,7 @@ _DT_OF_NP = {v: k for k, v in _NP_OF_DT.items()}
 # optimizer slot / bookkeeping variables the reference never restores
 # (code/pred_utils.py:166-174, code/multifuture_inference.py:282-285)
 OPTIMIZER_SLOT_NAMES = ("Adam", "beta1_power", "beta2_power", "Adam_1", "Adadelta_1",
-                        "Adadelta", "Momentum")
+                        "Adadelta", "Momentum", "RMSProp", "RMSProp_1")
 
 
 # ------------------------------------------------------------------ CRC-32C

@@ -164,7 +164,7 @@ def one_hot_grid(labels, H, W, dtype):
   return oh.reshape(tuple(lab.shape) + (H, W, 1))
 
 
-def run_encoder(x_seq, kernel, biases, C):
+def run_encoder(x_seq, kernel, biases, C, drop=None):
   """tf.nn.dynamic_rnn over [N, T, H, W, Cx] from the zero state with
   sequence_length == T (code/pred_models.py:212-215, 232-234; lengths are
   all obs_len, :1057-1062).  Returns the last (c, h)."""
@@ -172,7 +172,10 @@ def run_encoder(x_seq, kernel, biases, C):
   c = torch.zeros(N, H, W, C, dtype=x_seq.dtype)
   h = torch.zeros(N, H, W, C, dtype=x_seq.dtype)
   for t in range(T):
-    c, h = convlstm_cell(x_seq[:, t], c, h, kernel, biases)
+    x = x_seq[:, t]
+    if drop is not None:
+      x = drop(x)                  # DropoutWrapper(cell, keep_prob): input dropout
+    c, h = convlstm_cell(x, c, h, kernel, biases)
   return c, h
 
 
@@ -181,8 +184,84 @@ def argmax_lowest(x2d):
   return np.argmax(x2d.detach().numpy(), axis=1).astype("int32")
 
 
+def dropout_keep_mask(shape, keep_prob, seed, stream):
+  """Bernoulli(keep_prob) mask of `tf.nn.rnn_cell.DropoutWrapper(cell, keep_prob)`
+  (code/pred_models.py:130-132, 194-202, 241-249: INPUT dropout of all four cells while
+  training).  TensorFlow draws it from an unseeded random_uniform, so the reference's
+  masks are not reproducible; the engine, the TF-1 shim and this oracle share one
+  counter-based generator instead: element i of draw `stream` is kept iff the top 24
+  bits of hash32(i, seed, stream) fall below keep_prob * 2^24.  Draws are numbered in
+  the reference's cell-call order: per used scale enc-class steps, enc-regression
+  steps, class-decoder steps, regression-decoder steps."""
+  n = int(np.prod(shape))
+  i = np.arange(n, dtype=np.uint64)
+  x = (i * np.uint64(0x9E3779B1) + np.uint64(seed & 0xFFFFFFFF) * np.uint64(0x85EBCA77) +
+       np.uint64(stream & 0xFFFFFFFF) * np.uint64(0xC2B2AE3D)) & np.uint64(0xFFFFFFFF)
+  x ^= x >> np.uint64(16)
+  x = (x * np.uint64(0x7FEB352D)) & np.uint64(0xFFFFFFFF)
+  x ^= x >> np.uint64(15)
+  x = (x * np.uint64(0x846CA68B)) & np.uint64(0xFFFFFFFF)
+  x ^= x >> np.uint64(16)
+  thr = np.uint64(int(round(float(keep_prob) * (1 << 24))))
+  return ((x >> np.uint64(8)) < thr).reshape(shape)
+
+
+class _Dropout(object):
+  """Input dropout state of one forward: keep_prob, seed, running draw number."""
+
+  def __init__(self, keep_prob=1.0, seed=0):
+    self.keep, self.seed, self.stream = float(keep_prob), int(seed), 0
+
+  def __call__(self, x):
+    if self.keep >= 1.0:
+      return x
+    m = dropout_keep_mask(tuple(x.shape), self.keep, self.seed, self.stream)
+    self.stream += 1
+    return x * torch.from_numpy(m).to(x.dtype) * torch.tensor(1.0 / self.keep, dtype=x.dtype)
+
+
+SOFT_GRID_KERNELS = {   # code/pred_models.py:1084-1120 (`--soft_grid`)
+    1: (0.1, 1.0), 2: (0.01, 1.0), 3: (0.05, 1.0), 4: (0.0125, 0.9), 5: (0.05, 0.6),
+    6: (0.1, 0.2)}
+
+
+def soft_grid_kernel(soft_grid):
+  if soft_grid == 7:
+    k = np.full((5, 5), 0.0625)
+    k[1:4, 1:4] = 0.0125
+    k[2, 2] = 0.8
+    return k
+  ring, centre = SOFT_GRID_KERNELS[soft_grid]
+  k = np.full((3, 3), ring)
+  k[1, 1] = centre
+  return k
+
+
+def soft_grid_labels(labels, H, W, soft_grid):
+  """`--use_soft_grid_class` labels of Model.get_feed_dict (code/pred_models.py:
+  1077-1124): the one-hot map of every (n, t) convolved (scipy.ndimage.convolve,
+  mode='constant', cval 0) with the `--soft_grid` kernel; rows are NOT re-normalised.
+  labels [N, T] int -> float64 [N, T, H, W, 1] (the reference fills a numpy "float"
+  array; the placeholder then casts to float32)."""
+  lab = np.asarray(labels)
+  N, T = lab.shape
+  k = soft_grid_kernel(soft_grid)
+  r = k.shape[0] // 2
+  out = np.zeros((N, T, H, W, 1), dtype="float64")
+  for n in range(N):
+    for t in range(T):
+      y, x = divmod(int(lab[n, t]), W)
+      # the kernels are symmetric: convolve == correlate, a stamp of k around (y, x)
+      for dy in range(-r, r + 1):
+        for dx in range(-r, r + 1):
+          yy, xx = y + dy, x + dx
+          if 0 <= yy < H and 0 <= xx < W:
+            out[n, t, yy, xx, 0] = k[dy + r, dx + r]
+  return out
+
+
 def greedy_decoder(P, cfg, s, kind, first_input, state, T_pred, scene_mean,
-                   trace=None):
+                   trace=None, feedback=None, pred_gt=None, drop=None):
   """`Model.grid_decoder` under `tf.nn.raw_rnn` (code/pred_models.py:311-471)
   at test time (`input_onehot = not is_train or train_w_onehot`).
 
@@ -202,21 +281,30 @@ def greedy_decoder(P, cfg, s, kind, first_input, state, T_pred, scene_mean,
   c, h = state
   N, H, W, C = h.shape
   use_gnn = cfg.use_gnn and kind == "class"
+  # next-input rule of decoder_loop_fn (:388-436): "onehot" = one_hot(argmax(hidden2grid))
+  # (no gradient), "dense" = hidden2grid(h') itself (differentiable), "teacher" =
+  # pred_gt.read(time), i.e. the ground truth OF THE STEP THE INPUT FEEDS (:398)
+  if feedback is None:
+    feedback = "onehot" if kind == "class" else "dense"
   x_in = first_input
   outs, hs = [], []
   for t in range(T_pred):
     if use_gnn:
       h = h + gnn_dense(h, scene_mean)
     x = conv_layer(x_in, embW, embb, act=torch.tanh)
+    if drop is not None:
+      x = drop(x)                  # DropoutWrapper: input dropout (:241-249)
     c, h = convlstm_cell(x, c, h, kernel, biases)
     out = conv2d_same(h, outW)  # hidden2grid: no bias, identity (:948-950)
     outs.append(out)
     hs.append(h)
-    if kind == "class":
+    if feedback == "onehot":
       ids = argmax_lowest(out.reshape(N, H * W))
       x_in = one_hot_grid(ids, H, W, h.dtype)
       if trace is not None:
         trace.setdefault("greedy_ids_%d" % s, []).append(ids)
+    elif feedback == "teacher":
+      x_in = pred_gt[:, t + 1] if t + 1 < T_pred else None
     else:
       x_in = out
   return torch.stack(outs, dim=1), torch.stack(hs, dim=1)
@@ -342,7 +430,17 @@ def forward_tensors(P, cfg, feed, dtype=torch.float32, trace=None):
   (autograd-capable: the training oracle differentiates through it).
   Returns (grid_pred_decoded list_s, grid_pred_reg_decoded list_s, beam)."""
   assert cfg.use_scene_enc, "only the published --use_scene_enc wiring"
-  assert cfg.keep_prob == 1.0 or not cfg.is_train
+  # keep_prob = tf.cond(is_train, keep_prob, 1.0) (:130-132)
+  drop = None
+  if cfg.is_train and cfg.keep_prob < 1.0:
+    drop = _Dropout(cfg.keep_prob, int(feed.get("dropout_seed", 0)))
+  tf_mode = bool(getattr(cfg, "use_teacher_forcing", False))
+  if tf_mode:                      # :388-406
+    cls_fb = "teacher" if cfg.is_train else "dense"
+    reg_fb = "teacher" if cfg.is_train else "dense"
+  else:                            # input_onehot = not is_train or train_w_onehot (:285)
+    cls_fb = "onehot" if (not cfg.is_train or cfg.train_w_onehot) else "dense"
+    reg_fb = "dense"
   C = cfg.enc_hidden_size
   T_pred = int(feed["pred_length"])
   scene_convs = scene_stack(P, cfg, _t(feed["scene_feat"], dtype),
@@ -359,10 +457,10 @@ def forward_tensors(P, cfg, feed, dtype=torch.float32, trace=None):
     x_cls = scene_convs[s] * obs_oh                      # :210
     enc_c = run_encoder(
         x_cls, P["encoder_grid_class_%d/enc_grid_%d/kernel" % (s, s)],
-        P["encoder_grid_class_%d/enc_grid_%d/biases" % (s, s)], C)
+        P["encoder_grid_class_%d/enc_grid_%d/biases" % (s, s)], C, drop)
     enc_r = run_encoder(
         obs_reg, P["encoder_grid_reg_%d/enc_grid_regress_%d/kernel" % (s, s)],
-        P["encoder_grid_reg_%d/enc_grid_regress_%d/biases" % (s, s)], C)
+        P["encoder_grid_reg_%d/enc_grid_regress_%d/biases" % (s, s)], C, drop)
     scene_mean = scene_convs[s].mean(dim=1)              # :828
     if trace is not None:
       trace["enc_class_c_%d" % s] = enc_c[0].detach().numpy()
@@ -373,21 +471,27 @@ def forward_tensors(P, cfg, feed, dtype=torch.float32, trace=None):
     if cfg.use_beam_search:
       assert not cfg.is_train
       assert sum(cfg.use_grids) == 1, "only one scale test at a time"
+      reg_gt = None
       best, lg, ids, lps = beam_decoder(
           P, cfg, s, obs_oh[:, -1], enc_c, T_pred, scene_mean, trace)
       dec_cls = best
       beam_out = [lg, ids, lps]
     else:
-      # input_onehot = not is_train or train_w_onehot (:285)
-      assert (not cfg.is_train) or cfg.train_w_onehot, \
-          "training oracle: only the published --train_w_onehot wiring"
-      assert not (cfg.is_train and cfg.use_teacher_forcing)
+      cls_gt = reg_gt = None
+      if cls_fb == "teacher":      # grid_pred_labels_one_hot (:255-262) / grid_pred_regress
+        if getattr(cfg, "use_soft_grid_class", False):
+          cls_gt = _t(feed["grid_pred_soft"][s], dtype)
+        else:
+          cls_gt = one_hot_grid(np.asarray(feed["grid_pred_labels"][s]), H, W, dtype)
+        reg_gt = _t(feed["grid_pred_regress"][s], dtype)
       dec_cls, dec_h = greedy_decoder(
-          P, cfg, s, "class", obs_oh[:, -1], enc_c, T_pred, scene_mean, trace)
+          P, cfg, s, "class", obs_oh[:, -1], enc_c, T_pred, scene_mean, trace,
+          feedback=cls_fb, pred_gt=cls_gt, drop=drop)
       if trace is not None:
         trace["dec_class_h_%d" % s] = dec_h.detach().numpy()
     dec_reg, _ = greedy_decoder(
-        P, cfg, s, "reg", obs_reg[:, -1], enc_r, T_pred, scene_mean, trace)
+        P, cfg, s, "reg", obs_reg[:, -1], enc_r, T_pred, scene_mean, trace,
+        feedback=reg_fb, pred_gt=reg_gt if reg_fb == "teacher" else None, drop=drop)
     cls_out.append(dec_cls)
     reg_out.append(dec_reg)
   return cls_out, reg_out, beam_out
@@ -425,23 +529,53 @@ def huber_tf(pred, labels, delta=1.0):
   return (0.5 * q * q + delta * lin).mean()
 
 
+class _TFSoftmaxXent(torch.autograd.Function):
+  """tf.nn.softmax_cross_entropy_with_logits: loss = -sum(labels * log_softmax(logits));
+  REGISTERED gradient (TF-1.15 nn_grad.py, xent_op backprop) = grad * (softmax - labels)
+  whatever the labels sum to -- the true derivative only when they sum to 1.  The
+  reference feeds un-normalised soft labels (code/pred_models.py:1084-1124)."""
+
+  @staticmethod
+  def forward(ctx, logits, labels):
+    lsm = torch.log_softmax(logits, dim=-1)
+    ctx.save_for_backward(lsm, labels)
+    return -(labels * lsm).sum(-1)
+
+  @staticmethod
+  def backward(ctx, grad_loss):
+    lsm, labels = ctx.saved_tensors
+    return grad_loss[..., None] * (torch.exp(lsm) - labels), None
+
+
 def build_loss(P, cfg, cls_out, reg_out, feed, dtype=torch.float32):
-  """`Model.build_loss` (code/pred_models.py:961-1040), published switches
-  (hard labels, unmasked regression).  Returns (loss, wd_loss,
+  """`Model.build_loss` (code/pred_models.py:961-1040) incl. `--use_soft_grid_class`
+  (:974-990) and `--mask_grid_regression` (:999-1018).  Returns (loss, wd_loss,
   pred_grid_loss list [cls_0, reg_0, cls_1, ...])."""
-  assert not cfg.use_soft_grid_class and not cfg.mask_grid_regression
+  soft = bool(getattr(cfg, "use_soft_grid_class", False))
+  masked = bool(getattr(cfg, "mask_grid_regression", False))
   losses, pred_grid_loss = [], []
   for s, (H, W) in enumerate(cfg.scene_grids):
     if not cfg.use_grids[s]:
       continue
-    labels = torch.from_numpy(
-        np.asarray(feed["grid_pred_labels"][s]).astype("int64").reshape(-1))
     logits = cls_out[s].reshape(-1, H * W)                       # :984
-    lse = torch.logsumexp(logits, dim=-1)
-    ce = lse - logits.gather(1, labels[:, None])[:, 0]           # :991-993
+    if soft:
+      lab_soft = _t(feed["grid_pred_soft"][s], dtype).reshape(-1, H * W)
+      ce = _TFSoftmaxXent.apply(logits, lab_soft)                # :988-990
+      fg = lab_soft.reshape(-1) > 0
+    else:
+      labels = torch.from_numpy(
+          np.asarray(feed["grid_pred_labels"][s]).astype("int64").reshape(-1))
+      lse = torch.logsumexp(logits, dim=-1)
+      ce = lse - logits.gather(1, labels[:, None])[:, 0]         # :991-993
+      fg = F.one_hot(labels, H * W).reshape(-1) > 0
     cls_loss = ce.mean() * cfg.grid_loss_weight                  # :995, 1024
-    reg_loss = huber_tf(reg_out[s], _t(feed["grid_pred_regress"][s], dtype)) \
-        * cfg.grid_reg_loss_weight                               # :1020-1027
+    target = _t(feed["grid_pred_regress"][s], dtype)
+    if masked:                                                   # :999-1014
+      idx = torch.nonzero(fg)[:, 0]
+      reg_loss = huber_tf(reg_out[s].reshape(-1, 2)[idx], target.reshape(-1, 2)[idx])
+    else:
+      reg_loss = huber_tf(reg_out[s], target)                    # :1020-1022
+    reg_loss = reg_loss * cfg.grid_reg_loss_weight               # :1026-1027
     pred_grid_loss += [cls_loss, reg_loss]
     losses += [cls_loss, reg_loss]
   # wd_cost(".*/W", wd): wd * tf.nn.l2_loss(p) = wd * sum(p^2) / 2  (:1033, 1253-1275)
@@ -492,34 +626,82 @@ def adadelta_init(params):
   return {n: (np.zeros_like(v), np.zeros_like(v)) for n, v in params.items()}
 
 
+def optimizer_init(cfg, params):
+  """Slot variables as TF creates them: Adadelta / Adam two zero slots, Momentum one,
+  RMSProp `rms` = ONES and `momentum` = zeros; Adam's beta powers (float32 non-slot
+  variables, initial value beta) under the key ""."""
+  kind = cfg.optimizer
+  if kind == "adadelta":
+    return adadelta_init(params)
+  if kind == "momentum":
+    return {n: (np.zeros_like(v),) for n, v in params.items()}
+  if kind == "adam":
+    st = {n: (np.zeros_like(v), np.zeros_like(v)) for n, v in params.items()}
+    st[""] = (np.float32(0.9), np.float32(0.999))
+    return st
+  if kind == "rmsprop":
+    return {n: (np.ones_like(v), np.zeros_like(v)) for n, v in params.items()}
+  raise ValueError("Optimizer not implemented")       # code/pred_models.py:1681
+
+
+def apply_optimizer(cfg, lr, v, g, slots, npd, powers=None):
+  """One variable's update as the TF-1.15 training_ops kernels compute it
+  (code/pred_models.py:1667-1679 picks the optimizer).  -> (new value, new slots)."""
+  one = npd(1)
+  if cfg.optimizer == "adadelta":     # ApplyAdadelta, rho 0.95, eps 1e-8
+    rho, eps = npd(0.95), npd(1e-8)
+    acc, acc_up = slots
+    acc = acc.astype(npd) * rho + g * g * (one - rho)
+    upd = np.sqrt(acc_up.astype(npd) + eps) * (one / np.sqrt(acc + eps)) * g
+    new = (v.astype(npd) - upd * npd(lr)).astype(npd)
+    acc_up = acc_up.astype(npd) * rho + upd * upd * (one - rho)
+    return new, (acc, acc_up)
+  if cfg.optimizer == "momentum":     # ApplyMomentum, momentum 0.9, no Nesterov
+    (acc,) = slots
+    acc = acc.astype(npd) * npd(0.9) + g
+    return (v.astype(npd) - acc * npd(lr)).astype(npd), (acc,)
+  if cfg.optimizer == "adam":         # ApplyAdam, beta 0.9 / 0.999, eps 1e-8
+    m, vv = slots
+    b1p, b2p = powers
+    alpha = npd(np.float32(lr) * np.sqrt(np.float32(1) - np.float32(b2p)) /
+                (np.float32(1) - np.float32(b1p)))
+    m = m.astype(npd) + (g - m.astype(npd)) * npd(1.0 - 0.9)
+    vv = vv.astype(npd) + (g * g - vv.astype(npd)) * npd(1.0 - 0.999)
+    new = (v.astype(npd) - (m * alpha) / (np.sqrt(vv) + npd(1e-8))).astype(npd)
+    return new, (m, vv)
+  if cfg.optimizer == "rmsprop":      # ApplyRMSProp, decay 0.9, momentum 0, eps 1e-10
+    ms, mom = slots
+    ms = ms.astype(npd) + (g * g - ms.astype(npd)) * npd(1.0 - 0.9)
+    mom = mom.astype(npd) * npd(0.0) + (g * npd(lr)) * (one / np.sqrt(ms + npd(1e-10)))
+    return (v.astype(npd) - mom).astype(npd), (ms, mom)
+  raise ValueError("Optimizer not implemented")
+
+
 def train_step(params, opt_state, global_step, cfg, feed, dtype=torch.float32):
   """`Trainer.step` (code/pred_models.py:1719-1742): loss, gradients,
-  element-wise clip (:1700-1705), tf.train.AdadeltaOptimizer(lr, rho=0.95,
-  epsilon=1e-8).apply_gradients (:1671-1672, 1716), global_step += 1.
-  TF ApplyAdadelta:  accum = rho accum + (1-rho) g^2;
+  element-wise clip (:1700-1705), optimizer.apply_gradients (:1667-1679, 1716),
+  global_step += 1.  TF ApplyAdadelta:  accum = rho accum + (1-rho) g^2;
     update = sqrt(accum_update + eps) * rsqrt(accum + eps) * g;
-    var -= lr * update;  accum_update = rho accum_update + (1-rho) update^2.
+    var -= lr * update;  accum_update = rho accum_update + (1-rho) update^2
+  (the other optimizers: `apply_optimizer`).
   Returns (loss, wd_loss, pred_grid_loss, new_params, new_state, grads)."""
-  assert cfg.optimizer == "adadelta"
   loss, wd, pgl, grads = loss_and_grads(params, cfg, feed, dtype)
   lr = learning_rate(cfg, global_step)
   npd = np.float64 if dtype == torch.float64 else np.float32
-  rho, eps = npd(0.95), npd(1e-8)
   new_params, new_state = {}, {}
+  powers = opt_state.get("")
   for n, v in params.items():
     g = grads.get(n)
-    acc, acc_up = opt_state[n]
     if g is None:
-      new_params[n], new_state[n] = v, (acc, acc_up)
+      new_params[n], new_state[n] = v, opt_state[n]
       continue
     g = g.astype(npd)
     if cfg.clip_gradient_norm is not None:
       g = np.clip(g, -cfg.clip_gradient_norm, cfg.clip_gradient_norm)
-    acc = acc.astype(npd) * rho + g * g * (npd(1) - rho)
-    upd = np.sqrt(acc_up.astype(npd) + eps) * (npd(1) / np.sqrt(acc + eps)) * g
-    new_params[n] = (v.astype(npd) - upd * npd(lr)).astype(npd)
-    acc_up = acc_up.astype(npd) * rho + upd * upd * (npd(1) - rho)
-    new_state[n] = (acc, acc_up)
+    new_params[n], new_state[n] = apply_optimizer(cfg, lr, v, g, opt_state[n], npd, powers)
+  if powers is not None:
+    new_state[""] = (np.float32(powers[0]) * np.float32(0.9),
+                     np.float32(powers[1]) * np.float32(0.999))
   return loss, wd, pgl, new_params, new_state, grads
 
 

@@ -76,8 +76,71 @@ def train_case(name, cfg, seed, steps):
   print("wrote", name)
 
 
+# Switches of the reference beyond the published run: every case
+# is ONE config override set on scale 1 (9x16), batch 2; the frozen numbers are the
+# reference's own Trainer.step on the shim.  tests/shim_golden.py VARIANT_CASES mirrors
+# this table.
+VARIANT_CASES = [
+    # name, config overrides, steps
+    ("soft1", dict(use_soft_grid_class=True, soft_grid=1), 1),
+    ("soft7_mask", dict(use_soft_grid_class=True, soft_grid=7, mask_grid_regression=True), 1),
+    ("mask", dict(mask_grid_regression=True), 1),
+    ("teacher", dict(use_teacher_forcing=True), 1),
+    ("teacher_soft4", dict(use_teacher_forcing=True, use_soft_grid_class=True, soft_grid=4), 1),
+    ("no_onehot", dict(train_w_onehot=False), 1),
+    ("dropout07", dict(keep_prob=0.7), 1),
+    ("momentum", dict(optimizer="momentum", init_lr=0.01), 2),
+    ("rmsprop", dict(optimizer="rmsprop", init_lr=0.001), 2),
+    ("adam", dict(optimizer="adam", init_lr=0.001), 2),
+]
+VARIANT_SEED = synth.SEED_BASE + 40
+
+
+def variant_train_case(name, over, steps):
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), is_train=True, **over)
+  cfg.train_num_examples = 2
+  params = synth.make_params(cfg, seed=VARIANT_SEED, recurrent_gain=2.0, bias_scale=0.1)
+  out = {"steps": np.array([steps])}
+  slots, gs = {}, 0
+  for step in range(steps):
+    feed = synth.make_feed(cfg, seed=VARIANT_SEED + 100 + step)
+    feed["dropout_seed"] = 4242 + step
+    loss, wd, pgl, grads, params, slots, gs = rr.train_step(cfg, params, feed, slots, gs)
+    out["loss_%d" % step] = np.array([loss, wd] + pgl, dtype=np.float64)
+    for n in sorted(grads):
+      out["grad_%d|%s" % (step, n)] = digest(grads[n])
+    print(name, "step", step, "loss", loss)
+  for n in sorted(params):
+    out["param|%s" % n] = digest(params[n])
+  for n in sorted(slots):
+    if n == "":
+      out["opt_scalars"] = np.asarray(slots[n], dtype=np.float64)
+    else:
+      for i, sl in enumerate(slots[n]):
+        out["slot%d|%s" % (i, n)] = digest(np.asarray(sl))
+  out["global_step"] = np.array([gs])
+  np.savez_compressed(os.path.join(GOLD, "golden_shim_variant_%s.npz" % name), **out)
+  print("wrote golden_shim_variant_%s.npz" % name)
+
+
+def teacher_test_forward_case():
+  """--use_teacher_forcing at TEST time: the class decoder is fed its raw logits."""
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), use_teacher_forcing=True)
+  params = synth.make_params(cfg, seed=VARIANT_SEED + 1, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=VARIANT_SEED + 1)
+  cls, reg, _ = rr.forward(cfg, params, feed)
+  np.savez_compressed(os.path.join(GOLD, "golden_shim_variant_teacher_test.npz"),
+                      cls_1=np.asarray(cls[1]), reg_1=np.asarray(reg[1]))
+  print("wrote golden_shim_variant_teacher_test.npz")
+
+
 def main():
   assert rr.available(), "needs the reference checkout (/root/reference)"
+  if len(sys.argv) > 1 and sys.argv[1] == "variants":
+    for name, over, steps in VARIANT_CASES:
+      variant_train_case(name, over, steps)
+    teacher_test_forward_case()
+    return
   forward_case("golden_shim_greedy_cfg1.npz",
                synth.default_config(batch_size=4, use_grids=(1, 0)),
                synth.SEED_BASE + 0, 3.0, 0.1)

@@ -81,7 +81,8 @@ def _activation(tf, cfg):
   return tf.nn.tanh
 
 
-def build_model(cfg, params, feed, is_train=False, opt_slots=None, global_step=0):
+def build_model(cfg, params, feed, is_train=False, opt_slots=None, global_step=0,
+                dropout_seed=0):
   """Instantiate the reference's Model eagerly on `feed`:
   1. Model.__init__ with build_forward / build_loss stubbed -> placeholders only;
   2. the reference's own get_feed_dict(batch, is_train) -> values, bound;
@@ -93,7 +94,8 @@ def build_model(cfg, params, feed, is_train=False, opt_slots=None, global_step=0
   cfg.is_train = is_train
   p = dict(params)
   p["global_step"] = np.asarray(global_step, dtype="int32")
-  tf.reset_default_graph(params=p, strict=True, opt_slots=opt_slots)
+  tf.reset_default_graph(params=p, strict=True, opt_slots=opt_slots,
+                         dropout_seed=dropout_seed)
   real_fwd, real_loss = ref.Model.build_forward, ref.Model.build_loss
   ref.Model.build_forward = lambda self: None
   ref.Model.build_loss = lambda self: None
@@ -127,10 +129,12 @@ def forward(cfg, params, feed):
 
 def train_step(cfg, params, feed, opt_slots, global_step):
   """Trainer.step of the reference on the shim.
-  -> (loss, wd_loss, pred_grid_loss, grads {name: array}, new params, slots)"""
+  -> (loss, wd_loss, pred_grid_loss, grads {name: array}, new params, slots)
+  feed["dropout_seed"] seeds the shared dropout mask generator (keep_prob < 1)."""
   tf, ref, model, rcfg, batch = build_model(cfg, params, feed, is_train=True,
                                             opt_slots=opt_slots,
-                                            global_step=global_step)
+                                            global_step=global_step,
+                                            dropout_seed=int(feed.get("dropout_seed", 0)))
   trainer = ref.Trainer(model, rcfg)
   var = tf.trainable_variables()
   grads = {v._name: (None if g is None else g.numpy().copy())

@@ -287,15 +287,19 @@ class _State(object):
     self.strict = strict            # missing params are an error
     self.placeholders = []
     self.opt_slots = {}             # persists across resets if passed back in
+    self.dropout_seed = 0           # dropout_keep_mask seed of this graph
+    self.dropout_stream = 0         # draws so far (call order)
+    self.dropout_log = []           # (cell name, stream, shape) per draw
 
 
 _S = _State()
 
 
-def reset_default_graph(params=None, strict=True, opt_slots=None):
+def reset_default_graph(params=None, strict=True, opt_slots=None, dropout_seed=0):
   _S.reset(params, strict)
   if opt_slots is not None:
     _S.opt_slots = opt_slots
+  _S.dropout_seed = int(dropout_seed)
 
 
 def shim_state():
@@ -632,20 +636,56 @@ def _same_pads(in_size, k, stride):
 LSTMStateTuple = collections.namedtuple("LSTMStateTuple", ("c", "h"))
 
 
+class _TFSoftmaxXent(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, logits, labels):
+    lsm = torch.log_softmax(logits, dim=-1)
+    ctx.save_for_backward(lsm, labels)
+    return -(labels * lsm).sum(-1)
+
+  @staticmethod
+  def backward(ctx, grad_loss):
+    lsm, labels = ctx.saved_tensors
+    return grad_loss[..., None] * (torch.exp(lsm) - labels), None
+
+
+def dropout_keep_mask(shape, keep_prob, seed, stream):
+  """The reproducible Bernoulli(keep_prob) mask shared by this shim, the oracle and the
+  HIP engine (TF's own dropout draws from an unseeded random_uniform: the reference's
+  masks are not reproducible, only their distribution is).  Element i of draw `stream`
+  keeps iff the top 24 bits of a 32-bit integer hash of (seed, stream, i) fall below
+  keep_prob * 2^24."""
+  n = int(np.prod(shape))
+  i = np.arange(n, dtype=np.uint64)
+  x = (i * np.uint64(0x9E3779B1) + np.uint64(seed & 0xFFFFFFFF) * np.uint64(0x85EBCA77) +
+       np.uint64(stream & 0xFFFFFFFF) * np.uint64(0xC2B2AE3D)) & np.uint64(0xFFFFFFFF)
+  x ^= x >> np.uint64(16)
+  x = (x * np.uint64(0x7FEB352D)) & np.uint64(0xFFFFFFFF)
+  x ^= x >> np.uint64(15)
+  x = (x * np.uint64(0x846CA68B)) & np.uint64(0xFFFFFFFF)
+  x ^= x >> np.uint64(16)
+  thr = np.uint64(int(round(float(keep_prob) * (1 << 24))))
+  return ((x >> np.uint64(8)) < thr).reshape(shape)
+
+
 class _RNNCellNS(object):
   LSTMStateTuple = LSTMStateTuple
 
   class DropoutWrapper(object):
-    """tf.nn.rnn_cell.DropoutWrapper(cell, input_keep_prob): the V1 wrapper adds
-    no variable scope of its own.  Only keep_prob == 1 (identity) is needed:
-    every published run uses --keep_prob 1.0 (TRAINING.md:35)."""
+    """tf.nn.rnn_cell.DropoutWrapper(cell, input_keep_prob): the V1 wrapper adds no
+    variable scope of its own; it applies nn.dropout(inputs, keep_prob) -- keep with
+    probability keep_prob, scale kept elements by 1 / keep_prob -- to the cell INPUT
+    of every call.  The mask comes from `dropout_keep_mask` under the shim state's
+    `dropout_seed`; draws are numbered in call order (`dropout_stream`)."""
 
     def __init__(self, cell, input_keep_prob=1.0, output_keep_prob=1.0,
                  state_keep_prob=1.0, **unused):
-      for kp in (input_keep_prob, output_keep_prob, state_keep_prob):
+      for kp in (output_keep_prob, state_keep_prob):
         if float(_v(kp)) != 1.0:
-          raise NotImplementedError("DropoutWrapper with keep_prob != 1")
+          raise NotImplementedError("DropoutWrapper output/state keep_prob != 1")
       self._cell = cell
+      self._keep = float(_v(input_keep_prob))
+      self._stream_base = None
 
     @property
     def output_size(self):
@@ -655,6 +695,14 @@ class _RNNCellNS(object):
       return self._cell.zero_state(*a, **k)
 
     def __call__(self, inputs, state, scope=None):
+      if self._keep < 1.0:
+        x = _v(inputs)
+        stream = _S.dropout_stream
+        _S.dropout_stream += 1
+        _S.dropout_log.append((self._cell._name, stream, tuple(x.shape)))
+        keep = dropout_keep_mask(tuple(x.shape), self._keep, _S.dropout_seed, stream)
+        m = torch.from_numpy(keep).to(x.dtype)
+        inputs = Tensor(x * m * torch.tensor(1.0 / self._keep, dtype=x.dtype))
       return self._cell(inputs, state)
 
 
@@ -734,8 +782,13 @@ class _NN(object):
 
   @staticmethod
   def softmax_cross_entropy_with_logits(labels=None, logits=None, name=None):
-    lg = _v(logits)
-    return Tensor(-(_v(labels) * torch.log_softmax(lg, dim=-1)).sum(-1))
+    """loss = -sum(labels * log_softmax(logits)).  Its REGISTERED gradient w.r.t. the
+    logits (TF-1.15 nn_grad.py `_SoftmaxCrossEntropyWithLogitsGrad`, kernel xent_op:
+    `backprop = softmax - labels`) is grad_loss * (softmax(logits) - labels), whatever
+    the labels sum to -- it equals the true derivative only for labels that sum to 1;
+    the reference feeds un-normalised soft labels (code/pred_models.py:1088-1124, e.g.
+    soft_grid 1 sums to 1.8) and trains on exactly this gradient."""
+    return Tensor(_TFSoftmaxXent.apply(_v(logits), _v(labels)))
 
   @staticmethod
   def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, dtype=None,
@@ -909,17 +962,114 @@ class _AdadeltaOptimizer(object):
     return _TrainOp(run)
 
 
-class _Unsupported(object):
-  def __init__(self, *a, **k):
-    raise NotImplementedError("only AdadeltaOptimizer (the published configuration) "
-                              "is emulated")
+def _lr_value(lr):
+  v = _v(lr)
+  return float(v.item()) if isinstance(v, torch.Tensor) else float(v)
+
+
+class _SlotOptimizer(object):
+  """Shared plumbing: gradients are applied when the returned op is fetched; slots live
+  in shim_state().opt_slots[var name] as tuples (TF slot order)."""
+
+  def _update(self, gg, var, slots, lr, td):
+    raise NotImplementedError
+
+  def _begin(self):
+    pass
+
+  def _end(self):
+    pass
+
+  def apply_gradients(self, grads_and_vars, global_step=None, name=None):
+    gv = [(g, v) for g, v in grads_and_vars]
+
+    def run():
+      lr = _lr_value(self.lr)
+      with torch.no_grad():
+        self._begin()
+        for g, var in gv:
+          if g is None:
+            continue
+          gg = _v(g)
+          _S.opt_slots[var._name] = self._update(gg, var, _S.opt_slots.get(var._name), lr,
+                                                 gg.dtype)
+        self._end()
+        if global_step is not None:
+          global_step.value.add_(1)
+    return _TrainOp(run)
+
+
+class _MomentumOptimizer(_SlotOptimizer):
+  """tf.train.MomentumOptimizer(lr, momentum, use_nesterov=False); TF ApplyMomentum:
+  accum = accum * momentum + grad; var -= lr * accum.  Slot "Momentum"."""
+
+  def __init__(self, learning_rate, momentum, use_nesterov=False, **unused):
+    assert not use_nesterov
+    self.lr, self.momentum = learning_rate, momentum
+
+  def _update(self, gg, var, slots, lr, td):
+    acc = slots[0] if slots else torch.zeros_like(gg)
+    acc = acc * torch.tensor(self.momentum, dtype=td) + gg
+    var.value.sub_(acc * torch.tensor(lr, dtype=td))
+    return (acc,)
+
+
+class _AdamOptimizer(_SlotOptimizer):
+  """tf.train.AdamOptimizer(lr, beta1=0.9, beta2=0.999, epsilon=1e-8); TF ApplyAdam:
+  alpha = lr * sqrt(1 - beta2_power) / (1 - beta1_power); m += (g - m)(1 - beta1);
+  v += (g^2 - v)(1 - beta2); var -= m * alpha / (sqrt(v) + eps); afterwards
+  beta{1,2}_power *= beta{1,2} (float32 non-slot variables, initial value beta).
+  Slots "Adam" (m), "Adam_1" (v); the powers under the key "" of opt_slots."""
+
+  def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, **unused):
+    self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
+
+  def _begin(self):
+    pw = _S.opt_slots.get("", None)
+    if pw is None:
+      pw = (np.float32(self.b1), np.float32(self.b2))
+    self._pw = pw
+
+  def _update(self, gg, var, slots, lr, td):
+    m, v = slots if slots else (torch.zeros_like(gg), torch.zeros_like(gg))
+    b1p, b2p = self._pw
+    one = np.float32(1.0)
+    alpha = np.float32(lr) * np.sqrt(one - np.float32(b2p)) / (one - np.float32(b1p))
+    m = m + (gg - m) * torch.tensor(1.0 - self.b1, dtype=td)
+    v = v + (gg * gg - v) * torch.tensor(1.0 - self.b2, dtype=td)
+    var.value.sub_((m * torch.tensor(float(alpha), dtype=td)) /
+                   (torch.sqrt(v) + torch.tensor(self.eps, dtype=td)))
+    return (m, v)
+
+  def _end(self):
+    b1p, b2p = self._pw
+    _S.opt_slots[""] = (np.float32(b1p) * np.float32(self.b1),
+                        np.float32(b2p) * np.float32(self.b2))
+
+
+class _RMSPropOptimizer(_SlotOptimizer):
+  """tf.train.RMSPropOptimizer(lr, decay=0.9, momentum=0.0, epsilon=1e-10); TF
+  ApplyRMSProp: ms += (g^2 - ms)(1 - decay); mom = mom * momentum + (g * lr) *
+  rsqrt(ms + eps); var -= mom.  Slots "RMSProp" (ms, initialised to ONES) and
+  "RMSProp_1" (mom)."""
+
+  def __init__(self, learning_rate, decay=0.9, momentum=0.0, epsilon=1e-10, **unused):
+    self.lr, self.decay, self.momentum, self.eps = learning_rate, decay, momentum, epsilon
+
+  def _update(self, gg, var, slots, lr, td):
+    ms, mom = slots if slots else (torch.ones_like(gg), torch.zeros_like(gg))
+    ms = ms + (gg * gg - ms) * torch.tensor(1.0 - self.decay, dtype=td)
+    mom = mom * torch.tensor(self.momentum, dtype=td) + \
+        (gg * torch.tensor(lr, dtype=td)) * torch.rsqrt(ms + torch.tensor(self.eps, dtype=td))
+    var.value.sub_(mom)
+    return (ms, mom)
 
 
 class _Train(object):
   AdadeltaOptimizer = _AdadeltaOptimizer
-  MomentumOptimizer = _Unsupported
-  AdamOptimizer = _Unsupported
-  RMSPropOptimizer = _Unsupported
+  MomentumOptimizer = _MomentumOptimizer
+  AdamOptimizer = _AdamOptimizer
+  RMSPropOptimizer = _RMSPropOptimizer
 
   @staticmethod
   def exponential_decay(learning_rate, global_step, decay_steps, decay_rate,

@@ -67,3 +67,40 @@ def var_table(g):
     n, shp = str(s).split("|")
     out[n] = tuple(int(x) for x in shp.split(",")) if shp else ()
   return out
+
+
+# ---- switches beyond the published run: mirror of oracle/tf1_shim/make_shim_golden.py
+VARIANT_CASES = {
+    "soft1": (dict(use_soft_grid_class=True, soft_grid=1), 1),
+    "soft7_mask": (dict(use_soft_grid_class=True, soft_grid=7, mask_grid_regression=True), 1),
+    "mask": (dict(mask_grid_regression=True), 1),
+    "teacher": (dict(use_teacher_forcing=True), 1),
+    "teacher_soft4": (dict(use_teacher_forcing=True, use_soft_grid_class=True, soft_grid=4), 1),
+    "no_onehot": (dict(train_w_onehot=False), 1),
+    "dropout07": (dict(keep_prob=0.7), 1),
+    "momentum": (dict(optimizer="momentum", init_lr=0.01), 2),
+    "rmsprop": (dict(optimizer="rmsprop", init_lr=0.001), 2),
+    "adam": (dict(optimizer="adam", init_lr=0.001), 2),
+}
+VARIANT_SEED = synth.SEED_BASE + 40
+
+
+def variant_case(name):
+  """(fixture, cfg, params, feeds) of one reference Trainer run with a non-published
+  switch; feeds carry the dropout seed and (soft labels) the oracle's label maps."""
+  from oracle import multiverse_oracle as oracle
+  over, steps = VARIANT_CASES[name]
+  g = load("golden_shim_variant_%s.npz" % name)
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), is_train=True, **over)
+  cfg.train_num_examples = 2
+  params = synth.make_params(cfg, seed=VARIANT_SEED, recurrent_gain=2.0, bias_scale=0.1)
+  feeds = []
+  for step in range(steps):
+    feed = synth.make_feed(cfg, seed=VARIANT_SEED + 100 + step)
+    feed["dropout_seed"] = 4242 + step
+    if cfg.use_soft_grid_class:
+      feed["grid_pred_soft"] = [
+          oracle.soft_grid_labels(feed["grid_pred_labels"][s], h, w, cfg.soft_grid)
+          for s, (h, w) in enumerate(cfg.scene_grids)]
+    feeds.append(feed)
+  return g, cfg, params, feeds

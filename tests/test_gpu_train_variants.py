@@ -1,0 +1,155 @@
+# coding=utf-8
+"""GPU: the switches of the training / decoding path beyond the published run, through the
+C ABI, against (a) the frozen runs of the reference's own Trainer on the TF-1 shim
+(tests/golden/golden_shim_variant_*.npz) and (b) the CPU oracle:
+
+  --use_soft_grid_class (+ --soft_grid 1 / 4 / 7)   code/pred_models.py:974-990, 1077-1124
+  --mask_grid_regression                            :999-1018
+  --use_teacher_forcing (training AND test time)    :283-285, 388-406
+  training without --train_w_onehot                 :285, 427-435 (differentiable feedback)
+  --keep_prob < 1 (DropoutWrapper input dropout)    :130-132, 194-202, 241-249
+  --optimizer momentum / adam / rmsprop             :1667-1681
+
+Same bars as the published path: losses 1e-4 relative, every gradient tensor within 2e-3
+of its max (measured ~1e-6), parameters after the optimizer step(s).
+"""
+import numpy as np
+import pytest
+import torch
+
+from multiverse_amd import synth
+from oracle import multiverse_oracle as oracle
+
+import shim_golden as sg
+
+pytestmark = pytest.mark.gpu
+LOSS_VARIANTS = ["soft1", "soft7_mask", "mask", "teacher", "teacher_soft4", "no_onehot",
+                 "dropout07"]
+OPTIMIZERS = ["momentum", "rmsprop", "adam"]
+SLOTS = {"momentum": 1, "rmsprop": 2, "adam": 2}
+
+
+def _rel(a, b):
+  a = np.asarray(a, dtype=np.float64)
+  b = np.asarray(b, dtype=np.float64)
+  return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", LOSS_VARIANTS)
+def test_loss_and_decoder_switches(built_lib, name, mode):
+  g, cfg, params, feeds = sg.variant_case(name)
+  feed = feeds[0]
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode(mode)
+  eng.train_init()
+  eng.set_dropout_seed(feed["dropout_seed"])
+  loss, wd, pgl = eng.train_forward_backward(feed)
+  ref = g["loss_0"]
+  print("%s/%s: loss %.6f reference run %.6f parts %s / %s" % (name, mode, loss, ref[0], pgl,
+                                                              ref[2:]))
+  assert np.allclose([loss, wd] + pgl, ref, rtol=1e-4, atol=1e-5), (loss, ref)
+  _, _, _, og64 = oracle.loss_and_grads(params, cfg, feed, dtype=torch.float64)
+  worst = 0.0
+  for n, _ in eng.param_specs():
+    gr = eng.get_grad(n)
+    e_s, e_a = sg.digest_err(gr, g["grad_0|%s" % n])      # the reference's own gradients
+    e64 = _rel(gr, og64[n])                                # and the fp64 oracle, every element
+    worst = max(worst, e_s, e64)
+    assert e_s < 2e-3 and e_a < 2e-3 and e64 < 2e-3, (n, e_s, e_a, e64)
+  print("  worst gradient error (of max|g|): %.2e" % worst)
+  eng.train_apply(1.0)
+  for n, _ in eng.param_specs():
+    e_s, e_a = sg.digest_err(eng.get_param(n), g["param|%s" % n])
+    assert e_s < 1e-4 and e_a < 1e-5, (n, e_s, e_a)
+  eng.close()
+
+
+@pytest.mark.parametrize("name", OPTIMIZERS)
+def test_optimizers(built_lib, name):
+  g, cfg, params, feeds = sg.variant_case(name)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.train_init()
+  p, st = dict(params), oracle.optimizer_init(cfg, params)
+  for step, feed in enumerate(feeds):
+    loss, wd, pgl = eng.train_step(feed)
+    ol, _, _, p, st, _ = oracle.train_step(p, st, step, cfg, feed)
+    ref = g["loss_%d" % step]
+    print("%s step %d: loss %.6f oracle %.6f reference run %.6f" % (name, step, loss, ol, ref[0]))
+    tol = 2e-3 if (name == "adam" and step > 0) else 1e-4
+    assert abs(loss - ref[0]) < tol * max(1.0, abs(ref[0]))
+  lr = cfg.init_lr
+  for n, _ in eng.param_specs():
+    got = eng.get_param(n)
+    if name == "adam":
+      # Adam's step is ~lr * g / (|g| + 3e-7): wherever |g| sits at the fp32 noise floor
+      # the sign is noise, so parameters agree to a fraction of lr, the moments tightly
+      assert np.abs(got - p[n]).max() <= 2.0 * lr * len(feeds), n
+      assert np.median(np.abs(got - p[n])) <= 1e-3 * lr, n
+    else:
+      e_s, e_a = sg.digest_err(got, g["param|%s" % n])
+      upd = max(float(np.abs(p[n] - params[n]).max()), 1e-12)
+      assert np.abs(got - p[n]).max() <= 5e-3 * upd, (n, np.abs(got - p[n]).max(), upd)
+      assert e_s < 1e-4 and e_a < 1e-5, (n, e_s, e_a)
+    for i in range(SLOTS[name]):
+      sl = eng.get_opt_slot(n, i)
+      tol = 2e-2 if name == "adam" else 5e-3
+      assert _rel(sl, st[n][i]) < tol, (n, i, _rel(sl, st[n][i]))
+  if name == "adam":
+    assert np.allclose(eng.opt_scalars(), g["opt_scalars"], rtol=1e-6)
+    assert np.allclose(eng.opt_scalars(), (0.9 ** 3, 0.999 ** 3), rtol=1e-6)
+  assert eng.global_step == len(feeds)
+  eng.close()
+
+
+def test_unknown_optimizer_fails_like_the_reference(built_lib):
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), is_train=True)
+  cfg.optimizer = "sgd"
+  eng = built_lib.Engine(cfg, device=0)
+  with pytest.raises(built_lib.MvError, match="Optimizer not implemented"):
+    eng.train_init()
+  eng.close()
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+def test_test_time_teacher_forcing_feeds_raw_logits(built_lib, mode):
+  g = sg.load("golden_shim_variant_teacher_test.npz")
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), use_teacher_forcing=True)
+  params = synth.make_params(cfg, seed=sg.VARIANT_SEED + 1, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=sg.VARIANT_SEED + 1)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode(mode)
+  cls, reg = eng.forward_greedy(feed)
+  eng.close()
+  print("test-time teacher forcing %s: max|dcls| %.2e max|dreg| %.2e"
+        % (mode, np.abs(cls[1] - g["cls_1"]).max(), np.abs(reg[1] - g["reg_1"]).max()))
+  assert np.abs(cls[1] - g["cls_1"]).max() < 1e-4
+  assert np.abs(reg[1] - g["reg_1"]).max() < 1e-4
+  # and it is NOT the one-hot feedback
+  cfg0 = synth.default_config(batch_size=2, use_grids=(0, 1))
+  eng0 = built_lib.Engine(cfg0, device=0)
+  eng0.set_params(params)
+  cls0, _ = eng0.forward_greedy(feed)
+  eng0.close()
+  assert np.abs(cls0[1][:, 1:] - cls[1][:, 1:]).max() > 1e-3
+
+
+def test_dropout_mask_statistics_and_seed(built_lib):
+  """The engine's dropout: different seeds give different losses, the same seed the same
+  bits; the shared generator keeps ~keep_prob of the elements."""
+  g, cfg, params, feeds = sg.variant_case("dropout07")
+  feed = feeds[0]
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.train_init()
+  out = []
+  for seed in (1, 1, 2):
+    eng.set_dropout_seed(seed)
+    out.append(eng.train_forward_backward(feed)[0])
+  eng.close()
+  assert out[0] == out[1] and out[0] != out[2]
+  m = oracle.dropout_keep_mask((1 << 20,), 0.7, 99, 3)
+  assert abs(m.mean() - 0.7) < 2e-3

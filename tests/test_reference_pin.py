@@ -71,3 +71,40 @@ def test_live_reference_run_reproduces_the_fixture():
   assert (np.asarray(reg[1]) == g["reg_1"]).all()
   assert (np.asarray(beam[1]) == g["beam_ids"]).all()
   assert (np.asarray(beam[0]) == g["beam_logits"]).all()
+
+
+@pytest.mark.parametrize("name", sorted(sg.VARIANT_CASES))
+def test_oracle_variants_equal_reference_trainer(name):
+  """Soft grid labels (with TensorFlow's registered softmax-xent gradient), fg-masked
+  regression, teacher forcing, dense class feedback, input dropout and the three other
+  optimizers: the oracle against the reference's own Trainer.step on the shim."""
+  g, cfg, params, feeds = sg.variant_case(name)
+  p, st = dict(params), oracle.optimizer_init(cfg, params)
+  for step, feed in enumerate(feeds):
+    loss, wd, pgl, p, st, grads = oracle.train_step(p, st, step, cfg, feed)
+    ref = g["loss_%d" % step]
+    # a second Adam step starts from parameters that already differ by ~lr where |g| is
+    # at the fp32 noise floor (update ~ lr g / (|g| + 3e-7)): only its first step is tight
+    loose = name == "adam" and step > 0
+    assert np.allclose([loss, wd] + pgl, ref, rtol=1e-3 if loose else 2e-6, atol=1e-6), (loss, ref)
+    for n, gr in grads.items():
+      e_s, e_a = sg.digest_err(gr, g["grad_%d|%s" % (step, n)])
+      assert e_s < (5e-2 if loose else 2e-5) and e_a < (5e-2 if loose else 1e-4), (n, e_s, e_a)
+  if name != "adam":
+    for n in p:
+      e_s, e_a = sg.digest_err(p[n], g["param|%s" % n])
+      assert e_s < 2e-6 and e_a < 2e-6, (n, e_s, e_a)
+  if name == "adam":
+    assert np.allclose(st[""], g["opt_scalars"], rtol=1e-6)
+  assert int(g["global_step"][0]) == len(feeds)
+
+
+def test_oracle_test_time_teacher_forcing_equals_reference():
+  """--use_teacher_forcing without training: the class decoder eats its raw logits."""
+  g = sg.load("golden_shim_variant_teacher_test.npz")
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), use_teacher_forcing=True)
+  params = synth.make_params(cfg, seed=sg.VARIANT_SEED + 1, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=sg.VARIANT_SEED + 1)
+  cls, reg, _ = oracle.forward(params, cfg, feed)
+  assert np.abs(cls[1] - g["cls_1"]).max() <= 2e-5
+  assert np.abs(reg[1] - g["reg_1"]).max() <= 2e-5
