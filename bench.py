@@ -81,10 +81,12 @@ def main():
   ap.add_argument("--graph", type=int, default=None,
                   help="1: replay the forward as a captured hipGraph "
                        "(default: 0 greedy, 1 beam)")
-  ap.add_argument("--compute", choices=("f32", "f16x3"), default="f16x3",
+  ap.add_argument("--compute", choices=("f32", "f16x3", "bf16"), default="f16x3",
                   help="gate-convolution arithmetic of the inference forward: fp32 MFMA, "
                        "or f16x3 (two scaled fp16 planes per operand, three fp16 MFMAs "
-                       "per product, fp32 accumulate: fp32-class error)")
+                       "per product, fp32 accumulate: fp32-class error), or bf16 (BASELINE "
+                       "configs[4]: bf16 operands, one MFMA per product, fp32 accumulate; "
+                       "reduced precision, reported as such)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-batch", type=int, default=8)
   args = ap.parse_args()
@@ -196,7 +198,8 @@ def main():
     flops_traj *= 3.0   # forward + dgrad + wgrad of every gate convolution
     flops_traj_exec *= 3.0
   f16 = args.compute == "f16x3"
-  peak = PEAK_FP16_MFMA_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS
+  bf16 = args.compute == "bf16"
+  peak = PEAK_FP16_MFMA_TFLOPS if (f16 or bf16) else PEAK_FP32_MFMA_TFLOPS
   roofline = {
       "kernel": "+".join(mfma_kernels),
       "bound": "mfma",
@@ -253,7 +256,8 @@ def main():
   # of this same command (FETCH_SIZE and WRITE_SIZE cannot share a pass on
   # gfx950); bench.py cannot collect PMCs itself, so it quotes the committed
   # profile when the workload matches, else null.
-  pmc_name = "r1_f16x3_pmc_convlstm_step.json" if f16 else "r1_convlstm_pmc.json"
+  pmc_name = ("r1_f16x3_pmc_convlstm_step.json" if f16 else
+              "r2_bf16_pmc_convlstm_step.json" if bf16 else "r1_convlstm_pmc.json")
   pmc_path = os.path.join(ROOT, "profiles", pmc_name)
   if args.batch == 64 and not beam and not train and os.path.exists(pmc_path):
     with open(pmc_path) as f:
@@ -309,7 +313,9 @@ def main():
                     "RCCL all-reduce of the 21.3M-float gradient buffer" if world > 1
                     else "no all-reduce (1 rank)",
                     "forward, dgrad and wgrad on the fp16 matrix pipe (f16x3 split, "
-                    "fp32-class error)" if args.compute == "f16x3"
+                    "fp32-class error)" if args.compute == "f16x3" else
+                    "BASELINE configs[4]: forward in bf16 (one MFMA per product, reduced "
+                    "precision), dgrad and wgrad on the f16x3 split" if args.compute == "bf16"
                     else "fp32 matrix pipe"))
   else:
     metric = ("trajectories/sec (8-obs/12-pred, multi-scale 18x32+9x16 grid, "
@@ -319,7 +325,10 @@ def main():
                 "convolution on %s"
                 % (args.batch, ", hipGraph replay" if args.graph else "",
                    "the fp16 matrix pipe (f16x3 split, fp32-class error)" if
-                   args.compute == "f16x3" else "the fp32 matrix pipe"))
+                   args.compute == "f16x3" else
+                   "the bf16 matrix pipe (BASELINE configs[4]: bf16 operands, fp32 accumulate; "
+                   "REDUCED precision, not the fp32 headline)" if args.compute == "bf16"
+                   else "the fp32 matrix pipe"))
   out = {
       "metric": metric,
       "value": round(value, 2),
@@ -331,7 +340,11 @@ def main():
       "higher_is_better": True,
       "scaling": "weak",
       "vs_baseline": None,
-      "dtype": ("f16x3 (fp32 operands as two pre-scaled fp16 planes, 3 fp16 MFMAs per "
+      "dtype": ("bf16 (gate-convolution operands in bf16, one MFMA per product, fp32 "
+                "accumulate; fp32 state and every other kernel; REDUCED precision: logits within "
+                "3e-2 of their range, tests/test_gpu_bf16.py)" + (
+                    "; backward GEMMs on the f16x3 split" if train else "") if bf16 else
+                "f16x3 (fp32 operands as two pre-scaled fp16 planes, 3 fp16 MFMAs per "
                 "product, fp32 accumulate and state; measured error vs fp64 <= the fp32-MFMA "
                 "path's, argmax / beam ids bit-exact)" if (f16 and not train) else
                 "f16x3 gate convolutions (forward, dgrad, wgrad: fp32 operands as two "
@@ -351,7 +364,7 @@ def main():
       "roofline": roofline,
   }
 
-  if f16 and not train:
+  if (f16 or bf16) and not train:
     # the same workload on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), for reference
     eng.set_compute_mode("f32")
     one_step()
@@ -372,7 +385,7 @@ def main():
         "ms_per_step": round(1e3 * el / nref, 3), "steps": nref,
         "mfma_frac_of_fp32_peak": round(world * args.batch * nref / el / world *
                                         flops_traj_exec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
-    eng.set_compute_mode("f16x3")
+    eng.set_compute_mode(args.compute)
 
   if rank == 0 and world == 1 and not args.no_cpu_baseline and not beam:
     out["cpu_baseline"] = (cpu_baseline_train(min(args.cpu_batch, 4)) if train

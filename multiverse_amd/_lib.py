@@ -701,8 +701,9 @@ class Engine(object):
       raise MvError("mv_train_init has not been called")
 
   def set_compute_mode(self, mode):
-    """0 / "f32": fp32 MFMA; 1 / "f16x3": split-fp16 matrix pipe at fp32 accuracy."""
-    mode = {"f32": 0, "f16x3": 1}.get(mode, mode)
+    """0 / "f32": fp32 MFMA; 1 / "f16x3": split-fp16 matrix pipe at fp32 accuracy;
+    2 / "bf16": bf16 operands, fp32 accumulate and state (BASELINE configs[4])."""
+    mode = {"f32": 0, "f16x3": 1, "bf16": 2}.get(mode, mode)
     check(self.lib.mv_set_compute_mode(self.handle, int(mode)), self.handle)
 
   def set_graph_mode(self, on):

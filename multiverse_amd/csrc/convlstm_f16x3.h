@@ -34,6 +34,18 @@
 namespace mv {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// float -> bf16 bits, round to nearest even (operands of the bf16 mode)
+__host__ __device__ __forceinline__ uint16_t bf16_bits(float v) {
+  uint32_t u = __builtin_bit_cast(uint32_t, v);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);   // inf / nan: truncate
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__host__ __device__ __forceinline__ _Float16 bf16_as_half(float v) {
+  return __builtin_bit_cast(_Float16, bf16_bits(v));
+}
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPlanePad = 16;                       // zero halves in front of every operand plane
@@ -134,11 +146,11 @@ __global__ void pack_f16x3_kernel(const float* __restrict__ w, _Float16* __restr
 
 // x_small: the fp32 x chunk of the fp32 fragment pack, scaled by 2^16
 __global__ void scale_xchunk_kernel(const float* __restrict__ wpack, float* __restrict__ wx32,
-                                    int nch, size_t total) {
+                                    int nch, size_t total, float scale) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const size_t cb = idx / (kBN * kBK), i = idx - cb * (kBN * kBK);
-  wx32[idx] = wpack[(cb * nch + 0) * (size_t)(kBN * kBK) + i] * 65536.0f;
+  wx32[idx] = wpack[(cb * nch + 0) * (size_t)(kBN * kBK) + i] * scale;
 }
 
 // fp32 [M][C] -> two scaled fp16 planes in the operand layout (plane_index,
@@ -158,6 +170,13 @@ __global__ void split_planes_kernel(const float* __restrict__ in, _Float16* __re
   const f32x4* src = reinterpret_cast<const f32x4*>(in + (size_t)m * C + c8 * 8);
   const f32x4 v0 = src[0], v1 = src[1];
   f16x8 a, b;
+  const size_t o = plane_index(m, c8 * 8, C);
+  if (!p1) {          // bf16 mode: one unscaled plane
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = bf16_as_half(j < 4 ? v0[j] : v1[j - 4]);
+    *reinterpret_cast<f16x8*>(p0 + o) = a;
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float sv = (j < 4 ? v0[j] : v1[j - 4]) * kF16Scale;
@@ -165,7 +184,6 @@ __global__ void split_planes_kernel(const float* __restrict__ in, _Float16* __re
     a[j] = h0;
     b[j] = (_Float16)(sv - (float)h0);
   }
-  const size_t o = plane_index(m, c8 * 8, C);
   *reinterpret_cast<f16x8*>(p0 + o) = a;
   *reinterpret_cast<f16x8*>(p1 + o) = b;
 }
@@ -202,10 +220,14 @@ constexpr int kStageVec = kKpb * 2 * 4 * 64;     // f16x8 elements per stage (kK
 // EPI = kEpiLstm (forward, NG = 4) or kEpiStore (dgrad: the operand "h" is the gate
 // gradient G with 4C channels, the columns are input channels; NG active 32-column
 // sub-blocks in this column block; result scaled back by 2^-(8 + *g_exp)).
-template <int EPI, int NG>
+// NPL = operand planes: 2 = f16x3 (fp16 planes of 256 v, three MFMAs per product),
+// 1 = bf16 (ONE bf16 plane of v itself, one v_mfma_f32_32x32x16_bf16 per product, fp32
+// accumulate: the reduced-precision mode of BASELINE.json configs[4]; plane buffers and
+// packs hold bf16 bit patterns in the same 16-bit containers, same tile layout).
+template <int EPI, int NG, int NPL = 2>
 __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int cb, int mt,
                                                     int kslice, int n_kslice,
-                                                    f16x8* lds /* [2][kStageVec] */) {
+                                                    f16x8* lds /* [2][kKpb * NPL * 4 * 64] */) {
   const ConvLstmArgs& a = p.f;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -276,22 +298,23 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   // 3.7 VALU + 3.5 SALU -- against ~6 issue slots per 32-cycle MFMA: issue-bound at
   // 49 % MFMA busy, profiles/r1_f16x3_pmc_v2.json.)
   static_assert(kKpb == 3, "a stage is one stencil row");
+  constexpr int kBufVec = kKpb * NPL * 4 * 64;   // 16-B vectors per LDS stage buffer
   const int nxk = p.n_xk;
   const int nsteps = nxk + p.n_hk;
   const int nstages = nsteps / 3;
   const int nxst = nxk / 3;
   const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wp16) +
-                      (size_t)cb * p.w_ksteps * (2 * 4 * 64);
-  constexpr int kSV = 3 * 2 * NG * 64;         // 16-B vectors per stage (NG sub-blocks)
+                      (size_t)cb * p.w_ksteps * (NPL * 4 * 64);
+  constexpr int kSV = 3 * NPL * NG * 64;       // 16-B vectors per stage (NG sub-blocks)
   constexpr int kCopy = (kSV + kThreads16 - 1) / kThreads16;     // per thread
-  // stage vector v = ((kk*2 + plane)*NG + g)*64 + lane  ->  its place in the pack,
+  // stage vector v = ((kk*NPL + plane)*NG + g)*64 + lane  ->  its place in the pack,
   // which keeps four sub-block slots per (k-step, plane)
   auto pack_index = [&](int st, int v) -> size_t {
     const int ln = v & 63;
     int t = v >> 6;
     const int g = t % NG; t /= NG;
-    const int plane = t & 1, kk = t >> 1;
-    return ((size_t)(st * 3 + kk) * 2 + plane) * 256 + g * 64 + ln;
+    const int plane = t % NPL, kk = t / NPL;
+    return ((size_t)(st * 3 + kk) * NPL + plane) * 256 + g * 64 + ln;
   };
 
   const bool okx0 = (xpos - 1 >= 0) & (xpos - 1 < W), okx1 = (xpos >= 0) & (xpos < W),
@@ -337,91 +360,20 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
                          : -kPlanePad;                                                  \
     if (ISX) {                                                                          \
       A0 = *reinterpret_cast<const f16x8*>(x16 + off_);                                 \
-      A1 = *reinterpret_cast<const f16x8*>(x16 + xps + off_);                           \
+      if (NPL == 2) A1 = *reinterpret_cast<const f16x8*>(x16 + xps + off_);             \
     } else {                                                                            \
       A0 = *reinterpret_cast<const f16x8*>(h16 + off_);                                 \
-      A1 = *reinterpret_cast<const f16x8*>(h16 + hps + off_);                           \
+      if (NPL == 2) A1 = *reinterpret_cast<const f16x8*>(h16 + hps + off_);             \
     }                                                                                   \
   } while (0)
 
   // stage range of this workgroup (split-K: n_kslice equal ranges)
   const int st_lo = (nstages / n_kslice) * kslice;
   const int st_hi = n_kslice > 1 ? st_lo + nstages / n_kslice : nstages;
-#ifndef MV_CONV_VARIANT
-#define MV_CONV_VARIANT 1
-#endif
-#if MV_CONV_VARIANT == 0
-  // ---- variant 0 (round 1): weights staged global -> VGPR -> LDS, B fragments read
-  // from LDS right before their MFMAs
-  if (st_hi > st_lo) {
-    f16x8 stg[kCopy];
-#pragma unroll
-    for (int i = 0; i < kCopy; ++i)
-      if (i * kThreads16 + tid < kSV) stg[i] = wblk[pack_index(st_lo, i * kThreads16 + tid)];
-    {
-      f16x8* dst0 = lds + (st_lo & 1) * kStageVec;
-#pragma unroll
-      for (int i = 0; i < kCopy; ++i)
-        if (i * kThreads16 + tid < kSV) dst0[i * kThreads16 + tid] = stg[i];
-    }
-    bool c_isx = stage_isx(st_lo);
-    int c_rowoff = stage_rowoff(st_lo), c_cg = stage_cg(st_lo);
-    bool c_rowok = stage_rowok(st_lo);
-    f16x8 fa0, fa1;
-    MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 0, fa0, fa1);
-    __syncthreads();
-    for (int st = st_lo; st < st_hi; ++st) {
-      const bool more = st + 1 < st_hi;
-      const int stn = more ? st + 1 : st;
-      const bool n_isx = stage_isx(stn);
-      const int n_rowoff = stage_rowoff(stn), n_cg = stage_cg(stn);
-      const bool n_rowok = stage_rowok(stn);
-      const f16x8* buf = lds + (st & 1) * kStageVec;
-#pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
-        f16x8 fn0, fn1;
-        if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, fn0, fn1);
-        else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 0, fn0, fn1);   // (re-read at the very end)
-        // the next stage's weights are requested AFTER the first k-step's operands:
-        // vmcnt retires in order, and a copy issued at the top of the stage would
-        // sit in front of the A fragment the first MFMAs are waiting for
-        if (kk == 1 && more) {
-#pragma unroll
-          for (int i = 0; i < kCopy; ++i)
-            if (i * kThreads16 + tid < kSV) stg[i] = wblk[pack_index(st + 1, i * kThreads16 + tid)];
-        }
-        f16x8 b0[NG], b1[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          b0[g] = buf[((kk * 2 + 0) * NG + g) * 64 + lane];
-          b1[g] = buf[((kk * 2 + 1) * NG + g) * 64 + lane];
-        }
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, b0[g], acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b1[g], acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
-        fa0 = fn0; fa1 = fn1;
-      }
-      c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
-      if (more) {
-        f16x8* dst = lds + ((st + 1) & 1) * kStageVec;
-#pragma unroll
-        for (int i = 0; i < kCopy; ++i)
-          if (i * kThreads16 + tid < kSV) dst[i * kThreads16 + tid] = stg[i];
-      }
-      __syncthreads();
-    }
-  }
-#else
-  // ---- variant 1 (default): the stage copy is an LDS-DMA (global_load_lds, 16 B per
-  // lane: the pack IS the LDS image, lane-linear, so a wave's piece is one 1 KB run on
-  // both sides): no staging VGPRs (154 -> 126), no ds_write pass; 1.226 -> 1.207 ms per
-  // grouped launch.  Tried on top of it and dropped: a second
+  // The stage copy is an LDS-DMA (global_load_lds, 16 B per lane: the pack IS the LDS
+  // image, lane-linear, so a wave's piece is one 1 KB run on both sides).  Round 1 staged
+  // global -> VGPR -> ds_write: 24 more VGPRs (154 vs 126) and a write pass; 1.226 ->
+  // 1.207 ms per grouped launch.  Tried on top of it and dropped: a second
   // register set of B fragments read one k-step ahead (180 VGPRs, 2 waves per SIMD:
   // 1.317 ms; capped at 168 registers it spills: 1.380 ms) and A fragments requested
   // two k-steps ahead (140 VGPRs: 1.192 vs 1.184 ms on the same box) -- neither the
@@ -438,7 +390,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
               (__attribute__((address_space(3))) void*)(dstbuf + v0), 16, 0, 0);
       }
     };
-    stage_dma(st_lo, lds + (st_lo & 1) * kStageVec);
+    stage_dma(st_lo, lds + (st_lo & 1) * kBufVec);
     bool c_isx = stage_isx(st_lo);
     int c_rowoff = stage_rowoff(st_lo), c_cg = stage_cg(st_lo);
     bool c_rowok = stage_rowok(st_lo);
@@ -451,7 +403,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       const bool n_isx = stage_isx(stn);
       const int n_rowoff = stage_rowoff(stn), n_cg = stage_cg(stn);
       const bool n_rowok = stage_rowok(stn);
-      const f16x8* buf = lds + (st & 1) * kStageVec;
+      const f16x8* buf = lds + (st & 1) * kBufVec;
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
         f16x8 fn0, fn1;
@@ -459,29 +411,39 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 0, fn0, fn1);   // (re-read at the very end)
         // the DMA of the next stage goes out behind the first k-step's operands (vmcnt
         // retires in order); its target buffer was last read before the previous barrier
-        if (kk == 1 && more) stage_dma(st + 1, lds + ((st + 1) & 1) * kStageVec);
-        f16x8 b0[NG], b1[NG];
+        if (kk == 1 && more) stage_dma(st + 1, lds + ((st + 1) & 1) * kBufVec);
+        if constexpr (NPL == 2) {
+          f16x8 b0[NG], b1[NG];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          b0[g] = buf[((kk * 2 + 0) * NG + g) * 64 + lane];
-          b1[g] = buf[((kk * 2 + 1) * NG + g) * 64 + lane];
+          for (int g = 0; g < NG; ++g) {
+            b0[g] = buf[((kk * 2 + 0) * NG + g) * 64 + lane];
+            b1[g] = buf[((kk * 2 + 1) * NG + g) * 64 + lane];
+          }
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, b0[g], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b1[g], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
+        } else {
+          f16x8 b0[NG];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) b0[g] = buf[(kk * NG + g) * 64 + lane];
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, fa0), __builtin_bit_cast(bf16x8, b0[g]), acc[g], 0,
+                0, 0);
         }
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, b0[g], acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b1[g], acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
         fa0 = fn0; fa1 = fn1;
       }
       c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
       __syncthreads();
     }
   }
-#endif
 #undef MV_LOAD_A
   if (!wave_live) return;
 
@@ -514,7 +476,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   const int ch = cb * kChBlock + (lane & 31);
     const float bi = a.bias[ch], bj = a.bias[C + ch], bf = a.bias[2 * C + ch],
                 bo = a.bias[3 * C + ch];
-    _Float16* const tl = reinterpret_cast<_Float16*>(lds) + wave * 2048;
+    _Float16* const tl = reinterpret_cast<_Float16*>(lds) + wave * (1024 * NPL);
   #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -527,8 +489,9 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
           const int sr = a.src_row_c ? a.src_row_c[r] : r;
           cprev = a.c[((size_t)sr * HW + cell) * C + ch];
         }
-        const float gi = acc[0][reg] * kF16Unscale + bi, gj = acc[1][reg] * kF16Unscale + bj,
-                    gf = acc[2][reg] * kF16Unscale + bf, go = acc[3][reg] * kF16Unscale + bo;
+        constexpr float kUn = NPL == 2 ? kF16Unscale : 1.0f;   // bf16 operands are unscaled
+        const float gi = acc[0][reg] * kUn + bi, gj = acc[1][reg] * kUn + bj,
+                    gf = acc[2][reg] * kUn + bf, go = acc[3][reg] * kUn + bo;
         const float si = sigm_(gi), tj = tanh_(gj), sf = sigm_(gf + a.forget_bias),
                     so = sigm_(go);
         float cn = sf * cprev;
@@ -550,19 +513,23 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         // goes out as 16-byte vectors, 1 KB contiguous per tile and plane.  (Stored
         // straight from the accumulator layout these were 2-byte stores at a 16-byte
         // stride: slower than a separate split pass)
-        const float sc = hn_keep * kF16Scale;
-        const _Float16 h0 = (_Float16)sc;
         const int chl = lane & 31;
         const int tofs = (chl >> 4) * 512 + ((chl >> 3) & 1) * 256 + (chl & 7) + row * 8;
-        tl[tofs] = h0;
-        tl[1024 + tofs] = (_Float16)(sc - (float)h0);
+        if constexpr (NPL == 2) {
+          const float sc = hn_keep * kF16Scale;
+          const _Float16 h0 = (_Float16)sc;
+          tl[tofs] = h0;
+          tl[1024 + tofs] = (_Float16)(sc - (float)h0);
+        } else {
+          tl[tofs] = bf16_as_half(hn_keep);
+        }
       }
     }
     if (p.h16_out) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS ops of a wave retire in order
       const size_t tile0 = ((size_t)(m_wave >> 5) * (size_t)(C >> 4) + (size_t)cb * 2) * 512;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {        // q = plane * 2 + tile
+      for (int q = 0; q < 2 * NPL; ++q) {  // q = plane * 2 + tile
         const f16x8 v = *reinterpret_cast<const f16x8*>(tl + q * 512 + lane * 8);
         *reinterpret_cast<f16x8*>(p.h16_out + (size_t)(q >> 1) * p.h16_out_stride + tile0 +
                                   (size_t)(q & 1) * 512 + lane * 8) = v;
@@ -590,6 +557,72 @@ void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
     default: convlstm16_lds_body<kEpiLstm, 4>(g.p[3], block % g.p[3].f.n_colblocks, block / g.p[3].f.n_colblocks, 0, 1, lds); break;
   }
 }
+
+// The same step with ONE bf16 plane per operand (compute mode 2, BASELINE configs[4]).
+__global__ __launch_bounds__(kThreads16, MV_CONV_MINWAVES)
+void convlstm_step_bf16_kernel(const ConvLstm16Group g) {
+  __shared__ f16x8 lds[kStageVec];      // 2 buffers x 3 k-steps x 4 KB
+  int block = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxGroup - 1; ++i)
+    if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
+  if (pi > 0) block -= g.block_end[pi - 1];
+  switch (pi) {
+    case 0: convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[0], block % g.p[0].f.n_colblocks, block / g.p[0].f.n_colblocks, 0, 1, lds); break;
+    case 1: convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[1], block % g.p[1].f.n_colblocks, block / g.p[1].f.n_colblocks, 0, 1, lds); break;
+    case 2: convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[2], block % g.p[2].f.n_colblocks, block / g.p[2].f.n_colblocks, 0, 1, lds); break;
+    default: convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[3], block % g.p[3].f.n_colblocks, block / g.p[3].f.n_colblocks, 0, 1, lds); break;
+  }
+}
+
+// bf16 pack of the gate kernel: [cb][k-step][gate][lane][8], the f16x3 pack's order
+// with one unscaled bf16 plane.  Host and device twins (the device one runs after
+// every optimizer step).
+static inline size_t bf16_wpack_elems(int Cx, int C) {
+  return (size_t)(C / kChBlock) * (size_t)(f16x3_xksteps(Cx) + 9 * (C / 16)) * 4 * 64 * 8;
+}
+static inline void pack_bf16_weights(const float* w, int Cx, int C, _Float16* out) {
+  const int Cin = Cx + C, N4 = 4 * C;
+  const int nxk = f16x3_xksteps(Cx), nk = nxk + 9 * (C / 16);
+  for (int cb = 0; cb < C / kChBlock; ++cb)
+    for (int s = 0; s < nk; ++s) {
+      const bool is_x = s < nxk;
+      const int q = is_x ? s : s - nxk;
+      const int cg = q / 9, tap = q % 9;
+      for (int g = 0; g < 4; ++g)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 8; ++e) {
+            const int k = 8 * (l >> 5) + e;
+            const int ci = (is_x ? 0 : Cx) + cg * 16 + k;
+            const int n = g * C + cb * kChBlock + (l & 31);
+            out[(((size_t)cb * nk + s) * 4 + g) * 512 + (size_t)l * 8 + e] =
+                bf16_as_half(w[((size_t)tap * Cin + ci) * N4 + n]);
+          }
+    }
+}
+__global__ void pack_bf16_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
+                                 int Cx_total, int Cx16, int C, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx & 7;
+  const int l = (idx >> 3) & 63;
+  const int g = (idx >> 9) & 3;
+  const size_t t = idx >> 11;                    // cb * nk + s
+  const int nxk = 9 * (Cx16 / 16), nk = nxk + 9 * (C / 16);
+  const int s = t % nk, cb = t / nk;
+  const bool is_x = s < nxk;
+  const int q = is_x ? s : s - nxk;
+  const int cg = q / 9, tap = q - cg * 9;
+  const int k = 8 * (l >> 5) + e;
+  const int ci = (is_x ? 0 : Cx_total) + cg * 16 + k;
+  const int n = g * C + cb * kChBlock + (l & 31);
+  const int Cin = Cx_total + C, N4 = 4 * C;
+  out[idx] = bf16_as_half(w[((size_t)tap * Cin + ci) * N4 + n]);
+}
+
+static inline void launch_convlstm_bf16_steps(const ConvLstm16Args* probs, int n,
+                                              hipStream_t stream);
 
 // dgrad on the fp16 matrix pipe: d[h | x] = conv3x3(G, W^T flipped) with G as two
 // fp16 planes under a per-tensor power-of-two scale (split_planes_dyn_kernel) and
@@ -757,6 +790,20 @@ __global__ void split_planes_dyn_kernel(const float* __restrict__ in, _Float16* 
   const size_t o = plane_index(m, c8 * 8, C);
   *reinterpret_cast<f16x8*>(p0 + o) = a;
   *reinterpret_cast<f16x8*>(p1 + o) = b;
+}
+
+static inline void launch_convlstm_bf16_steps(const ConvLstm16Args* probs, int n,
+                                              hipStream_t stream) {
+  ConvLstm16Group g{};
+  g.n = n;
+  unsigned total = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = probs[i];
+    total += convlstm16_blocks(probs[i].f);
+    g.block_end[i] = (int32_t)total;
+  }
+  for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
+  hipLaunchKernelGGL(convlstm_step_bf16_kernel, dim3(total), dim3(kThreads16), 0, stream, g);
 }
 
 static inline void launch_convlstm16_steps(const ConvLstm16Args* probs, int n,

@@ -133,6 +133,13 @@ __device__ __forceinline__ void emb_store8(float* __restrict__ x, _Float16* p16,
   if (p16) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     h8 a, b;
+    const size_t o = plane_index((long long)m, c8 * 8, E);
+    if (pst == 0) {        // bf16 mode: one unscaled plane
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = bf16_half_bits(v[j]);
+      *reinterpret_cast<h8*>(p16 + o) = a;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float s = v[j] * 256.0f;
@@ -140,7 +147,6 @@ __device__ __forceinline__ void emb_store8(float* __restrict__ x, _Float16* p16,
       a[j] = h0;
       b[j] = (_Float16)(s - (float)h0);
     }
-    const size_t o = plane_index((long long)m, c8 * 8, E);
     *reinterpret_cast<h8*>(p16 + o) = a;
     *reinterpret_cast<h8*>(p16 + pst + o) = b;
   }

@@ -102,6 +102,8 @@ struct ConvCell {           // one ConvLSTMCell: packed kernel + biases
   DevBuf<float> wpack;
   DevBuf<_Float16> wp16;    // f16x3 compute mode: two scaled fp16 planes, fragment order
   DevBuf<float> wx32;       // f16x3, Cx <= 3: the fp32 x chunk scaled by 2^16
+  DevBuf<_Float16> wpb;     // bf16 compute mode: one unscaled bf16 plane, fragment order
+  DevBuf<float> wx32u;      // bf16, Cx <= 3: the fp32 x chunk, unscaled
   bool host_stale = false;  // device copy was updated by the optimizer
   int Cx = 0;
 };
@@ -171,7 +173,8 @@ struct mv_engine {
   DevBuf<int32_t> bm_trace;        // [N, B, T]
   DevBuf<float> bm_out_logits;     // [N, B, T, K]
   DevBuf<int32_t> bm_out_ids;      // [N, B, T]
-  // 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3 split on the fp16 matrix pipe
+  // 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3 split on the fp16 matrix pipe,
+  // 2 = bf16 operands / fp32 accumulate (one plane, one MFMA per product)
   int compute_mode = 0;
   DevBuf<_Float16> px16[mv::kMaxGroup], ph16[mv::kMaxGroup];   // fallback plane scratch per slot
   // planes that travel with an fp32 operand buffer: producers (conv epilogue, graph
@@ -179,12 +182,13 @@ struct mv_engine {
   struct PlaneBuf { _Float16* p; size_t n; bool valid; };
   std::map<const float*, PlaneBuf> planes;
   std::vector<std::unique_ptr<DevBuf<_Float16>>> plane_store;
-  _Float16* plane_out(const float* dst, size_t* stride) {   // producer side
-    if (compute_mode != 1) return nullptr;
+  // producer side; stride 0 tells the producer kernels to write ONE bf16 plane
+  _Float16* plane_out(const float* dst, size_t* stride) {
+    if (compute_mode == 0) return nullptr;
     auto it = planes.find(dst);
     if (it == planes.end()) return nullptr;
     it->second.valid = true;
-    *stride = it->second.n;
+    *stride = compute_mode == 2 ? 0 : it->second.n;
     return it->second.p;
   }
   void plane_invalidate(const float* dst) {
@@ -463,6 +467,46 @@ void ensure_packed16(mv_engine* e, ConvCell& cc) {
                       hipMemcpyHostToDevice));
 }
 
+// bf16 packs (one unscaled plane; the 2-channel regression-encoder input keeps its fp32
+// chunk), from the CURRENT weights.
+void ensure_packed_bf16(mv_engine* e, ConvCell& cc) {
+  if (cc.wpb.p) return;
+  const int C = e->cfg.hidden_size;
+  MV_REQUIRE(mv::f16x3_cx_supported(cc.Cx), "bf16: Cx %d unsupported", cc.Cx);
+  if (cc.host_stale) {
+    HIP_CHECK(hipMemcpy(cc.kernel->host.data(), cc.kernel->dev.p,
+                        cc.kernel->elems() * sizeof(float), hipMemcpyDeviceToHost));
+    cc.host_stale = false;
+  }
+  const bool small = cc.Cx > 0 && 9 * cc.Cx <= mv::kBK;
+  const int Cx16 = small ? 0 : cc.Cx;
+  std::vector<_Float16> pb(mv::bf16_wpack_elems(Cx16, C));
+  if (small) {
+    const int Cin = cc.Cx + C, N4 = 4 * C;
+    std::vector<float> wh((size_t)9 * C * N4);
+    for (int t = 0; t < 9; ++t)
+      memcpy(&wh[(size_t)t * C * N4], &cc.kernel->host[((size_t)t * Cin + cc.Cx) * N4],
+             (size_t)C * N4 * sizeof(float));
+    mv::pack_bf16_weights(wh.data(), 0, C, pb.data());
+    std::vector<float> packed(mv::convlstm_wpack_elems(cc.Cx, C));
+    mv::pack_convlstm_weights(cc.kernel->host.data(), cc.Cx, C, packed.data());
+    const int nch = mv::convlstm_xchunks(cc.Cx) + 9 * (C / mv::kBK);
+    std::vector<float> wx((size_t)(C / mv::kChBlock) * mv::kBN * mv::kBK);
+    for (int cb = 0; cb < C / mv::kChBlock; ++cb)
+      memcpy(&wx[(size_t)cb * mv::kBN * mv::kBK],
+             &packed[((size_t)cb * nch + 0) * mv::kBN * mv::kBK],
+             (size_t)mv::kBN * mv::kBK * sizeof(float));
+    cc.wx32u.alloc(wx.size());
+    HIP_CHECK(hipMemcpy(cc.wx32u.p, wx.data(), wx.size() * sizeof(float),
+                        hipMemcpyHostToDevice));
+  } else {
+    mv::pack_bf16_weights(cc.kernel->host.data(), cc.Cx, C, pb.data());
+  }
+  cc.wpb.alloc(pb.size());
+  HIP_CHECK(hipMemcpy(cc.wpb.p, pb.data(), pb.size() * sizeof(_Float16),
+                      hipMemcpyHostToDevice));
+}
+
 void ensure_params(mv_engine* e) {
   for (auto& p : e->params)
     MV_REQUIRE(p->set, "parameter %s not set (mv_set_param)", p->name.c_str());
@@ -474,6 +518,9 @@ void ensure_params(mv_engine* e) {
     if (e->compute_mode == 1)
       for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
         ensure_packed16(e, *cc);
+    if (e->compute_mode == 2)
+      for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
+        ensure_packed_bf16(e, *cc);
     if (!S.wq_valid) {     // hidden2grid tap packs, from the CURRENT device weights
       const int C = e->cfg.hidden_size;
       hipLaunchKernelGGL(mv::pack_h2g_kernel, dim3(cdiv((size_t)C * 32, 256)), dim3(256), 0,
@@ -530,9 +577,10 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     const ConvLstmArgs& a = probs[i];
     ConvCell* cc = cell_of_pack(e, a.wpack);
     mv::ConvLstm16Args& q = p16[i];
+    const bool bf16 = e->compute_mode == 2;
     q.f = a;
-    q.wp16 = cc->wp16.p;
-    q.wx32 = cc->wx32.p;
+    q.wp16 = bf16 ? cc->wpb.p : cc->wp16.p;
+    q.wx32 = bf16 ? cc->wx32u.p : cc->wx32.p;
     const size_t cells = (size_t)a.rows * a.H * a.W;
     q.n_xk = a.x_small ? 0 : mv::f16x3_xksteps(a.Cx);
     q.n_hk = a.zero_state ? 0 : 9 * (a.C / 16);
@@ -569,9 +617,10 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       MV_REQUIRE(e->px16[i].n >= 2 * pst, "internal: f16x3 x plane scratch");
       _Float16* p0 = e->px16[i].p + mv::kPlanePad;
       q.x16 = p0; q.x_plane_stride = (int64_t)pst;
-      launch(e, "split_planes", 0, 8.0 * n, [&] {
+      launch(e, "split_planes", 0, (bf16 ? 6.0 : 8.0) * n, [&] {
         hipLaunchKernelGGL(mv::split_planes_kernel, dim3(mv::split_planes_blocks(cells, a.Cx)),
-                           dim3(256), 0, e->stream, a.x, p0, p0 + pst, (int)cells, a.Cx);
+                           dim3(256), 0, e->stream, a.x, p0, bf16 ? (_Float16*)nullptr : p0 + pst,
+                           (int)cells, a.Cx);
       });
       }
     }
@@ -584,15 +633,19 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       MV_REQUIRE(e->ph16[i].n >= 2 * pst, "internal: f16x3 h plane scratch");
       _Float16* p0 = e->ph16[i].p + mv::kPlanePad;
       q.h16 = p0; q.h_plane_stride = (int64_t)pst;
-      launch(e, "split_planes", 0, 8.0 * n, [&] {
+      launch(e, "split_planes", 0, (bf16 ? 6.0 : 8.0) * n, [&] {
         hipLaunchKernelGGL(mv::split_planes_kernel, dim3(mv::split_planes_blocks(cells, a.C)),
-                           dim3(256), 0, e->stream, a.h, p0, p0 + pst, (int)cells, a.C);
+                           dim3(256), 0, e->stream, a.h, p0, bf16 ? (_Float16*)nullptr : p0 + pst,
+                           (int)cells, a.C);
       });
       }
     }
   }
   launch(e, "convlstm_step", flops, bytes, [&] {
-    mv::launch_convlstm16_steps(p16.data(), (int)p16.size(), e->stream);
+    if (e->compute_mode == 2)
+      mv::launch_convlstm_bf16_steps(p16.data(), (int)p16.size(), e->stream);
+    else
+      mv::launch_convlstm16_steps(p16.data(), (int)p16.size(), e->stream);
   }, dense);
 }
 
@@ -631,12 +684,21 @@ void run_scene(mv_engine* e) {
     const size_t total = (size_t)U * Ho * Wo * Co;
     float* out = e->scene_conv[i].p;
     const float *w = e->scene_W[i]->dev.p, *b = e->scene_b[i]->dev.p;
+    if (k == 1 && Co <= 64) {     // --scene_conv_kernel 1: the dense 1x1 projection, on MFMA
+      const size_t M = (size_t)U * Ho * Wo;
+      launch(e, "scene_proj1x1_mfma", 2.0 * M * Ci * Co,
+             4.0 * (total + (double)M * Ci), [&] {
+        hipLaunchKernelGGL(mv::scene_proj1x1_mfma_kernel, dim3(cdiv(M, 128)), dim3(256), 0,
+                           e->stream, in, w, b, out, U, Hi, Wi, Ci, Ho, Wo, Co);
+      });
+    } else {
     launch(e, "scene_conv_s2_tanh", 2.0 * total * k * k * Ci,
            4.0 * (total + (double)U * Hi * Wi * Ci), [&] {
       hipLaunchKernelGGL(mv::scene_conv_s2_tanh_kernel, dim3(cdiv(total, 256)),
                          dim3(256), 0, e->stream, in, w, b, out, U, Hi, Wi, Ci,
                          Ho, Wo, Co, k, pad_h / 2, pad_w / 2);
     });
+    }
     in = out; Hi = Ho; Wi = Wo; Ci = Co;
   }
   for (int s = 0; s < c.num_scales; ++s) {
@@ -703,7 +765,7 @@ void run_gnn(mv_engine* e, ScaleState& S, const float* h, const int32_t* src_row
   _Float16* p16 = e->plane_out(out, &pst);
   // f16x3 inference: the only consumer of h + GNN(h) is the gate convolution, which
   // reads the operand planes -- the fp32 copy is not written at all
-  const bool need_f32 = !(v2 && p16 && !e->train && e->compute_mode == 1);
+  const bool need_f32 = !(v2 && p16 && !e->train && e->compute_mode != 0);
   launch(e, "gnn_attend", cells * (9.0 * 2 * 2 * (c.hidden_size + c.scene_conv_dim) +
                                    9.0 * 2 * c.hidden_size),
          4.0 * cells * c.hidden_size * (1.0 + (need_f32 ? 1.0 : 0.0) + (p16 ? 1.0 : 0.0)) +
@@ -1386,6 +1448,7 @@ int mv_set_param(mv_handle h, const char* tf_name, const float* data,
       for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
         if (cc->kernel == p) {
           cc->wpack.release(); cc->wp16.release(); cc->wx32.release();
+          cc->wpb.release(); cc->wx32u.release();
           cc->host_stale = false;
         }
     }
@@ -1675,8 +1738,9 @@ int mv_set_opt_slot(mv_handle h, const char* tf_name, int32_t slot, const float*
 int mv_set_compute_mode(mv_handle h, int32_t mode) {
   if (!h) return 1;
   return guarded(h, [&] {
-    MV_REQUIRE(mode == 0 || mode == 1, "compute mode %d (0 = fp32 MFMA, 1 = f16x3)", mode);
-    if (mode == 1) {
+    MV_REQUIRE(mode >= 0 && mode <= 2, "compute mode %d (0 = fp32 MFMA, 1 = f16x3, 2 = bf16)",
+               mode);
+    if (mode != 0) {
       // operand-plane scratch per group slot: even slots class-sized (N*B rows),
       // odd slots regression-sized (N rows), largest enabled grid
       const mv_config& c = h->cfg;
@@ -1693,7 +1757,7 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
         HIP_CHECK(hipMemset(h->ph16[i].p, 0, h->ph16[i].n * sizeof(_Float16)));
       }
     }
-    if (mode == 1 && h->planes.empty()) {
+    if (mode != 0 && h->planes.empty()) {
       for (int s = 0; s < h->cfg.num_scales; ++s) {
         ScaleState& S = h->sc[s];
         if (!S.use) continue;

@@ -275,14 +275,23 @@ void run_pack(mv_engine* e, TrainChain& ch) {
                        e->stream, cc.kernel->dev.p, ch.wdpack.p, Cx, C, nch, total);
   }
   cc.host_stale = true;     // the host copy no longer matches the device weights
-  if (e->compute_mode == 1) {   // f16x3 planes of the updated kernel, on the device
+  if (e->compute_mode != 0) {   // matrix-pipe planes of the updated kernel, on the device
     const bool small = Cx > 0 && 9 * Cx <= mv::kBK;
     const int Cx16 = small ? 0 : Cx;
-    const size_t halves = mv::f16x3_wpack_elems(Cx16, C);
-    cc.wp16.alloc(halves);
-    const size_t threads = halves / 2;
-    hipLaunchKernelGGL(mv::pack_f16x3_kernel, dim3(cdiv(threads, 256)), dim3(256), 0,
-                       e->stream, cc.kernel->dev.p, cc.wp16.p, Cx, Cx16, C, threads);
+    if (e->compute_mode == 1) {
+      const size_t halves = mv::f16x3_wpack_elems(Cx16, C);
+      cc.wp16.alloc(halves);
+      const size_t threads = halves / 2;
+      hipLaunchKernelGGL(mv::pack_f16x3_kernel, dim3(cdiv(threads, 256)), dim3(256), 0,
+                         e->stream, cc.kernel->dev.p, cc.wp16.p, Cx, Cx16, C, threads);
+      cc.wpb.release(); cc.wx32u.release();
+    } else {                    // bf16 forward; dgrad / wgrad stay on the f16x3 split
+      const size_t halves = mv::bf16_wpack_elems(Cx16, C);
+      cc.wpb.alloc(halves);
+      hipLaunchKernelGGL(mv::pack_bf16_kernel, dim3(cdiv(halves, 256)), dim3(256), 0,
+                         e->stream, cc.kernel->dev.p, cc.wpb.p, Cx, Cx16, C, halves);
+      cc.wp16.release(); cc.wx32.release();
+    }
     {
       const size_t dh = mv::f16x3_dgrad_wpack_elems(Cx, C);
       ch.wd16.alloc(dh);
@@ -292,12 +301,14 @@ void run_pack(mv_engine* e, TrainChain& ch) {
     if (small) {
       const size_t n = (size_t)(C / mv::kChBlock) * mv::kBN * mv::kBK;
       const int nch = mv::convlstm_xchunks(Cx) + 9 * (C / mv::kBK);
-      cc.wx32.alloc(n);
+      DevBuf<float>& dst = e->compute_mode == 1 ? cc.wx32 : cc.wx32u;
+      dst.alloc(n);
       hipLaunchKernelGGL(mv::scale_xchunk_kernel, dim3(cdiv(n, 256)), dim3(256), 0, e->stream,
-                         cc.wpack.p, cc.wx32.p, nch, n);
+                         cc.wpack.p, dst.p, nch, n, e->compute_mode == 1 ? 65536.0f : 1.0f);
     }
   } else {
     cc.wp16.release(); cc.wx32.release();   // rebuilt lazily if the mode is switched on
+    cc.wpb.release(); cc.wx32u.release();
   }
 }
 
@@ -680,7 +691,7 @@ void run_dgrad_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     fl += flops[i];
     by += (double)probs[i].rows * probs[i].H * probs[i].W * (probs[i].C + 288.0) * 4.0;
   }
-  if (e->compute_mode == 1) {
+  if (e->compute_mode != 0) {
     run_dgrad_group_f16x3(e, probs, chains, slots, fl, by);
     return;
   }
@@ -702,7 +713,7 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
   MV_REQUIRE(mv::wgrad_partial_elems(wa) <= t.partial.n, "internal: wgrad partial buffer");
   const double cells = (double)wa.R * H * W;
   const size_t ncols = (size_t)9 * (ch.Cx + C) * 4 * C;
-  const bool f16 = e->compute_mode == 1 && mv::wgrad16_ok(W, C);
+  const bool f16 = e->compute_mode != 0 && mv::wgrad16_ok(W, C);
   if (f16) {
     // both operands as cell-contiguous fp16 plane pairs, then the f16x3 GEMMs
     // (convlstm_wgrad_f16x3.h): h rows, x rows; bias partials fall out of the G pass
@@ -817,7 +828,7 @@ void train_backward(mv_engine* e) {
       HIP_CHECK(hipMemsetAsync(R.dsmean.p, 0, (size_t)N * e->sc[s].K * D * sizeof(float),
                                e->stream));
   }
-  const bool f16 = e->compute_mode == 1;
+  const bool f16 = e->compute_mode != 0;
   if (f16) {
     MV_REQUIRE(Tp <= 32 && To <= 32, "f16x3 training: at most 32 steps per chain");
     HIP_CHECK(hipMemsetAsync(t.gmax.p, 0, t.gmax.n * sizeof(int32_t), e->stream));

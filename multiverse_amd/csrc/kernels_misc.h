@@ -14,13 +14,20 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // f16x3 compute mode (convlstm_f16x3.h): a producer of a ConvLSTM operand can
 // emit the two pre-scaled fp16 planes of its output next to the fp32 value, so
 // that no separate split pass is needed.  p16 == nullptr: off.
+// stride == 0 selects the bf16 mode: ONE plane holding bf16(v) (compute mode 2).
+__device__ __forceinline__ _Float16 bf16_half_bits(float v) {
+  uint32_t u = __builtin_bit_cast(uint32_t, v);
+  if ((u & 0x7f800000u) != 0x7f800000u) u += 0x7fffu + ((u >> 16) & 1u);   // RNE
+  return __builtin_bit_cast(_Float16, (uint16_t)(u >> 16));
+}
 __device__ __forceinline__ void emit_planes(_Float16* p16, size_t stride, size_t idx, int C,
                                             float v) {
   if (!p16) return;
-  const float s = v * 256.0f;
-  const _Float16 h0 = (_Float16)s;
   const size_t m = idx / (size_t)C;
   const size_t o = plane_index((long long)m, (int)(idx - m * C), C);
+  if (stride == 0) { p16[o] = bf16_half_bits(v); return; }
+  const float s = v * 256.0f;
+  const _Float16 h0 = (_Float16)s;
   p16[o] = h0;
   p16[stride + o] = (_Float16)(s - (float)h0);
 }
@@ -62,6 +69,52 @@ __global__ void scene_conv_s2_tanh_kernel(const float* __restrict__ in,
     }
   }
   out[idx] = tanhf(acc + b[co]);
+}
+
+// --scene_conv_kernel 1 (code/train.py:65, conv2d code/pred_models.py:155-165): the scene
+// stack degenerates to a strided 1x1 projection, a true dense GEMM
+//   out[(u, oy, ox)][co] = tanh(sum_ci in[u, 2 oy, 2 ox, ci] W[ci][co] + b[co])
+// (SAME padding of a 1x1 stride-2 conv is zero: the even input positions), M = U Ho Wo
+// rows, K = Ci (11 / 64), N = Co <= 64 -- the one place BASELINE.json's north_star puts on
+// the matrix cores.  v_mfma_f32_32x32x2_f32: exact fp32, the same ci-ordered fmaf chain as
+// the generic kernel above.  A wave owns 32 rows x Co columns (two accumulators).
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256)
+void scene_proj1x1_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                               const float* __restrict__ b, float* __restrict__ out, int U,
+                               int Hi, int Wi, int Ci, int Ho, int Wo, int Co) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int M = U * Ho * Wo;
+  const int m_wave = (blockIdx.x * 4 + wave) * 32;
+  if (m_wave >= M) return;
+  const int m = m_wave + (lane & 31);
+  const int kh = lane >> 5;                       // which of the k-step's two channels
+  size_t src = 0;
+  if (m < M) {
+    const int ox = m % Wo, r = m / Wo, oy = r % Ho, u = r / Ho;
+    src = (((size_t)u * Hi + 2 * oy) * Wi + 2 * ox) * Ci;
+  }
+  f32x16_t acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  const int col = lane & 31;
+  for (int kk = 0; kk < (Ci + 1) / 2; ++kk) {
+    const int ci = 2 * kk + kh;
+    const bool okc = ci < Ci;
+    const float a = (okc && m < M) ? in[src + ci] : 0.f;
+    const float b0 = (okc && col < Co) ? w[(size_t)ci * Co + col] : 0.f;
+    const float b1 = (okc && 32 + col < Co) ? w[(size_t)ci * Co + 32 + col] : 0.f;
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    const int mm = m_wave + row;
+    if (mm >= M) continue;
+    if (col < Co) out[(size_t)mm * Co + col] = tanhf(acc0[reg] + b[col]);
+    if (32 + col < Co) out[(size_t)mm * Co + 32 + col] = tanhf(acc1[reg] + b[32 + col]);
+  }
 }
 
 // mean over the T_o observed frames of the per-sample scene feature
@@ -251,16 +304,22 @@ void gnn_attend_kernel(const float* __restrict__ h,
   if (p16) {
     typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
     f16x4_t a, b;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float sc = o[j] * 256.0f;
-      const _Float16 h0 = (_Float16)sc;
-      a[j] = h0;
-      b[j] = (_Float16)(sc - (float)h0);
-    }
     const size_t idx = plane_index((long long)m * K + cell, lane * 4, C);   // 4 of one 8-group
-    *reinterpret_cast<f16x4_t*>(p16 + idx) = a;
-    *reinterpret_cast<f16x4_t*>(p16 + p16_stride + idx) = b;
+    if (p16_stride == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = bf16_half_bits(o[j]);
+      *reinterpret_cast<f16x4_t*>(p16 + idx) = a;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sc = o[j] * 256.0f;
+        const _Float16 h0 = (_Float16)sc;
+        a[j] = h0;
+        b[j] = (_Float16)(sc - (float)h0);
+      }
+      *reinterpret_cast<f16x4_t*>(p16 + idx) = a;
+      *reinterpret_cast<f16x4_t*>(p16 + p16_stride + idx) = b;
+    }
   }
 }
 
@@ -479,16 +538,22 @@ void gnn_attend_v2_kernel(const float* __restrict__ h, const float* __restrict__
       if (p16) {
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
         h8 pa, pb;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float sc = o[j] * 256.0f;
-          const _Float16 h0h = (_Float16)sc;
-          pa[j] = h0h;
-          pb[j] = (_Float16)(sc - (float)h0h);
-        }
         const size_t idx = plane_index(m2, ch, C);
-        *reinterpret_cast<h8*>(p16 + idx) = pa;
-        *reinterpret_cast<h8*>(p16 + p16_stride + idx) = pb;
+        if (p16_stride == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pa[j] = bf16_half_bits(o[j]);
+          *reinterpret_cast<h8*>(p16 + idx) = pa;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float sc = o[j] * 256.0f;
+            const _Float16 h0h = (_Float16)sc;
+            pa[j] = h0h;
+            pb[j] = (_Float16)(sc - (float)h0h);
+          }
+          *reinterpret_cast<h8*>(p16 + idx) = pa;
+          *reinterpret_cast<h8*>(p16 + p16_stride + idx) = pb;
+        }
       }
     }
     __syncthreads();

@@ -1,0 +1,141 @@
+# coding=utf-8
+"""GPU: the reduced-precision compute mode of BASELINE.json configs[4] -- bf16 operands of
+the gate convolutions (one v_mfma_f32_32x32x16_bf16 per product instead of the f16x3
+mode's three fp16 MFMAs), fp32 accumulate, fp32 state / LSTM update / every other kernel.
+
+This is NOT held to the fp32 bars (argmax bit-exact, 1e-4): bf16 carries 8 significand
+bits.  Its own stated tolerance, asserted here:
+  * class logits / regression maps within BF16_TOL = 3e-2 of the output range
+    (max |.| of the fp32 oracle's tensor) -- measured values are printed;
+  * SURVEY.md 8a-F6 audit on 256 trajectories: a per-step argmax may differ from the
+    fp32 oracle's only where the oracle's top-1 / top-2 margin is below MARGIN_TOL =
+    2 x BF16_TOL x range; the flip rate per margin decade is printed;
+  * one training step: losses within 2 % of the fp32 oracle's, every gradient tensor's
+    cosine with the oracle's > 0.98.
+"""
+import numpy as np
+import pytest
+
+from multiverse_amd import synth
+from oracle import multiverse_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+BF16_TOL = 3e-2
+
+
+def _engine(built_lib, cfg, params, mode="bf16"):
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode(mode)
+  return eng
+
+
+@pytest.mark.parametrize("gain,bias", [(1.0, 0.0), (3.0, 0.1)])
+def test_bf16_forward_within_its_stated_tolerance(built_lib, gain, bias):
+  cfg = synth.default_config(batch_size=4, use_grids=(1, 1))
+  params = synth.make_params(cfg, recurrent_gain=gain, bias_scale=bias)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 71)
+  eng = _engine(built_lib, cfg, params)
+  cls, reg = eng.forward_greedy(feed)
+  eng.set_graph_mode(True)
+  cls2, reg2 = eng.forward_greedy(feed)
+  eng.close()
+  ocls, oreg, _ = oracle.forward(params, cfg, feed)
+  for s in range(2):
+    assert (cls[s] == cls2[s]).all() and (reg[s] == reg2[s]).all()     # deterministic
+    # logits are comparable up to the first argmax flip of a row
+    N, Tp = 4, cfg.pred_len
+    gi = cls[s].reshape(N, Tp, -1).argmax(-1)
+    oi = ocls[s].reshape(N, Tp, -1).argmax(-1)
+    rng_c, rng_r = np.abs(ocls[s]).max(), np.abs(oreg[s]).max()
+    ec = 0.0
+    for n in range(N):
+      bad = np.nonzero(gi[n] != oi[n])[0]
+      upto = int(bad[0]) + 1 if bad.size else Tp
+      ec = max(ec, float(np.abs(cls[s][n, :upto] - ocls[s][n, :upto]).max()))
+    er = float(np.abs(reg[s] - oreg[s]).max())
+    print("bf16 gain %.0f scale %d: logits err %.3g of range %.3g (%.2e), reg err %.3g of "
+          "range %.3g (%.2e), %d / %d step ids equal"
+          % (gain, s, ec, rng_c, ec / rng_c, er, rng_r, er / rng_r, int((gi == oi).sum()),
+             gi.size))
+    assert ec <= BF16_TOL * rng_c
+    assert er <= BF16_TOL * rng_r or not (gi == oi).all()
+
+
+def test_bf16_argmax_flip_audit_256_trajectories(built_lib):
+  """per-step argmax flip rate against the oracle's margin histogram."""
+  N = 256
+  cfg = synth.default_config(batch_size=N, use_grids=(1, 1))
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 2, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 72)
+  ocls, _, _ = oracle.forward(params, cfg, feed)
+  flips_total = {}
+  for mode in ("bf16", "f16x3"):
+    eng = _engine(built_lib, cfg, params, mode)
+    cls, _ = eng.forward_greedy(feed)
+    eng.close()
+    for s in range(2):
+      Tp = cfg.pred_len
+      lg = ocls[s].reshape(N, Tp, -1)
+      rng = float(np.abs(lg).max())
+      margin = oracle.logit_margins(lg) / rng               # relative to the range
+      gi = cls[s].reshape(N, Tp, -1).argmax(-1)
+      oi = lg.argmax(-1)
+      # a row is comparable up to and including its first flip (the feedback diverges after)
+      comparable = np.zeros((N, Tp), dtype=bool)
+      first_flip = np.zeros((N, Tp), dtype=bool)
+      for n in range(N):
+        bad = np.nonzero(gi[n] != oi[n])[0]
+        upto = int(bad[0]) + 1 if bad.size else Tp
+        comparable[n, :upto] = True
+        if bad.size:
+          first_flip[n, bad[0]] = True
+      edges = [0, 1e-4, 1e-3, 1e-2, 1e-1, np.inf]
+      line = []
+      for lo, hi in zip(edges[:-1], edges[1:]):
+        sel = comparable & (margin >= lo) & (margin < hi)
+        line.append("[%g,%g): %d/%d" % (lo, hi, int((first_flip & sel).sum()), int(sel.sum())))
+      nflip = int(first_flip.sum())
+      flips_total[(mode, s)] = nflip
+      print("%-5s scale %d: rows with a flip %d/%d; first flips per oracle-margin bin "
+            "(fraction of the logit range): %s" % (mode, s, nflip, N, "  ".join(line)))
+      if mode == "bf16":
+        worst = float(margin[first_flip].max()) if nflip else 0.0
+        print("      largest oracle margin under a bf16 flip: %.3g of the range" % worst)
+        assert worst < 2 * BF16_TOL
+      else:
+        assert nflip == 0 or float(margin[first_flip].max()) < 1e-4 / rng
+  assert flips_total[("f16x3", 0)] <= 1 and flips_total[("f16x3", 1)] <= 1
+
+
+def test_bf16_training_step_and_beam_run(built_lib):
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1), is_train=True)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 73)
+  eng = _engine(built_lib, cfg, params)
+  eng.train_init()
+  loss, wd, pgl = eng.train_forward_backward(feed)
+  grads = {n: eng.get_grad(n) for n, _ in eng.param_specs()}
+  eng.train_apply(1.0)                       # device-side bf16 re-pack of the new weights
+  loss2, _, _ = eng.train_forward_backward(feed)
+  eng.close()
+  oloss, owd, opgl, og = oracle.loss_and_grads(params, cfg, feed)
+  print("bf16 train: loss %.5f oracle %.5f parts %s / %s; after one step %.5f"
+        % (loss, oloss, np.round(pgl, 4), np.round(opgl, 4), loss2))
+  assert abs(loss - oloss) < 2e-2 * abs(oloss) and np.isfinite(loss2) and loss2 < loss
+  worst = 1.0
+  for n in sorted(grads):
+    a, b = grads[n].reshape(-1).astype(np.float64), og[n].reshape(-1).astype(np.float64)
+    cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+    worst = min(worst, cos)
+    assert np.isfinite(a).all() and cos > 0.98, (n, cos)
+  print("  worst gradient cosine vs the fp32 oracle: %.5f" % worst)
+  # beam decode in bf16: runs, finite, ids in range, beams distinct
+  bcfg = synth.default_config(batch_size=2, use_grids=(1, 0), beam_size=5)
+  bparams = synth.make_params(bcfg, recurrent_gain=3.0, bias_scale=0.1)
+  beng = _engine(built_lib, bcfg, bparams)
+  arrs, s = beng.forward_beam(synth.make_feed(bcfg, seed=synth.SEED_BASE + 74))
+  beng.close()
+  assert np.isfinite(arrs["logits"]).all() and np.isfinite(arrs["logprobs"]).all()
+  assert arrs["ids"].min() >= 0 and arrs["ids"].max() < 18 * 32
+  assert (np.diff(arrs["logprobs"], axis=1) <= 1e-6).all()      # sorted best first

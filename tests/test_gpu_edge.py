@@ -88,3 +88,61 @@ def test_beam_variants(built_lib, mode, B, diverse, fix):
   _, oreg, obeam = oracle.forward(params, cfg, feed, trace=trace)
   compare_beams(arrs, oreg[1], obeam[0], obeam[1], obeam[2],
                 np.stack(trace["beam_step_topvals"], axis=-1), trace["beam_trace"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_scene_conv_kernel_1_is_a_dense_projection_on_mfma(built_lib, mode):
+  """--scene_conv_kernel 1 (code/train.py:65): the scene stack as two strided 1x1
+  projections, run as fp32 MFMA GEMMs (scene_proj1x1_mfma_kernel); forward parity and one
+  training step's gradients of the projection weights."""
+  import torch
+  cfg = synth.default_config(batch_size=3, use_grids=(1, 1), scene_conv_kernel=1)
+  params = synth.make_params(cfg, recurrent_gain=2.0, bias_scale=0.1)
+  assert params["person_pred/scene_conv1/W"].shape == (1, 1, 11, 64)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 66)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode(mode)
+  eng.set_profiling(True)
+  cls, reg = eng.forward_greedy(feed)
+  stats = eng.kernel_stats()
+  eng.set_profiling(False)
+  eng.close()
+  assert stats["scene_proj1x1_mfma"]["launches"] == 2 and "scene_conv_s2_tanh" not in stats
+  ocls, oreg, _ = oracle.forward(params, cfg, feed)
+  _check(cfg, cls, reg, ocls, oreg, cfg.pred_len)
+  tcfg = synth.default_config(batch_size=2, use_grids=(0, 1), scene_conv_kernel=1, is_train=True)
+  tparams = synth.make_params(tcfg, recurrent_gain=2.0, bias_scale=0.1)
+  tfeed = synth.make_feed(tcfg, seed=synth.SEED_BASE + 67)
+  eng = built_lib.Engine(tcfg, device=0)
+  eng.set_params(tparams)
+  eng.set_compute_mode(mode)
+  eng.train_init()
+  loss, _, _ = eng.train_forward_backward(tfeed)
+  ol, _, _, og = oracle.loss_and_grads(tparams, tcfg, tfeed, dtype=torch.float64)
+  assert abs(loss - ol) < 1e-4 * abs(ol)
+  for n in ("person_pred/scene_conv1/W", "person_pred/scene_conv2/W", "person_pred/scene_conv2/b"):
+    g = eng.get_grad(n)
+    assert np.abs(g - og[n]).max() <= 2e-3 * max(np.abs(og[n]).max(), 1e-30), n
+  eng.close()
+
+
+def test_second_engine_with_smaller_beam_does_not_shrink_the_lds_limit(built_lib):
+  """hipFuncAttributeMaxDynamicSharedMemorySize of the beam step is process
+  wide; a later, smaller engine / mv_op_beam_step must not lower it under a live one."""
+  big = synth.default_config(batch_size=1, use_grids=(1, 0), beam_size=20)
+  params = synth.make_params(big, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(big, seed=synth.SEED_BASE + 68)
+  e1 = built_lib.Engine(big, device=0)
+  e1.set_params(params)
+  a, _ = e1.forward_beam(feed)
+  small = synth.default_config(batch_size=1, use_grids=(0, 1), beam_size=2)
+  e2 = built_lib.Engine(small, device=0)          # 2 * 144 candidates: a much smaller LDS ask
+  rng = np.random.default_rng(0)
+  built_lib.op_beam_step(rng.normal(size=(1, 2, 16)).astype("float32"),
+                         np.zeros((1, 2), "float32"), 2, False, 1.0, 0)
+  b, _ = e1.forward_beam(feed)                    # 94 KB of LDS again
+  e1.close()
+  e2.close()
+  for k in a:
+    assert (a[k] == b[k]).all(), k
