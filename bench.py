@@ -112,13 +112,17 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
   red_dev = "cuda" if backend == "nccl" else "cpu"
   torch.cuda.set_device(local_rank)
-  use_dist = world > 1
+  # MV_ALLREDUCE=lib-force: run the multi-rank code path (process group, RCCL bootstrap,
+  # in-library all-reduce) on a world of ONE rank -- the only form a 1-GPU box can check
+  use_dist = world > 1 or (os.environ.get("MV_ALLREDUCE") == "lib-force" and
+                           "RANK" in os.environ)
   if use_dist:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend=backend)  # nccl == RCCL; barrier + max only
 
   beam = args.workload == "beam"
   train = args.workload == "train"
+  lib_allreduce = False
   if args.batch is None:
     args.batch = 128 if beam else 32 if train else 64
   if args.graph is None:
@@ -142,6 +146,9 @@ def main():
     from multiverse_amd import parallel
     eng.train_init(world=world)
     eng.upload_targets(feed)
+    # gradient all-reduce inside the library (RCCL, bucketed, side stream) unless
+    # MV_ALLREDUCE=torch or the backend is not RCCL
+    lib_allreduce = use_dist and parallel.init_engine_comm(eng)
 
   def one_step():
     if not train:
@@ -149,6 +156,9 @@ def main():
       return
     # Trainer.step on the resident batch: forward + loss + backward, all-reduce
     # (sum) of the flat gradient buffer over the ranks, clip + Adadelta
+    if lib_allreduce:
+      eng.train_step(None)       # buckets all-reduced during the backward pass, then 1/world
+      return
     eng.train_forward_backward(None)
     if use_dist:
       parallel.allreduce_engine_grads(eng, local_rank)
@@ -355,7 +365,11 @@ def main():
       "config": {"workload": workload,
                  "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                  "obs_len": cfg.obs_len, "pred_len": cfg.pred_len,
-                 "parallelism": ("data-parallel x%d, gradient all-reduce (RCCL)" % world
+                 "parallelism": ("data-parallel x%d, gradient all-reduce (RCCL%s)" % (
+                                     world, ", in-library: one bucket per ConvLSTM kernel on a "
+                                     "side stream, overlapped with the backward pass"
+                                     if lib_allreduce else " via torch.distributed, one "
+                                     "blocking call after the backward pass")
                                  if train else
                                  "batch-sharded x%d, no data-path collective" % world),
                  "alg_gflop_per_trajectory": round(flops_traj / 1e9, 2),
@@ -364,6 +378,13 @@ def main():
       "roofline": roofline,
   }
 
+  if train:
+    out["rccl_ranks"] = world if use_dist else 0
+    ci = eng.comm_info()
+    if ci:
+      out["allreduce"] = {"where": "libmultiverse_hip (RCCL)",
+                          "collectives_per_step": ci["buckets"],
+                          "MB_per_step": round(ci["bytes"] / 1e6, 1)}
   if (f16 or bf16) and not train:
     # the same workload on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), for reference
     eng.set_compute_mode("f32")

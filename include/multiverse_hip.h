@@ -225,6 +225,23 @@ int  mv_train_forward_backward(mv_handle h, const mv_inputs* in,
 int  mv_upload_targets(mv_handle h, const mv_targets* tg);
 int  mv_grad_buffer(mv_handle h, float** device_ptr, int64_t* elems);
 int  mv_train_apply(mv_handle h, float grad_scale);
+/* -- in-library gradient all-reduce (RCCL over xGMI) ----
+ * One process per GPU.  Rank 0 draws an id (mv_comm_unique_id) and hands its 128 bytes to
+ * the other ranks out of band (any bootstrap: a file, MPI, torch.distributed); every rank
+ * then calls mv_allreduce_init(h, rank, world, id) after hipSetDevice / mv_create on ITS
+ * device.  From then on mv_train_forward_backward leaves the SUM over the ranks in the
+ * gradient buffer: the buffer is reduced in buckets (one per ConvLSTM kernel + biases, then
+ * the small tensors as one group) on a side stream, each bucket issued as soon as its
+ * gradients are final, overlapped with the rest of the backward pass; mv_train_step
+ * applies 1/world before the clip and the optimizer.  RCCL is dlopen'ed at the first call;
+ * a single-device user never needs it. */
+#define MV_COMM_ID_BYTES 128
+int  mv_comm_unique_id(uint8_t* id_out /* [MV_COMM_ID_BYTES] */);
+int  mv_allreduce_init(mv_handle h, int32_t rank, int32_t world,
+                       const uint8_t* unique_id /* [MV_COMM_ID_BYTES] */);
+/* rank / world of the communicator, collectives and bytes of the last step */
+int  mv_allreduce_info(mv_handle h, int32_t* rank, int32_t* world, int32_t* buckets,
+                       double* bytes);
 /* tf.gradients(loss, var) of the last forward_backward, by variable name */
 int  mv_get_grad(mv_handle h, const char* tf_name, float* out, int64_t capacity_elems);
 int  mv_get_global_step(mv_handle h, int64_t* step);

@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "mv_upload_targets", "mv_grad_buffer", "mv_train_apply", "mv_get_grad", "mv_get_global_step",
     "mv_set_global_step", "mv_get_opt_slot", "mv_set_opt_slot",
     "mv_set_dropout_seed", "mv_get_opt_scalars", "mv_set_opt_scalars",
+    "mv_comm_unique_id", "mv_allreduce_init", "mv_allreduce_info",
     "mv_op_convlstm_bwd", "mv_op_gnn_bwd",
     "mv_set_grid_centers", "mv_upload_inputs_compact", "mv_upload_targets_compact",
 ]
@@ -218,6 +219,9 @@ def load():
   lib.mv_get_grad.argtypes = [h, C.c_char_p, _fp, C.c_int64]
   lib.mv_get_global_step.argtypes = [h, C.POINTER(C.c_int64)]
   lib.mv_set_global_step.argtypes = [h, C.c_int64]
+  lib.mv_comm_unique_id.argtypes = [_u8p]
+  lib.mv_allreduce_init.argtypes = [h, C.c_int32, C.c_int32, _u8p]
+  lib.mv_allreduce_info.argtypes = [h, _ip, _ip, _ip, _dp]
   lib.mv_set_dropout_seed.argtypes = [h, C.c_uint32]
   lib.mv_get_opt_scalars.argtypes = [h, _fp, _fp]
   lib.mv_set_opt_scalars.argtypes = [h, C.c_float, C.c_float]
@@ -345,6 +349,16 @@ def make_train_config(cfg, world=1):
   t.grid_loss_weight = float(cfg.grid_loss_weight)
   t.grid_reg_loss_weight = float(cfg.grid_reg_loss_weight)
   return t
+
+
+MV_COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+  """128-byte RCCL unique id (rank 0 draws it, every rank passes it to comm_init)."""
+  buf = (C.c_uint8 * MV_COMM_ID_BYTES)()
+  check(load().mv_comm_unique_id(buf))
+  return bytes(buf)
 
 
 class Engine(object):
@@ -676,6 +690,21 @@ class Engine(object):
     a = f32(value)
     check(self.lib.mv_set_opt_slot(self.handle, name.encode(), int(slot), fptr(a),
                                    a.size), self.handle)
+
+  # ---- in-library gradient all-reduce (RCCL)
+  def comm_init(self, rank, world, unique_id):
+    if len(unique_id) != MV_COMM_ID_BYTES:
+      raise MvError("unique id must be %d bytes" % MV_COMM_ID_BYTES)
+    buf = (C.c_uint8 * MV_COMM_ID_BYTES).from_buffer_copy(unique_id)
+    check(self.lib.mv_allreduce_init(self.handle, int(rank), int(world), buf), self.handle)
+    self.comm_world = int(world)
+
+  def comm_info(self):
+    r, w, b, by = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
+    if self.lib.mv_allreduce_info(self.handle, C.byref(r), C.byref(w), C.byref(b),
+                                  C.byref(by)) != 0:
+      return None
+    return {"rank": r.value, "world": w.value, "buckets": b.value, "bytes": by.value}
 
   def set_dropout_seed(self, seed):
     check(self.lib.mv_set_dropout_seed(self.handle, int(seed) & 0xFFFFFFFF), self.handle)

@@ -27,6 +27,7 @@
 #include "kernels_misc.h"
 #include "decode_tail.h"
 #include "train_kernels.h"
+#include "comm.h"
 
 struct mv_train_holder;
 
@@ -202,6 +203,8 @@ struct mv_engine {
     for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
     graphs.clear();
   }
+  // in-library gradient all-reduce (mv_allreduce_init, comm.h); null: single device
+  mv::Comm* comm = nullptr;
   // training state (mv_train_init)
   mv_train_holder* train = nullptr;
   bool train_packs_valid = false;
@@ -1400,6 +1403,14 @@ int mv_destroy(mv_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->drop_graphs();
+  if (h->comm) {
+    if (h->comm->stream) (void)hipStreamSynchronize(h->comm->stream);
+    if (h->comm->comm) (void)mv::rccl().CommDestroy(h->comm->comm);
+    if (h->comm->ready) (void)hipEventDestroy(h->comm->ready);
+    if (h->comm->done) (void)hipEventDestroy(h->comm->done);
+    if (h->comm->stream) (void)hipStreamDestroy(h->comm->stream);
+    delete h->comm;
+  }
   delete h->train;
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1643,7 +1654,9 @@ int mv_train_step(mv_handle h, const mv_inputs* in, const mv_targets* tg, mv_los
     MV_REQUIRE((in == nullptr) == (tg == nullptr),
                "mv_train_step: give both inputs and targets, or neither (resident)");
     train_fwd_bwd(h, in, tg, out);
-    train_apply(h, 1.0f);
+    // with a communicator the gradients are the SUM over the ranks (reduced inside
+    // train_fwd_bwd, overlapped with the backward pass): mean, then clip + optimizer
+    train_apply(h, h->comm ? 1.0f / (float)h->comm->world : 1.0f);
   });
 }
 
@@ -1684,6 +1697,51 @@ int mv_get_global_step(mv_handle h, int64_t* step) {
 int mv_set_global_step(mv_handle h, int64_t step) {
   if (!h || !h->train) return 1;
   h->train->st.global_step = step;
+  return 0;
+}
+
+int mv_comm_unique_id(uint8_t* id_out) {
+  return guarded(nullptr, [&] {
+    MV_REQUIRE(id_out, "mv_comm_unique_id: NULL buffer");
+    mv::RcclApi& r = mv::rccl();
+    MV_REQUIRE(r.ok, "RCCL unavailable: %s", r.error.c_str());
+    ncclUniqueId id;
+    ncclResult_t rc = r.GetUniqueId(&id);
+    MV_REQUIRE(rc == ncclSuccess, "ncclGetUniqueId: %s", r.GetErrorString(rc));
+    static_assert(sizeof(id) == MV_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_out, &id, sizeof(id));
+  });
+}
+
+int mv_allreduce_init(mv_handle h, int32_t rank, int32_t world, const uint8_t* unique_id) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(unique_id && world >= 1 && rank >= 0 && rank < world,
+               "mv_allreduce_init: bad arguments (rank %d of %d)", rank, world);
+    MV_REQUIRE(!h->comm, "mv_allreduce_init: communicator already initialised");
+    mv::RcclApi& r = mv::rccl();
+    MV_REQUIRE(r.ok, "RCCL unavailable: %s", r.error.c_str());
+    std::unique_ptr<mv::Comm> c(new mv::Comm());
+    c->rank = rank; c->world = world;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclResult_t rc = r.CommInitRank(&c->comm, world, id, rank);   // device: hipSetDevice above
+    MV_REQUIRE(rc == ncclSuccess, "ncclCommInitRank(rank %d of %d): %s", rank, world,
+               r.GetErrorString(rc));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    h->comm = c.release();
+  });
+}
+
+int mv_allreduce_info(mv_handle h, int32_t* rank, int32_t* world, int32_t* buckets,
+                      double* bytes) {
+  if (!h || !h->comm) return 1;
+  if (rank) *rank = h->comm->rank;
+  if (world) *world = h->comm->world;
+  if (buckets) *buckets = h->comm->buckets_last;
+  if (bytes) *bytes = h->comm->bytes_last;
   return 0;
 }
 

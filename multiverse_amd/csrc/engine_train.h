@@ -700,6 +700,70 @@ void run_dgrad_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
   });
 }
 
+// In-library gradient all-reduce (comm.h): the elements [off, off + n) of the flat
+// gradient buffer are final on the main stream -> reduce them (sum over the ranks) on the
+// side stream while the backward pass goes on.
+void comm_reduce_range(mv_engine* e, size_t off, size_t n) {
+  mv::Comm* c = e->comm;
+  if (!c || n == 0) return;
+  TrainState& t = TS(e);
+  HIP_CHECK(hipEventRecord(c->ready, e->stream));
+  HIP_CHECK(hipStreamWaitEvent(c->stream, c->ready, 0));
+  float* p = t.grad.p + off;
+  ncclResult_t rc = mv::rccl().AllReduce(p, p, n, ncclFloat, ncclSum, c->comm, c->stream);
+  MV_REQUIRE(rc == ncclSuccess, "ncclAllReduce(%zu floats at %zu): %s", n, off,
+             mv::rccl().GetErrorString(rc));
+  c->buckets_last += 1;
+  c->bytes_last += 4.0 * n;
+}
+// one bucket = a ConvLSTM kernel and its biases (adjacent in the parameter table)
+void comm_reduce_cell(mv_engine* e, const ConvCell& cc) {
+  if (!e->comm) return;
+  TrainState& t = TS(e);
+  const size_t ik = param_index(e, cc.kernel), ib = param_index(e, cc.biases);
+  MV_REQUIRE(ib == ik + 1, "internal: kernel / biases not adjacent");
+  const size_t end = ib + 1 < t.goff.size() ? t.goff[ib + 1] : t.total_elems;
+  comm_reduce_range(e, t.goff[ik], end - t.goff[ik]);
+}
+// everything that is not a ConvLSTM bucket (scene convs, embeddings, hidden2grid), as
+// one group once the weight-decay pass has touched the */W gradients; then the main
+// stream waits for the side stream
+void comm_reduce_rest_and_join(mv_engine* e) {
+  mv::Comm* c = e->comm;
+  if (!c) return;
+  TrainState& t = TS(e);
+  std::vector<char> taken(e->params.size(), 0);
+  for (int s = 0; s < e->cfg.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg}) {
+      taken[param_index(e, cc->kernel)] = 1;
+      taken[param_index(e, cc->biases)] = 1;
+    }
+  }
+  HIP_CHECK(hipEventRecord(c->ready, e->stream));
+  HIP_CHECK(hipStreamWaitEvent(c->stream, c->ready, 0));
+  mv::RcclApi& r = mv::rccl();
+  ncclResult_t rc = r.GroupStart();
+  MV_REQUIRE(rc == ncclSuccess, "ncclGroupStart: %s", r.GetErrorString(rc));
+  for (size_t i = 0; i < e->params.size();) {
+    if (taken[i]) { ++i; continue; }
+    size_t j = i;
+    while (j < e->params.size() && !taken[j]) ++j;      // a contiguous run of small tensors
+    const size_t off = t.goff[i], end = j < t.goff.size() ? t.goff[j] : t.total_elems;
+    float* p = t.grad.p + off;
+    rc = r.AllReduce(p, p, end - off, ncclFloat, ncclSum, c->comm, c->stream);
+    MV_REQUIRE(rc == ncclSuccess, "ncclAllReduce: %s", r.GetErrorString(rc));
+    c->buckets_last += 1;
+    c->bytes_last += 4.0 * (end - off);
+    i = j;
+  }
+  rc = r.GroupEnd();
+  MV_REQUIRE(rc == ncclSuccess, "ncclGroupEnd: %s", r.GetErrorString(rc));
+  HIP_CHECK(hipEventRecord(c->done, c->stream));
+  HIP_CHECK(hipStreamWaitEvent(e->stream, c->done, 0));
+}
+
 // gslot: first gmax slot of the chain's steps (f16x3 mode), see train_backward
 void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H, int W,
                int gslot) {
@@ -967,8 +1031,10 @@ void train_backward(mv_engine* e) {
     const size_t NK = (size_t)N * S.K, NKC = NK * C;
     for (int b = 0; b < 2; ++b) {
       run_wgrad(e, R.enc[b], R.hs[b].p, To, S.H, S.W, (2 * s + b) * 64 + 32);
+      comm_reduce_cell(e, *R.enc[b].cell);       // bucket: overlaps the remaining wgrads
       const float* hin = (b == 0 && c.use_gnn) ? R.hg.p : R.hs[b].p + (size_t)To * NKC;
       run_wgrad(e, R.dec[b], hin, Tp, S.H, S.W, (2 * s + b) * 64);
+      comm_reduce_cell(e, *R.dec[b].cell);
     }
     // class-decoder grid_emb: its input maps of all steps, [Tp][N][K] -- slot 0 the
     // one-hot of the last observed cell, slot t the one-hot argmax / the logits of step
@@ -1066,6 +1132,7 @@ void train_backward(mv_engine* e) {
     hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream,
                        t.losses.p + base + 1, (size_t)nW, t.losses.p + base, 1.0f, 0);
   }
+  comm_reduce_rest_and_join(e);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1095,6 +1162,7 @@ void train_fwd_bwd(mv_engine* e, const mv_inputs* in, const mv_targets* tg, mv_l
     train_pack_all(e);
     e->train_packs_valid = true;
   }
+  if (e->comm) { e->comm->buckets_last = 0; e->comm->bytes_last = 0; }
   train_forward(e);
   train_losses(e);
   train_backward(e);

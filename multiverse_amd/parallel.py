@@ -118,6 +118,29 @@ def allreduce_engine_grads(engine, device_index=None):
   torch.cuda.synchronize(device_index)
 
 
+def init_engine_comm(engine):
+  """Give `engine` an RCCL communicator over the ranks of the initialised torch process
+  group (used only as the bootstrap: rank 0's 128-byte unique id is broadcast through
+  it).  Afterwards `Engine.train_step` all-reduces inside the library, bucketed and
+  overlapped with the backward pass (include/multiverse_hip.h mv_allreduce_init).
+  Returns False -- and changes nothing -- for world 1, a non-RCCL backend (gloo: several
+  ranks may share one GPU there, which RCCL refuses) or MV_ALLREDUCE=torch."""
+  import os
+  import torch.distributed as dist
+  from multiverse_amd import _lib
+  mode = os.environ.get("MV_ALLREDUCE", "lib")
+  if not (dist.is_available() and dist.is_initialized()):
+    return False
+  # "lib-force": also on a world of one rank (exercises this bootstrap on a 1-GPU box)
+  if (world_size() == 1 and mode != "lib-force") or dist.get_backend() != "nccl" or \
+      mode == "torch":
+    return False
+  box = [_lib.comm_unique_id() if dist.get_rank() == 0 else None]
+  dist.broadcast_object_list(box, src=0)
+  engine.comm_init(dist.get_rank(), dist.get_world_size(), box[0])
+  return True
+
+
 def allreduce_mean_arrays(arrays):
   """In-place mean over ranks of a dict of numpy arrays (gloo / host path; used
   by the CPU tests of the data-parallel gradient rule)."""

@@ -298,6 +298,8 @@ class Trainer(object):
       raise _lib.MvError("Trainer needs a config with is_train=True")
     from multiverse_amd import parallel
     model.engine.train_init(config, world=parallel.world_size())
+    # data parallel over RCCL: the all-reduce runs inside the library
+    self.lib_allreduce = parallel.init_engine_comm(model.engine)
 
   @property
   def global_step(self):
@@ -323,6 +325,9 @@ class Trainer(object):
       feed = None
     if world == 1:
       loss, wd_loss, pred_grid_loss = eng.train_step(feed)
+    elif self.lib_allreduce:     # buckets reduced on a side stream during the backward pass
+      loss, wd_loss, pred_grid_loss = eng.train_step(feed)
+      loss, pred_grid_loss = parallel.mean_over_ranks(loss, pred_grid_loss)
     else:
       loss, wd_loss, pred_grid_loss = eng.train_forward_backward(feed)
       parallel.allreduce_engine_grads(eng)

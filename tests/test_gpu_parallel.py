@@ -125,3 +125,36 @@ def test_two_ranks_one_gpu_engine_equals_single_process(built_lib, tmp_path):
   ieng.close()
   assert (cls[0] == dp["cls0"]).all() and (cls[1] == dp["cls1"]).all()
   assert (reg[0] == dp["reg0"]).all() and (reg[1] == dp["reg1"]).all()
+
+
+def test_in_library_rccl_allreduce_world1_is_the_identity(built_lib):
+  """mv_allreduce_init + the bucketed side-stream all-reduce inside mv_train_step, on a
+  world of one rank (RCCL refuses two ranks on one GPU): same bits as without a
+  communicator, every element of the gradient buffer covered exactly once."""
+  from multiverse_amd import synth
+  cfg = _cfg(2, synth, True)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0, bias_scale=0.1)
+  outs = []
+  for with_comm in (False, True):
+    eng = built_lib.Engine(cfg, device=0)
+    eng.set_params(params)
+    eng.set_compute_mode("f16x3")
+    eng.train_init()
+    if with_comm:
+      eng.comm_init(0, 1, built_lib.comm_unique_id())
+    for step in range(2):
+      eng.train_step(synth.make_feed(cfg, seed=synth.SEED_BASE + 200 + step))
+    info = eng.comm_info()
+    outs.append({n: eng.get_param(n) for n, _ in eng.param_specs()})
+    if with_comm:
+      _, nelem = eng.grad_buffer()
+      print("in-library all-reduce:", info)
+      assert info["world"] == 1 and info["rank"] == 0
+      # 8 ConvLSTM buckets + the scene convs + one run of small tensors per scale
+      assert info["buckets"] == 8 + 1 + 2
+      assert info["bytes"] == 4.0 * nelem
+    else:
+      assert info is None
+    eng.close()
+  for n in outs[0]:
+    assert (outs[0][n] == outs[1][n]).all(), n
