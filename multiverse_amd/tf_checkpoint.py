@@ -25,9 +25,14 @@ is followed by a 1-byte compression type (0 = none, 1 = snappy) and a masked
 CRC-32C of block + type.  BundleWriter writes uncompressed blocks; compressed
 index blocks written by other tools are decoded with the snappy decoder below.
 
-Everything here was written from the published format descriptions; it cannot be
-validated against a real TensorFlow install in this environment, so the tests
-check self-consistency (round trip, CRCs, block structure) only.
+Everything here was written from the published format descriptions; no TensorFlow can
+be installed in this environment.  The reader is pinned by (a) round trips through the
+writer below and (b) `tests/golden/tf_bundle_v2`, a checkpoint hand-assembled byte by
+byte by an independent script (its own CRC / varint / block / snappy code) from the
+same published descriptions.  `python -m multiverse_amd.tf_checkpoint <ckpt>` prints a
+checkpoint's variable table in the `--check_model` format for diffing against a
+TensorFlow-1.15 listing.  Single-file V1 checkpoints (`*.ckpt` without `.index`,
+accepted by the reference's `initialize`, code/pred_utils.py:196-199) are NOT read.
 """
 
 from __future__ import annotations
@@ -599,3 +604,28 @@ def _update_state(prefix, max_to_keep, written):
     f.write('model_checkpoint_path: "%s"\n' % base)
     for p in allp:
       f.write('all_model_checkpoint_paths: "%s"\n' % p)
+
+
+def main(argv=None):
+  """`python -m multiverse_amd.tf_checkpoint <checkpoint dir or prefix> [--all]`: one line
+  per variable, `<name>:0 <shape>`, the format of the reference's `train.py --check_model`
+  (code/train.py:154-166), optimizer slots and global_step hidden like there unless
+  --all."""
+  import sys
+  argv = list(sys.argv[1:] if argv is None else argv)
+  show_all = "--all" in argv
+  paths = [a for a in argv if not a.startswith("--")]
+  if len(paths) != 1:
+    raise SystemExit("usage: python -m multiverse_amd.tf_checkpoint <ckpt> [--all]")
+  hidden = OPTIMIZER_SLOT_NAMES + ("global_step",)
+  total = 0
+  for name, shape, dt in list_variables(paths[0]):
+    if not show_all and any(c in name for c in hidden):
+      continue
+    total += int(np.prod(shape)) if len(shape) else 1
+    print("%s:0 %s" % (name, tuple(shape)))
+  print("# %d elements" % total)
+
+
+if __name__ == "__main__":
+  main()

@@ -246,3 +246,58 @@ def test_run_inference_decode_and_metrics(tmp_path):
   one = mf.decode_trajectories(args_g, np.eye(144, dtype="f4")[[5, 7]].reshape(2, 9, 16, 1),
                                np.zeros((2, 9, 16, 2), "f4"), None, 2, 1)
   assert len(one) == 3 and np.allclose(one[0][1], centers[7])
+
+
+# ------------------------------------------------------------ bytes we did not write
+
+BUNDLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_bundle_v2")
+
+
+def test_reader_on_a_hand_assembled_bundle():
+  """tests/golden/tf_bundle_v2 was assembled byte by byte from the LevelDB table format,
+  the snappy format description and tensor_bundle.proto by make_tf_bundle_fixture.py (its
+  own bitwise CRC-32C, its own varint / protobuf / block code): three data blocks with
+  prefix-compressed keys and several restart points, the middle one SNAPPY-compressed with
+  a back-reference, shortened separator keys in the index block."""
+  exp = np.load(os.path.join(BUNDLE, "expected.npz"))
+  assert tc.resolve_checkpoint(BUNDLE).endswith("model.ckpt-7")
+  listed = {n: (tuple(s), dt) for n, s, dt in tc.list_variables(BUNDLE)}
+  allv = tc.load_checkpoint(BUNDLE, skip_optimizer_slots=False, verify_crc=True)
+  assert len(allv) == len(exp.files) == len(listed) == 10
+  for k in exp.files:
+    n = k.replace("|", "/")
+    assert allv[n].dtype == exp[k].dtype and allv[n].shape == exp[k].shape, n
+    assert (allv[n] == exp[k]).all(), n
+    assert listed[n] == (exp[k].shape, exp[k].dtype), n
+  # the reference's restore list: no global_step, no optimizer slots, person_pred only
+  w = tc.load_checkpoint(BUNDLE, scope="person_pred")
+  assert sorted(w) == sorted(k.replace("|", "/") for k in exp.files
+                             if k.startswith("person_pred") and not k.endswith("Adadelta"))
+  # the fixture really contains what it claims: one block of type 1 (snappy), three
+  # index entries
+  raw = open(os.path.join(BUNDLE, "model.ckpt-7.index"), "rb").read()
+  entries = tc.read_table(os.path.join(BUNDLE, "model.ckpt-7.index"), verify=True)
+  assert [k for k, _ in entries][0] == b"" and len(entries) == 11
+  assert raw[-8:] == (0xdb4775248b80fb57).to_bytes(8, "little")
+
+
+def test_corrupted_hand_assembled_bundle_is_rejected(tmp_path):
+  import shutil
+  d = str(tmp_path / "b")
+  shutil.copytree(BUNDLE, d)
+  p = os.path.join(d, "model.ckpt-7.data-00000-of-00001")
+  buf = bytearray(open(p, "rb").read())
+  buf[100] ^= 0x40
+  open(p, "wb").write(bytes(buf))
+  with pytest.raises(IOError, match="CRC"):
+    tc.load_checkpoint(d, skip_optimizer_slots=False, verify_crc=True)
+
+
+def test_checkpoint_dump_cli(capsys):
+  """`python -m multiverse_amd.tf_checkpoint <ckpt>`: the variable table of any checkpoint,
+  the counterpart of `train.py --check_model` (code/train.py:154-166) for diffing names
+  against a TensorFlow-1.15 machine's own listing."""
+  tc.main([BUNDLE])
+  out = capsys.readouterr().out
+  assert "person_pred/scene_conv1/W:0 (3, 3, 11, 2)" in out
+  assert "global_step" not in out          # hidden like --check_model hides it
