@@ -242,6 +242,30 @@ int  mv_allreduce_init(mv_handle h, int32_t rank, int32_t world,
 /* rank / world of the communicator, collectives and bytes of the last step */
 int  mv_allreduce_info(mv_handle h, int32_t* rank, int32_t* world, int32_t* buckets,
                        double* bytes);
+/* -- SimAug training extras (SimAug/code/pred_models.py:60-172
+ * white_box_attack, :346-543 multiview_augmentation): targeted FGSM / PGD on the scene
+ * features and mixup, on the SAME forward / backward kernels.  The attack loss is the
+ * class cross entropy against target labels: run the engine with those labels as
+ * grid_pred_labels, grid_reg_loss_weight = 0 and wd = 0 (sign() ignores the loss scale).
+ *   mv_attack_begin        snapshot the resident scene features as "clean" and make the
+ *                          backward pass go down to d loss / d scene_feat
+ *   mv_set/get_scene_feat  replace / read the resident features [U, SH, SW, SC] (the
+ *                          attack perturbs per (n, t): upload U = N*T_o frames)
+ *   mv_get_scene_grad      d loss / d scene_feat of the last mv_train_forward_backward
+ *   mv_attack_step         x <- clip(x - step * sign(g), clip(clean - eps, -1, 1),
+ *                          clip(clean + eps, -1, 1))   (FGSM: step = eps, once)
+ *   mv_scene_mix           x <- other * weight + x * (1 - weight); other NULL = clean
+ *   mv_get_sample_losses   per-sample mean cross entropy [N] of the last step (the
+ *                          multi-view selection ranks views by it)
+ *   mv_attack_end          back to plain training */
+int  mv_attack_begin(mv_handle h);
+int  mv_attack_end(mv_handle h);
+int  mv_set_scene_feat(mv_handle h, const float* scene_feat);
+int  mv_get_scene_feat(mv_handle h, float* out);
+int  mv_get_scene_grad(mv_handle h, float* out);
+int  mv_attack_step(mv_handle h, float epsilon, float step);
+int  mv_scene_mix(mv_handle h, const float* other, float weight);
+int  mv_get_sample_losses(mv_handle h, int32_t scale, float* out);
 /* tf.gradients(loss, var) of the last forward_backward, by variable name */
 int  mv_get_grad(mv_handle h, const char* tf_name, float* out, int64_t capacity_elems);
 int  mv_get_global_step(mv_handle h, int64_t* step);

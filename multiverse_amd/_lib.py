@@ -35,6 +35,8 @@ EXPORTED_SYMBOLS = [
     "mv_set_global_step", "mv_get_opt_slot", "mv_set_opt_slot",
     "mv_set_dropout_seed", "mv_get_opt_scalars", "mv_set_opt_scalars",
     "mv_comm_unique_id", "mv_allreduce_init", "mv_allreduce_info",
+    "mv_attack_begin", "mv_attack_end", "mv_set_scene_feat", "mv_get_scene_feat",
+    "mv_get_scene_grad", "mv_attack_step", "mv_scene_mix", "mv_get_sample_losses",
     "mv_op_convlstm_bwd", "mv_op_gnn_bwd",
     "mv_set_grid_centers", "mv_upload_inputs_compact", "mv_upload_targets_compact",
 ]
@@ -222,6 +224,14 @@ def load():
   lib.mv_comm_unique_id.argtypes = [_u8p]
   lib.mv_allreduce_init.argtypes = [h, C.c_int32, C.c_int32, _u8p]
   lib.mv_allreduce_info.argtypes = [h, _ip, _ip, _ip, _dp]
+  lib.mv_attack_begin.argtypes = [h]
+  lib.mv_attack_end.argtypes = [h]
+  lib.mv_set_scene_feat.argtypes = [h, _fp]
+  lib.mv_get_scene_feat.argtypes = [h, _fp]
+  lib.mv_get_scene_grad.argtypes = [h, _fp]
+  lib.mv_attack_step.argtypes = [h, C.c_float, C.c_float]
+  lib.mv_scene_mix.argtypes = [h, _fp, C.c_float]
+  lib.mv_get_sample_losses.argtypes = [h, C.c_int32, _fp]
   lib.mv_set_dropout_seed.argtypes = [h, C.c_uint32]
   lib.mv_get_opt_scalars.argtypes = [h, _fp, _fp]
   lib.mv_set_opt_scalars.argtypes = [h, C.c_float, C.c_float]
@@ -428,6 +438,7 @@ class Engine(object):
     inp.obs_scene = iptr(obs_scene)
     inp.scene_feat = fptr(scene_feat)
     inp.num_scene_frames = int(scene_feat.shape[0])
+    self._num_frames = int(scene_feat.shape[0])
     inp.pred_len = int(feed.get("pred_length", cfg.pred_len))
     for s, (h, w) in enumerate(cfg.scene_grids):
       if not cfg.use_grids[s]:
@@ -705,6 +716,43 @@ class Engine(object):
                                   C.byref(by)) != 0:
       return None
     return {"rank": r.value, "world": w.value, "buckets": b.value, "bytes": by.value}
+
+  # ---- SimAug extras: attacks on the resident scene features
+  def _scene_shape(self):
+    cfg = self.cfg
+    return (self._num_frames, cfg.scene_h, cfg.scene_w, cfg.scene_class)
+
+  def attack_begin(self):
+    check(self.lib.mv_attack_begin(self.handle), self.handle)
+
+  def attack_end(self):
+    check(self.lib.mv_attack_end(self.handle), self.handle)
+
+  def set_scene_feat(self, a):
+    a = f32(a).reshape(self._scene_shape())
+    check(self.lib.mv_set_scene_feat(self.handle, fptr(a)), self.handle)
+
+  def get_scene_feat(self):
+    out = np.empty(self._scene_shape(), dtype=np.float32)
+    check(self.lib.mv_get_scene_feat(self.handle, fptr(out)), self.handle)
+    return out
+
+  def get_scene_grad(self):
+    out = np.empty(self._scene_shape(), dtype=np.float32)
+    check(self.lib.mv_get_scene_grad(self.handle, fptr(out)), self.handle)
+    return out
+
+  def attack_step(self, epsilon, step):
+    check(self.lib.mv_attack_step(self.handle, float(epsilon), float(step)), self.handle)
+
+  def scene_mix(self, other, weight):
+    o = None if other is None else f32(other).reshape(self._scene_shape())
+    check(self.lib.mv_scene_mix(self.handle, fptr(o), float(weight)), self.handle)
+
+  def sample_losses(self, scale):
+    out = np.empty((self.cfg.batch_size,), dtype=np.float32)
+    check(self.lib.mv_get_sample_losses(self.handle, int(scale), fptr(out)), self.handle)
+    return out
 
   def set_dropout_seed(self, seed):
     check(self.lib.mv_set_dropout_seed(self.handle, int(seed) & 0xFFFFFFFF), self.handle)

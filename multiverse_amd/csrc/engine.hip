@@ -1745,6 +1745,106 @@ int mv_allreduce_info(mv_handle h, int32_t* rank, int32_t* world, int32_t* bucke
   return 0;
 }
 
+// ---- SimAug training extras: targeted attacks on the scene features
+int mv_attack_begin(mv_handle h) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train, "mv_train_init has not been called");
+    MV_REQUIRE(h->inputs_ready, "no inputs uploaded");
+    TrainState& t = TS(h);
+    const size_t n = (size_t)h->num_frames * h->cfg.scene_h * h->cfg.scene_w * h->cfg.scene_class;
+    t.scene_clean.alloc((size_t)h->cfg.batch_size * h->cfg.obs_len * h->cfg.scene_h *
+                        h->cfg.scene_w * h->cfg.scene_class);
+    HIP_CHECK(hipMemcpyAsync(t.scene_clean.p, h->scene_feat.p, n * sizeof(float),
+                             hipMemcpyDeviceToDevice, h->stream));
+    t.want_dscene = true;
+    t.have_dscene = false;
+  });
+}
+
+int mv_attack_end(mv_handle h) {
+  if (!h || !h->train) return 1;
+  TS(h).want_dscene = false;
+  return 0;
+}
+
+int mv_set_scene_feat(mv_handle h, const float* scene_feat) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(scene_feat && h->inputs_ready, "mv_set_scene_feat: NULL / no inputs uploaded");
+    const size_t n = (size_t)h->num_frames * h->cfg.scene_h * h->cfg.scene_w * h->cfg.scene_class;
+    HIP_CHECK(hipMemcpy(h->scene_feat.p, scene_feat, n * sizeof(float), hipMemcpyHostToDevice));
+  });
+}
+
+int mv_get_scene_feat(mv_handle h, float* out) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(out && h->inputs_ready, "mv_get_scene_feat: NULL / no inputs uploaded");
+    const size_t n = (size_t)h->num_frames * h->cfg.scene_h * h->cfg.scene_w * h->cfg.scene_class;
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(hipMemcpy(out, h->scene_feat.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+int mv_get_scene_grad(mv_handle h, float* out) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train && TS(h).have_dscene, "no input gradient (mv_attack_begin, then "
+               "mv_train_forward_backward)");
+    const size_t n = (size_t)h->num_frames * h->cfg.scene_h * h->cfg.scene_w * h->cfg.scene_class;
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(hipMemcpy(out, TS(h).dscene.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+int mv_attack_step(mv_handle h, float epsilon, float step) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train && TS(h).have_dscene && TS(h).scene_clean.p,
+               "mv_attack_step: mv_attack_begin + mv_train_forward_backward first");
+    const size_t n = (size_t)h->num_frames * h->cfg.scene_h * h->cfg.scene_w * h->cfg.scene_class;
+    hipLaunchKernelGGL(mv::adv_step_kernel, dim3(cdiv(n, 256)), dim3(256), 0, h->stream,
+                       h->scene_feat.p, TS(h).dscene.p, TS(h).scene_clean.p, epsilon, step, n);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
+int mv_scene_mix(mv_handle h, const float* other, float weight) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train && h->inputs_ready, "mv_scene_mix: training engine with inputs");
+    const size_t n = (size_t)h->num_frames * h->cfg.scene_h * h->cfg.scene_w * h->cfg.scene_class;
+    TrainState& t = TS(h);
+    const float* src = t.scene_clean.p;        // other == NULL: mix with the clean features
+    DevBuf<float> tmp;
+    if (other) {
+      tmp.alloc(n);
+      HIP_CHECK(hipMemcpy(tmp.p, other, n * sizeof(float), hipMemcpyHostToDevice));
+      src = tmp.p;
+    }
+    MV_REQUIRE(src, "mv_scene_mix: no clean copy (mv_attack_begin)");
+    hipLaunchKernelGGL(mv::mix_kernel, dim3(cdiv(n, 256)), dim3(256), 0, h->stream,
+                       h->scene_feat.p, src, weight, n);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int mv_get_sample_losses(mv_handle h, int32_t scale, float* out) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train && TS(h).have_grads, "no losses (mv_train_forward_backward)");
+    MV_REQUIRE(scale >= 0 && scale < h->cfg.num_scales && h->sc[scale].use && out,
+               "mv_get_sample_losses: scale %d", scale);
+    const int N = h->cfg.batch_size, Tp = h->pred_len;
+    TrainState& t = TS(h);
+    hipLaunchKernelGGL(mv::loss_rows_mean_kernel, dim3(cdiv(N, 256)), dim3(256), 0, h->stream,
+                       t.sc[scale].loss_row.p, t.scratch.p, Tp, N);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(hipMemcpy(out, t.scratch.p, N * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
 int mv_set_dropout_seed(mv_handle h, uint32_t seed) {
   if (!h || !h->train) return 1;
   h->train->st.dropout_seed = seed;

@@ -54,6 +54,9 @@ struct TrainState {
   DevBuf<float> grad, accum, accum_update;
   TrainScale sc[MV_MAX_SCALES];
   DevBuf<float> dys[MV_MAX_SCALES], dpre_sc[MV_MAX_SCALES];   // scene stack backward
+  DevBuf<float> dscene;           // [U, SH, SW, SC] d loss / d scene_feat (SimAug attacks)
+  DevBuf<float> scene_clean;      // the clean features an attack perturbs
+  bool want_dscene = false, have_dscene = false;
   DevBuf<float> partial;          // split-K partials / reduction scratch
   DevBuf<float> scratch;          // second-stage scratch
   DevBuf<float> losses;           // [2*MV_MAX_SCALES + 1 + nW] device scalars
@@ -1100,6 +1103,16 @@ void train_backward(mv_engine* e) {
     const int ph = std::max((Ho - 1) * 2 + k - Hi, 0), pw = std::max((Wo - 1) * 2 + k - Wi, 0);
     const size_t nw = (size_t)k * k * Ci * D;
     const float* in = i == 0 ? e->scene_feat.p : e->scene_conv[i - 1].p;
+    if (i == 0 && t.want_dscene) {     // down to the input: d loss / d scene_feat
+      const size_t nin = (size_t)U * Hi * Wi * Ci;
+      t.dscene.alloc((size_t)c.batch_size * c.obs_len * Hi * Wi * Ci);
+      launch(e, "scene_input_dgrad", 2.0 * nin * k * k * D / 4, 4.0 * (nin + n), [&] {
+        hipLaunchKernelGGL(mv::conv_s2_dgrad_kernel, dim3(cdiv(nin, 256)), dim3(256), 0,
+                           e->stream, t.dpre_sc[0].p, e->scene_W[0]->dev.p, t.dscene.p, U, Hi,
+                           Wi, Ci, Ho, Wo, D, k, ph / 2, pw / 2, 0);
+      });
+      t.have_dscene = true;
+    }
     launch(e, "scene_conv_wgrad", 2.0 * n * k * k * Ci, 4.0 * nw, [&] {
       // output rows (u, oy) in <= 64 slabs, partials folded in slab order
       const int rows = U * Ho, rps = (rows + 63) / 64, nslab = (rows + rps - 1) / rps;

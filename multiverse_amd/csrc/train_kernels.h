@@ -685,6 +685,39 @@ __global__ void conv_s2_wgrad_kernel(const float* __restrict__ in,
   dw[(size_t)blockIdx.y * total + idx] = acc;
 }
 
+// ------------------------------------------------------------ SimAug (N4)
+// One targeted FGSM / PGD step on the scene features (SimAug/code/pred_models.py:94-126
+// one_step_attack): x <- clip(x - step * sign(g), lo, hi) with lo = clip(clean - eps, -1, 1),
+// hi = clip(clean + eps, -1, 1) (:137-138); tf.sign(0) = 0.
+__global__ void adv_step_kernel(float* __restrict__ x, const float* __restrict__ g,
+                                const float* __restrict__ clean, float eps, float step,
+                                size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gv = g[i];
+  const float sg = gv > 0.f ? 1.f : (gv < 0.f ? -1.f : 0.f);
+  const float lo = fminf(fmaxf(clean[i] - eps, -1.f), 1.f);
+  const float hi = fminf(fmaxf(clean[i] + eps, -1.f), 1.f);
+  const float v = x[i] - sg * step;
+  x[i] = fminf(fmaxf(v, lo), hi);          // tf.clip_by_value: min(max(v, lo), hi)
+}
+// mixup (:151-166, :529-536): x <- other * weight + x * (1 - weight)
+__global__ void mix_kernel(float* __restrict__ x, const float* __restrict__ other, float weight,
+                           size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  x[i] = other[i] * weight + x[i] * (1.f - weight);
+}
+// per-sample mean over the T steps of the per-row cross entropy (:403-404), rows time-major
+__global__ void loss_rows_mean_kernel(const float* __restrict__ loss_row, float* __restrict__ out,
+                                      int T, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += loss_row[(size_t)t * N + n];
+  out[n] = s / (float)T;
+}
+
 // ------------------------------------------------------------ optimizer
 // grad += wd * w  (the d/dw of wd * l2_loss(w), wd_cost code/pred_models.py:1253-1275)
 __global__ void add_scaled_kernel(float* __restrict__ g, const float* __restrict__ w,

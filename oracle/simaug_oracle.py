@@ -1,0 +1,83 @@
+# coding=utf-8
+"""CPU ORACLE for the SimAug training extras  --  TEST INFRASTRUCTURE ONLY.
+
+Restates `white_box_attack` (SimAug/code/pred_models.py:60-172) and
+`multiview_augmentation` (:346-543, experiments 1 / 2 / 4) on the torch-CPU oracle of the
+network (oracle/multiverse_oracle.py; SimAug's `build_tower` :544 is the same graph as
+code/pred_models.py build_forward), with torch.autograd playing `tf.gradients(loss, input)`.
+
+**parity unpinned**: SimAug/code/pred_models.py is a second 2 100-line TF-1 graph file with
+unseeded random ops; it has not been executed on the TF-1 shim, and the reference ships no
+fixtures for it.  What IS checked: this restatement against the HIP engine under identical,
+injected random draws (tests/test_gpu_simaug.py), and the underlying network / gradients
+against the reference-run goldens of code/pred_models.py.
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import torch
+
+from oracle import multiverse_oracle as oracle
+
+
+def _scale_of(cfg):
+  assert sum(bool(u) for u in cfg.use_grids) == 1, "only one scale for adv train"   # :292
+  return [i for i, u in enumerate(cfg.use_grids) if u][0]
+
+
+def class_loss_and_input_grad(params, cfg, feed, scene, target, dtype=torch.float32):
+  """one_step_attack's loss (:94-110): per-row sparse softmax cross entropy of the target
+  scale's logits against `target`; returns (per-sample mean loss [N], d sum(loss) / d scene)."""
+  s = _scale_of(cfg)
+  H, W = cfg.scene_grids[s]
+  P = oracle.Params(params, dtype)
+  x = torch.tensor(np.asarray(scene), dtype=dtype, requires_grad=True)
+  f = dict(feed)
+  f["scene_feat"] = x
+  cls_out, _, _ = oracle.forward_tensors(P, cfg, f, dtype)
+  logits = cls_out[s].reshape(-1, H * W)
+  lab = torch.from_numpy(np.asarray(target).astype("int64").reshape(-1))
+  ce = torch.logsumexp(logits, dim=-1) - logits.gather(1, lab[:, None])[:, 0]
+  g, = torch.autograd.grad(ce.sum(), x)
+  N = cfg.batch_size
+  return ce.detach().reshape(N, -1).mean(dim=1).numpy(), g.numpy()
+
+
+def fgsm_step(x, g, clean, eps, step):
+  """:118-123 -- x - step * sign(g), clipped to [clip(clean - eps, -1, 1), clip(clean + eps, -1, 1)]"""
+  lo = np.clip(clean - eps, -1.0, 1.0)
+  hi = np.clip(clean + eps, -1.0, 1.0)
+  return np.minimum(np.maximum(x - np.sign(g) * np.float32(step), lo), hi).astype("float32")
+
+
+def white_box_attack(params, cfg, feed, draws, mirror, norm_feat=False):
+  """`mirror` = multiverse_amd.simaug (its pure-numpy helpers random_targets / start_adv
+  consume `draws` in the reference's order); -> (adv features, target labels)."""
+  s = _scale_of(cfg)
+  h, w = cfg.scene_grids[s]
+  target = mirror.random_targets(feed["grid_pred_labels"][s], h * w, draws)
+  clean = np.asarray(feed["scene_feat"], dtype="float32")
+  tcfg = copy.copy(cfg)
+  tcfg.is_train = True
+
+  def attack(start):
+    x = mirror._softmax_last(start) if norm_feat else start
+    if cfg.adv_use_fgsm:
+      _, g = class_loss_and_input_grad(params, tcfg, feed, x, target)
+      return fgsm_step(x, g, clean, cfg.adv_epsilon, cfg.adv_epsilon)
+    for _ in range(int(cfg.adv_num_iter)):
+      _, g = class_loss_and_input_grad(params, tcfg, feed, x, target)
+      x = fgsm_step(x, g, clean, cfg.adv_epsilon, cfg.adv_step_size)
+    return x
+
+  adv = attack(mirror.start_adv(clean, cfg, draws))
+  if getattr(cfg, "use_mixup", False):
+    weight = np.float32(draws.beta(cfg.mixup_alpha))
+    if getattr(cfg, "mixup_mix_adv", False):
+      adv2 = attack(mirror.start_adv(clean, cfg, draws))
+      adv = adv2 * weight + adv * (np.float32(1) - weight)
+    else:
+      adv = clean * weight + adv * (np.float32(1) - weight)
+  return adv.astype("float32"), target

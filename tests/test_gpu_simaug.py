@@ -1,0 +1,135 @@
+# coding=utf-8
+"""GPU: SimAug training extras through the C ABI -- the gradient of the
+attack loss w.r.t. the scene features, targeted FGSM / PGD (+ mixup) and the multi-view
+selection -- against the torch-autograd restatement oracle/simaug_oracle.py under identical
+injected random draws (SimAug/code/pred_models.py:60-172, 346-543)."""
+import copy
+
+import numpy as np
+import pytest
+
+from multiverse_amd import simaug, synth
+from oracle import simaug_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(built_lib, N=2, **over):
+  cfg = synth.default_config(batch_size=N, use_grids=(0, 1), is_train=True)
+  for k, v in dict(norm_input=True, adv_train=True, adv_epsilon=0.1, adv_step_size=0.03,
+                   adv_num_iter=3, adv_start_from_clean_prob=0.0, adv_use_fgsm=True,
+                   use_mixup=False, mixup_alpha=1.0, mixup_mix_adv=False,
+                   multiview_max_num=3, multiview_exp=1,
+                   multiview_max_weight_for_first=False).items():
+    setattr(cfg, k, v)
+  for k, v in over.items():
+    setattr(cfg, k, v)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 50, recurrent_gain=2.0, bias_scale=0.1)
+  feed = simaug.per_step_scene_feed(cfg, synth.make_feed(cfg, seed=synth.SEED_BASE + 51))
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.train_init()
+  return cfg, params, feed, eng
+
+
+def test_input_gradient_of_the_attack_loss(built_lib):
+  """d sum(CE(target)) / d scene_feat: the backward pass taken down to the input."""
+  cfg, params, feed, eng = _setup(built_lib)
+  s = 1
+  target = simaug.random_targets(feed["grid_pred_labels"][s], 9 * 16, simaug.Draws(3))
+  eng.train_init(simaug.attack_config(cfg))
+  eng.upload(feed)
+  eng.upload_targets(simaug._attack_feed(feed, s, target))
+  eng.attack_begin()
+  eng.train_forward_backward(None)
+  g = eng.get_scene_grad()
+  losses = eng.sample_losses(s)
+  eng.close()
+  tcfg = copy.copy(cfg)
+  ol, og = simaug_oracle.class_loss_and_input_grad(params, tcfg, feed, feed["scene_feat"], target)
+  # the engine differentiates the MEAN over N*T_p rows (grid_loss_weight 1): rescale
+  og = og / float(cfg.batch_size * cfg.pred_len)
+  err = np.abs(g - og).max() / np.abs(og).max()
+  big = np.abs(og) > 1e-4 * np.abs(og).max()
+  print("d loss / d scene_feat: rel err %.2e, sign agreement on |g| > 1e-4 max: %.6f; "
+        "per-sample losses %s / %s" % (err, (np.sign(g[big]) == np.sign(og[big])).mean(),
+                                       losses, ol))
+  assert err < 2e-3
+  assert (np.sign(g[big]) == np.sign(og[big])).mean() == 1.0
+  assert np.allclose(losses, ol, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name,over", [
+    ("fgsm", dict()),
+    ("pgd3", dict(adv_use_fgsm=False)),
+    ("fgsm_mix_clean", dict(use_mixup=True)),
+    ("fgsm_mix_adv", dict(use_mixup=True, mixup_mix_adv=True)),
+    ("fgsm_clean_start_norm_feat", dict(adv_start_from_clean_prob=1.0)),
+])
+def test_white_box_attack_matches_the_oracle(built_lib, name, over):
+  cfg, params, feed, eng = _setup(built_lib, **over)
+  adv, target = simaug.white_box_attack(eng, cfg, feed, simaug.Draws(11))
+  # the engine trains on the adversarial features it now holds
+  eng.upload_targets(feed)
+  loss = eng.train_step(None)[0]
+  eng.close()
+  oadv, otarget = simaug_oracle.white_box_attack(params, cfg, feed, simaug.Draws(11), simaug)
+  assert (target == otarget).all() and (target != feed["grid_pred_labels"][1]).all()
+  clean = feed["scene_feat"]
+  same = np.abs(adv - oadv) < 1e-6
+  print("%s: adversarial features equal on %.5f of the elements; max |adv - clean| %.4f; "
+        "training loss on them %.5f" % (name, same.mean(), np.abs(adv - clean).max(), loss))
+  # sign(g) is discontinuous at g = 0: a handful of elements at the fp32 noise floor of the
+  # gradient may take the other branch (by 2 * step); everything else is identical
+  assert same.mean() > 0.999
+  assert np.abs(adv - clean).max() <= cfg.adv_epsilon + 1e-6 and np.abs(adv).max() <= 1.0 + 1e-6
+  assert np.isfinite(loss)
+
+
+@pytest.mark.parametrize("exp", [1, 2, 4])
+def test_multiview_augmentation(built_lib, exp):
+  cfg, params, feed, eng = _setup(built_lib, multiview_exp=exp)
+  eng.close()
+  N, M = cfg.batch_size, cfg.multiview_max_num
+  mcfg = copy.copy(cfg)
+  mcfg.batch_size = N * M
+  engm = built_lib.Engine(mcfg, device=0)
+  engm.set_params(params)
+  engm.train_init()
+  rng = np.random.default_rng(5)
+  extra = rng.integers(0, 9 * 16, size=(N, M, cfg.pred_len)).astype("int32")
+  mixed, weight, adv_loss = simaug.multiview_augmentation(engm, cfg, feed, extra, simaug.Draws(21))
+  engm.close()
+  # oracle: the per-view FGSM step and losses, then the same selection / mix on the host
+  d = simaug.Draws(21)
+  clean = feed["scene_feat"]
+  T = cfg.obs_len
+  tiled = dict(feed)
+  tiled["scene_feat"] = np.repeat(clean.reshape((N, T) + clean.shape[1:]), M, axis=0).reshape(
+      (-1,) + clean.shape[1:])
+  tiled["obs_scene"] = np.arange(N * M * T, dtype="int32").reshape(N * M, T)
+  for key in ("grid_obs_labels", "grid_obs_regress"):
+    tiled[key] = [None if a is None else np.repeat(np.asarray(a), M, axis=0) for a in feed[key]]
+  start = simaug.start_adv(tiled["scene_feat"], cfg, d)
+  tcfg = copy.copy(mcfg)
+  ol, og = simaug_oracle.class_loss_and_input_grad(params, tcfg, tiled, start,
+                                                   extra.reshape(N * M, -1))
+  assert np.allclose(adv_loss.reshape(-1), ol, rtol=1e-4)
+  oadv = simaug_oracle.fgsm_step(start, og, start, cfg.adv_epsilon, cfg.adv_epsilon)
+  oadv = oadv.reshape((N, M, T) + clean.shape[1:])
+  order = np.argsort(-ol.reshape(N, M), axis=1, kind="stable")
+  rows = np.arange(N)
+  if exp == 1:
+    i1, i2 = order[:, 0], order[:, 1]
+  elif exp == 4:
+    i1, i2 = order[:, M - 1], order[:, M - 2]
+  else:
+    i1 = d.index(N, 0, M)
+    i2 = np.mod(i1 + d.index(N, 1, M), M)
+  w = d.beta(cfg.mixup_alpha)
+  omixed = (oadv[rows, i1] * np.float32(w) + oadv[rows, i2] * np.float32(1 - w)).reshape(mixed.shape)
+  assert abs(w - weight) < 1e-12 and (i1 != i2).all()
+  same = np.abs(mixed - omixed) < 1e-6
+  print("multiview exp %d: mixed features equal on %.5f of the elements, weight %.4f, "
+        "attack losses %s" % (exp, same.mean(), weight, np.round(adv_loss, 4)))
+  assert same.mean() > 0.999

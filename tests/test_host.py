@@ -31,8 +31,9 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 
 def test_struct_layout_matches_header(built_lib):
-  # 21 int32/float fields + 3 arrays of MV_MAX_SCALES -> 4-byte packed
-  assert ctypes.sizeof(built_lib.mv_config) == 4 * (18 + 3 * built_lib.MV_MAX_SCALES)
+  # 19 int32/float fields + 3 arrays of MV_MAX_SCALES -> 4-byte packed (offsets: see
+  # test_ctypes_structs_match_the_c_header)
+  assert ctypes.sizeof(built_lib.mv_config) == 4 * (19 + 3 * built_lib.MV_MAX_SCALES)
   assert ctypes.sizeof(built_lib.mv_inputs) == 8 * 2 + 4 * 2 + 8 * 2 * built_lib.MV_MAX_SCALES
   assert ctypes.sizeof(built_lib.mv_outputs) == 8 * 2 * built_lib.MV_MAX_SCALES
   assert ctypes.sizeof(built_lib.mv_beam_outputs) == 8 * 5
@@ -205,15 +206,32 @@ def test_trainer_rejects_unbuilt_switches():
   cfg = synth.default_config(batch_size=2, is_train=False)
   with pytest.raises(_lib.MvError, match="is_train"):
     pred_models.Trainer(None, cfg)
-  for field, val, msg in (("optimizer", "adam", "adadelta"),
-                          ("train_w_onehot", False, "train_w_onehot"),
-                          ("use_teacher_forcing", True, "train_w_onehot"),
-                          ("use_soft_grid_class", True, "soft_grid"),
-                          ("keep_prob", 0.7, "keep_prob")):
+  cfg = synth.default_config(batch_size=2, is_train=True)
+  cfg.optimizer = "sgd"
+  with pytest.raises(_lib.MvError, match="Optimizer not implemented"):   # code/pred_models.py:748
+    _lib.make_train_config(cfg)
+  cfg = synth.default_config(batch_size=2, is_train=True)
+  cfg.use_single_decoder = True
+  with pytest.raises(_lib.MvError, match="use_single_decoder"):
+    pred_models.Model._check_config(cfg)
+  # every published training switch maps onto mv_train_config
+  for field, val, attr, want in (("optimizer", "adam", "optimizer", 2),
+                                 ("optimizer", "momentum", "optimizer", 1),
+                                 ("optimizer", "rmsprop", "optimizer", 3),
+                                 ("train_w_onehot", False, "class_feedback", 1),
+                                 ("use_teacher_forcing", True, "class_feedback", 2),
+                                 ("use_teacher_forcing", True, "reg_teacher_forcing", 1),
+                                 ("use_soft_grid_class", True, "use_soft_grid_class", 1),
+                                 ("mask_grid_regression", True, "mask_grid_regression", 1)):
     cfg = synth.default_config(batch_size=2, is_train=True)
     setattr(cfg, field, val)
-    with pytest.raises(_lib.MvError, match=msg):
-      _lib.make_train_config(cfg)
+    assert getattr(_lib.make_train_config(cfg), attr) == want, (field, attr)
+  cfg = synth.default_config(batch_size=2, is_train=True)
+  cfg.keep_prob = 0.7
+  assert abs(_lib.make_train_config(cfg).keep_prob - 0.7) < 1e-7
+  # data-parallel: the schedule counts GLOBAL batches
+  cfg = synth.default_config(batch_size=20, is_train=True, train_num_examples=1000)
+  assert _lib.make_train_config(cfg, world=4).decay_steps == int(1000 / 80 * 2.0)
   tc = _lib.make_train_config(synth.default_config(batch_size=20, is_train=True,
                                                    train_num_examples=1000))
   assert tc.decay_steps == int(1000 / 20 * 2.0) and tc.do_clip == 1
