@@ -46,7 +46,8 @@ def algorithmic_counts(cfg, beam=1, executed=False):
   """FLOPs / state bytes per trajectory of the ConvLSTM sweep:
   2*K*9*(Cx+C)*4C per step; each step reads x,h,c and writes h,c once.  Dense = as the
   reference computes it; executed = the first encoder step starts from the zero state
-  and never multiplies (or reads) the h half -- those FLOPs are NOT counted as achieved."""
+  and never multiplies (or reads) the h half, and the first beam-decoder step runs once per
+  sample instead of once per (identical) beam row -- those FLOPs are NOT counted as achieved."""
   C, D, E = cfg.enc_hidden_size, cfg.scene_conv_dim, cfg.emb_size
   To, Tp = cfg.obs_len, cfg.pred_len
   flops = 0.0
@@ -62,6 +63,10 @@ def algorithmic_counts(cfg, beam=1, executed=False):
       if executed and enc:
         flops -= rows * 2.0 * K * 9 * C * 4 * C
         nbytes -= rows * K * 2 * C * 4.0
+      if executed and rows > 1:
+        # the first beam step sees B identical rows per sample: run once per sample
+        flops -= (rows - 1) * 2.0 * K * 9 * (cx + C) * 4 * C
+        nbytes -= (rows - 1) * K * (cx + 4 * C) * 4.0
   return flops, nbytes
 
 

@@ -1005,6 +1005,14 @@ __global__ void tile_rows_kernel(const float* __restrict__ in, float* __restrict
       reinterpret_cast<const mv::f32x4_t*>(in)[(r / B) * row_elems4 + off];
 }
 
+// logits[(n*B + b), :] = logits[(n*B), :] for b > 0 (the shared first beam step)
+__global__ void tile_beam0_kernel(float* __restrict__ logits, int K, int B, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t r = idx / K;
+  if (r % B) logits[idx] = logits[(r - r % B) * K + (idx - r * K)];
+}
+
 __global__ void beam_backtrace_kernel(const int32_t* __restrict__ step_ids,
                                       const int32_t* __restrict__ step_parents,
                                       int32_t* __restrict__ out_ids,
@@ -1047,9 +1055,15 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
   const int N = c.batch_size, T = c.obs_len, B = c.beam_size, K = S.K,
             C = c.hidden_size;
   const int R = N * B;
-  // tile encoder state to beams (:497-502).  The encoder wrote rows [0,N) of
-  // cls_*[cur]; expand into the other buffer.
-  {
+  // The reference tiles the encoder state and the first input over the beams (:497-502,
+  // 531-532), so the first cell step (and the attention before it) sees B identical rows
+  // per sample.  Rows are independent in every kernel of the step, so that step runs ONCE
+  // per sample on the N encoder rows (bit-identical to the tiled computation): its logits
+  // are copied to the B beam rows, and the first selection hands out state rows n instead
+  // of n * B + parent.  MV_BEAM_SHARED_FIRST=0 restores the tiled first step for A/B runs.
+  static const bool shared_first =
+      !(getenv("MV_BEAM_SHARED_FIRST") && atoi(getenv("MV_BEAM_SHARED_FIRST")) == 0);
+  if (!shared_first) {
     const int cc = cur.cls[s];
     const size_t row4 = (size_t)K * C / 4, total4 = (size_t)R * row4;
     launch(e, "beam_tile_state", 0, 8.0 * total4 * 16, [&] {
@@ -1066,26 +1080,31 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
   const size_t lds_bytes = ((size_t)2 * B * K + 512) * sizeof(float);
   const int32_t* src = nullptr;  // state row indirection for the next cell step
   for (int time = 0; time <= Tp; ++time) {
+    // rows the state holds going INTO this iteration's kernels
+    const bool one_per_sample = shared_first && time <= 1;
+    const int rows_now = one_per_sample ? N : R;
     if (time > 0) {
-      // cell step on R rows; h comes from the GNN buffer (identity rows) when
-      // use_gnn, c through the parent indirection
+      // cell step; h comes from the GNN buffer (identity rows) when use_gnn, c through
+      // the parent indirection
       const int cc = cur.cls[s];
       const float* hin = c.use_gnn ? S.cls_hg.p : S.cls_h[cc].p;
       std::vector<ConvLstmArgs> probs;
       probs.push_back(conv_problem(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cc].p,
                                    c.use_gnn ? nullptr : src, src, S.cls_h[cc ^ 1].p,
-                                   S.cls_c[cc ^ 1].p, R, S.H, S.W, false, 0,
+                                   S.cls_c[cc ^ 1].p, rows_now, S.H, S.W, false, 0,
                                    /*want_h16=*/!c.use_gnn));
       cur.cls[s] ^= 1;
       const bool v2 = tail_v2();
       probs.push_back(reg_decoder_problem(e, s, cur, time - 1, Tp, !v2));
       run_conv_group(e, probs);
       float* logits = e->bm_logits.p + (size_t)(time - 1) * R * K;
+      // one row per sample: the logits land in beam 0's row of each sample
+      const size_t lrow = one_per_sample ? (size_t)B * K : (size_t)K;
       if (v2) {
         TailPlan pl{};
         pl.s = s;
-        pl.cls_h = S.cls_h[cur.cls[s]].p; pl.cls_rows = R;
-        pl.cls_out = logits; pl.cls_stride = K; pl.cls_next = false;   // beam_step selects
+        pl.cls_h = S.cls_h[cur.cls[s]].p; pl.cls_rows = rows_now;
+        pl.cls_out = logits; pl.cls_stride = lrow; pl.cls_next = false;   // beam_step selects
         pl.reg_h = S.reg_h[cur.reg[s]].p;
         pl.reg_out = S.out_reg.p + (size_t)(time - 1) * K * 2;
         pl.reg_stride = (int64_t)Tp * K * 2; pl.reg_next = time < Tp;
@@ -1093,7 +1112,12 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
       } else {
         reg_decoder_output(e, s, cur, time - 1, Tp);
         run_hidden2grid<1>(e, S, S.cls_h[cur.cls[s]].p, S.out_cls_W->dev.p, logits,
-                           (size_t)K, R);
+                           lrow, rows_now);
+      }
+      if (one_per_sample) {
+        const size_t total = (size_t)R * K;
+        hipLaunchKernelGGL(tile_beam0_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                           e->stream, logits, K, B, total);
       }
       int32_t* ids = e->bm_ids.p + (size_t)(time - 1) * R;
       int32_t* parents = e->bm_parents.p + (size_t)(time - 1) * R;
@@ -1101,19 +1125,27 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
         hipLaunchKernelGGL(mv::beam_step_kernel, dim3(N), dim3(512), lds_bytes,
                            e->stream, logits, e->bm_lp[lpi].p, B, K, time,
                            c.diverse_beam, logf(c.diverse_gamma), c.fix_num_timestep,
-                           e->bm_lp[lpi ^ 1].p, ids, parents, e->bm_src_row.p);
+                           e->bm_lp[lpi ^ 1].p, ids, parents, e->bm_src_row.p,
+                           one_per_sample ? 1 : B);
         HIP_CHECK(hipGetLastError());   // a refused LDS size must not pass silently
       });
       lpi ^= 1;
       src = e->bm_src_row.p;
       if (time == Tp) break;
       run_emb_onehot(e, S, ids, 1, S.xbuf_cls.p, R);
+    } else if (shared_first) {
+      // one_hot(last observed cell) (:497-498, 531-532), one row per sample
+      run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, N, 1);
     } else {
-      // one_hot(last observed cell), tiled over beams (:497-498, 531-532)
       run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, R, B);
     }
-    if (c.use_gnn)
-      run_gnn(e, S, S.cls_h[cur.cls[s]].p, src, S.cls_hg.p, R, B);
+    if (c.use_gnn) {
+      // time 0 (shared): N rows in, N rows out; afterwards R rows gathered through src
+      // (which, after the first selection, indexes the N-row state)
+      const int out_rows = (shared_first && time == 0) ? N : R;
+      run_gnn(e, S, S.cls_h[cur.cls[s]].p, src, S.cls_hg.p, out_rows,
+              (shared_first && time == 0) ? 1 : B);
+    }
   }
   // back-trace (:689-806)
   hipLaunchKernelGGL(beam_backtrace_kernel, dim3(cdiv(R, 256)), dim3(256), 0,
@@ -2100,7 +2132,7 @@ int mv_op_beam_step(int device, const float* logits, const float* prev_logprob,
     dn.alloc((size_t)N * B); di.alloc((size_t)N * B); dpa.alloc((size_t)N * B);
     hipLaunchKernelGGL(mv::beam_step_kernel, dim3(N), dim3(512), lds, ctx.stream, dl.p,
                        dp.p, B, K, time, diverse, logf(gamma), fix_num_timestep, dn.p,
-                       di.p, dpa.p, (int32_t*)nullptr);
+                       di.p, dpa.p, (int32_t*)nullptr, B);
     HIP_CHECK(hipGetLastError());
     ctx.down(new_logprob, dn, (size_t)N * B);
     ctx.down(ids, di, (size_t)N * B);

@@ -648,7 +648,7 @@ void beam_step_kernel(const float* __restrict__ logits,
                       int diverse, float log_gamma, int fix_num_timestep,
                       float* __restrict__ new_lp, int32_t* __restrict__ ids,
                       int32_t* __restrict__ parents,
-                      int32_t* __restrict__ state_src_row) {
+                      int32_t* __restrict__ state_src_row, int state_rows_per_sample) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* lp = sm;                 // [B*K]
   float* red = sm + B * K;        // [256] reduction scratch
@@ -721,7 +721,7 @@ void beam_step_kernel(const float* __restrict__ logits,
       new_lp[(size_t)n * B + sel] = (time > fix_num_timestep) ? best : 0.f;
       ids[(size_t)n * B + sel] = bi - par * K;
       parents[(size_t)n * B + sel] = par;
-      if (state_src_row) state_src_row[(size_t)n * B + sel] = n * B + par;
+      if (state_src_row) state_src_row[(size_t)n * B + sel] = n * state_rows_per_sample + par;
       lp[bi] = -INFINITY;  // remove from the candidate set
     }
     __syncthreads();

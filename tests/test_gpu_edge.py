@@ -146,3 +146,54 @@ def test_second_engine_with_smaller_beam_does_not_shrink_the_lds_limit(built_lib
   e2.close()
   for k in a:
     assert (a[k] == b[k]).all(), k
+
+
+_TILED_FIRST_STEP = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from multiverse_amd import _lib, synth
+cfg = synth.default_config(batch_size=3, use_grids=(1, 0), beam_size=5)
+cfg.diverse_beam = True
+for gnn in (True, False):
+  cfg.use_gnn = gnn
+  params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 71)
+  eng = _lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode("f16x3")
+  arrs, s = eng.forward_beam(feed)
+  eng.close()
+  np.savez(%(out)r %% int(gnn), **{k: np.asarray(v) for k, v in arrs.items()})
+"""
+
+
+def test_shared_first_beam_step_is_bitwise_the_tiled_one(built_lib, tmp_path):
+  """The first beam-decoder step runs once per sample (the B tiled rows are identical,
+  code/pred_models.py:497-502): every output equals, bit for bit, the run that tiles the
+  state first (MV_BEAM_SHARED_FIRST=0, read once per process -> a subprocess)."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = str(tmp_path / "tiled_%d.npz")
+  env = dict(os.environ, MV_BEAM_SHARED_FIRST="0")
+  subprocess.check_call([sys.executable, "-c", _TILED_FIRST_STEP % dict(root=root, out=out)],
+                        env=env)
+  cfg = synth.default_config(batch_size=3, use_grids=(1, 0), beam_size=5)
+  cfg.diverse_beam = True
+  for gnn in (True, False):
+    cfg.use_gnn = gnn
+    params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+    feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 71)
+    eng = built_lib.Engine(cfg, device=0)
+    eng.set_params(params)
+    eng.set_compute_mode("f16x3")
+    eng.set_profiling(True)
+    arrs, s = eng.forward_beam(feed)
+    stats = eng.kernel_stats()
+    eng.close()
+    assert "beam_tile_state" not in stats
+    tiled = np.load(out % int(gnn))
+    for k, v in arrs.items():
+      assert (np.asarray(v) == tiled[k]).all(), (gnn, k)
