@@ -170,6 +170,7 @@ struct mv_engine {
   DevBuf<float> bm_logits;         // [T, N, B, K] per-step logits
   DevBuf<int32_t> bm_ids, bm_parents;  // [T, N, B]
   DevBuf<float> bm_lp[2];          // [N, B]
+  DevBuf<float> bm_cand;           // [N, B, K] candidate log-probs of one step
   DevBuf<int32_t> bm_src_row;      // [N*B]
   DevBuf<int32_t> bm_trace;        // [N, B, T]
   DevBuf<float> bm_out_logits;     // [N, B, T, K]
@@ -245,8 +246,43 @@ void ensure_beam_step_lds(int device, size_t lds) {
   if (lds > cur) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mv::beam_step_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mv::beam_select_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     cur = lds;
   }
+}
+
+// One beam step (log-softmax + diversity penalty + top-B).  K <= 1024: the rank count on
+// one wave per (n, b) row over the whole chip, then the per-sample selection; larger K
+// (or MV_BEAM_STEP=v1): the single-launch kernel.  `cand` = [N*B, K] scratch.
+void launch_beam_step(hipStream_t stream, const float* logits, const float* prev_lp,
+                      float* cand, int N, int B, int K, int time, int diverse,
+                      float log_gamma, int fix_num_timestep, float* new_lp, int32_t* ids,
+                      int32_t* parents, int32_t* src_row, int rows_per_sample) {
+  static const bool v1 = getenv("MV_BEAM_STEP") && strcmp(getenv("MV_BEAM_STEP"), "v1") == 0;
+  if (v1 || K > 64 * mv::kBeamRankJ || !cand) {
+    hipLaunchKernelGGL(mv::beam_step_kernel, dim3(N), dim3(512),
+                       ((size_t)2 * B * K + 512) * sizeof(float), stream, logits, prev_lp, B,
+                       K, time, diverse, log_gamma, fix_num_timestep, new_lp, ids, parents,
+                       src_row, rows_per_sample);
+    HIP_CHECK(hipGetLastError());   // a refused LDS size must not pass silently
+    return;
+  }
+  const int R = N * B;
+  const dim3 grid(cdiv((size_t)R, 4)), block(256);
+  if (K <= 64 * 3)
+    hipLaunchKernelGGL(mv::beam_rank_kernel<3>, grid, block, 0, stream, logits, prev_lp, R, B,
+                       K, time, diverse, log_gamma, cand);
+  else if (K <= 64 * 9)
+    hipLaunchKernelGGL(mv::beam_rank_kernel<9>, grid, block, 0, stream, logits, prev_lp, R, B,
+                       K, time, diverse, log_gamma, cand);
+  else
+    hipLaunchKernelGGL(mv::beam_rank_kernel<mv::kBeamRankJ>, grid, block, 0, stream, logits,
+                       prev_lp, R, B, K, time, diverse, log_gamma, cand);
+  hipLaunchKernelGGL(mv::beam_select_kernel, dim3(N), dim3(1024),
+                     ((size_t)B * K + 64) * sizeof(float), stream, cand, B, K, time,
+                     fix_num_timestep, new_lp, ids, parents, src_row, rows_per_sample);
+  HIP_CHECK(hipGetLastError());
 }
 
 // Launch wrapper: optional hipEvent bracket per launch for the roofline figure.
@@ -403,6 +439,7 @@ void alloc_buffers(mv_engine* e) {
       e->bm_ids.alloc(Tp * R);
       e->bm_parents.alloc(Tp * R);
       e->bm_lp[0].alloc(R); e->bm_lp[1].alloc(R);
+      e->bm_cand.alloc((size_t)R * K);
       e->bm_src_row.alloc(R);
       e->bm_trace.alloc(R * Tp);
       e->bm_out_logits.alloc(R * Tp * K);
@@ -1077,7 +1114,6 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
   }
   HIP_CHECK(hipMemsetAsync(e->bm_lp[0].p, 0, (size_t)R * sizeof(float), e->stream));
   int lpi = 0;
-  const size_t lds_bytes = ((size_t)2 * B * K + 512) * sizeof(float);
   const int32_t* src = nullptr;  // state row indirection for the next cell step
   for (int time = 0; time <= Tp; ++time) {
     // rows the state holds going INTO this iteration's kernels
@@ -1122,12 +1158,10 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
       int32_t* ids = e->bm_ids.p + (size_t)(time - 1) * R;
       int32_t* parents = e->bm_parents.p + (size_t)(time - 1) * R;
       launch(e, "beam_step", 0, 4.0 * R * K, [&] {
-        hipLaunchKernelGGL(mv::beam_step_kernel, dim3(N), dim3(512), lds_bytes,
-                           e->stream, logits, e->bm_lp[lpi].p, B, K, time,
-                           c.diverse_beam, logf(c.diverse_gamma), c.fix_num_timestep,
-                           e->bm_lp[lpi ^ 1].p, ids, parents, e->bm_src_row.p,
-                           one_per_sample ? 1 : B);
-        HIP_CHECK(hipGetLastError());   // a refused LDS size must not pass silently
+        launch_beam_step(e->stream, logits, e->bm_lp[lpi].p, e->bm_cand.p, N, B, K, time,
+                         c.diverse_beam, logf(c.diverse_gamma), c.fix_num_timestep,
+                         e->bm_lp[lpi ^ 1].p, ids, parents, e->bm_src_row.p,
+                         one_per_sample ? 1 : B);
       });
       lpi ^= 1;
       src = e->bm_src_row.p;
@@ -2130,10 +2164,10 @@ int mv_op_beam_step(int device, const float* logits, const float* prev_logprob,
     ctx.up(dl, logits, (size_t)N * B * K);
     ctx.up(dp, prev_logprob, (size_t)N * B);
     dn.alloc((size_t)N * B); di.alloc((size_t)N * B); dpa.alloc((size_t)N * B);
-    hipLaunchKernelGGL(mv::beam_step_kernel, dim3(N), dim3(512), lds, ctx.stream, dl.p,
-                       dp.p, B, K, time, diverse, logf(gamma), fix_num_timestep, dn.p,
-                       di.p, dpa.p, (int32_t*)nullptr, B);
-    HIP_CHECK(hipGetLastError());
+    DevBuf<float> dc;
+    dc.alloc((size_t)N * B * K);
+    launch_beam_step(ctx.stream, dl.p, dp.p, dc.p, N, B, K, time, diverse, logf(gamma),
+                     fix_num_timestep, dn.p, di.p, dpa.p, (int32_t*)nullptr, B);
     ctx.down(new_logprob, dn, (size_t)N * B);
     ctx.down(ids, di, (size_t)N * B);
     ctx.down(parents, dpa, (size_t)N * B);

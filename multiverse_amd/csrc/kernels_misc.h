@@ -728,6 +728,138 @@ void beam_step_kernel(const float* __restrict__ logits,
   }
 }
 
+// The same step in two launches, so that the O(K^2) rank count of the diversity penalty
+// spreads over the whole chip instead of one CU per sample (447 us -> ~60 us per step at
+// N=128, B=20, K=576):
+//   beam_rank_kernel    one WAVE per (n, b) row, the row held in registers (lane l owns
+//                       k = l + 64 j); element u is broadcast with v_readlane and compared
+//                       against the 64 * J owned values; writes the candidates lp [R, K].
+//                       Same arithmetic, in the same order, as beam_step_kernel.
+//   beam_select_kernel  one workgroup per sample: candidates in LDS, every thread caches
+//                       the best of the ones it owns, B rounds of (wave reduce -> 16-entry
+//                       LDS table -> every thread re-derives the winner); only the winner's
+//                       owner rescans.  One barrier per round.
+constexpr int kBeamRankJ = 16;   // K <= 1024
+
+template <int J>
+__global__ __launch_bounds__(256)
+void beam_rank_kernel(const float* __restrict__ logits, const float* __restrict__ prev_lp,
+                      int R, int B, int K, int time, int diverse, float log_gamma,
+                      float* __restrict__ cand) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  if (time <= 1 && (r % B) != 0) return;   // only beam 0 is a candidate at the first step
+  const float* row = logits + (size_t)r * K;
+  float v[J];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int k = lane + 64 * j;
+    v[j] = k < K ? row[k] : -INFINITY;
+    mx = fmaxf(mx, v[j]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+    if (lane + 64 * j < K) s += expf(v[j] - mx);
+  s = wave_sum(s);
+  const float lse = logf(s);
+  const float pl = prev_lp[r];
+#pragma unroll
+  for (int j = 0; j < J; ++j) v[j] = pl + ((v[j] - mx) - lse);
+  if (diverse) {
+    int rank[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) rank[j] = 0;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      const int lim = min(64, K - 64 * jj);      // uniform
+      for (int l = 0; l < lim; ++l) {
+        const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                                      __builtin_bit_cast(int, v[jj]), l));
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          // u = l + 64 jj precedes kv = lane + 64 j  <=>  jj < j, or jj == j and l < lane
+          const bool before = jj < j || (jj == j && l < lane);
+          rank[j] += (o > v[j] || (before && o == v[j])) ? 1 : 0;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) v[j] = v[j] + log_gamma * (float)rank[j];
+  }
+  float* out = cand + (size_t)r * K;
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+    if (lane + 64 * j < K) out[lane + 64 * j] = v[j];
+}
+
+__device__ __forceinline__ bool beam_better(float v, int i, float bv, int bi) {
+  return v > bv || (v == bv && i < bi);
+}
+
+// Dynamic LDS: lp [B*K] + 2 x 16 (value, index) reduction entries.
+__global__ __launch_bounds__(1024)
+void beam_select_kernel(const float* __restrict__ cand, int B, int K, int time,
+                        int fix_num_timestep, float* __restrict__ new_lp,
+                        int32_t* __restrict__ ids, int32_t* __restrict__ parents,
+                        int32_t* __restrict__ state_src_row, int state_rows_per_sample) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncand = (time > 1) ? B * K : K;
+  float* lp = sm;
+  float* redv = sm + B * K;                              // [2][16]
+  int* redi = reinterpret_cast<int*>(redv + 32);         // [2][16]
+  const float* src = cand + (size_t)n * B * K;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = tid; v < ncand; v += 1024) {
+    const float x = src[v];
+    lp[v] = x;
+    if (beam_better(x, v, best, bi)) { best = x; bi = v; }
+  }
+  for (int sel = 0; sel < B; ++sel) {
+    float wv = best;
+    int wi = bi;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(wv, off, 64);
+      const int oi = __shfl_xor(wi, off, 64);
+      if (beam_better(ov, oi, wv, wi)) { wv = ov; wi = oi; }
+    }
+    const int pp = (sel & 1) * 16;
+    if (lane == 0) { redv[pp + wave] = wv; redi[pp + wave] = wi; }
+    __syncthreads();
+    wv = redv[pp];
+    wi = redi[pp];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) {
+      const float ov = redv[pp + w];
+      const int oi = redi[pp + w];
+      if (beam_better(ov, oi, wv, wi)) { wv = ov; wi = oi; }
+    }
+    if (tid == 0) {
+      const int par = wi / K;
+      new_lp[(size_t)n * B + sel] = (time > fix_num_timestep) ? wv : 0.f;
+      ids[(size_t)n * B + sel] = wi - par * K;
+      parents[(size_t)n * B + sel] = par;
+      if (state_src_row) state_src_row[(size_t)n * B + sel] = n * state_rows_per_sample + par;
+    }
+    if ((wi & 1023) == tid) {          // the owner removes the winner and rescans its own
+      lp[wi] = -INFINITY;
+      best = -INFINITY;
+      bi = 0x7fffffff;
+      for (int v = tid; v < ncand; v += 1024) {
+        const float x = lp[v];
+        if (beam_better(x, v, best, bi)) { best = x; bi = v; }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------ batch assembly
 // Dense regression maps from one (x, y) per row-step: out[r, cell, :] =
 // (float)(xy[r, :] - centre[cell, :]) in double, the rounding of
