@@ -796,32 +796,67 @@ void run_encoders(mv_engine* e, Cursors& cur) {
   }
 }
 
-void run_gnn(mv_engine* e, ScaleState& S, const float* h, const int32_t* src_row,
-             float* out, int rows, int sm_div) {
+// One attention pass per job; the LDS-tiled kernel takes up to two jobs per launch (the
+// two grid scales of a greedy step are 62 + 22 us back to back, one round of workgroups
+// each: together they fill the chip better).
+struct GnnJob {
+  ScaleState* S; const float* h; const int32_t* src_row; float* out; int rows, sm_div;
+};
+
+void run_gnn_jobs(mv_engine* e, const std::vector<GnnJob>& jobs) {
   const mv_config& c = e->cfg;
-  const size_t cells = (size_t)rows * S.K;
   static const bool v2 = !(getenv("MV_GNN") && strcmp(getenv("MV_GNN"), "v1") == 0);
-  size_t pst = 0;
-  _Float16* p16 = e->plane_out(out, &pst);
-  // f16x3 inference: the only consumer of h + GNN(h) is the gate convolution, which
-  // reads the operand planes -- the fp32 copy is not written at all
-  const bool need_f32 = !(v2 && p16 && !e->train && e->compute_mode != 0);
-  launch(e, "gnn_attend", cells * (9.0 * 2 * 2 * (c.hidden_size + c.scene_conv_dim) +
-                                   9.0 * 2 * c.hidden_size),
-         4.0 * cells * c.hidden_size * (1.0 + (need_f32 ? 1.0 : 0.0) + (p16 ? 1.0 : 0.0)) +
-             4.0 * (cells / sm_div) * c.scene_conv_dim, [&] {
-    if (v2 && S.W <= 32 && c.hidden_size == 256 && c.scene_conv_dim <= 64) {
+  for (size_t j0 = 0; j0 < jobs.size();) {
+    const GnnJob& A = jobs[j0];
+    const bool tiled = v2 && A.S->W <= 32 && c.hidden_size == 256 && c.scene_conv_dim <= 64;
+    size_t nj = 1;
+    if (tiled && j0 + 1 < jobs.size() && jobs[j0 + 1].S->W <= 32) nj = 2;
+    mv::GnnGroup grp{};
+    double flops = 0, bytes = 0;
+    unsigned nblocks = 0;
+    for (size_t j = 0; j < nj; ++j) {
+      const GnnJob& J = jobs[j0 + j];
+      const size_t cells = (size_t)J.rows * J.S->K;
+      size_t pst = 0;
+      _Float16* p16 = e->plane_out(J.out, &pst);
+      // f16x3 inference: the only consumer of h + GNN(h) is the gate convolution, which
+      // reads the operand planes -- the fp32 copy is not written at all
+      const bool need_f32 = !(tiled && p16 && !e->train && e->compute_mode != 0);
+      flops += cells * (9.0 * 2 * 2 * (c.hidden_size + c.scene_conv_dim) +
+                        9.0 * 2 * c.hidden_size);
+      bytes += 4.0 * cells * c.hidden_size *
+                   (1.0 + (need_f32 ? 1.0 : 0.0) + (p16 ? 1.0 : 0.0)) +
+               4.0 * (cells / J.sm_div) * c.scene_conv_dim;
       int ng = 0;
       const unsigned nb = mv::gnn_v2_blocks(cells, &ng);
-      hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nb), dim3(256), 0, e->stream, h,
-                         S.scene_mean.p, src_row, need_f32 ? out : (float*)nullptr, rows, S.H,
-                         S.W, c.hidden_size, c.scene_conv_dim, sm_div, p16, pst, ng);
-    } else {
-      hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
-                         e->stream, h, S.scene_mean.p, src_row, out, rows, S.H, S.W,
-                         c.hidden_size, c.scene_conv_dim, sm_div, p16, pst);
+      mv::GnnProblem& P = grp.p[j];
+      P.h = J.h; P.scene_mean = J.S->scene_mean.p; P.src_row = J.src_row;
+      P.out = need_f32 ? J.out : nullptr; P.p16 = p16; P.p16_stride = pst;
+      P.M = J.rows; P.H = J.S->H; P.W = J.S->W; P.sm_div = J.sm_div; P.ngroups = ng;
+      if (j == 0) grp.nblocks0 = nb;
+      nblocks += nb;
     }
-  });
+    if (nj == 1) grp.nblocks0 = nblocks;
+    launch(e, "gnn_attend", flops, bytes, [&] {
+      if (tiled) {
+        hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nblocks), dim3(256), 0, e->stream,
+                           grp, c.hidden_size, c.scene_conv_dim);
+      } else {
+        const size_t cells = (size_t)A.rows * A.S->K;
+        size_t pst = 0;
+        _Float16* p16 = e->plane_out(A.out, &pst);
+        hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
+                           e->stream, A.h, A.S->scene_mean.p, A.src_row, A.out, A.rows,
+                           A.S->H, A.S->W, c.hidden_size, c.scene_conv_dim, A.sm_div, p16, pst);
+      }
+    });
+    j0 += nj;
+  }
+}
+
+void run_gnn(mv_engine* e, ScaleState& S, const float* h, const int32_t* src_row,
+             float* out, int rows, int sm_div) {
+  run_gnn_jobs(e, {GnnJob{&S, h, src_row, out, rows, sm_div}});
 }
 
 template <int P>
@@ -974,15 +1009,19 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
   const bool v2 = tail_v2();
   for (int t = 0; t < Tp; ++t) {
     std::vector<ConvLstmArgs> probs;
+    if (c.use_gnn) {
+      std::vector<GnnJob> jobs;
+      for (int s = 0; s < c.num_scales; ++s)
+        if (e->sc[s].use)
+          jobs.push_back(GnnJob{&e->sc[s], e->sc[s].cls_h[cur.cls[s]].p, nullptr,
+                                e->sc[s].cls_hg.p, N, 1});
+      run_gnn_jobs(e, jobs);
+    }
     for (int s = 0; s < c.num_scales; ++s) {
       ScaleState& S = e->sc[s];
       if (!S.use) continue;
       const int cc = cur.cls[s];
-      const float* hin = S.cls_h[cc].p;
-      if (c.use_gnn) {
-        run_gnn(e, S, S.cls_h[cc].p, nullptr, S.cls_hg.p, N, 1);
-        hin = S.cls_hg.p;
-      }
+      const float* hin = c.use_gnn ? S.cls_hg.p : S.cls_h[cc].p;
       if (t == 0)  // one_hot(last observed cell)
         run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, N);
       else if (c.class_feedback_dense)   // raw logits of the previous step (:388-406)
@@ -2117,9 +2156,11 @@ int mv_op_gnn(int device, const float* h, const float* scene_mean, int32_t M,
     if (!(getenv("MV_GNN") && strcmp(getenv("MV_GNN"), "v1") == 0) && W <= 32) {
       int ng = 0;
       const unsigned nb = mv::gnn_v2_blocks(cells, &ng);
-      hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nb), dim3(256), 0, ctx.stream, dh.p,
-                         ds.p, (const int32_t*)nullptr, dout.p, M, H, W, C, D, 1,
-                         (_Float16*)nullptr, (size_t)0, ng);
+      mv::GnnGroup grp{};
+      grp.p[0] = mv::GnnProblem{dh.p, ds.p, nullptr, dout.p, nullptr, 0, M, H, W, 1, ng};
+      grp.nblocks0 = nb;
+      hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nb), dim3(256), 0, ctx.stream, grp,
+                         C, D);
     } else {
       hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
                          ctx.stream, dh.p, ds.p, (const int32_t*)nullptr, dout.p, M, H,

@@ -342,18 +342,35 @@ void gnn_attend_kernel(const float* __restrict__ h,
 constexpr int kGnnPitch = 68;        // floats per staged cell and chunk (64 + 4: bank spread)
 constexpr int kGnnStage = 98;        // 32 + 2*32 + 2 cells for W <= 32
 
+// One launch serves up to two problems (the two grid scales of a greedy decode step):
+// blocks [0, nblocks0) belong to p[0], the rest to p[1]; both counts are multiples of 8,
+// so the block -> XCD mapping below holds for each.
+struct GnnProblem {
+  const float* h; const float* scene_mean; const int32_t* src_row; float* out;
+  _Float16* p16; size_t p16_stride;
+  int M, H, W, sm_div, ngroups;
+};
+struct GnnGroup { GnnProblem p[2]; unsigned nblocks0; };
+
 __global__ __launch_bounds__(256)
-void gnn_attend_v2_kernel(const float* __restrict__ h, const float* __restrict__ scene_mean,
-                          const int32_t* __restrict__ src_row, float* __restrict__ out,
-                          int M, int H, int W, int C, int D, int sm_div,
-                          _Float16* p16, size_t p16_stride, int ngroups) {
+void gnn_attend_v2_kernel(const GnnGroup grp, int C, int D) {
   __shared__ __attribute__((aligned(16))) float buf[kGnnStage * kGnnPitch];
   __shared__ float ssq[kGnnStage];
   __shared__ float edot[32 * 9];
   __shared__ float alpha[32 * 9];
   __shared__ int hsrc[kGnnStage], ssrc[kGnnStage];
+  const bool second = blockIdx.x >= grp.nblocks0;
+  const GnnProblem& pr = grp.p[second ? 1 : 0];
+  const unsigned blk = second ? blockIdx.x - grp.nblocks0 : blockIdx.x;
+  const float* __restrict__ h = pr.h;
+  const float* __restrict__ scene_mean = pr.scene_mean;
+  const int32_t* __restrict__ src_row = pr.src_row;
+  float* __restrict__ out = pr.out;
+  _Float16* p16 = pr.p16;
+  const size_t p16_stride = pr.p16_stride;
+  const int M = pr.M, H = pr.H, W = pr.W, sm_div = pr.sm_div, ngroups = pr.ngroups;
   const int per = (ngroups + 7) >> 3;
-  const int g = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int g = (blk & 7) * per + (blk >> 3);
   if (g >= ngroups) return;
   const int tid = threadIdx.x;
   const int K = H * W;
