@@ -78,6 +78,7 @@ struct ConvLstm16Group {
   ConvLstm16Args p[kMaxGroup];
   int32_t block_end[kMaxGroup];
   int32_t n;
+  int32_t map_mode;    // forward step: 0 = column block per XCD, 1 = row tile per XCD
 };
 
 static inline int f16x3_xksteps(int Cx) { return (Cx % 16 == 0) ? 9 * (Cx / 16) : 0; }
@@ -538,6 +539,30 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   }
 }
 
+// block -> (column block cb, row tile mt) of the forward step.  A workgroup reads the
+// operand planes of its 256 cells and ONE column block's weights.
+//   mode 0  cb = block % 8: a column block per XCD -- its L2 keeps that block's 1.3 MB of
+//           weights, and every XCD streams ALL the activations (8x the activation bytes
+//           over the fabric);
+//   mode 1  mt % 8 = block % 8: a row tile lives on one XCD, whose eight column-block
+//           workgroups (consecutive on that XCD) share the tile's planes through its L2;
+//           the weights (10.6 MB per gate kernel) stream to every XCD instead.  The grid
+//           is padded to a multiple of 8 row tiles (dead workgroups exit at once).
+__device__ __forceinline__ bool step_block_map(const ConvLstmArgs& a, int block, int mode,
+                                               int& cb, int& mt) {
+  const int ncb = a.n_colblocks;
+  if (mode == 0) {
+    cb = block % ncb;
+    mt = block / ncb;
+    return true;
+  }
+  const int q = block >> 3;
+  cb = q % ncb;
+  mt = (q / ncb) * 8 + (block & 7);
+  const int mtiles = (a.rows * a.H * a.W + kBlockRows16 - 1) / kBlockRows16;
+  return mt < mtiles;
+}
+
 #ifndef MV_CONV_MINWAVES
 #define MV_CONV_MINWAVES (MV_CONV_WAVES == 8 ? 4 : 2)
 #endif
@@ -550,11 +575,12 @@ void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
   for (int i = 0; i < kMaxGroup - 1; ++i)
     if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
   if (pi > 0) block -= g.block_end[pi - 1];
+  int cb, mt;
   switch (pi) {
-    case 0: convlstm16_lds_body<kEpiLstm, 4>(g.p[0], block % g.p[0].f.n_colblocks, block / g.p[0].f.n_colblocks, 0, 1, lds); break;
-    case 1: convlstm16_lds_body<kEpiLstm, 4>(g.p[1], block % g.p[1].f.n_colblocks, block / g.p[1].f.n_colblocks, 0, 1, lds); break;
-    case 2: convlstm16_lds_body<kEpiLstm, 4>(g.p[2], block % g.p[2].f.n_colblocks, block / g.p[2].f.n_colblocks, 0, 1, lds); break;
-    default: convlstm16_lds_body<kEpiLstm, 4>(g.p[3], block % g.p[3].f.n_colblocks, block / g.p[3].f.n_colblocks, 0, 1, lds); break;
+    case 0: if (step_block_map(g.p[0].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4>(g.p[0], cb, mt, 0, 1, lds); break;
+    case 1: if (step_block_map(g.p[1].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4>(g.p[1], cb, mt, 0, 1, lds); break;
+    case 2: if (step_block_map(g.p[2].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4>(g.p[2], cb, mt, 0, 1, lds); break;
+    default: if (step_block_map(g.p[3].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4>(g.p[3], cb, mt, 0, 1, lds); break;
   }
 }
 
@@ -568,11 +594,12 @@ void convlstm_step_bf16_kernel(const ConvLstm16Group g) {
   for (int i = 0; i < kMaxGroup - 1; ++i)
     if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
   if (pi > 0) block -= g.block_end[pi - 1];
+  int cb, mt;
   switch (pi) {
-    case 0: convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[0], block % g.p[0].f.n_colblocks, block / g.p[0].f.n_colblocks, 0, 1, lds); break;
-    case 1: convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[1], block % g.p[1].f.n_colblocks, block / g.p[1].f.n_colblocks, 0, 1, lds); break;
-    case 2: convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[2], block % g.p[2].f.n_colblocks, block / g.p[2].f.n_colblocks, 0, 1, lds); break;
-    default: convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[3], block % g.p[3].f.n_colblocks, block / g.p[3].f.n_colblocks, 0, 1, lds); break;
+    case 0: if (step_block_map(g.p[0].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[0], cb, mt, 0, 1, lds); break;
+    case 1: if (step_block_map(g.p[1].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[1], cb, mt, 0, 1, lds); break;
+    case 2: if (step_block_map(g.p[2].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[2], cb, mt, 0, 1, lds); break;
+    default: if (step_block_map(g.p[3].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[3], cb, mt, 0, 1, lds); break;
   }
 }
 
@@ -678,6 +705,17 @@ void convlstm_dgrad_f16x3_kernel(const ConvLstm16Group g) {
 static inline unsigned convlstm16_blocks(const ConvLstmArgs& a) {
   const size_t M = (size_t)a.rows * a.H * a.W;
   return (unsigned)((M + kBlockRows16 - 1) / kBlockRows16) * (unsigned)a.n_colblocks;
+}
+// MV_CONV_MAP=1: row tile per XCD (step_block_map); grid padded to 8 row tiles
+static inline int conv_step_map_mode() {
+  static const int m = getenv("MV_CONV_MAP") ? atoi(getenv("MV_CONV_MAP")) : 0;
+  return m;
+}
+static inline unsigned convlstm16_step_blocks(const ConvLstmArgs& a, int mode) {
+  if (mode == 0) return convlstm16_blocks(a);
+  const size_t M = (size_t)a.rows * a.H * a.W;
+  const size_t mt = (M + kBlockRows16 - 1) / kBlockRows16;
+  return (unsigned)(((mt + 7) / 8) * 8) * (unsigned)a.n_colblocks;
 }
 
 static inline void launch_convlstm16_dgrads(const ConvLstm16Args* probs, int n,
@@ -796,10 +834,11 @@ static inline void launch_convlstm_bf16_steps(const ConvLstm16Args* probs, int n
                                               hipStream_t stream) {
   ConvLstm16Group g{};
   g.n = n;
+  g.map_mode = conv_step_map_mode();
   unsigned total = 0;
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
-    total += convlstm16_blocks(probs[i].f);
+    total += convlstm16_step_blocks(probs[i].f, g.map_mode);
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
@@ -810,10 +849,11 @@ static inline void launch_convlstm16_steps(const ConvLstm16Args* probs, int n,
                                            hipStream_t stream) {
   ConvLstm16Group g{};
   g.n = n;
+  g.map_mode = conv_step_map_mode();
   unsigned total = 0;
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
-    total += convlstm16_blocks(probs[i].f);
+    total += convlstm16_step_blocks(probs[i].f, g.map_mode);
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;

@@ -1,7 +1,6 @@
 set -u
 cd ${GRAFT_REPO_ROOT:-.}
-mkdir -p gpurun_out/s20
-(time timeout 1200 python -m pytest tests/test_gpu_edge.py tests/test_gpu_forward.py tests/test_gpu_at_size.py tests/test_gpu_kernels.py -q -x) > gpurun_out/s20/tests.log 2>&1
-echo "tests rc $?" >> gpurun_out/s20/tests.log
-grep -vE "^\s*$|amdgpu.ids" gpurun_out/s20/tests.log | tail -8
-python bench.py --no-cpu-baseline > gpurun_out/s20/bench_greedy.json 2> gpurun_out/s20/bench_greedy.err; tail -1 gpurun_out/s20/bench_greedy.json | cut -c1-300
+mkdir -p gpurun_out/s22
+MV_CONV_MAP=1 bash tools/profile_workload.sh r2_greedy_map1 > gpurun_out/s22/prof_greedy.log 2>&1
+MV_CONV_MAP=1 bash tools/profile_workload.sh r2_beam_map1 --workload beam > gpurun_out/s22/prof_beam.log 2>&1
+ls gpurun_out/prof_r2_greedy_map1 gpurun_out/prof_r2_beam_map1
