@@ -42,12 +42,15 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 (v_mfma_f3
 PEAK_HBM_GBS = 8000.0
 
 
-def algorithmic_counts(cfg, beam=1, executed=False):
+def algorithmic_counts(cfg, beam=1, executed=False, sparse_x=False):
   """FLOPs / state bytes per trajectory of the ConvLSTM sweep:
   2*K*9*(Cx+C)*4C per step; each step reads x,h,c and writes h,c once.  Dense = as the
-  reference computes it; executed = the first encoder step starts from the zero state
-  and never multiplies (or reads) the h half, and the first beam-decoder step runs once per
-  sample instead of once per (identical) beam row -- those FLOPs are NOT counted as achieved."""
+  reference computes it.  Executed = what the launches multiply, NOT counting
+    * the h half of the first encoder step (zero state: never read, never multiplied),
+    * (B - 1) of the B identical rows of the first beam-decoder step (run once per sample),
+    * sparse_x (f16x3 / bf16 inference): the x k-steps of the class encoder (x is zero
+      except at one cell per row) and of the class decoder (x is the embedding of a one-hot
+      map), which enter the gate kernel as table terms in its epilogue."""
   C, D, E = cfg.enc_hidden_size, cfg.scene_conv_dim, cfg.emb_size
   To, Tp = cfg.obs_len, cfg.pred_len
   flops = 0.0
@@ -56,17 +59,17 @@ def algorithmic_counts(cfg, beam=1, executed=False):
     if not cfg.use_grids[s]:
       continue
     K = h * w
-    for cx, steps, rows, enc in ((D, To, 1, True), (2, To, 1, True), (E, Tp, beam, False),
-                                 (E, Tp, 1, False)):
-      flops += rows * steps * 2.0 * K * 9 * (cx + C) * 4 * C
-      nbytes += rows * steps * K * (cx + 4 * C) * 4.0
+    for cx, steps, rows, enc, cls in ((D, To, 1, True, True), (2, To, 1, True, False),
+                                      (E, Tp, beam, False, True), (E, Tp, 1, False, False)):
+      rs = rows * steps
+      if executed and rows > 1:
+        rs -= rows - 1          # first beam step: once per sample
+      cxe = 0 if (executed and sparse_x and cls) else cx
+      flops += rs * 2.0 * K * 9 * (cxe + C) * 4 * C
+      nbytes += rs * K * (cxe + 4 * C) * 4.0
       if executed and enc:
         flops -= rows * 2.0 * K * 9 * C * 4 * C
         nbytes -= rows * K * 2 * C * 4.0
-      if executed and rows > 1:
-        # the first beam step sees B identical rows per sample: run once per sample
-        flops -= (rows - 1) * 2.0 * K * 9 * (cx + C) * 4 * C
-        nbytes -= (rows - 1) * K * (cx + 4 * C) * 4.0
   return flops, nbytes
 
 
@@ -208,7 +211,10 @@ def main():
   # achieved = algorithmic FLOPs the launches EXECUTED (zero-state steps skip the h half)
   achieved_tf = conv["flops"] / conv_s / 1e12
   flops_traj, bytes_traj = algorithmic_counts(cfg, args.beam if beam else 1)
-  flops_traj_exec, _ = algorithmic_counts(cfg, args.beam if beam else 1, executed=True)
+  sparse_x = (not train and args.compute != "f32" and
+              os.environ.get("MV_SPARSE_X", "1") != "0")
+  flops_traj_exec, _ = algorithmic_counts(cfg, args.beam if beam else 1, executed=True,
+                                          sparse_x=sparse_x)
   if train:
     flops_traj *= 3.0   # forward + dgrad + wgrad of every gate convolution
     flops_traj_exec *= 3.0

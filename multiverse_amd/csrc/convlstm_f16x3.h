@@ -369,8 +369,10 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   } while (0)
 
   // stage range of this workgroup (split-K: n_kslice equal ranges)
-  const int st_lo = (nstages / n_kslice) * kslice;
+  int st_lo = (nstages / n_kslice) * kslice;
   const int st_hi = n_kslice > 1 ? st_lo + nstages / n_kslice : nstages;
+  if constexpr (EPI == kEpiLstm)
+    if (a.sx_corr) st_lo = nxst;           // sparse x: its k-steps are table terms (epilogue)
   // The stage copy is an LDS-DMA (global_load_lds, 16 B per lane: the pack IS the LDS
   // image, lane-linear, so a wave's piece is one 1 KB run on both sides).  Round 1 staged
   // global -> VGPR -> ds_write: 24 more VGPRs (154 vs 126) and a write pass; 1.226 ->
@@ -475,24 +477,79 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     }
   } else {
   const int ch = cb * kChBlock + (lane & 31);
-    const float bi = a.bias[ch], bj = a.bias[C + ch], bf = a.bias[2 * C + ch],
-                bo = a.bias[3 * C + ch];
+    // sparse x: the registers hold the INTERIOR class of the bias table
+    const float* const b0 = a.sx_bias ? a.sx_bias + (size_t)4 * 4 * C : a.bias;
+    const float bi = b0[ch], bj = b0[C + ch], bf = b0[2 * C + ch], bo = b0[3 * C + ch];
     _Float16* const tl = reinterpret_cast<_Float16*>(lds) + wave * (1024 * NPL);
+    // (image row, cell) of the wave's 32 cells without a division per register: the tile
+    // starts in image row r0 at cell0 and crosses at most one row boundary (HW >= 32 is
+    // not required: the wrap loop below runs HW-many cells at a time)
+    const int r0 = __builtin_amdgcn_readfirstlane(m_wave / HW);
+    const int cell0 = __builtin_amdgcn_readfirstlane(m_wave - r0 * HW);
+    // sparse x: hot cells of the (at most two, for HW >= 32) image rows of the tile
+    int hot_y[2] = {0, 0}, hot_x[2] = {0, 0};
+    if (a.sx_corr) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        int rr = r0 + k;
+        if (rr >= a.rows) rr = a.rows - 1;
+        const int hr = a.sx_hot_div > 1 ? rr / a.sx_hot_div : rr;
+        const uint32_t hyx = a.sx_cellyx[a.sx_hot[(size_t)hr * a.sx_hot_stride]];
+        hot_y[k] = (int)(hyx >> 16); hot_x[k] = (int)(hyx & 0xffffu);
+      }
+    }
   #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
       const int m = m_wave + row;
       float hn_keep = 0.f;                 // cells past the end: zero planes
       if (m < M_total) {
+        int r = r0, cell = cell0 + row;
+        while (cell >= HW) { cell -= HW; ++r; }
         float cprev = 0.f;
         if (!a.zero_state) {
-          const int r = m / HW, cell = m - r * HW;
           const int sr = a.src_row_c ? a.src_row_c[r] : r;
           cprev = a.c[((size_t)sr * HW + cell) * C + ch];
         }
         constexpr float kUn = NPL == 2 ? kF16Unscale : 1.0f;   // bf16 operands are unscaled
-        const float gi = acc[0][reg] * kUn + bi, gj = acc[1][reg] * kUn + bj,
-                    gf = acc[2][reg] * kUn + bf, go = acc[3][reg] * kUn + bo;
+        float gi = acc[0][reg] * kUn, gj = acc[1][reg] * kUn, gf = acc[2][reg] * kUn,
+              go = acc[3][reg] * kUn;
+        if (a.sx_corr) {
+          const uint32_t yx = a.sx_cellyx[cell];
+          const int y = (int)(yx >> 16), x = (int)(yx & 0xffffu);
+          float ci = bi, cj = bj, cf = bf, co = bo;
+          if (a.sx_bias) {
+            const int cls = 3 * (y == 0 ? 0 : (y == H - 1 ? 2 : 1)) +
+                            (x == 0 ? 0 : (x == W - 1 ? 2 : 1));
+            if (cls != 4) {
+              const float* bt = a.sx_bias + (size_t)cls * 4 * C + ch;
+              ci = bt[0]; cj = bt[C]; cf = bt[2 * C]; co = bt[3 * C];
+            }
+          }
+          int hy, hx;
+          if (r - r0 < 2) {
+            hy = r == r0 ? hot_y[0] : hot_y[1];
+            hx = r == r0 ? hot_x[0] : hot_x[1];
+          } else {                          // HW < 32: more than two image rows in a tile
+            const int hr = a.sx_hot_div > 1 ? r / a.sx_hot_div : r;
+            const uint32_t hyx = a.sx_cellyx[a.sx_hot[(size_t)hr * a.sx_hot_stride]];
+            hy = (int)(hyx >> 16); hx = (int)(hyx & 0xffffu);
+          }
+          const int dy = y - hy, dx = x - hx, rad = a.sx_rad;
+          if (dy >= -rad && dy <= rad && dx >= -rad && dx <= rad) {
+            const int side = 2 * rad + 1;
+            const int idx = a.sx_by_class
+                                ? 3 * (hy == 0 ? 0 : (hy == H - 1 ? 2 : 1)) +
+                                      (hx == 0 ? 0 : (hx == W - 1 ? 2 : 1))
+                                : r;
+            const float* ct = a.sx_corr +
+                              ((size_t)idx * side * side + (dy + rad) * side + (dx + rad)) * 4 * C + ch;
+            ci += ct[0]; cj += ct[C]; cf += ct[2 * C]; co += ct[3 * C];
+          }
+          gi += ci; gj += cj; gf += cf; go += co;
+        } else {
+          gi += bi; gj += bj; gf += bf; go += bo;
+        }
         const float si = sigm_(gi), tj = tanh_(gj), sf = sigm_(gf + a.forget_bias),
                     so = sigm_(go);
         float cn = sf * cprev;

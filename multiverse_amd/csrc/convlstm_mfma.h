@@ -81,6 +81,21 @@ struct ConvLstmArgs {
   float forget_bias;
   int32_t want_h16;     // host-side hint (f16x3 mode): the next consumer of h' is a gate
                         // convolution, emit its operand planes from the epilogue
+  // --- sparse x (f16x3 / bf16 inference, class chains).  The x operand of the class
+  // encoder is zero except at ONE cell per row, the class decoder's is a constant
+  // vector except within one cell of the hot cell: their k-steps (20 % / 11 % of the
+  // launch) multiply zeros or recompute constants.  With sx_corr set the kernel skips
+  // the x k-steps and the epilogue adds
+  //   sx_bias[border class of the cell][4C]        (bias + conv of the constant part)
+  //   sx_corr[index][offset of the cell from the hot cell][4C]   within sx_rad cells,
+  // index = row (encoder: per-row table of the step) or border class of the hot cell
+  // (decoder: weights-only table).  Border class = 3 * (y == 0 ? 0 : y == H-1 ? 2 : 1) +
+  // (x == 0 ? 0 : x == W-1 ? 2 : 1).
+  const float* sx_bias;        // [9][4C] or null (plain bias)
+  const float* sx_corr;        // null: dense x
+  const int32_t* sx_hot;       // hot cell of row r: sx_hot[(r / sx_hot_div) * sx_hot_stride]
+  const uint32_t* sx_cellyx;   // [H*W]: y << 16 | x
+  int32_t sx_hot_stride, sx_hot_div, sx_rad, sx_by_class;
 };
 
 struct ConvLstmGroup {

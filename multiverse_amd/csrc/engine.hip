@@ -26,6 +26,7 @@
 #include "convlstm_wgrad_f16x3.h"
 #include "kernels_misc.h"
 #include "decode_tail.h"
+#include "sparse_x.h"
 #include "train_kernels.h"
 #include "comm.h"
 
@@ -143,6 +144,11 @@ struct ScaleState {
   DevBuf<float> q_cls, q_reg;               // [R, K, 9], [N, K, 18]
   DevBuf<float> wq_cls, wq_reg;             // pack_h2g_kernel of out_cls_W / out_reg_W
   bool wq_valid = false;
+  // sparse x operand of the class chains (sparse_x.h)
+  DevBuf<uint32_t> sx_cellyx;               // [K] y << 16 | x
+  DevBuf<float> sx_dec_bias, sx_dec_corr;   // [9][4C], [9][25][4C]: functions of the weights
+  DevBuf<float> sx_enc_corr;                // [N][9][4C]: the current encoder step
+  bool sx_valid = false;
 };
 
 }  // namespace
@@ -434,6 +440,9 @@ void alloc_buffers(mv_engine* e) {
     S.ids.alloc(R);
     S.q_cls.alloc(R * K * 9); S.q_reg.alloc(N * K * 18);
     S.wq_cls.alloc(C * 32); S.wq_reg.alloc(C * 32);
+    S.sx_cellyx.alloc(K);
+    S.sx_dec_bias.alloc(9 * 4 * C); S.sx_dec_corr.alloc(9 * 25 * 4 * C);
+    S.sx_enc_corr.alloc(N * 9 * 4 * C);
     if (B > 1) {
       e->bm_logits.alloc(Tp * R * K);
       e->bm_ids.alloc(Tp * R);
@@ -547,6 +556,14 @@ void ensure_packed_bf16(mv_engine* e, ConvCell& cc) {
                       hipMemcpyHostToDevice));
 }
 
+bool sparse_x_on(const mv_engine* e, const ScaleState& S) {
+  static const bool off = getenv("MV_SPARSE_X") && atoi(getenv("MV_SPARSE_X")) == 0;
+  const mv_config& c = e->cfg;
+  return !off && e->compute_mode != 0 && !e->train && S.use && S.H >= 3 && S.W >= 3 &&
+         S.dec_cls.Cx == c.emb_size && c.emb_size % 16 == 0 && c.scene_conv_dim % 16 == 0 &&
+         c.scene_conv_dim <= 64;
+}
+
 void ensure_params(mv_engine* e) {
   for (auto& p : e->params)
     MV_REQUIRE(p->set, "parameter %s not set (mv_set_param)", p->name.c_str());
@@ -569,12 +586,35 @@ void ensure_params(mv_engine* e) {
                          e->stream, S.out_reg_W->dev.p, S.wq_reg.p, C, 2);
       S.wq_valid = true;
     }
+    if (!S.sx_valid && sparse_x_on(e, S)) {
+      const int C = e->cfg.hidden_size;
+      hipLaunchKernelGGL(mv::cell_yx_kernel, dim3(cdiv((size_t)S.K, 256)), dim3(256), 0,
+                         e->stream, S.sx_cellyx.p, S.H, S.W);
+      hipLaunchKernelGGL(mv::sx_decoder_tables_kernel,
+                         dim3(cdiv((size_t)(9 + 9 * 25) * 4 * C, 256)), dim3(256), 0, e->stream,
+                         S.dec_cls.kernel->dev.p, S.dec_cls.biases->dev.p, S.emb_cls_W->dev.p,
+                         S.emb_cls_b->dev.p, S.dec_cls.Cx, C, S.sx_dec_bias.p, S.sx_dec_corr.p);
+      S.sx_valid = true;
+    }
   }
 }
 
 // ------------------------------------------------------------------ launches
 
 using mv::ConvLstmArgs;
+
+// class-chain x operands as table terms (sparse_x.h): f16x3 / bf16 inference engines only
+// (the training forward keeps the dense x: the backward pass needs it).  MV_SPARSE_X=0
+// restores the dense operand for A/B runs.
+void set_sparse_x(mv_engine* e, ScaleState& S, ConvLstmArgs& a, bool decoder,
+                  const int32_t* hot, int hot_stride, int hot_div) {
+  a.sx_bias = decoder ? S.sx_dec_bias.p : nullptr;
+  a.sx_corr = decoder ? S.sx_dec_corr.p : S.sx_enc_corr.p;
+  a.sx_hot = hot; a.sx_hot_stride = hot_stride; a.sx_hot_div = hot_div;
+  a.sx_cellyx = S.sx_cellyx.p;
+  a.sx_rad = decoder ? 2 : 1;
+  a.sx_by_class = decoder ? 1 : 0;
+}
 
 ConvLstmArgs conv_problem(mv_engine* e, const ConvCell& cc, const float* x,
                           const float* h, const float* c, const int32_t* src_row_h,
@@ -646,7 +686,7 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       auto it = e->planes.find(src);
       return (it != e->planes.end() && it->second.valid) ? &it->second : nullptr;
     };
-    if (!a.x_small && a.Cx > 0) {
+    if (!a.x_small && a.Cx > 0 && !a.sx_corr) {
       MV_REQUIRE((size_t)a.x_row_stride == (size_t)a.H * a.W * a.Cx,
                  "internal: f16x3 needs a contiguous x operand");
       const size_t n = cells * a.Cx;
@@ -699,8 +739,10 @@ void run_conv_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs) {
     // dense: the step as the reference computes it; executed: a zero-state step
     // (first encoder step) never multiplies the h half and never reads h, c
     dense += 2.0 * M * 9.0 * (a.Cx + a.C) * 4.0 * a.C;
-    flops += 2.0 * M * 9.0 * (a.Cx + (a.zero_state ? 0 : a.C)) * 4.0 * a.C;
-    bytes += M * (a.Cx + (a.zero_state ? 2.0 : 4.0) * a.C) * 4.0;   // x,(h,c) in; h,c out
+    // sparse x: the x k-steps are not executed (table terms in the epilogue)
+    const double cx = a.sx_corr ? 0.0 : (double)a.Cx;
+    flops += 2.0 * M * 9.0 * (cx + (a.zero_state ? 0 : a.C)) * 4.0 * a.C;
+    bytes += M * (cx + (a.zero_state ? 2.0 : 4.0) * a.C) * 4.0;   // x,(h,c) in; h,c out
   }
   if (e->compute_mode != 0) {
     run_conv_group_f16x3(e, probs, flops, bytes, dense);
@@ -771,6 +813,18 @@ void run_encoders(mv_engine* e, Cursors& cur) {
       ScaleState& S = e->sc[s];
       if (!S.use) continue;
       const size_t total = (size_t)N * S.K * D;
+      const bool sparse = sparse_x_on(e, S);
+      if (sparse) {
+        const size_t nc = (size_t)N * 9 * 4 * c.hidden_size;
+        launch(e, "sx_encoder_corr", 2.0 * nc * D, 4.0 * nc, [&] {
+          hipLaunchKernelGGL(mv::sx_encoder_corr_kernel,
+                             dim3(cdiv((size_t)4 * c.hidden_size, 256), 9,
+                                  cdiv((size_t)N, mv::kSxRows)),
+                             dim3(256), 0, e->stream, S.enc_cls.kernel->dev.p, e->scene_conv[s].p,
+                             e->obs_scene.p, S.labels.p, N, T, t, S.K, D, c.hidden_size,
+                             S.sx_enc_corr.p);
+        });
+      } else {
       launch(e, "enc_class_input", 0, 4.0 * total, [&] {
         size_t pst = 0;
         _Float16* p16 = e->plane_out(S.xbuf_cls.p, &pst);
@@ -779,6 +833,7 @@ void run_encoders(mv_engine* e, Cursors& cur) {
                            e->obs_scene.p, S.labels.p, S.xbuf_cls.p, N, T, t, S.K, D, p16,
                            pst);
       });
+      }
       // x = grid_obs_regress[:, t] is read in place through the row stride
       const size_t row = (size_t)S.K * 2;
       const int cc = cur.cls[s], cr = cur.reg[s];
@@ -786,6 +841,7 @@ void run_encoders(mv_engine* e, Cursors& cur) {
                                    S.cls_c[cc].p, nullptr, nullptr, S.cls_h[cc ^ 1].p,
                                    S.cls_c[cc ^ 1].p, N, S.H, S.W, t == 0, 0,
                                    /*want_h16=*/t + 1 < T || !c.use_gnn));
+      if (sparse) set_sparse_x(e, S, probs.back(), false, S.labels.p + t, T, 1);
       probs.push_back(conv_problem(e, S.enc_reg, S.obs_reg.p + (size_t)t * row,
                                    S.reg_h[cr].p, S.reg_c[cr].p, nullptr, nullptr,
                                    S.reg_h[cr ^ 1].p, S.reg_c[cr ^ 1].p, N, S.H, S.W,
@@ -970,12 +1026,14 @@ void run_tail(mv_engine* e, const std::vector<TailPlan>& plans) {
     a.rows = pl.cls_rows; a.H = S.H; a.W = S.W; a.P = 1; a.E = E; a.onehot = 1;
     tbytes += 4.0 * cc * (9 + 1);
     if (pl.cls_next) {
-      size_t pst = 0;
       a.ids_out = S.ids.p;
-      a.emb_w = S.emb_cls_W->dev.p; a.emb_b = S.emb_cls_b->dev.p;
-      a.x_out = S.xbuf_cls.p;
-      a.x16 = e->plane_out(S.xbuf_cls.p, &pst); a.x16_stride = (int64_t)pst;
-      tbytes += 4.0 * cc * E * (a.x16 ? 2 : 1);
+      if (!sparse_x_on(e, S)) {     // sparse x: the next step needs the id, not the embedding
+        size_t pst = 0;
+        a.emb_w = S.emb_cls_W->dev.p; a.emb_b = S.emb_cls_b->dev.p;
+        a.x_out = S.xbuf_cls.p;
+        a.x16 = e->plane_out(S.xbuf_cls.p, &pst); a.x16_stride = (int64_t)pst;
+        tbytes += 4.0 * cc * E * (a.x16 ? 2 : 1);
+      }
     }
     tp.push_back(a);
     mv::TailProblem b{};
@@ -1022,7 +1080,11 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
       if (!S.use) continue;
       const int cc = cur.cls[s];
       const float* hin = c.use_gnn ? S.cls_hg.p : S.cls_h[cc].p;
-      if (t == 0)  // one_hot(last observed cell)
+      // sparse x: the embedding of a one-hot map enters the gate kernel as table terms
+      const bool sparse = sparse_x_on(e, S) && (t == 0 || !c.class_feedback_dense);
+      if (sparse)
+        ;
+      else if (t == 0)  // one_hot(last observed cell)
         run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, N);
       else if (c.class_feedback_dense)   // raw logits of the previous step (:388-406)
         run_emb_dense(e, S, S.out_cls.p + (size_t)(t - 1) * S.K, (size_t)Tp * S.K,
@@ -1033,6 +1095,10 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
                                    nullptr, nullptr, S.cls_h[cc ^ 1].p,
                                    S.cls_c[cc ^ 1].p, N, S.H, S.W, false, 0,
                                    /*want_h16=*/!c.use_gnn));
+      if (sparse) {
+        if (t == 0) set_sparse_x(e, S, probs.back(), true, S.labels.p + (T - 1), T, 1);
+        else set_sparse_x(e, S, probs.back(), true, S.ids.p, 1, 1);
+      }
       cur.cls[s] ^= 1;
       probs.push_back(reg_decoder_problem(e, s, cur, t, Tp, !v2));
     }
@@ -1154,6 +1220,7 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
   HIP_CHECK(hipMemsetAsync(e->bm_lp[0].p, 0, (size_t)R * sizeof(float), e->stream));
   int lpi = 0;
   const int32_t* src = nullptr;  // state row indirection for the next cell step
+  const bool sparse = sparse_x_on(e, S);
   for (int time = 0; time <= Tp; ++time) {
     // rows the state holds going INTO this iteration's kernels
     const bool one_per_sample = shared_first && time <= 1;
@@ -1168,6 +1235,12 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
                                    c.use_gnn ? nullptr : src, src, S.cls_h[cc ^ 1].p,
                                    S.cls_c[cc ^ 1].p, rows_now, S.H, S.W, false, 0,
                                    /*want_h16=*/!c.use_gnn));
+      if (sparse) {
+        if (time == 1)
+          set_sparse_x(e, S, probs.back(), true, S.labels.p + (T - 1), T, one_per_sample ? 1 : B);
+        else
+          set_sparse_x(e, S, probs.back(), true, e->bm_ids.p + (size_t)(time - 2) * R, 1, 1);
+      }
       cur.cls[s] ^= 1;
       const bool v2 = tail_v2();
       probs.push_back(reg_decoder_problem(e, s, cur, time - 1, Tp, !v2));
@@ -1205,7 +1278,9 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
       lpi ^= 1;
       src = e->bm_src_row.p;
       if (time == Tp) break;
-      run_emb_onehot(e, S, ids, 1, S.xbuf_cls.p, R);
+      if (!sparse) run_emb_onehot(e, S, ids, 1, S.xbuf_cls.p, R);
+    } else if (sparse) {
+      // the embedded one-hot input enters the gate kernel as table terms (sparse_x.h)
     } else if (shared_first) {
       // one_hot(last observed cell) (:497-498, 531-532), one row per sample
       run_emb_onehot(e, S, S.labels.p + (T - 1), T, S.xbuf_cls.p, N, 1);
@@ -1557,7 +1632,7 @@ int mv_set_param(mv_handle h, const char* tf_name, const float* data,
     p->set = true;
     h->drop_graphs();   // captured launches hold the old device pointers
     h->train_packs_valid = false;
-    for (int s = 0; s < h->cfg.num_scales; ++s) h->sc[s].wq_valid = false;
+    for (int s = 0; s < h->cfg.num_scales; ++s) h->sc[s].wq_valid = h->sc[s].sx_valid = false;
     // invalidate the packed copy of a ConvLSTM kernel
     for (int s = 0; s < h->cfg.num_scales; ++s) {
       ScaleState& S = h->sc[s];

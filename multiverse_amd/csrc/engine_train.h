@@ -1243,7 +1243,7 @@ void train_apply(mv_engine* e, float grad_scale) {
   }
   if (t.tc.optimizer == 2) { t.beta1_power *= 0.9f; t.beta2_power *= 0.999f; }
   train_pack_all(e);
-  for (int s = 0; s < e->cfg.num_scales; ++s) e->sc[s].wq_valid = false;
+  for (int s = 0; s < e->cfg.num_scales; ++s) e->sc[s].wq_valid = e->sc[s].sx_valid = false;
   t.global_step += 1;
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(e->stream));

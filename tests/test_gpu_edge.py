@@ -197,3 +197,65 @@ def test_shared_first_beam_step_is_bitwise_the_tiled_one(built_lib, tmp_path):
     tiled = np.load(out % int(gnn))
     for k, v in arrs.items():
       assert (np.asarray(v) == tiled[k]).all(), (gnn, k)
+
+
+_DENSE_X = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from multiverse_amd import _lib, synth
+out = {}
+for mode in ("f16x3", "bf16"):
+  cfg = synth.default_config(batch_size=3, use_grids=(1, 1))
+  params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 72)
+  eng = _lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode(mode)
+  cls, reg = eng.forward_greedy(feed)
+  eng.close()
+  for s in range(2):
+    out["%%s_cls%%d" %% (mode, s)] = cls[s]
+    out["%%s_reg%%d" %% (mode, s)] = reg[s]
+np.savez(%(out)r, **out)
+"""
+
+
+def test_sparse_x_table_terms_equal_the_dense_x_operand(built_lib, tmp_path):
+  """The class chains' x operands as epilogue table terms (sparse_x.h) against the same
+  engine multiplying the dense operand (MV_SPARSE_X=0, read once per process): fp32-class
+  agreement in f16x3, the same argmax everywhere; the x k-steps are gone from the FLOPs the
+  launches report."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = str(tmp_path / "dense_x.npz")
+  subprocess.check_call([sys.executable, "-c", _DENSE_X % dict(root=root, out=out)],
+                        env=dict(os.environ, MV_SPARSE_X="0"))
+  dense = np.load(out)
+  for mode, tol in (("f16x3", 2e-5), ("bf16", 3e-2)):
+    cfg = synth.default_config(batch_size=3, use_grids=(1, 1))
+    params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+    feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 72)
+    eng = built_lib.Engine(cfg, device=0)
+    eng.set_params(params)
+    eng.set_compute_mode(mode)
+    eng.set_profiling(True)
+    cls, reg = eng.forward_greedy(feed)
+    stats = eng.kernel_stats()
+    eng.close()
+    assert "sx_encoder_corr" in stats and "enc_class_input" not in stats
+    assert stats["convlstm_step"]["flops"] < 0.93 * stats["convlstm_step"]["flops_dense"]
+    worst = 0.0
+    for s in range(2):
+      d = float(np.abs(cls[s] - dense["%s_cls%d" % (mode, s)]).max())
+      scale = float(np.abs(dense["%s_cls%d" % (mode, s)]).max())
+      worst = max(worst, d / scale)
+      assert d <= tol * scale, (mode, s, d, scale)
+      assert np.abs(reg[s] - dense["%s_reg%d" % (mode, s)]).max() <= tol * max(
+          1.0, float(np.abs(dense["%s_reg%d" % (mode, s)]).max()))
+      if mode == "f16x3":
+        assert (cls[s].reshape(3, cfg.pred_len, -1).argmax(-1) ==
+                dense["%s_cls%d" % (mode, s)].reshape(3, cfg.pred_len, -1).argmax(-1)).all()
+    print("%s: sparse-x vs dense-x class logits, max rel diff %.2e" % (mode, worst))

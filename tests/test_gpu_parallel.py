@@ -70,11 +70,17 @@ def _worker(rank, world, port, outdir):
   assert eng.global_step == STEPS
   out = {n: eng.get_param(n) for n, _ in eng.param_specs()}
   out.update({"slot0|" + n: eng.get_opt_slot(n, 0) for n, _ in eng.param_specs()})
-  # inference on the trained weights: this rank's shard of a fresh batch
+  eng.close()
+  # inference on the trained weights: this rank's shard of a fresh batch, on an inference
+  # engine (a training engine keeps the dense x operand of the class chains for its backward
+  # pass; the inference engine folds it into table terms -- same values, other rounding)
   feed = synth.make_feed(gcfg, seed=synth.SEED_BASE + 300)
   shard, _ = parallel.shard_feed(feed, rank, world, N_GLOBAL)
-  cls, reg = eng.forward_greedy(shard)
-  eng.close()
+  ieng = _lib.Engine(_cfg(hi - lo, synth, False), device=0)
+  ieng.set_params({n: out[n] for n in params})
+  ieng.set_compute_mode("f16x3")
+  cls, reg = ieng.forward_greedy(shard)
+  ieng.close()
   full = [parallel.gather_to_rank0(a) for a in (cls[0], cls[1], reg[0], reg[1])]
   if rank == 0:
     out["losses"] = np.asarray(losses)

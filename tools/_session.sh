@@ -1,6 +1,6 @@
 set -u
 cd ${GRAFT_REPO_ROOT:-.}
-mkdir -p gpurun_out/s22
-MV_CONV_MAP=1 bash tools/profile_workload.sh r2_greedy_map1 > gpurun_out/s22/prof_greedy.log 2>&1
-MV_CONV_MAP=1 bash tools/profile_workload.sh r2_beam_map1 --workload beam > gpurun_out/s22/prof_beam.log 2>&1
-ls gpurun_out/prof_r2_greedy_map1 gpurun_out/prof_r2_beam_map1
+mkdir -p gpurun_out/s26
+(time timeout 1500 python -m pytest tests/test_gpu_parallel.py tests/test_gpu_reference_pin.py tests/test_gpu_simaug.py tests/test_gpu_train.py tests/test_gpu_train_variants.py tests/test_gpu_cli.py tests/test_gpu_dropin.py -q -x) > gpurun_out/s26/tests.log 2>&1
+echo "tests rc $?" >> gpurun_out/s26/tests.log
+grep -E "passed|failed|error|rc " gpurun_out/s26/tests.log | tail -5
