@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -1102,6 +1103,12 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
       cur.cls[s] ^= 1;
       probs.push_back(reg_decoder_problem(e, s, cur, t, Tp, !v2));
     }
+    // longest tiles first: the dense-x problems (162 k-steps per tile) are dispatched
+    // before the sparse-x ones (144), so the last, partly filled round of workgroups is
+    // made of the short ones
+    std::stable_sort(probs.begin(), probs.end(), [](const ConvLstmArgs& a, const ConvLstmArgs& b) {
+      return (a.sx_corr == nullptr) > (b.sx_corr == nullptr);
+    });
     run_conv_group(e, probs);
     if (v2) {
       std::vector<TailPlan> plans;
