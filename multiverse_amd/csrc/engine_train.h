@@ -197,6 +197,13 @@ void run_colsum(mv_engine* e, const float* x, size_t rows, size_t ncols, float* 
                        rows, ncols, rows);
     return;
   }
+  if (ncols <= 128 && 256 % ncols == 0) {     // narrow: all 256 threads on 1 KB runs
+    hipLaunchKernelGGL(mv::colsum_narrow_kernel, dim3((unsigned)nslab), dim3(256), 0,
+                       e->stream, x, tmp, rows, (int)ncols, rps);
+    hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, gy), dim3(256), 0, e->stream, tmp, out,
+                       nslab, ncols, nslab);
+    return;
+  }
   hipLaunchKernelGGL(mv::colsum_kernel, dim3((unsigned)nslab, gy), dim3(256), 0,
                      e->stream, x, tmp, rows, ncols, rps);
   hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, gy), dim3(256), 0, e->stream, tmp, out,
@@ -243,7 +250,15 @@ void run_small_wgrad(mv_engine* e, const float* in, const float* dout, float* dw
              "internal: small wgrad partial buffer");
   launch(e, "conv3x3_small_wgrad", 2.0 * cells * 9 * Ci * Co,
          4.0 * cells * (9.0 * Ci + Co), [&] {
-    if (Ci > Co)
+    const size_t lds2 = ((size_t)(cpb + 2 * W + 2) * Co + cpb) * sizeof(float);
+    if (Ci > Co && Ci <= 256 && (Co == 1 || Co == 2) && G == 1 && lds2 <= 48 * 1024) {
+      if (Co == 1)
+        hipLaunchKernelGGL(mv::h2g_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), lds2,
+                           e->stream, in, dout, t.partial.p, R, H, W, Ci, cpb);
+      else
+        hipLaunchKernelGGL(mv::h2g_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), lds2,
+                           e->stream, in, dout, t.partial.p, R, H, W, Ci, cpb);
+    } else if (Ci > Co)
       hipLaunchKernelGGL(mv::conv3x3_small_wgrad_kernel<true>, dim3((unsigned)nblk),
                          dim3(threads), lds, e->stream, in, dout, t.partial.p, R, H, W, Ci,
                          Co, cpb, G);
@@ -608,6 +623,10 @@ void run_gate_bwd(mv_engine* e, float* gates, const float* c_prev, const float* 
                   int32_t* gmax_bits = nullptr) {
   const size_t total = cells * C;
   launch(e, "lstm_gate_bwd", 30.0 * total, 4.0 * total * 13, [&] {
+    if (C % 4 == 0)
+      hipLaunchKernelGGL(mv::lstm_gate_bwd4_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0,
+                         e->stream, gates, c_prev, c_new, dh, dc, total / 4, C, gmax_bits);
+    else
     hipLaunchKernelGGL(mv::lstm_gate_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
                        e->stream, gates, c_prev, c_new, dh, dc, total, C, gmax_bits);
   });
