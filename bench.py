@@ -99,6 +99,13 @@ def main():
   ap.add_argument("--cpu-batch", type=int, default=8)
   args = ap.parse_args()
 
+  # The contract is ONE JSON line on stdout.  RCCL / HIP print banners and warnings on
+  # fd 1 from native code (seen: "RCCL version ..." once the communicator is created), so
+  # fd 1 is pointed at stderr for the whole run and the line goes out through a saved copy.
+  sys.stdout.flush()
+  real_stdout = os.fdopen(os.dup(1), "w")
+  os.dup2(2, 1)
+
   import torch
   import torch.distributed as dist
   from multiverse_amd import _lib, synth
@@ -277,8 +284,8 @@ def main():
   # of this same command (FETCH_SIZE and WRITE_SIZE cannot share a pass on
   # gfx950); bench.py cannot collect PMCs itself, so it quotes the committed
   # profile when the workload matches, else null.
-  pmc_name = ("r1_f16x3_pmc_convlstm_step.json" if f16 else
-              "r2_bf16_pmc_convlstm_step.json" if bf16 else "r1_convlstm_pmc.json")
+  pmc_name = ("r2_greedy_pmc_convlstm_step_f16x3_lds.json" if f16 else
+              "r2_greedy_bf16_pmc_convlstm_step_bf16.json" if bf16 else "r1_convlstm_pmc.json")
   pmc_path = os.path.join(ROOT, "profiles", pmc_name)
   if args.batch == 64 and not beam and not train and os.path.exists(pmc_path):
     with open(pmc_path) as f:
@@ -293,9 +300,9 @@ def main():
 
   if train and f16 and args.batch == 32:
     # the three matrix kernels of the training step, launch-weighted
-    names = {"convlstm_step": "r1_train_pmc_convlstm_step_f16x3_lds.json",
-             "convlstm_dgrad": "r1_train_pmc_convlstm_dgrad.json",
-             "convlstm_wgrad": "r1_train_pmc_convlstm_wgrad_f16x3.json"}
+    names = {"convlstm_step": "r2_train_pmc_convlstm_step_f16x3_lds.json",
+             "convlstm_dgrad": "r2_train_pmc_convlstm_dgrad.json",
+             "convlstm_wgrad": "r2_train_pmc_convlstm_wgrad_f16x3.json"}
     tot, raw, n, ok = 0.0, 0.0, 0, True
     for k, fn in names.items():
       pth = os.path.join(ROOT, "profiles", fn)
@@ -428,7 +435,8 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
   if rank == 0:
-    print(json.dumps(out))
+    real_stdout.write(json.dumps(out) + "\n")
+    real_stdout.flush()
 
 
 def effective_cores():

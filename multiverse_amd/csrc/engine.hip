@@ -148,7 +148,7 @@ struct ScaleState {
   // sparse x operand of the class chains (sparse_x.h)
   DevBuf<uint32_t> sx_cellyx;               // [K] y << 16 | x
   DevBuf<float> sx_dec_bias, sx_dec_corr;   // [9][4C], [9][25][4C]: functions of the weights
-  DevBuf<float> sx_enc_corr;                // [N][9][4C]: the current encoder step
+  DevBuf<float> sx_enc_corr;                // [T_o][N][9][4C]: every encoder step
   bool sx_valid = false;
 };
 
@@ -443,7 +443,7 @@ void alloc_buffers(mv_engine* e) {
     S.wq_cls.alloc(C * 32); S.wq_reg.alloc(C * 32);
     S.sx_cellyx.alloc(K);
     S.sx_dec_bias.alloc(9 * 4 * C); S.sx_dec_corr.alloc(9 * 25 * 4 * C);
-    S.sx_enc_corr.alloc(N * 9 * 4 * C);
+    S.sx_enc_corr.alloc(T * N * 9 * 4 * C);
     if (B > 1) {
       e->bm_logits.alloc(Tp * R * K);
       e->bm_ids.alloc(Tp * R);
@@ -815,16 +815,17 @@ void run_encoders(mv_engine* e, Cursors& cur) {
       if (!S.use) continue;
       const size_t total = (size_t)N * S.K * D;
       const bool sparse = sparse_x_on(e, S);
+      const size_t nc = (size_t)N * 9 * 4 * c.hidden_size;   // table of one step
       if (sparse) {
-        const size_t nc = (size_t)N * 9 * 4 * c.hidden_size;
-        launch(e, "sx_encoder_corr", 2.0 * nc * D, 4.0 * nc, [&] {
-          hipLaunchKernelGGL(mv::sx_encoder_corr_kernel,
-                             dim3(cdiv((size_t)4 * c.hidden_size, 256), 9,
-                                  cdiv((size_t)N, mv::kSxRows)),
-                             dim3(256), 0, e->stream, S.enc_cls.kernel->dev.p, e->scene_conv[s].p,
-                             e->obs_scene.p, S.labels.p, N, T, t, S.K, D, c.hidden_size,
-                             S.sx_enc_corr.p);
-        });
+        if (t == 0)      // the tables of all T_o steps in one launch
+          launch(e, "sx_encoder_corr", 2.0 * nc * D * T, 4.0 * nc * T, [&] {
+            hipLaunchKernelGGL(mv::sx_encoder_corr_kernel,
+                               dim3(cdiv((size_t)4 * c.hidden_size, 256), 9,
+                                    cdiv((size_t)N, mv::kSxRows) * T),
+                               dim3(256), 0, e->stream, S.enc_cls.kernel->dev.p,
+                               e->scene_conv[s].p, e->obs_scene.p, S.labels.p, N, T, -1, S.K, D,
+                               c.hidden_size, S.sx_enc_corr.p);
+          });
       } else {
       launch(e, "enc_class_input", 0, 4.0 * total, [&] {
         size_t pst = 0;
@@ -842,7 +843,10 @@ void run_encoders(mv_engine* e, Cursors& cur) {
                                    S.cls_c[cc].p, nullptr, nullptr, S.cls_h[cc ^ 1].p,
                                    S.cls_c[cc ^ 1].p, N, S.H, S.W, t == 0, 0,
                                    /*want_h16=*/t + 1 < T || !c.use_gnn));
-      if (sparse) set_sparse_x(e, S, probs.back(), false, S.labels.p + t, T, 1);
+      if (sparse) {
+        set_sparse_x(e, S, probs.back(), false, S.labels.p + t, T, 1);
+        probs.back().sx_corr = S.sx_enc_corr.p + (size_t)t * nc;
+      }
       probs.push_back(conv_problem(e, S.enc_reg, S.obs_reg.p + (size_t)t * row,
                                    S.reg_h[cr].p, S.reg_c[cr].p, nullptr, nullptr,
                                    S.reg_h[cr ^ 1].p, S.reg_c[cr ^ 1].p, N, S.H, S.W,

@@ -84,7 +84,14 @@ void sx_encoder_corr_kernel(const float* __restrict__ w, const float* __restrict
   __shared__ float s[kSxRows][64];          // D <= 64 (host-checked)
   const int N4 = 4 * C, Cin = D + C;
   const int col = blockIdx.x * 256 + threadIdx.x;
-  const int o = blockIdx.y, n0 = blockIdx.z * kSxRows;
+  // blockIdx.z = step * row groups + row group: all T_o steps of the encoder in one launch
+  // (t < 0), or the single step t
+  const int ngrp = (N + kSxRows - 1) / kSxRows;
+  const int o = blockIdx.y, n0 = (int)(blockIdx.z % ngrp) * kSxRows;
+  if (t < 0) {
+    t = (int)(blockIdx.z / ngrp);
+    corr += (size_t)t * N * 9 * 4 * C;
+  }
   for (int i = threadIdx.x; i < kSxRows * D; i += 256) {
     const int k = i / D, ch = i - k * D;
     const int n = n0 + k < N ? n0 + k : N - 1;
