@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define MV_MAX_SCALES 2
-#define MV_ABI_VERSION 2
+#define MV_ABI_VERSION 3
 
 typedef struct mv_engine* mv_handle;
 
@@ -66,6 +66,14 @@ typedef struct mv_config {
    * raw logits, no argmax / one-hot -- to the class decoder's grid_emb.  0 = the
    * published one-hot feedback. */
   int32_t class_feedback_dense;
+  /* --use_single_decoder (code/pred_models.py:274,287-296; "# bad" in code/train.py:98): no
+   * regression decoder; the offsets are hidden2grid(class-decoder states) through ONE
+   * kernel "person_pred/decode_reg/out_dec_grid/W" shared by the scales.  The regression
+   * encoder's variables still exist (it is built, :232-234) but are neither run nor
+   * trained.  Greedy decode and training; refused with beam search (the reference's
+   * inference script reshapes the [N*B, ...] offsets of that combination as [1, T, -1, 2],
+   * code/multifuture_inference.py:478). */
+  int32_t use_single_decoder;
 } mv_config;
 
 /* The feed_dict of Model.get_feed_dict (pred_models.py:1042-1194), minus the

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 MV_MAX_SCALES = 2
-MV_ABI_VERSION = 2
+MV_ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmultiverse_hip.so")
@@ -67,6 +67,7 @@ class mv_config(C.Structure):
       ("diverse_gamma", C.c_float),
       ("fix_num_timestep", C.c_int32),
       ("class_feedback_dense", C.c_int32),
+      ("use_single_decoder", C.c_int32),
   ]
 
 
@@ -299,6 +300,7 @@ def make_config(cfg):
   # (code/pred_models.py:388-406, the not-training arm of the teacher_forcing branch)
   c.class_feedback_dense = 1 if (getattr(cfg, "use_teacher_forcing", False) and
                                  not getattr(cfg, "is_train", False)) else 0
+  c.use_single_decoder = 1 if getattr(cfg, "use_single_decoder", False) else 0
   return c
 
 

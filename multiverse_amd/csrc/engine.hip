@@ -92,6 +92,7 @@ struct Param {
   std::vector<float> host;
   DevBuf<float> dev;
   bool set = false;
+  bool no_grad = false;     // exists in the graph / checkpoints but is neither run nor trained
   size_t elems() const {
     size_t e = 1;
     for (auto d : shape) e *= (size_t)d;
@@ -160,6 +161,7 @@ struct mv_engine {
   hipStream_t stream = nullptr;
   std::string err;
   std::vector<std::unique_ptr<Param>> params;
+  Param* decode_reg_W = nullptr;   // --use_single_decoder: the offset kernel shared by the scales
   std::map<std::string, Param*> by_name;
   std::vector<Param*> scene_W, scene_b;
   ScaleState sc[MV_MAX_SCALES];
@@ -357,20 +359,37 @@ void build_param_table(mv_engine* e) {
     cell(S.enc_cls, "encoder_grid_class_%d/enc_grid_%d", D);
     cell(S.enc_reg, "encoder_grid_reg_%d/enc_grid_regress_%d", 2);
     cell(S.dec_cls, "decoder_grid_class_%d/decoder_rnn/dec_grid_%d", E);
-    cell(S.dec_reg, "decoder_grid_reg_%d/decoder_rnn/dec_grid_reg_%d", E);
     snprintf(nm, sizeof(nm), "person_pred/decoder_grid_class_%d/decoder_rnn/grid_emb/W", s);
     S.emb_cls_W = e->add_param(nm, {3, 3, 1, E});
     snprintf(nm, sizeof(nm), "person_pred/decoder_grid_class_%d/decoder_rnn/grid_emb/b", s);
     S.emb_cls_b = e->add_param(nm, {E});
+    snprintf(nm, sizeof(nm), "person_pred/hidden2grid_decoder_grid_class_%d/out_dec_grid/W", s);
+    S.out_cls_W = e->add_param(nm, {3, 3, C, 1});
+    if (c.use_single_decoder) {
+      // --use_single_decoder (code/pred_models.py:287-296): no regression decoder; ONE
+      // offset kernel for all scales (scope "decode_reg" has no scale index).  The
+      // regression encoder is built by the reference but feeds nothing: its variables
+      // exist (checkpoints hold them), it is not run and not trained.
+      S.enc_reg.kernel->no_grad = S.enc_reg.biases->no_grad = true;
+      if (!e->decode_reg_W)
+        e->decode_reg_W = e->add_param("person_pred/decode_reg/out_dec_grid/W", {3, 3, C, 2});
+      S.out_reg_W = e->decode_reg_W;
+      continue;
+    }
+    cell(S.dec_reg, "decoder_grid_reg_%d/decoder_rnn/dec_grid_reg_%d", E);
     snprintf(nm, sizeof(nm), "person_pred/decoder_grid_reg_%d/decoder_rnn/grid_emb/W", s);
     S.emb_reg_W = e->add_param(nm, {3, 3, 2, E});
     snprintf(nm, sizeof(nm), "person_pred/decoder_grid_reg_%d/decoder_rnn/grid_emb/b", s);
     S.emb_reg_b = e->add_param(nm, {E});
-    snprintf(nm, sizeof(nm), "person_pred/hidden2grid_decoder_grid_class_%d/out_dec_grid/W", s);
-    S.out_cls_W = e->add_param(nm, {3, 3, C, 1});
     snprintf(nm, sizeof(nm), "person_pred/hidden2grid_decoder_grid_reg_%d/out_dec_grid/W", s);
     S.out_reg_W = e->add_param(nm, {3, 3, C, 2});
   }
+}
+
+// the ConvLSTM cells a forward / training step of this engine runs
+std::vector<ConvCell*> active_cells(const mv_engine* e, ScaleState& S) {
+  if (e->cfg.use_single_decoder) return {&S.enc_cls, &S.dec_cls};
+  return {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg};
 }
 
 void validate_config(const mv_config& c) {
@@ -391,6 +410,9 @@ void validate_config(const mv_config& c) {
   MV_REQUIRE(c.beam_size >= 1, "beam_size must be >= 1");
   MV_REQUIRE(!(c.class_feedback_dense && c.beam_size > 1), "class_feedback_dense: greedy only "
              "(grid_decoder_beam_search always feeds one-hot ids)");
+  MV_REQUIRE(!(c.use_single_decoder && c.beam_size > 1), "use_single_decoder with beam search is "
+             "not built (the reference's inference script mis-shapes its [N*B,...] offsets, "
+             "code/multifuture_inference.py:478)");
   int hh = c.scene_h, ww = c.scene_w, used = 0;
   for (int s = 0; s < c.num_scales; ++s) {
     hh = (hh + 1) / 2; ww = (ww + 1) / 2;   // stride-2 SAME conv chain
@@ -571,14 +593,11 @@ void ensure_params(mv_engine* e) {
   for (int s = 0; s < e->cfg.num_scales; ++s) {
     ScaleState& S = e->sc[s];
     if (!S.use) continue;
-    ensure_packed(e, S.enc_cls); ensure_packed(e, S.enc_reg);
-    ensure_packed(e, S.dec_cls); ensure_packed(e, S.dec_reg);
+    for (ConvCell* cc : active_cells(e, S)) ensure_packed(e, *cc);
     if (e->compute_mode == 1)
-      for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
-        ensure_packed16(e, *cc);
+      for (ConvCell* cc : active_cells(e, S)) ensure_packed16(e, *cc);
     if (e->compute_mode == 2)
-      for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
-        ensure_packed_bf16(e, *cc);
+      for (ConvCell* cc : active_cells(e, S)) ensure_packed_bf16(e, *cc);
     if (!S.wq_valid) {     // hidden2grid tap packs, from the CURRENT device weights
       const int C = e->cfg.hidden_size;
       hipLaunchKernelGGL(mv::pack_h2g_kernel, dim3(cdiv((size_t)C * 32, 256)), dim3(256), 0,
@@ -642,7 +661,7 @@ ConvLstmArgs conv_problem(mv_engine* e, const ConvCell& cc, const float* x,
 ConvCell* cell_of_pack(mv_engine* e, const float* wpack) {
   for (int s = 0; s < e->cfg.num_scales; ++s) {
     ScaleState& S = e->sc[s];
-    for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
+    for (ConvCell* cc : active_cells(e, S))
       if (cc->wpack.p == wpack) return cc;
   }
   throw HipError{"internal: unknown weight pack"};
@@ -847,10 +866,11 @@ void run_encoders(mv_engine* e, Cursors& cur) {
         set_sparse_x(e, S, probs.back(), false, S.labels.p + t, T, 1);
         probs.back().sx_corr = S.sx_enc_corr.p + (size_t)t * nc;
       }
-      probs.push_back(conv_problem(e, S.enc_reg, S.obs_reg.p + (size_t)t * row,
-                                   S.reg_h[cr].p, S.reg_c[cr].p, nullptr, nullptr,
-                                   S.reg_h[cr ^ 1].p, S.reg_c[cr ^ 1].p, N, S.H, S.W,
-                                   t == 0, (size_t)T * row));
+      if (!c.use_single_decoder)     // single decoder: the regression encoder feeds nothing
+        probs.push_back(conv_problem(e, S.enc_reg, S.obs_reg.p + (size_t)t * row,
+                                     S.reg_h[cr].p, S.reg_c[cr].p, nullptr, nullptr,
+                                     S.reg_h[cr ^ 1].p, S.reg_c[cr ^ 1].p, N, S.H, S.W,
+                                     t == 0, (size_t)T * row));
       cur.cls[s] ^= 1; cur.reg[s] ^= 1;
     }
     run_conv_group(e, probs);
@@ -1105,7 +1125,7 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
         else set_sparse_x(e, S, probs.back(), true, S.ids.p, 1, 1);
       }
       cur.cls[s] ^= 1;
-      probs.push_back(reg_decoder_problem(e, s, cur, t, Tp, !v2));
+      if (!c.use_single_decoder) probs.push_back(reg_decoder_problem(e, s, cur, t, Tp, !v2));
     }
     // longest tiles first: the dense-x problems (162 k-steps per tile) are dispatched
     // before the sparse-x ones (144), so the last, partly filled round of workgroups is
@@ -1127,6 +1147,10 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
         pl.reg_h = S.reg_h[cur.reg[s]].p;
         pl.reg_out = S.out_reg.p + (size_t)t * S.K * 2; pl.reg_stride = (int64_t)Tp * S.K * 2;
         pl.reg_next = t + 1 < Tp;
+        if (c.use_single_decoder) {    // offsets from the class decoder's state (:287-296)
+          pl.reg_h = pl.cls_h;
+          pl.reg_next = false;
+        }
         plans.push_back(pl);
       }
       run_tail(e, plans);
@@ -1144,7 +1168,11 @@ void run_decoders_greedy(mv_engine* e, Cursors& cur, int Tp) {
                              logits, orow, S.ids.p, N, S.K);
         });
       }
-      reg_decoder_output(e, s, cur, t, Tp);
+      if (c.use_single_decoder)
+        run_hidden2grid<2>(e, S, S.cls_h[cur.cls[s]].p, S.out_reg_W->dev.p,
+                           S.out_reg.p + (size_t)t * S.K * 2, (size_t)Tp * S.K * 2, N);
+      else
+        reg_decoder_output(e, s, cur, t, Tp);
     }
   }
 }

@@ -54,6 +54,7 @@ struct TrainState {
   DevBuf<float> grad, accum, accum_update;
   TrainScale sc[MV_MAX_SCALES];
   DevBuf<float> dys[MV_MAX_SCALES], dpre_sc[MV_MAX_SCALES];   // scene stack backward
+  DevBuf<float> single_w;         // --use_single_decoder: one scale's d decode_reg W
   DevBuf<float> dscene;           // [U, SH, SW, SC] d loss / d scene_feat (SimAug attacks)
   DevBuf<float> scene_clean;      // the clean features an attack perturbs
   bool want_dscene = false, have_dscene = false;
@@ -139,9 +140,11 @@ void train_alloc(mv_engine* e) {
       max_partial = std::max(max_partial, mv::wgrad_partial_elems(wa));
     };
     chain(R.enc[0], &S.enc_cls, To, true);
-    chain(R.enc[1], &S.enc_reg, To, false);
     chain(R.dec[0], &S.dec_cls, Tp, true);
-    chain(R.dec[1], &S.dec_reg, Tp, true);
+    if (!c.use_single_decoder) {     // single decoder: no regression chains at all
+      chain(R.enc[1], &S.enc_reg, To, false);
+      chain(R.dec[1], &S.dec_reg, Tp, true);
+    }
     if (c.use_gnn) {
       R.hg.alloc(Tp * NK * C, mv::kWgradPad);
       R.gnn_a.alloc(NK * 9); R.gnn_de.alloc(NK * 9); R.gnn_n.alloc(NK);
@@ -181,6 +184,7 @@ void train_alloc(mv_engine* e) {
   }
   t.partial.alloc(max_partial);
   t.scratch.alloc((size_t)1 << 20);
+  t.single_w.alloc((size_t)9 * C * 2);
   t.losses.alloc(64);
 }
 
@@ -334,7 +338,8 @@ void train_pack_all(mv_engine* e) {
   for (int s = 0; s < e->cfg.num_scales; ++s) {
     if (!e->sc[s].use) continue;
     TrainScale& R = TS(e).sc[s];
-    for (int b = 0; b < 2; ++b) { run_pack(e, R.enc[b]); run_pack(e, R.dec[b]); }
+    const int nb = e->cfg.use_single_decoder ? 1 : 2;
+    for (int b = 0; b < nb; ++b) { run_pack(e, R.enc[b]); run_pack(e, R.dec[b]); }
   }
 }
 
@@ -461,12 +466,14 @@ void train_forward(mv_engine* e) {
             D = c.scene_conv_dim, E = c.emb_size;
   const int cls_fb = t.tc.class_feedback;        // 0 one-hot, 1 dense logits, 2 ground truth
   const bool reg_tf = t.tc.reg_teacher_forcing != 0;
+  const int nb = c.use_single_decoder ? 1 : 2;   // branches run: class (+ regression)
   train_prepare_targets(e);
   run_scene(e);
   for (int s = 0; s < c.num_scales; ++s) {
     ScaleState& S = e->sc[s];
     if (!S.use) continue;
     TrainScale& R = t.sc[s];
+    if (c.use_single_decoder) continue;
     // regression-encoder x operand, time-major
     const size_t tot = (size_t)N * To * S.K * 2;
     hipLaunchKernelGGL(mv::transpose_nt_kernel, dim3(cdiv(tot, 256)), dim3(256), 0,
@@ -488,8 +495,9 @@ void train_forward(mv_engine* e) {
                            xc, N, To, ts, S.K, D);
       });
       run_dropout(e, xc, total, s, 0, ts);
-      run_dropout(e, R.enc[1].xs.p + (size_t)ts * N * S.K * 2, (size_t)N * S.K * 2, s, 1, ts);
-      for (int b = 0; b < 2; ++b) {
+      if (nb == 2)
+        run_dropout(e, R.enc[1].xs.p + (size_t)ts * N * S.K * 2, (size_t)N * S.K * 2, s, 1, ts);
+      for (int b = 0; b < nb; ++b) {
         const float* x = b == 0 ? xc : R.enc[1].xs.p + (size_t)ts * N * S.K * 2;
         probs.push_back(train_problem(
             e, R.enc[b], x, R.hs[b].p + ts * NKC, R.cs[b].p + ts * NKC,
@@ -527,6 +535,7 @@ void train_forward(mv_engine* e) {
                                     R.cs[0].p + (slot + 1) * NKC,
                                     R.dec[0].gates.p + (size_t)ts * 4 * NKC, S.H, S.W,
                                     false));
+      if (nb == 1) continue;       // single decoder: offsets come from the class states
       // regression decoder
       float* xr = R.dec[1].xs.p + (size_t)ts * NK * E;
       if (ts == 0) {   // regio slot 0 = obs_grid_reg[:, -1]
@@ -563,7 +572,7 @@ void train_forward(mv_engine* e) {
                              (size_t)S.K, R.ids.p + (size_t)(ts + 1) * N, N, S.K);
         });
       }
-      run_hidden2grid<2>(e, S, R.hs[1].p + slot * NKC, S.out_reg_W->dev.p,
+      run_hidden2grid<2>(e, S, R.hs[nb - 1].p + slot * NKC, S.out_reg_W->dev.p,
                          R.regio.p + (size_t)(ts + 1) * NK * 2, (size_t)S.K * 2, N);
     }
   }
@@ -758,7 +767,7 @@ void comm_reduce_rest_and_join(mv_engine* e) {
   for (int s = 0; s < e->cfg.num_scales; ++s) {
     ScaleState& S = e->sc[s];
     if (!S.use) continue;
-    for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg}) {
+    for (ConvCell* cc : active_cells(e, S)) {
       taken[param_index(e, cc->kernel)] = 1;
       taken[param_index(e, cc->biases)] = 1;
     }
@@ -915,6 +924,7 @@ void train_backward(mv_engine* e) {
                                e->stream));
   }
   const bool f16 = e->compute_mode != 0;
+  const int nb = c.use_single_decoder ? 1 : 2;
   if (f16) {
     MV_REQUIRE(Tp <= 32 && To <= 32, "f16x3 training: at most 32 steps per chain");
     HIP_CHECK(hipMemsetAsync(t.gmax.p, 0, t.gmax.n * sizeof(int32_t), e->stream));
@@ -936,9 +946,9 @@ void train_backward(mv_engine* e) {
       run_small_dgrad(e, R.dlogits.p + (size_t)ts * NK, (size_t)S.K, S.out_cls_W->dev.p,
                       dh_a[s][0], (size_t)S.K * C, N, S.H, S.W, C, 1, true);
       run_small_dgrad(e, R.dreg.p + (size_t)ts * NK * 2, (size_t)S.K * 2,
-                      S.out_reg_W->dev.p, dh_a[s][1], (size_t)S.K * C, N, S.H, S.W, C, 2,
+                      S.out_reg_W->dev.p, dh_a[s][nb - 1], (size_t)S.K * C, N, S.H, S.W, C, 2,
                       true);
-      for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < nb; ++b) {
         float* G = R.dec[b].gates.p + (size_t)ts * 4 * NKC;
         const int gs = (2 * s + b) * 64 + ts;
         run_gate_bwd(e, G, R.cs[b].p + slot * NKC, R.cs[b].p + (slot + 1) * NKC,
@@ -978,7 +988,7 @@ void train_backward(mv_engine* e) {
       }
       std::swap(dh_a[s][1], dh_b[s][1]);
       // decoder input embeddings: d x -> d pre-activation (in place)
-      for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < nb; ++b) {
         float* dx = R.dec[b].dxs.p + (size_t)ts * NK * E;
         const size_t total = NK * E;
         run_dropout(e, dx, total, s, 2 + b, ts);       // backward of the input dropout
@@ -996,7 +1006,7 @@ void train_backward(mv_engine* e) {
       }
       // regression decoder: the step's input was grid_emb(out_reg[t-1]) -> d out_reg[t-1]
       // (teacher forcing feeds the ground truth instead: no gradient path)
-      if (ts > 0 && !t.tc.reg_teacher_forcing)
+      if (ts > 0 && !t.tc.reg_teacher_forcing && nb == 2)
         run_small_dgrad(e, R.dec[1].dxs.p + (size_t)ts * NK * E, (size_t)S.K * E,
                         S.emb_reg_W->dev.p, R.dreg.p + (size_t)(ts - 1) * NK * 2,
                         (size_t)S.K * 2, N, S.H, S.W, 2, E, true);
@@ -1019,7 +1029,7 @@ void train_backward(mv_engine* e) {
       if (!S.use) continue;
       TrainScale& R = t.sc[s];
       const size_t NK = (size_t)N * S.K, NKC = NK * C;
-      for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < nb; ++b) {
         float* G = R.enc[b].gates.p + (size_t)ts * 4 * NKC;
         const int gs = (2 * s + b) * 64 + 32 + ts;    // encoder steps: 32..
         const bool need_dh = ts > 0, need_dx = (b == 0);
@@ -1046,12 +1056,13 @@ void train_backward(mv_engine* e) {
     }
   }
   // ---- parameter gradients
+  bool single_first_done = false;
   for (int s = 0; s < c.num_scales; ++s) {
     ScaleState& S = e->sc[s];
     if (!S.use) continue;
     TrainScale& R = t.sc[s];
     const size_t NK = (size_t)N * S.K, NKC = NK * C;
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < nb; ++b) {
       run_wgrad(e, R.enc[b], R.hs[b].p, To, S.H, S.W, (2 * s + b) * 64 + 32);
       comm_reduce_cell(e, *R.enc[b].cell);       // bucket: overlaps the remaining wgrads
       const float* hin = (b == 0 && c.use_gnn) ? R.hg.p : R.hs[b].p + (size_t)To * NKC;
@@ -1076,18 +1087,36 @@ void train_backward(mv_engine* e) {
     run_small_wgrad(e, R.onehot.p, R.dec[0].dxs.p, grad_of(e, S.emb_cls_W), Tp * N, S.H,
                     S.W, 1, E);
     run_colsum(e, R.dec[0].dxs.p, (size_t)Tp * NK, E, grad_of(e, S.emb_cls_b), t.partial.p);
-    if (t.tc.reg_teacher_forcing)     // slot 0 of reg_in: obs_grid_reg[:, -1], as regio's
-      HIP_CHECK(hipMemcpyAsync(R.reg_in.p, R.regio.p, NK * 2 * sizeof(float),
-                               hipMemcpyDeviceToDevice, e->stream));
-    run_small_wgrad(e, t.tc.reg_teacher_forcing ? R.reg_in.p : R.regio.p, R.dec[1].dxs.p,
-                    grad_of(e, S.emb_reg_W), Tp * N, S.H,
-                    S.W, 2, E);
-    run_colsum(e, R.dec[1].dxs.p, (size_t)Tp * NK, E, grad_of(e, S.emb_reg_b), t.partial.p);
+    if (nb == 2) {
+      if (t.tc.reg_teacher_forcing)     // slot 0 of reg_in: obs_grid_reg[:, -1], as regio's
+        HIP_CHECK(hipMemcpyAsync(R.reg_in.p, R.regio.p, NK * 2 * sizeof(float),
+                                 hipMemcpyDeviceToDevice, e->stream));
+      run_small_wgrad(e, t.tc.reg_teacher_forcing ? R.reg_in.p : R.regio.p, R.dec[1].dxs.p,
+                      grad_of(e, S.emb_reg_W), Tp * N, S.H,
+                      S.W, 2, E);
+      run_colsum(e, R.dec[1].dxs.p, (size_t)Tp * NK, E, grad_of(e, S.emb_reg_b), t.partial.p);
+    }
     // hidden2grid
     run_small_wgrad(e, R.hs[0].p + (size_t)(To + 1) * NKC, R.dlogits.p,
                     grad_of(e, S.out_cls_W), Tp * N, S.H, S.W, C, 1);
-    run_small_wgrad(e, R.hs[1].p + (size_t)(To + 1) * NKC, R.dreg.p,
-                    grad_of(e, S.out_reg_W), Tp * N, S.H, S.W, C, 2);
+    if (nb == 2) {
+      run_small_wgrad(e, R.hs[1].p + (size_t)(To + 1) * NKC, R.dreg.p,
+                      grad_of(e, S.out_reg_W), Tp * N, S.H, S.W, C, 2);
+    } else {
+      // single decoder: ONE offset kernel for all scales -- the scales' gradients add up
+      // (in scale order, so the sum is deterministic)
+      const size_t nw = (size_t)9 * C * 2;
+      if (!single_first_done) {
+        run_small_wgrad(e, R.hs[0].p + (size_t)(To + 1) * NKC, R.dreg.p,
+                        grad_of(e, S.out_reg_W), Tp * N, S.H, S.W, C, 2);
+        single_first_done = true;
+      } else {
+        run_small_wgrad(e, R.hs[0].p + (size_t)(To + 1) * NKC, R.dreg.p, t.single_w.p,
+                        Tp * N, S.H, S.W, C, 2);
+        hipLaunchKernelGGL(mv::add_scaled_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, e->stream,
+                           grad_of(e, S.out_reg_W), t.single_w.p, 1.0f, nw);
+      }
+    }
   }
   // ---- scene stack
   const int U = e->num_frames, L = c.num_scales, k = c.scene_conv_kernel;
@@ -1236,6 +1265,7 @@ void train_apply(mv_engine* e, float grad_scale) {
   const float alpha = lr * sqrtf(1.0f - t.beta2_power) / (1.0f - t.beta1_power);
   for (size_t i = 0; i < e->params.size(); ++i) {
     Param* p = e->params[i].get();
+    if (p->no_grad) continue;      // tf.gradients gave None: apply_gradients skips the variable
     const size_t n = p->elems(), o = t.goff[i];
     float *s0 = t.accum.p + o, *s1 = t.accum_update.p + o;
     const float* g = t.grad.p + o;

@@ -111,6 +111,15 @@ def param_shapes(cfg):
     shapes[p + "decoder_grid_class_%d/decoder_rnn/dec_grid_%d/biases" % (s, s)] = (4 * C,)
     shapes[p + "decoder_grid_class_%d/decoder_rnn/grid_emb/W" % s] = (3, 3, 1, E)
     shapes[p + "decoder_grid_class_%d/decoder_rnn/grid_emb/b" % s] = (E,)
+    if getattr(cfg, "use_single_decoder", False):
+      # --use_single_decoder (code/pred_models.py:287-296): no regression decoder; the offsets
+      # come from the class decoder's states through ONE kernel shared by the scales (the
+      # scope "decode_reg" does not carry the scale index).  The regression ENCODER is still
+      # built (:232-234), so its variables exist in the graph and in checkpoints.
+      shapes[p + "hidden2grid_decoder_grid_class_%d/out_dec_grid/W" % s] = (3, 3, C, 1)
+      shapes[p + "decode_reg/out_dec_grid/W"] = (3, 3, C, 2)
+      continue
+    # (insertion order is the order make_params draws in: the fixtures depend on it)
     shapes[p + "decoder_grid_reg_%d/decoder_rnn/dec_grid_reg_%d/kernel" % (s, s)] = (k, k, E + C, 4 * C)
     shapes[p + "decoder_grid_reg_%d/decoder_rnn/dec_grid_reg_%d/biases" % (s, s)] = (4 * C,)
     shapes[p + "decoder_grid_reg_%d/decoder_rnn/grid_emb/W" % s] = (3, 3, 2, E)

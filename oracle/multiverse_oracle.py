@@ -489,9 +489,17 @@ def forward_tensors(P, cfg, feed, dtype=torch.float32, trace=None):
           feedback=cls_fb, pred_gt=cls_gt, drop=drop)
       if trace is not None:
         trace["dec_class_h_%d" % s] = dec_h.detach().numpy()
-    dec_reg, _ = greedy_decoder(
-        P, cfg, s, "reg", obs_reg[:, -1], enc_r, T_pred, scene_mean, trace,
-        feedback=reg_fb, pred_gt=reg_gt if reg_fb == "teacher" else None, drop=drop)
+    if getattr(cfg, "use_single_decoder", False):
+      # decode the offsets from the class decoder's states (:287-296): one 3x3 conv
+      # 256 -> 2, scope "decode_reg" (shared by the scales), no regression decoder
+      assert not cfg.use_beam_search, "single decoder: greedy / training only (DESIGN.md 8)"
+      Nn, Tt = dec_h.shape[0], dec_h.shape[1]
+      dec_reg = conv_layer(dec_h.reshape((Nn * Tt,) + tuple(dec_h.shape[2:])),
+                           P["decode_reg/out_dec_grid/W"]).reshape(Nn, Tt, H, W, 2)
+    else:
+      dec_reg, _ = greedy_decoder(
+          P, cfg, s, "reg", obs_reg[:, -1], enc_r, T_pred, scene_mean, trace,
+          feedback=reg_fb, pred_gt=reg_gt if reg_fb == "teacher" else None, drop=drop)
     cls_out.append(dec_cls)
     reg_out.append(dec_reg)
   return cls_out, reg_out, beam_out

@@ -134,12 +134,50 @@ def teacher_test_forward_case():
   print("wrote golden_shim_variant_teacher_test.npz")
 
 
+def single_decoder_case():
+  """--use_single_decoder (code/pred_models.py:274,287-296) on BOTH scales: the offset kernel
+  person_pred/decode_reg/out_dec_grid/W is shared by the scales, the regression encoder's
+  variables exist without a gradient.  A greedy Tester.step and two Trainer.steps."""
+  out = {}
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1), use_single_decoder=True)
+  params = synth.make_params(cfg, seed=VARIANT_SEED + 2, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=VARIANT_SEED + 2)
+  cls, reg, _ = rr.forward(cfg, params, feed)
+  out["var_names"] = np.array(["%s|%s" % (n, ",".join(map(str, s)))
+                               for n, s in rr.variable_names()])
+  for s in range(2):
+    out["cls_%d" % s], out["reg_%d" % s] = np.asarray(cls[s]), np.asarray(reg[s])
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1), use_single_decoder=True,
+                             is_train=True)
+  cfg.train_num_examples = 2
+  params = synth.make_params(cfg, seed=VARIANT_SEED + 3, recurrent_gain=2.0, bias_scale=0.1)
+  slots, gs, steps = {}, 0, 2
+  for step in range(steps):
+    feed = synth.make_feed(cfg, seed=VARIANT_SEED + 103 + step)
+    loss, wd, pgl, grads, params, slots, gs = rr.train_step(cfg, params, feed, slots, gs)
+    out["loss_%d" % step] = np.array([loss, wd] + pgl, dtype=np.float64)
+    for n in sorted(grads):
+      if grads[n] is not None:
+        out["grad_%d|%s" % (step, n)] = digest(grads[n])
+    out["no_grad"] = np.array(sorted(n for n in grads if grads[n] is None))
+    print("single_decoder step", step, "loss", loss)
+  for n in sorted(params):
+    out["param|%s" % n] = digest(params[n])
+  out["steps"] = np.array([steps])
+  out["global_step"] = np.array([gs])
+  np.savez_compressed(os.path.join(GOLD, "golden_shim_single_decoder.npz"), **out)
+  print("wrote golden_shim_single_decoder.npz")
+
+
 def main():
   assert rr.available(), "needs the reference checkout (/root/reference)"
   if len(sys.argv) > 1 and sys.argv[1] == "variants":
     for name, over, steps in VARIANT_CASES:
       variant_train_case(name, over, steps)
     teacher_test_forward_case()
+    return
+  if len(sys.argv) > 1 and sys.argv[1] == "single":
+    single_decoder_case()
     return
   forward_case("golden_shim_greedy_cfg1.npz",
                synth.default_config(batch_size=4, use_grids=(1, 0)),

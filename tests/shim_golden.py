@@ -104,3 +104,18 @@ def variant_case(name):
           for s, (h, w) in enumerate(cfg.scene_grids)]
     feeds.append(feed)
   return g, cfg, params, feeds
+
+
+def single_decoder_case():
+  """golden_shim_single_decoder.npz: (fixture, (cfg, params, feed) of the greedy run,
+  (cfg, params, feeds) of the two training steps)."""
+  g = load("golden_shim_single_decoder.npz")
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1), use_single_decoder=True)
+  params = synth.make_params(cfg, seed=VARIANT_SEED + 2, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=VARIANT_SEED + 2)
+  tcfg = synth.default_config(batch_size=2, use_grids=(1, 1), use_single_decoder=True,
+                              is_train=True)
+  tcfg.train_num_examples = 2
+  tparams = synth.make_params(tcfg, seed=VARIANT_SEED + 3, recurrent_gain=2.0, bias_scale=0.1)
+  feeds = [synth.make_feed(tcfg, seed=VARIANT_SEED + 103 + s) for s in range(int(g["steps"][0]))]
+  return g, (cfg, params, feed), (tcfg, tparams, feeds)

@@ -153,3 +153,60 @@ def test_dropout_mask_statistics_and_seed(built_lib):
   assert out[0] == out[1] and out[0] != out[2]
   m = oracle.dropout_keep_mask((1 << 20,), 0.7, 99, 3)
   assert abs(m.mean() - 0.7) < 2e-3
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+def test_single_decoder(built_lib, mode):
+  """--use_single_decoder (code/pred_models.py:274,287-296), both scales: offsets decoded
+  from the class decoder's states by ONE kernel shared by the scales; the regression
+  encoder's variables exist but are neither run nor trained.  Greedy forward and two
+  training steps against the frozen reference runs, gradients also against the fp64 oracle."""
+  g, (cfg, params, feed), (tcfg, tparams, feeds) = sg.single_decoder_case()
+  eng = built_lib.Engine(cfg, device=0)
+  assert sorted(n for n, _ in eng.param_specs()) == sorted(params)
+  eng.set_params(params)
+  eng.set_compute_mode(mode)
+  eng.set_profiling(True)
+  cls, reg = eng.forward_greedy(feed)
+  stats = eng.kernel_stats()
+  eng.close()
+  # two chains per scale instead of four
+  assert stats["convlstm_step"]["flops_dense"] < 0.55 * 2 * 2 * 20 * 2.0 * 9 * 288 * 1024 * (576 + 144)
+  for s in range(2):
+    K = cfg.scene_grids[s][0] * cfg.scene_grids[s][1]
+    assert (cls[s].reshape(2, -1, K).argmax(-1) == g["cls_%d" % s].reshape(2, -1, K).argmax(-1)).all()
+    assert np.abs(cls[s] - g["cls_%d" % s]).max() <= 1e-4
+    assert np.abs(reg[s] - g["reg_%d" % s]).max() <= 1e-4
+  eng = built_lib.Engine(tcfg, device=0)
+  eng.set_params(tparams)
+  eng.set_compute_mode(mode)
+  eng.train_init()
+  no_grad = sorted(str(n) for n in g["no_grad"])
+  for step, fd in enumerate(feeds):
+    p_before = {n: eng.get_param(n) for n in tparams}
+    loss, wd, pgl = eng.train_forward_backward(fd)
+    ref = g["loss_%d" % step]
+    print("single decoder/%s step %d: loss %.6f reference run %.6f" % (mode, step, loss, ref[0]))
+    assert np.allclose([loss, wd] + pgl, ref, rtol=1e-4, atol=1e-5), (loss, ref)
+    if step == 0:
+      _, _, _, og64 = oracle.loss_and_grads(p_before, tcfg, fd, dtype=torch.float64)
+      for n, _ in eng.param_specs():
+        gr = eng.get_grad(n)
+        if n in no_grad:
+          assert not gr.any() and og64.get(n) is None
+          continue
+        e_s, e_a = sg.digest_err(gr, g["grad_0|%s" % n])
+        e64 = _rel(gr, og64[n])
+        assert e_s < 2e-3 and e_a < 2e-3 and e64 < 2e-3, (n, e_s, e_a, e64)
+    eng.train_apply(1.0)
+  assert eng.global_step == len(feeds)
+  for n, _ in eng.param_specs():
+    e_s, e_a = sg.digest_err(eng.get_param(n), g["param|%s" % n])
+    assert e_s < 1e-5 and e_a < 1e-5, (n, e_s, e_a)
+  for n in no_grad:
+    assert (eng.get_param(n) == tparams[n]).all()
+  eng.close()
+  # refused with beam search
+  bcfg = synth.default_config(batch_size=2, use_grids=(1, 0), use_single_decoder=True, beam_size=5)
+  with pytest.raises(built_lib.MvError, match="use_single_decoder"):
+    built_lib.Engine(bcfg, device=0)

@@ -31,9 +31,9 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 
 def test_struct_layout_matches_header(built_lib):
-  # 19 int32/float fields + 3 arrays of MV_MAX_SCALES -> 4-byte packed (offsets: see
+  # 20 int32/float fields + 3 arrays of MV_MAX_SCALES -> 4-byte packed (offsets: see
   # test_ctypes_structs_match_the_c_header)
-  assert ctypes.sizeof(built_lib.mv_config) == 4 * (19 + 3 * built_lib.MV_MAX_SCALES)
+  assert ctypes.sizeof(built_lib.mv_config) == 4 * (20 + 3 * built_lib.MV_MAX_SCALES)
   assert ctypes.sizeof(built_lib.mv_inputs) == 8 * 2 + 4 * 2 + 8 * 2 * built_lib.MV_MAX_SCALES
   assert ctypes.sizeof(built_lib.mv_outputs) == 8 * 2 * built_lib.MV_MAX_SCALES
   assert ctypes.sizeof(built_lib.mv_beam_outputs) == 8 * 5
@@ -212,6 +212,8 @@ def test_trainer_rejects_unbuilt_switches():
     _lib.make_train_config(cfg)
   cfg = synth.default_config(batch_size=2, is_train=True)
   cfg.use_single_decoder = True
+  pred_models.Model._check_config(cfg)           # greedy / training: built
+  cfg.use_beam_search = True
   with pytest.raises(_lib.MvError, match="use_single_decoder"):
     pred_models.Model._check_config(cfg)
   # every published training switch maps onto mv_train_config

@@ -108,3 +108,35 @@ def test_oracle_test_time_teacher_forcing_equals_reference():
   cls, reg, _ = oracle.forward(params, cfg, feed)
   assert np.abs(cls[1] - g["cls_1"]).max() <= 2e-5
   assert np.abs(reg[1] - g["reg_1"]).max() <= 2e-5
+
+
+def test_oracle_single_decoder_equals_reference():
+  """--use_single_decoder on both scales (shared decode_reg kernel, regression encoder
+  without a gradient): greedy forward and two Trainer.steps of the reference on the shim."""
+  g, (cfg, params, feed), (tcfg, tparams, feeds) = sg.single_decoder_case()
+  names = sg.var_table(g)
+  names.pop("global_step", None)
+  assert sorted(names) == sorted(params)
+  assert names["person_pred/decode_reg/out_dec_grid/W"] == (3, 3, 256, 2)
+  assert not any("decoder_grid_reg" in n for n in names)
+  cls, reg, _ = oracle.forward(params, cfg, feed)
+  for s in range(2):
+    assert np.abs(cls[s] - g["cls_%d" % s]).max() <= 2e-5
+    assert np.abs(reg[s] - g["reg_%d" % s]).max() <= 2e-5
+  p, st = dict(tparams), oracle.optimizer_init(tcfg, tparams)
+  no_grad = sorted(str(n) for n in g["no_grad"])
+  assert no_grad == sorted(n for n in tparams if "encoder_grid_reg" in n)
+  for step, feed in enumerate(feeds):
+    loss, wd, pgl, p, st, grads = oracle.train_step(p, st, step, tcfg, feed)
+    assert np.allclose([loss, wd] + pgl, g["loss_%d" % step], rtol=2e-6, atol=1e-6)
+    assert sorted(n for n in tparams if grads.get(n) is None) == no_grad
+    for n, gr in grads.items():
+      if gr is None:
+        continue
+      e_s, e_a = sg.digest_err(gr, g["grad_%d|%s" % (step, n)])
+      assert e_s < 2e-5 and e_a < 1e-4, (n, e_s, e_a)
+  for n in p:
+    e_s, e_a = sg.digest_err(p[n], g["param|%s" % n])
+    assert e_s < 2e-6 and e_a < 2e-6, (n, e_s, e_a)
+  for n in no_grad:                       # never touched by apply_gradients
+    assert (p[n] == tparams[n]).all()
