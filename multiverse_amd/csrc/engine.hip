@@ -920,7 +920,7 @@ void run_gnn_jobs(mv_engine* e, const std::vector<GnnJob>& jobs) {
     if (nj == 1) grp.nblocks0 = nblocks;
     launch(e, "gnn_attend", flops, bytes, [&] {
       if (tiled) {
-        hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nblocks), dim3(256), 0, e->stream,
+        hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nblocks), dim3(mv::kGnnThreads), 0, e->stream,
                            grp, c.hidden_size, c.scene_conv_dim);
       } else {
         const size_t cells = (size_t)A.rows * A.S->K;
@@ -2273,7 +2273,7 @@ int mv_op_gnn(int device, const float* h, const float* scene_mean, int32_t M,
       mv::GnnGroup grp{};
       grp.p[0] = mv::GnnProblem{dh.p, ds.p, nullptr, dout.p, nullptr, 0, M, H, W, 1, ng};
       grp.nblocks0 = nb;
-      hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nb), dim3(256), 0, ctx.stream, grp,
+      hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nb), dim3(mv::kGnnThreads), 0, ctx.stream, grp,
                          C, D);
     } else {
       hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,

@@ -340,7 +340,16 @@ void gnn_attend_kernel(const float* __restrict__ h,
 // Consecutive 32-cell groups are mapped to the same XCD (block % 8 -> contiguous range of
 // groups) so that a group's halo cells are its neighbours' own cells in that L2.
 constexpr int kGnnPitch = 68;        // floats per staged cell and chunk (64 + 4: bank spread)
-constexpr int kGnnStage = 98;        // 32 + 2*32 + 2 cells for W <= 32
+// cells per workgroup: MV_GNN_CELLS = 32 (256 threads, 98 staged cells: every staged byte is
+// read 3.1 x per pass) or 64 (512 threads, 130 staged cells: 2.0 x).  Same arithmetic per cell
+// in the same order: bitwise the same result.  Measured (beam 20, 2 560 rows, same box): 64
+// cells 16.7 ms per forward, 32 cells 15.8 -- the kernel is not bound by its L2 re-reads.
+#ifndef MV_GNN_CELLS
+#define MV_GNN_CELLS 32
+#endif
+constexpr int kGnnCells = MV_GNN_CELLS;
+constexpr int kGnnThreads = kGnnCells * 8;
+constexpr int kGnnStage = kGnnCells + 2 * 32 + 2;   // + a halo of W + 1 <= 33 cells each side
 
 // One launch serves up to two problems (the two grid scales of a greedy decode step):
 // blocks [0, nblocks0) belong to p[0], the rest to p[1]; both counts are multiples of 8,
@@ -352,12 +361,12 @@ struct GnnProblem {
 };
 struct GnnGroup { GnnProblem p[2]; unsigned nblocks0; };
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kGnnThreads)
 void gnn_attend_v2_kernel(const GnnGroup grp, int C, int D) {
   __shared__ __attribute__((aligned(16))) float buf[kGnnStage * kGnnPitch];
   __shared__ float ssq[kGnnStage];
-  __shared__ float edot[32 * 9];
-  __shared__ float alpha[32 * 9];
+  __shared__ float edot[kGnnCells * 9];
+  __shared__ float alpha[kGnnCells * 9];
   __shared__ int hsrc[kGnnStage], ssrc[kGnnStage];
   const bool second = blockIdx.x >= grp.nblocks0;
   const GnnProblem& pr = grp.p[second ? 1 : 0];
@@ -375,9 +384,9 @@ void gnn_attend_v2_kernel(const GnnGroup grp, int C, int D) {
   const int tid = threadIdx.x;
   const int K = H * W;
   const long long Mtot = (long long)M * K;
-  const long long m0 = (long long)g * 32;
+  const long long m0 = (long long)g * kGnnCells;
   const long long s0 = m0 - W - 1 > 0 ? m0 - W - 1 : 0;
-  const long long s1 = m0 + 32 + W + 1 < Mtot ? m0 + 32 + W + 1 : Mtot;
+  const long long s1 = m0 + kGnnCells + W + 1 < Mtot ? m0 + kGnnCells + W + 1 : Mtot;
   const int NS = (int)(s1 - s0);
   if (tid < NS) {
     const long long m = s0 + tid;
@@ -388,8 +397,8 @@ void gnn_attend_v2_kernel(const GnnGroup grp, int C, int D) {
   }
   // pass-1 role: own cell i1 = tid >> 3, channel slice sl = tid & 7
   const int i1 = tid >> 3, sl = tid & 7;
-  // pass-2 role: own cell i2 = tid & 31, channel group c8 = tid >> 5
-  const int i2 = tid & 31, c8 = tid >> 5;
+  // pass-2 role: own cell i2 = tid % cells, channel group c8 = tid / cells
+  const int i2 = tid % kGnnCells, c8 = tid / kGnnCells;
   auto cell_info = [&](int i, int& li, int& mask) {
     const long long m = m0 + i;
     li = (int)(m - s0);
@@ -412,12 +421,12 @@ void gnn_attend_v2_kernel(const GnnGroup grp, int C, int D) {
   // before chunk q is computed on, so their HBM / L2 latency runs under the compute
   // phase.  (First version: load -> wait -> store inside a run-time loop: seven
   // serialised round trips per chunk, 48 us per workgroup.)
-  constexpr int kIt = (kGnnStage * 16 + 255) / 256;     // 7
+  constexpr int kIt = (kGnnStage * 16 + kGnnThreads - 1) / kGnnThreads;     // 7 (32 cells) / 5 (64)
   f32x4_t val[kIt];
   auto stage_load = [&](int q) {     // q < 4: channels q*64.. of h; q == 4: scene_mean
 #pragma unroll
     for (int k = 0; k < kIt; ++k) {
-      const int v = tid + k * 256;
+      const int v = tid + k * kGnnThreads;
       const int ls = v >> 4, part = v & 15;
       val[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       if (v < NS * 16) {
@@ -436,7 +445,7 @@ void gnn_attend_v2_kernel(const GnnGroup grp, int C, int D) {
   auto stage_store = [&]() {
 #pragma unroll
     for (int k = 0; k < kIt; ++k) {
-      const int v = tid + k * 256;
+      const int v = tid + k * kGnnThreads;
       if (v < NS * 16)
         *reinterpret_cast<f32x4_t*>(&buf[(v >> 4) * kGnnPitch + (v & 15) * 4]) = val[k];
     }
@@ -468,7 +477,7 @@ void gnn_attend_v2_kernel(const GnnGroup grp, int C, int D) {
         if ((mask1 >> t) & 1)
           pd[t] += dot8(fi, &buf[(li1 + (t / 3 - 1) * W + (t % 3 - 1)) * kGnnPitch + sl * 8]);
     }
-    for (int base = 0; base < NS * 8; base += 256) {     // |u|^2 of every staged cell
+    for (int base = 0; base < NS * 8; base += kGnnThreads) {     // |u|^2 of every staged cell
       const int idx = base + tid;
       const int ls = idx >> 3;
       float pp = 0.f;
@@ -492,7 +501,7 @@ void gnn_attend_v2_kernel(const GnnGroup grp, int C, int D) {
     if (sl == 0) edot[i1 * 9 + t] = v;
   }
   __syncthreads();
-  if (tid < 32) {                     // softmax over the in-image neighbours of cell tid
+  if (tid < kGnnCells) {              // softmax over the in-image neighbours of cell tid
     int li, mask;
     cell_info(tid, li, mask);
     float e[9];
@@ -577,7 +586,7 @@ void gnn_attend_v2_kernel(const GnnGroup grp, int C, int D) {
   }
 }
 static inline unsigned gnn_v2_blocks(size_t cells, int* ngroups) {
-  const size_t g = (cells + 31) / 32;
+  const size_t g = (cells + kGnnCells - 1) / kGnnCells;
   *ngroups = (int)g;
   return (unsigned)(((g + 7) / 8) * 8);
 }
