@@ -274,6 +274,18 @@ int  mv_get_scene_grad(mv_handle h, float* out);
 int  mv_attack_step(mv_handle h, float epsilon, float step);
 int  mv_scene_mix(mv_handle h, const float* other, float weight);
 int  mv_get_sample_losses(mv_handle h, int32_t scale, float* out);
+/* SimAug multi-view experiment 3 (SimAug/code/pred_models.py:486-517, 616-636, 1371-1398): the
+ * training step on MIXED-UP labels.  obs_labels2[s] [N, T_o] / pred_labels2[s] [N, T_p] = the
+ * grid labels of the selected extra camera view (NULL for unused scales); `weight` = the beta
+ * weight of the original labels: the class-encoder input and the first decoder input use
+ * w * one_hot(label) + one_hot(label2) * (1 - w), the class loss is
+ * softmax_cross_entropy_with_logits_v2 against the same mix of the future labels;
+ * sample_weight [N] (or NULL) multiplies each sample's class-loss rows (double_weighting: the
+ * focal weights).  In force for every following mv_train_* call until cleared. */
+int  mv_set_label_mixup(mv_handle h, const int32_t* const* obs_labels2,
+                        const int32_t* const* pred_labels2, float weight,
+                        const float* sample_weight);
+int  mv_clear_label_mixup(mv_handle h);
 /* tf.gradients(loss, var) of the last forward_backward, by variable name */
 int  mv_get_grad(mv_handle h, const char* tf_name, float* out, int64_t capacity_elems);
 int  mv_get_global_step(mv_handle h, int64_t* step);

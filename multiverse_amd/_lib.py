@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = [
     "mv_comm_unique_id", "mv_allreduce_init", "mv_allreduce_info",
     "mv_attack_begin", "mv_attack_end", "mv_set_scene_feat", "mv_get_scene_feat",
     "mv_get_scene_grad", "mv_attack_step", "mv_scene_mix", "mv_get_sample_losses",
+    "mv_set_label_mixup", "mv_clear_label_mixup",
     "mv_op_convlstm_bwd", "mv_op_gnn_bwd",
     "mv_set_grid_centers", "mv_upload_inputs_compact", "mv_upload_targets_compact",
 ]
@@ -233,6 +234,8 @@ def load():
   lib.mv_attack_step.argtypes = [h, C.c_float, C.c_float]
   lib.mv_scene_mix.argtypes = [h, _fp, C.c_float]
   lib.mv_get_sample_losses.argtypes = [h, C.c_int32, _fp]
+  lib.mv_set_label_mixup.argtypes = [h, C.POINTER(_ip), C.POINTER(_ip), C.c_float, _fp]
+  lib.mv_clear_label_mixup.argtypes = [h]
   lib.mv_set_dropout_seed.argtypes = [h, C.c_uint32]
   lib.mv_get_opt_scalars.argtypes = [h, _fp, _fp]
   lib.mv_set_opt_scalars.argtypes = [h, C.c_float, C.c_float]
@@ -755,6 +758,31 @@ class Engine(object):
     out = np.empty((self.cfg.batch_size,), dtype=np.float32)
     check(self.lib.mv_get_sample_losses(self.handle, int(scale), fptr(out)), self.handle)
     return out
+
+  def set_label_mixup(self, obs_labels2, pred_labels2, weight, sample_weight=None):
+    """SimAug multi-view experiment 3: train on w * one_hot(label) + (1 - w) * one_hot(label2)
+    (lists over scales of [N, T_o] / [N, T_p] int arrays, None for unused scales) until
+    clear_label_mixup(); sample_weight [N]: per-sample weights of the class loss."""
+    S = len(self.cfg.scene_grids)
+    keep, po, pp = [], (_ip * MV_MAX_SCALES)(), (_ip * MV_MAX_SCALES)()
+    for s in range(S):
+      if not self.cfg.use_grids[s]:
+        continue
+      o = np.ascontiguousarray(obs_labels2[s], dtype=np.int32).reshape(self.cfg.batch_size, -1)
+      p = np.ascontiguousarray(pred_labels2[s], dtype=np.int32).reshape(self.cfg.batch_size, -1)
+      if o.shape[1] != self.cfg.obs_len or p.shape[1] != getattr(self, "_pred_len", p.shape[1]):
+        raise MvError("set_label_mixup: labels of scale %d have shapes %s / %s" %
+                      (s, o.shape, p.shape))
+      keep += [o, p]
+      po[s], pp[s] = o.ctypes.data_as(_ip), p.ctypes.data_as(_ip)
+    sw = None
+    if sample_weight is not None:
+      sw = np.ascontiguousarray(sample_weight, dtype=np.float32).reshape(self.cfg.batch_size)
+    check(self.lib.mv_set_label_mixup(self.handle, po, pp, float(weight),
+                                      fptr(sw) if sw is not None else None), self.handle)
+
+  def clear_label_mixup(self):
+    check(self.lib.mv_clear_label_mixup(self.handle), self.handle)
 
   def set_dropout_seed(self, seed):
     check(self.lib.mv_set_dropout_seed(self.handle, int(seed) & 0xFFFFFFFF), self.handle)

@@ -2064,6 +2064,46 @@ int mv_get_sample_losses(mv_handle h, int32_t scale, float* out) {
   });
 }
 
+int mv_set_label_mixup(mv_handle h, const int32_t* const* obs_labels2,
+                       const int32_t* const* pred_labels2, float weight,
+                       const float* sample_weight) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(h->train, "mv_train_init has not been called");
+    MV_REQUIRE(obs_labels2 && pred_labels2, "mv_set_label_mixup: NULL argument");
+    MV_REQUIRE(weight >= 0.f && weight <= 1.f, "mv_set_label_mixup: weight %g not in [0, 1]",
+               (double)weight);
+    TrainState& t = TS(h);
+    const int N = h->cfg.batch_size, To = h->cfg.obs_len, Tp = h->pred_len;
+    for (int s = 0; s < h->cfg.num_scales; ++s) {
+      if (!h->sc[s].use) continue;
+      MV_REQUIRE(obs_labels2[s] && pred_labels2[s], "mv_set_label_mixup: scale %d is NULL", s);
+      const int K = h->sc[s].K;
+      for (int i = 0; i < N * To; ++i)
+        MV_REQUIRE(obs_labels2[s][i] >= 0 && obs_labels2[s][i] < K,
+                   "mv_set_label_mixup: observed label %d out of range", obs_labels2[s][i]);
+      for (int i = 0; i < N * Tp; ++i)
+        MV_REQUIRE(pred_labels2[s][i] >= 0 && pred_labels2[s][i] < K,
+                   "mv_set_label_mixup: future label %d out of range", pred_labels2[s][i]);
+      HIP_CHECK(hipMemcpy(t.sc[s].obs_labels2.p, obs_labels2[s], (size_t)N * To * sizeof(int32_t),
+                          hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(t.sc[s].pred_labels2.p, pred_labels2[s],
+                          (size_t)N * Tp * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    if (sample_weight)
+      HIP_CHECK(hipMemcpy(t.sample_w.p, sample_weight, (size_t)N * sizeof(float),
+                          hipMemcpyHostToDevice));
+    t.mix_on = true; t.mix_sw = sample_weight != nullptr; t.mix_w = weight;
+  });
+}
+
+int mv_clear_label_mixup(mv_handle h) {
+  if (!h || !h->train) return 1;
+  TS(h).mix_on = TS(h).mix_sw = false;
+  TS(h).mix_w = 1.f;
+  return 0;
+}
+
 int mv_set_dropout_seed(mv_handle h, uint32_t seed) {
   if (!h || !h->train) return 1;
   h->train->st.dropout_seed = seed;

@@ -44,6 +44,9 @@ struct TrainScale {
   DevBuf<float> gt_cls;           // [Tp][N][K] one-hot / soft ground-truth class maps
   DevBuf<float> reg_in;           // [Tp][N][K][2] teacher forcing: regression-decoder inputs
   DevBuf<int32_t> fg_count;       // [1] cells with gt_cls > 0
+  // SimAug label mixup (multi-view experiment 3)
+  DevBuf<int32_t> obs_labels2, pred_labels2;   // [N][To], [N][Tp]: the selected extra view
+  DevBuf<float> mix_cls;          // [Tp][N][K] mixed-up class targets
 };
 
 struct TrainState {
@@ -55,6 +58,9 @@ struct TrainState {
   TrainScale sc[MV_MAX_SCALES];
   DevBuf<float> dys[MV_MAX_SCALES], dpre_sc[MV_MAX_SCALES];   // scene stack backward
   DevBuf<float> single_w;         // --use_single_decoder: one scale's d decode_reg W
+  bool mix_on = false, mix_sw = false;   // label mixup in force / with per-sample weights
+  float mix_w = 1.f;              // beta weight of the ORIGINAL labels
+  DevBuf<float> sample_w;         // [N] focal weights (double_weighting)
   DevBuf<float> dscene;           // [U, SH, SW, SC] d loss / d scene_feat (SimAug attacks)
   DevBuf<float> scene_clean;      // the clean features an attack perturbs
   bool want_dscene = false, have_dscene = false;
@@ -156,6 +162,7 @@ void train_alloc(mv_engine* e) {
     R.loss_row.alloc(Tp * N); R.loss_elem.alloc(Tp * NK * 2);
     R.pred_labels.alloc(N * Tp); R.pred_reg.alloc(N * Tp * K * 2);
     R.gt_cls.alloc(Tp * NK); R.reg_in.alloc(Tp * NK * 2); R.fg_count.alloc(1);
+    R.obs_labels2.alloc(N * To); R.pred_labels2.alloc(N * Tp); R.mix_cls.alloc(Tp * NK);
     // small-conv wgrad partials: blocks x 9 x Ci*Co (<= 512)
     max_partial = std::max(max_partial, (size_t)4096 * 9 * 512);
     max_partial = std::max(max_partial, (size_t)64 * c.scene_conv_kernel * c.scene_conv_kernel * std::max<size_t>(D, c.scene_class) * D);
@@ -185,6 +192,7 @@ void train_alloc(mv_engine* e) {
   t.partial.alloc(max_partial);
   t.scratch.alloc((size_t)1 << 20);
   t.single_w.alloc((size_t)9 * C * 2);
+  t.sample_w.alloc(N);
   t.losses.alloc(64);
 }
 
@@ -492,7 +500,8 @@ void train_forward(mv_engine* e) {
       launch(e, "enc_class_input", 0, 4.0 * total, [&] {
         hipLaunchKernelGGL(mv::enc_class_input_kernel, dim3(cdiv(total, 256)), dim3(256),
                            0, e->stream, e->scene_conv[s].p, e->obs_scene.p, S.labels.p,
-                           xc, N, To, ts, S.K, D);
+                           xc, N, To, ts, S.K, D, (_Float16*)nullptr, (size_t)0,
+                           t.mix_on ? R.obs_labels2.p : (const int32_t*)nullptr, t.mix_w);
       });
       run_dropout(e, xc, total, s, 0, ts);
       if (nb == 2)
@@ -523,7 +532,15 @@ void train_forward(mv_engine* e) {
         hin = R.hg.p + ts * NKC;
       }
       float* xc = R.dec[0].xs.p + (size_t)ts * NK * E;
-      if (ts == 0) run_emb_onehot(e, S, S.labels.p + (To - 1), To, xc, N);
+      if (ts == 0 && t.mix_on) {
+        // label mixup: the first input is grid_emb of the MIXED map of the last observed
+        // step (obs_grid_class[:, -1], SimAug/code/pred_models.py:616-636), kept in slot 0
+        // of `onehot` for the embedding's wgrad
+        hipLaunchKernelGGL(mv::twohot_map_kernel, dim3(cdiv(NK, 256)), dim3(256), 0, e->stream,
+                           S.labels.p + (To - 1), R.obs_labels2.p + (To - 1), To, 0, t.mix_w,
+                           R.onehot.p, 1, N, S.K);
+        run_emb_dense(e, S, R.onehot.p, (size_t)S.K, xc, N, S.emb_cls_W, S.emb_cls_b, 1);
+      } else if (ts == 0) run_emb_onehot(e, S, S.labels.p + (To - 1), To, xc, N);
       else if (cls_fb == 0) run_emb_onehot(e, S, R.ids.p + (size_t)ts * N, 1, xc, N);
       else   // dense input map: the previous step's logits, or the step's ground truth
         run_emb_dense(e, S, cls_fb == 1 ? R.logits.p + (size_t)(ts - 1) * NK
@@ -591,7 +608,19 @@ void train_losses(mv_engine* e) {
     const size_t NK = (size_t)N * S.K;
     const float cs = t.tc.grid_loss_weight / (float)((size_t)N * Tp);
     launch(e, "ce_loss", 0, 8.0 * Tp * NK, [&] {
-      if (t.tc.use_soft_grid_class)
+      if (t.mix_on) {
+        // mixed-up targets w * one_hot(label) + one_hot(extra view's label) * (1 - w)
+        // (SimAug/code/pred_models.py:1371-1390), optionally weighted per sample (:1391-1398)
+        hipLaunchKernelGGL(mv::twohot_map_kernel, dim3(cdiv((size_t)Tp * NK, 256)), dim3(256), 0,
+                           e->stream, R.pred_labels.p, R.pred_labels2.p, Tp, 1, t.mix_w,
+                           R.mix_cls.p, Tp, N, S.K);
+        hipLaunchKernelGGL(mv::ce_soft_loss_kernel, dim3(Tp * N), dim3(64), 0, e->stream,
+                           R.logits.p, R.mix_cls.p, R.loss_row.p, R.dlogits.p, S.K, cs);
+        if (t.mix_sw)
+          hipLaunchKernelGGL(mv::scale_rows_kernel, dim3(cdiv((size_t)Tp * NK, 256)), dim3(256),
+                             0, e->stream, R.loss_row.p, R.dlogits.p, t.sample_w.p, Tp * N, N,
+                             S.K);
+      } else if (t.tc.use_soft_grid_class)
         hipLaunchKernelGGL(mv::ce_soft_loss_kernel, dim3(Tp * N), dim3(64), 0, e->stream,
                            R.logits.p, R.gt_cls.p, R.loss_row.p, R.dlogits.p, S.K, cs);
       else
@@ -1072,8 +1101,9 @@ void train_backward(mv_engine* e) {
     // class-decoder grid_emb: its input maps of all steps, [Tp][N][K] -- slot 0 the
     // one-hot of the last observed cell, slot t the one-hot argmax / the logits of step
     // t-1 / the ground-truth map of step t, by feedback mode
-    hipLaunchKernelGGL(mv::onehot_map_kernel, dim3(cdiv(NK, 256)), dim3(256), 0, e->stream,
-                       S.labels.p + (To - 1), To, R.onehot.p, N, S.K);
+    if (!t.mix_on)     // (label mixup: slot 0 already holds the mixed map of the forward)
+      hipLaunchKernelGGL(mv::onehot_map_kernel, dim3(cdiv(NK, 256)), dim3(256), 0, e->stream,
+                         S.labels.p + (To - 1), To, R.onehot.p, N, S.K);
     if (Tp > 1) {
       const size_t rest = (size_t)(Tp - 1) * NK;
       if (t.tc.class_feedback == 0)
@@ -1132,7 +1162,8 @@ void train_backward(mv_engine* e) {
         hipLaunchKernelGGL(mv::scene_grad_gather_kernel, dim3(cdiv(n, 256)), dim3(256), 0,
                            e->stream, c.use_gnn ? R.dsmean.p : (const float*)nullptr,
                            R.enc[0].dxs.p, e->obs_scene.p, e->sc[i].labels.p, t.dys[i].p,
-                           U, N, To, Ho * Wo, D);
+                           U, N, To, Ho * Wo, D,
+                           t.mix_on ? R.obs_labels2.p : (const int32_t*)nullptr, t.mix_w);
       });
     } else {
       HIP_CHECK(hipMemsetAsync(t.dys[i].p, 0, n * sizeof(float), e->stream));

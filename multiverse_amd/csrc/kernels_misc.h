@@ -142,7 +142,9 @@ __global__ void enc_class_input_kernel(const float* __restrict__ conv,
                                        const int32_t* __restrict__ labels,
                                        float* __restrict__ out, int N, int T,
                                        int t, int K, int D, _Float16* p16 = nullptr,
-                                       size_t p16_stride = 0) {
+                                       size_t p16_stride = 0,
+                                       const int32_t* __restrict__ labels2 = nullptr,
+                                       float mixw = 1.f) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per = (size_t)K * D;
   if (idx >= (size_t)N * per) return;
@@ -150,7 +152,13 @@ __global__ void enc_class_input_kernel(const float* __restrict__ conv,
   const size_t off = idx - (size_t)n * per;
   const int cell = off / D;
   float v = 0.f;
-  if (cell == labels[n * T + t])
+  if (labels2) {
+    // label mixup (SimAug/code/pred_models.py:616-636): the one-hot map is
+    // w * one_hot(l1) + one_hot(l2) * (1 - w), then the same product
+    const float m = mixw * (cell == labels[n * T + t] ? 1.f : 0.f) +
+                    (cell == labels2[n * T + t] ? 1.f : 0.f) * (1.f - mixw);
+    if (m != 0.f) v = conv[(size_t)obs_scene[n * T + t] * per + off] * m;
+  } else if (cell == labels[n * T + t])
     v = conv[(size_t)obs_scene[n * T + t] * per + off];
   out[idx] = v;
   emit_planes(p16, p16_stride, idx, D, v);

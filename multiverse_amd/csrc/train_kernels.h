@@ -748,7 +748,9 @@ __global__ void scene_grad_gather_kernel(const float* __restrict__ dmean,
                                          const int32_t* __restrict__ obs_scene,
                                          const int32_t* __restrict__ labels,
                                          float* __restrict__ dsc, int U, int N, int T,
-                                         int K, int D) {
+                                         int K, int D,
+                                         const int32_t* __restrict__ labels2 = nullptr,
+                                         float mixw = 1.f) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per = (size_t)K * D;
   if (idx >= (size_t)U * per) return;
@@ -760,10 +762,40 @@ __global__ void scene_grad_gather_kernel(const float* __restrict__ dmean,
     for (int t = 0; t < T; ++t) {
       if (obs_scene[n * T + t] != u) continue;
       if (dmean) acc += dmean[(size_t)n * per + off] / (float)T;
-      if (labels[n * T + t] == cell)
+      if (labels2) {       // label mixup: the class-encoder input was scene_conv * m
+        const float m = mixw * (labels[n * T + t] == cell ? 1.f : 0.f) +
+                        (labels2[n * T + t] == cell ? 1.f : 0.f) * (1.f - mixw);
+        if (m != 0.f) acc += dxenc[((size_t)t * N + n) * per + off] * m;
+      } else if (labels[n * T + t] == cell)
         acc += dxenc[((size_t)t * N + n) * per + off];
     }
   dsc[idx] = acc;
+}
+
+// ------------------------------------------------------------ label mixup (SimAug, exp 3)
+// out [T][N][K] (time-major) = w * one_hot(l1[n * sn + t * st]) + one_hot(l2[..]) * (1 - w)
+__global__ void twohot_map_kernel(const int32_t* __restrict__ l1, const int32_t* __restrict__ l2,
+                                  int sn, int st, float w, float* __restrict__ out, int T,
+                                  int N, int K) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)T * N * K) return;
+  const int k = (int)(idx % K);
+  const size_t r = idx / K;
+  const int n = (int)(r % N), t = (int)(r / N);
+  const size_t li = (size_t)n * sn + (size_t)t * st;
+  out[idx] = w * (l1[li] == k ? 1.f : 0.f) + (l2[li] == k ? 1.f : 0.f) * (1.f - w);
+}
+
+// per-sample weights on the class loss (double_weighting, :1391-1398): rows time-major
+// r = t * N + n; the loss row and its gradient row are scaled by sw[n]
+__global__ void scale_rows_kernel(float* __restrict__ loss_row, float* __restrict__ drows,
+                                  const float* __restrict__ sw, int rows, int N, int K) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)rows * K) return;
+  const size_t r = idx / K;
+  const float f = sw[r % N];
+  drows[idx] = drows[idx] * f;
+  if (idx - r * K == 0) loss_row[r] = loss_row[r] * f;
 }
 
 // dgrad of conv k x k, stride 2, SAME: din[u][iy][ix][ci] (+)= sum dpre[u][oy][ox][co] W[ky][kx][ci][co]

@@ -7,7 +7,10 @@
   multiview_augmentation    SimAug/code/pred_models.py:346-543  one FGSM step per extra
                             camera view (targets = that view's own future grid labels),
                             selection of two views by attack loss (exp 1 / 4) or at random
-                            (exp 2), Beta-weighted mixup
+                            (exp 2), Beta-weighted mixup; exp 3: the hardest view's
+                            adversarial features mixed with the CLEAN features of a selected
+                            extra view, the labels mixed up the same way
+                            (mv_set_label_mixup) and the class loss focal-weighted
 
 The network, its backward pass and the element-wise attack / mixup updates run in the HIP
 engine (mv_attack_begin / mv_train_forward_backward / mv_attack_step / mv_scene_mix /
@@ -166,8 +169,7 @@ def multiview_augmentation(engine_m, cfg, feed, extra_pred_labels, draws):
   s = _scale_of(cfg)
   N, M, T = cfg.batch_size, int(cfg.multiview_max_num), cfg.obs_len
   if cfg.multiview_exp == 3:
-    raise _lib.MvError("multiview_exp 3 (label mixup + focal weighting in build_loss) is "
-                       "not built; experiments 1, 2 and 4 are")
+    raise _lib.MvError("multiview_exp 3 mixes labels too: use multiview_augmentation_exp3")
   if cfg.multiview_exp not in (1, 2, 4):
     raise _lib.MvError("Please set experiment number")                      # :523-525
   mcfg = copy.copy(cfg)
@@ -209,3 +211,71 @@ def multiview_augmentation(engine_m, cfg, feed, extra_pred_labels, draws):
     weight = max(weight, 1.0 - weight)
   mixed = (feat1 * np.float32(weight) + feat2 * np.float32(1.0 - weight)).astype("float32")
   return mixed.reshape(N * T, SH, SW, SC), weight, adv_loss
+
+
+def _tile_feed(cfg, feed, M, scene):
+  """every per-sample input M times (:418-448), row n * M + m; `scene` [N*M*T_o, SH, SW, SC]"""
+  N, T = cfg.batch_size, cfg.obs_len
+  tiled = {"pred_length": feed.get("pred_length", cfg.pred_len), "scene_feat": scene}
+  tiled["obs_scene"] = np.arange(N * M * T, dtype="int32").reshape(N * M, T)
+  for key in ("grid_obs_labels", "grid_obs_regress", "grid_pred_regress"):
+    tiled[key] = [None if a is None else np.repeat(np.asarray(a), M, axis=0) for a in feed[key]]
+  return tiled
+
+
+def multiview_augmentation_exp3(engine_m, cfg, feed, extra_pred_labels, extra_scene, draws):
+  """Experiment 3 (:486-517): one FGSM step per extra view as in the other experiments; the
+  view with the highest attack loss gives adv_feat1 and the focal weight
+  (1 - exp(-loss))^fl_gamma; adv_feat2 = the CLEAN features `extra_scene`
+  [N, M, T_o, SH, SW, SC] of the selected view (the hardest, or a random one with
+  cfg.multiview_random); Beta-weighted mix.  With cfg.multiview_use_adv_for_loss the attack
+  losses are re-evaluated at the adversarial features (a second attack pass whose features
+  are discarded, :488-497).
+  -> (mixed features [N*T_o, SH, SW, SC], beta weight, selected view index [N], focal
+  weights [N], attack losses [N, M]).  The caller mixes the labels of the selected view with
+  the same weight: engine.set_label_mixup(obs2, pred2, weight, focal if cfg.double_weighting)."""
+  s = _scale_of(cfg)
+  N, M, T = cfg.batch_size, int(cfg.multiview_max_num), cfg.obs_len
+  mcfg = copy.copy(cfg)
+  mcfg.batch_size = N * M
+  clean = np.asarray(feed["scene_feat"], dtype="float32")
+  SH, SW, SC = clean.shape[1:]
+  tile_clean = np.repeat(clean.reshape(N, T, SH, SW, SC), M, axis=0).reshape(-1, SH, SW, SC)
+  targets = [None] * len(cfg.scene_grids)
+  targets[s] = np.asarray(extra_pred_labels, dtype="int32").reshape(N * M, -1)
+
+  def one_step_attack(features):
+    start = start_adv(features, cfg, draws)
+    tiled = _tile_feed(cfg, feed, M, start)
+    tiled["grid_pred_labels"] = targets
+    engine_m.upload(tiled)
+    engine_m.upload_targets(tiled)
+    engine_m.attack_begin()                                  # bounds: start +- eps (:400-403)
+    engine_m.train_forward_backward(None)
+    loss = engine_m.sample_losses(s).reshape(N, M)
+    engine_m.attack_step(cfg.adv_epsilon, cfg.adv_epsilon)
+    out = engine_m.get_scene_feat()
+    engine_m.attack_end()
+    return out, loss
+
+  engine_m.train_init(attack_config(mcfg))
+  adv_flat, adv_loss = one_step_attack(tile_clean)
+  if getattr(cfg, "multiview_use_adv_for_loss", False):      # :488-497
+    _, adv_loss = one_step_attack(adv_flat)
+  engine_m.train_init(mcfg)
+  adv_out = adv_flat.reshape(N, M, T, SH, SW, SC)
+  order = np.argsort(-adv_loss, axis=1, kind="stable")       # tf.nn.top_k(sorted)
+  top = np.take_along_axis(adv_loss, order[:, :1], axis=1)[:, 0]
+  focal = ((np.float32(1.0) - np.exp(-top.astype("float32"))) **
+           np.float32(cfg.fl_gamma)).astype("float32")       # :502
+  rows = np.arange(N)
+  feat1 = adv_out[rows, order[:, 0]]
+  select = order[:, 0].astype("int32")
+  if getattr(cfg, "multiview_random", False):                # :511-513
+    select = draws.index(N, 0, M)
+  feat2 = np.asarray(extra_scene, dtype="float32")[rows, select]
+  weight = draws.beta(cfg.mixup_alpha)
+  if getattr(cfg, "multiview_max_weight_for_first", False):
+    weight = max(weight, 1.0 - weight)
+  mixed = (feat1 * np.float32(weight) + feat2 * np.float32(1.0 - weight)).astype("float32")
+  return mixed.reshape(N * T, SH, SW, SC), weight, select, focal, adv_loss

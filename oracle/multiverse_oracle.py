@@ -453,6 +453,13 @@ def forward_tensors(P, cfg, feed, dtype=torch.float32, trace=None):
       continue
     labels = np.asarray(feed["grid_obs_labels"][s])
     obs_oh = one_hot_grid(labels, H, W, dtype)           # [N,T,H,W,1]
+    if feed.get("mix_weight") is not None:
+      # SimAug label mixup (SimAug/code/pred_models.py:616-636, multi-view experiment 3):
+      # obs_grid_class = w * one_hot(label) + one_hot(extra view's label) * (1 - w); it
+      # masks the scene features AND its last step is the class decoder's first input
+      w = torch.tensor(float(feed["mix_weight"]), dtype=torch.float32).to(dtype)
+      obs_oh = w * obs_oh + one_hot_grid(np.asarray(feed["mix_obs_labels"][s]), H, W,
+                                         dtype) * (1 - w)
     obs_reg = _t(feed["grid_obs_regress"][s], dtype)     # [N,T,H,W,2]
     x_cls = scene_convs[s] * obs_oh                      # :210
     enc_c = run_encoder(
@@ -566,7 +573,19 @@ def build_loss(P, cfg, cls_out, reg_out, feed, dtype=torch.float32):
     if not cfg.use_grids[s]:
       continue
     logits = cls_out[s].reshape(-1, H * W)                       # :984
-    if soft:
+    if feed.get("mix_weight") is not None:
+      # SimAug/code/pred_models.py:1371-1398: mixed-up one-hot targets under
+      # softmax_cross_entropy_with_logits_v2, optional per-sample (focal) weights
+      w = torch.tensor(float(feed["mix_weight"]), dtype=torch.float32).to(dtype)
+      l1 = torch.from_numpy(np.asarray(feed["grid_pred_labels"][s]).astype("int64").reshape(-1))
+      l2 = torch.from_numpy(np.asarray(feed["mix_pred_labels"][s]).astype("int64").reshape(-1))
+      mix = F.one_hot(l1, H * W).to(dtype) * w + F.one_hot(l2, H * W).to(dtype) * (1 - w)
+      ce = _TFSoftmaxXent.apply(logits, mix)
+      if feed.get("mix_sample_weight") is not None:
+        sw = _t(np.asarray(feed["mix_sample_weight"], dtype="float32"), dtype)
+        ce = ce * sw[:, None].expand(-1, logits.shape[0] // sw.shape[0]).reshape(-1)
+      fg = F.one_hot(l1, H * W).reshape(-1) > 0
+    elif soft:
       lab_soft = _t(feed["grid_pred_soft"][s], dtype).reshape(-1, H * W)
       ce = _TFSoftmaxXent.apply(logits, lab_soft)                # :988-990
       fg = lab_soft.reshape(-1) > 0

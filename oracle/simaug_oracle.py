@@ -10,7 +10,10 @@ code/pred_models.py build_forward), with torch.autograd playing `tf.gradients(lo
 unseeded random ops; it has not been executed on the TF-1 shim, and the reference ships no
 fixtures for it.  What IS checked: this restatement against the HIP engine under identical,
 injected random draws (tests/test_gpu_simaug.py), and the underlying network / gradients
-against the reference-run goldens of code/pred_models.py.
+against the reference-run goldens of code/pred_models.py.  The label mixup of experiment 3
+(two-hot inputs, mixed targets, focal sample weights) is restated in
+oracle/multiverse_oracle.py (feed keys mix_weight / mix_obs_labels / mix_pred_labels /
+mix_sample_weight), equally unpinned.
 """
 from __future__ import annotations
 

@@ -133,3 +133,97 @@ def test_multiview_augmentation(built_lib, exp):
   print("multiview exp %d: mixed features equal on %.5f of the elements, weight %.4f, "
         "attack losses %s" % (exp, same.mean(), weight, np.round(adv_loss, 4)))
   assert same.mean() > 0.999
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+def test_label_mixup_training_step(built_lib, mode):
+  """mv_set_label_mixup (multi-view experiment 3, SimAug/code/pred_models.py:616-636,
+  1371-1398): two-hot class-encoder inputs and first decoder input, mixed-up targets under
+  softmax_cross_entropy_with_logits_v2, per-sample focal weights -- losses and every gradient
+  against the oracle's autograd in fp64; weight 1 is the plain training step."""
+  import torch
+  from oracle import multiverse_oracle as oracle
+  cfg = synth.default_config(batch_size=3, use_grids=(0, 1), is_train=True)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 60, recurrent_gain=2.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 61)
+  rng = np.random.default_rng(9)
+  obs2 = [None, rng.integers(0, 144, size=(3, cfg.obs_len)).astype("int32")]
+  pred2 = [None, rng.integers(0, 144, size=(3, cfg.pred_len)).astype("int32")]
+  obs2[1][0] = feed["grid_obs_labels"][1][0]          # a sample whose two views coincide
+  sw = np.array([0.4, 1.7, 1.0], dtype="float32")
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode(mode)
+  eng.train_init()
+  plain = eng.train_forward_backward(feed)
+  g_plain = {n: eng.get_grad(n) for n, _ in eng.param_specs()}
+  eng.set_label_mixup(obs2, pred2, 1.0)
+  same = eng.train_forward_backward(None)
+  # (the mixed-target loss is -sum q log p over all K cells, the sparse one lse - logit[label]:
+  # equal up to fp32 rounding, not bit for bit)
+  assert np.allclose([same[0]] + same[2], [plain[0]] + plain[2], rtol=2e-6)
+  for n in g_plain:
+    assert np.abs(eng.get_grad(n) - g_plain[n]).max() <= 2e-5 * max(np.abs(g_plain[n]).max(), 1e-30), n
+  for w, weights in ((0.65, None), (0.3, sw)):
+    eng.set_label_mixup(obs2, pred2, w, weights)
+    loss, wd, pgl = eng.train_forward_backward(None)
+    f = dict(feed, mix_weight=w, mix_obs_labels=obs2, mix_pred_labels=pred2,
+             mix_sample_weight=weights)
+    ol, owd, opgl, og = oracle.loss_and_grads(params, cfg, f, dtype=torch.float64)
+    worst = 0.0
+    for n, _ in eng.param_specs():
+      g = eng.get_grad(n)
+      err = float(np.abs(g - og[n]).max() / max(np.abs(og[n]).max(), 1e-30))
+      worst = max(worst, err)
+      assert err < 2e-3, (n, err)
+    print("label mixup %s w=%.2f%s: loss %.6f oracle %.6f, worst gradient error %.2e of max"
+          % (mode, w, " + sample weights" if weights is not None else "", loss, ol, worst))
+    assert np.allclose([loss, wd] + pgl, [ol, owd] + opgl, rtol=1e-4, atol=1e-5)
+  eng.clear_label_mixup()
+  again = eng.train_forward_backward(None)
+  assert again[0] == plain[0] and again[2] == plain[2]     # cleared: the plain step, bitwise
+  eng.close()
+
+
+def test_multiview_experiment_3(built_lib):
+  """Experiment 3: hardest view's adversarial features x clean features of the selected
+  view, focal weights from the top attack loss; against the oracle under the same draws."""
+  cfg, params, feed, eng = _setup(built_lib, multiview_exp=3, fl_gamma=2.0,
+                                  multiview_random=False, multiview_use_adv_for_loss=False,
+                                  double_weighting=True)
+  eng.close()
+  N, M, T = cfg.batch_size, cfg.multiview_max_num, cfg.obs_len
+  mcfg = copy.copy(cfg)
+  mcfg.batch_size = N * M
+  engm = built_lib.Engine(mcfg, device=0)
+  engm.set_params(params)
+  engm.train_init()
+  rng = np.random.default_rng(5)
+  extra = rng.integers(0, 9 * 16, size=(N, M, cfg.pred_len)).astype("int32")
+  clean = feed["scene_feat"]
+  extra_scene = (rng.uniform(size=(N, M, T) + clean.shape[1:]) > 0.5).astype("float32")
+  mixed, weight, select, focal, adv_loss = simaug.multiview_augmentation_exp3(
+      engm, cfg, feed, extra, extra_scene, simaug.Draws(31))
+  engm.close()
+  d = simaug.Draws(31)
+  tile = np.repeat(clean.reshape((N, T) + clean.shape[1:]), M, axis=0).reshape(
+      (-1,) + clean.shape[1:])
+  start = simaug.start_adv(tile, cfg, d)
+  tiled = simaug._tile_feed(cfg, feed, M, start)
+  ol, og = simaug_oracle.class_loss_and_input_grad(params, copy.copy(mcfg), tiled, start,
+                                                   extra.reshape(N * M, -1))
+  assert np.allclose(adv_loss.reshape(-1), ol, rtol=1e-4)
+  oadv = simaug_oracle.fgsm_step(start, og, start, cfg.adv_epsilon, cfg.adv_epsilon).reshape(
+      (N, M, T) + clean.shape[1:])
+  order = np.argsort(-ol.reshape(N, M), axis=1, kind="stable")
+  rows = np.arange(N)
+  assert (select == order[:, 0]).all()
+  top = ol.reshape(N, M)[rows, order[:, 0]]
+  assert np.allclose(focal, (1.0 - np.exp(-top)) ** cfg.fl_gamma, rtol=1e-5)
+  w = d.beta(cfg.mixup_alpha)
+  omixed = (oadv[rows, order[:, 0]] * np.float32(w) +
+            extra_scene[rows, order[:, 0]] * np.float32(1 - w)).reshape(mixed.shape)
+  same = np.abs(mixed - omixed) < 1e-6
+  print("multiview exp 3: mixed features equal on %.5f of the elements, weight %.4f, focal %s"
+        % (same.mean(), weight, np.round(focal, 4)))
+  assert abs(w - weight) < 1e-12 and same.mean() > 0.999
