@@ -181,6 +181,7 @@ struct mv_engine {
   DevBuf<float> bm_lp[2];          // [N, B]
   DevBuf<float> bm_cand;           // [N, B, K] candidate log-probs of one step
   DevBuf<int32_t> bm_src_row;      // [N*B]
+  DevBuf<int32_t> bm_ref;          // [N*B] 1 = some surviving beam continues this state row
   DevBuf<int32_t> bm_trace;        // [N, B, T]
   DevBuf<float> bm_out_logits;     // [N, B, T, K]
   DevBuf<int32_t> bm_out_ids;      // [N, B, T]
@@ -267,13 +268,14 @@ void ensure_beam_step_lds(int device, size_t lds) {
 void launch_beam_step(hipStream_t stream, const float* logits, const float* prev_lp,
                       float* cand, int N, int B, int K, int time, int diverse,
                       float log_gamma, int fix_num_timestep, float* new_lp, int32_t* ids,
-                      int32_t* parents, int32_t* src_row, int rows_per_sample) {
+                      int32_t* parents, int32_t* src_row, int rows_per_sample,
+                      int32_t* row_ref = nullptr) {
   static const bool v1 = getenv("MV_BEAM_STEP") && strcmp(getenv("MV_BEAM_STEP"), "v1") == 0;
   if (v1 || K > 64 * mv::kBeamRankJ || !cand) {
     hipLaunchKernelGGL(mv::beam_step_kernel, dim3(N), dim3(512),
                        ((size_t)2 * B * K + 512) * sizeof(float), stream, logits, prev_lp, B,
                        K, time, diverse, log_gamma, fix_num_timestep, new_lp, ids, parents,
-                       src_row, rows_per_sample);
+                       src_row, rows_per_sample, row_ref);
     HIP_CHECK(hipGetLastError());   // a refused LDS size must not pass silently
     return;
   }
@@ -290,7 +292,7 @@ void launch_beam_step(hipStream_t stream, const float* logits, const float* prev
                        prev_lp, R, B, K, time, diverse, log_gamma, cand);
   hipLaunchKernelGGL(mv::beam_select_kernel, dim3(N), dim3(1024),
                      ((size_t)B * K + 64) * sizeof(float), stream, cand, B, K, time,
-                     fix_num_timestep, new_lp, ids, parents, src_row, rows_per_sample);
+                     fix_num_timestep, new_lp, ids, parents, src_row, rows_per_sample, row_ref);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -473,6 +475,7 @@ void alloc_buffers(mv_engine* e) {
       e->bm_lp[0].alloc(R); e->bm_lp[1].alloc(R);
       e->bm_cand.alloc((size_t)R * K);
       e->bm_src_row.alloc(R);
+      e->bm_ref.alloc(R);
       e->bm_trace.alloc(R * Tp);
       e->bm_out_logits.alloc(R * Tp * K);
       e->bm_out_ids.alloc(R * Tp);
@@ -882,6 +885,7 @@ void run_encoders(mv_engine* e, Cursors& cur) {
 // each: together they fill the chip better).
 struct GnnJob {
   ScaleState* S; const float* h; const int32_t* src_row; float* out; int rows, sm_div;
+  const int32_t* row_ref = nullptr;
 };
 
 void run_gnn_jobs(mv_engine* e, const std::vector<GnnJob>& jobs) {
@@ -914,6 +918,7 @@ void run_gnn_jobs(mv_engine* e, const std::vector<GnnJob>& jobs) {
       P.h = J.h; P.scene_mean = J.S->scene_mean.p; P.src_row = J.src_row;
       P.out = need_f32 ? J.out : nullptr; P.p16 = p16; P.p16_stride = pst;
       P.M = J.rows; P.H = J.S->H; P.W = J.S->W; P.sm_div = J.sm_div; P.ngroups = ng;
+      P.row_ref = J.row_ref;
       if (j == 0) grp.nblocks0 = nb;
       nblocks += nb;
     }
@@ -1260,6 +1265,16 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
   int lpi = 0;
   const int32_t* src = nullptr;  // state row indirection for the next cell step
   const bool sparse = sparse_x_on(e, S);
+  // Graph attention BEFORE the parent gather: h + GNN(h) depends on the state row alone, and
+  // the B beams of a sample descend from few distinct parents, so it is computed once per
+  // state row that some surviving beam continues (beam_select marks them in bm_ref; the rest
+  // are skipped) and the next cell step reads it through the parent indirection, like c.
+  // Bit-identical to attention after the gather.  MV_BEAM_GNN_DEDUPE=0 gathers first.
+  static const bool dedupe_env =
+      !(getenv("MV_BEAM_GNN_DEDUPE") && atoi(getenv("MV_BEAM_GNN_DEDUPE")) == 0);
+  const bool dedupe = dedupe_env && shared_first && c.use_gnn && K <= 64 * mv::kBeamRankJ &&
+                      !(getenv("MV_BEAM_STEP") && strcmp(getenv("MV_BEAM_STEP"), "v1") == 0) &&
+                      !(getenv("MV_GNN") && strcmp(getenv("MV_GNN"), "v1") == 0);
   for (int time = 0; time <= Tp; ++time) {
     // rows the state holds going INTO this iteration's kernels
     const bool one_per_sample = shared_first && time <= 1;
@@ -1271,9 +1286,9 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
       const float* hin = c.use_gnn ? S.cls_hg.p : S.cls_h[cc].p;
       std::vector<ConvLstmArgs> probs;
       probs.push_back(conv_problem(e, S.dec_cls, S.xbuf_cls.p, hin, S.cls_c[cc].p,
-                                   c.use_gnn ? nullptr : src, src, S.cls_h[cc ^ 1].p,
-                                   S.cls_c[cc ^ 1].p, rows_now, S.H, S.W, false, 0,
-                                   /*want_h16=*/!c.use_gnn));
+                                   (c.use_gnn && !dedupe) ? nullptr : src, src,
+                                   S.cls_h[cc ^ 1].p, S.cls_c[cc ^ 1].p, rows_now, S.H, S.W,
+                                   false, 0, /*want_h16=*/!c.use_gnn));
       if (sparse) {
         if (time == 1)
           set_sparse_x(e, S, probs.back(), true, S.labels.p + (T - 1), T, one_per_sample ? 1 : B);
@@ -1308,11 +1323,13 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
       }
       int32_t* ids = e->bm_ids.p + (size_t)(time - 1) * R;
       int32_t* parents = e->bm_parents.p + (size_t)(time - 1) * R;
+      if (dedupe)
+        HIP_CHECK(hipMemsetAsync(e->bm_ref.p, 0, (size_t)R * sizeof(int32_t), e->stream));
       launch(e, "beam_step", 0, 4.0 * R * K, [&] {
         launch_beam_step(e->stream, logits, e->bm_lp[lpi].p, e->bm_cand.p, N, B, K, time,
                          c.diverse_beam, logf(c.diverse_gamma), c.fix_num_timestep,
                          e->bm_lp[lpi ^ 1].p, ids, parents, e->bm_src_row.p,
-                         one_per_sample ? 1 : B);
+                         one_per_sample ? 1 : B, dedupe ? e->bm_ref.p : nullptr);
       });
       lpi ^= 1;
       src = e->bm_src_row.p;
@@ -1329,9 +1346,17 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
     if (c.use_gnn) {
       // time 0 (shared): N rows in, N rows out; afterwards R rows gathered through src
       // (which, after the first selection, indexes the N-row state)
+      if (dedupe) {
+        // on the state rows themselves (N of them up to the first selection)
+        GnnJob job{&S, S.cls_h[cur.cls[s]].p, nullptr, S.cls_hg.p, rows_now,
+                   one_per_sample ? 1 : B};
+        job.row_ref = time >= 2 ? e->bm_ref.p : nullptr;
+        run_gnn_jobs(e, {job});
+      } else {
       const int out_rows = (shared_first && time == 0) ? N : R;
       run_gnn(e, S, S.cls_h[cur.cls[s]].p, src, S.cls_hg.p, out_rows,
               (shared_first && time == 0) ? 1 : B);
+      }
     }
   }
   // back-trace (:689-806)
@@ -2311,7 +2336,7 @@ int mv_op_gnn(int device, const float* h, const float* scene_mean, int32_t M,
       int ng = 0;
       const unsigned nb = mv::gnn_v2_blocks(cells, &ng);
       mv::GnnGroup grp{};
-      grp.p[0] = mv::GnnProblem{dh.p, ds.p, nullptr, dout.p, nullptr, 0, M, H, W, 1, ng};
+      grp.p[0] = mv::GnnProblem{dh.p, ds.p, nullptr, dout.p, nullptr, 0, M, H, W, 1, ng, nullptr};
       grp.nblocks0 = nb;
       hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nb), dim3(mv::kGnnThreads), 0, ctx.stream, grp,
                          C, D);

@@ -366,6 +366,7 @@ struct GnnProblem {
   const float* h; const float* scene_mean; const int32_t* src_row; float* out;
   _Float16* p16; size_t p16_stride;
   int M, H, W, sm_div, ngroups;
+  const int32_t* row_ref;   // optional [M]: rows with 0 are not computed (no beam continues them)
 };
 struct GnnGroup { GnnProblem p[2]; unsigned nblocks0; };
 
@@ -393,6 +394,12 @@ void gnn_attend_v2_kernel(const GnnGroup grp, int C, int D) {
   const int K = H * W;
   const long long Mtot = (long long)M * K;
   const long long m0 = (long long)g * kGnnCells;
+  if (pr.row_ref) {     // beam decode: skip the rows no surviving beam descends from
+    const long long mlast = m0 + kGnnCells - 1 < Mtot ? m0 + kGnnCells - 1 : Mtot - 1;
+    bool any = false;
+    for (long long r = m0 / K; r <= mlast / K; ++r) any |= pr.row_ref[r] != 0;
+    if (!any) return;
+  }
   const long long s0 = m0 - W - 1 > 0 ? m0 - W - 1 : 0;
   const long long s1 = m0 + kGnnCells + W + 1 < Mtot ? m0 + kGnnCells + W + 1 : Mtot;
   const int NS = (int)(s1 - s0);
@@ -682,7 +689,8 @@ void beam_step_kernel(const float* __restrict__ logits,
                       int diverse, float log_gamma, int fix_num_timestep,
                       float* __restrict__ new_lp, int32_t* __restrict__ ids,
                       int32_t* __restrict__ parents,
-                      int32_t* __restrict__ state_src_row, int state_rows_per_sample) {
+                      int32_t* __restrict__ state_src_row, int state_rows_per_sample,
+                      int32_t* __restrict__ row_ref = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* lp = sm;                 // [B*K]
   float* red = sm + B * K;        // [256] reduction scratch
@@ -756,6 +764,7 @@ void beam_step_kernel(const float* __restrict__ logits,
       ids[(size_t)n * B + sel] = bi - par * K;
       parents[(size_t)n * B + sel] = par;
       if (state_src_row) state_src_row[(size_t)n * B + sel] = n * state_rows_per_sample + par;
+      if (row_ref) row_ref[n * state_rows_per_sample + par] = 1;   // a state row some beam continues
       lp[bi] = -INFINITY;  // remove from the candidate set
     }
     __syncthreads();
@@ -840,7 +849,8 @@ __global__ __launch_bounds__(1024)
 void beam_select_kernel(const float* __restrict__ cand, int B, int K, int time,
                         int fix_num_timestep, float* __restrict__ new_lp,
                         int32_t* __restrict__ ids, int32_t* __restrict__ parents,
-                        int32_t* __restrict__ state_src_row, int state_rows_per_sample) {
+                        int32_t* __restrict__ state_src_row, int state_rows_per_sample,
+                        int32_t* __restrict__ row_ref = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncand = (time > 1) ? B * K : K;
@@ -881,6 +891,7 @@ void beam_select_kernel(const float* __restrict__ cand, int B, int K, int time,
       ids[(size_t)n * B + sel] = wi - par * K;
       parents[(size_t)n * B + sel] = par;
       if (state_src_row) state_src_row[(size_t)n * B + sel] = n * state_rows_per_sample + par;
+      if (row_ref) row_ref[n * state_rows_per_sample + par] = 1;   // a state row some beam continues
     }
     if ((wi & 1023) == tid) {          // the owner removes the winner and rescans its own
       lp[wi] = -INFINITY;
