@@ -95,6 +95,10 @@ def main():
                        "per product, fp32 accumulate: fp32-class error), or bf16 (BASELINE "
                        "configs[4]: bf16 operands, one MFMA per product, fp32 accumulate; "
                        "reduced precision, reported as such)")
+  ap.add_argument("--scene-conv-kernel", type=int, choices=(1, 3), default=3,
+                  help="--scene_conv_kernel of the reference (code/train.py:65): 3 = the published "
+                       "3x3 stride-2 stack; 1 = the dense 1x1 projections, run as MFMA GEMMs "
+                       "(BASELINE configs[4] names it)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-batch", type=int, default=8)
   args = ap.parse_args()
@@ -144,12 +148,14 @@ def main():
     args.graph = 1 if beam else 0
   if beam:
     cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 0),
-                               beam_size=args.beam)
+                               beam_size=args.beam, scene_conv_kernel=args.scene_conv_kernel)
   elif train:
-    cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 1), is_train=True)
+    cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 1), is_train=True,
+                               scene_conv_kernel=args.scene_conv_kernel)
     args.graph = 0
   else:
-    cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 1))
+    cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 1),
+                               scene_conv_kernel=args.scene_conv_kernel)
   params = synth.make_params(cfg, seed=synth.SEED_BASE + 2)  # reference initialisers
   feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 2 + 1000 * rank)
   eng = _lib.Engine(cfg, device=local_rank)
@@ -266,6 +272,18 @@ def main():
                 "beam_tile_state", "dgrad_slice_sum", "tanh_bwd", "conv3x3_small_dgrad",
                 "conv3x3_small_wgrad")},
   }
+  if "scene_proj1x1_mfma" in stats and stats["scene_proj1x1_mfma"]["total_ms"] > 0:
+    # north_star: "MFMA utilisation on the 1x1 projection against gfx950 peak" -- the dense
+    # 1x1 scene-feature projections (K = 11 and 64 channels) on v_mfma_f32_32x32x2_f32;
+    # with so little reduction depth they are bound by reading the feature maps, not by MFMA
+    sp = stats["scene_proj1x1_mfma"]
+    roofline["scene_proj1x1_mfma"] = {
+        "launches": sp["launches"], "ms": round(sp["total_ms"], 4),
+        "TFLOPs": round(sp["flops"] / (sp["total_ms"] * 1e-3) / 1e12, 3),
+        "frac_of_fp32_mfma_peak": round(sp["flops"] / (sp["total_ms"] * 1e-3) / 1e12 /
+                                        PEAK_FP32_MFMA_TFLOPS, 5),
+        "GBs": round(sp["bytes"] / (sp["total_ms"] * 1e-3) / 1e9, 1),
+        "frac_of_hbm_peak": round(sp["bytes"] / (sp["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
   if f16:
     # achieved / frac count ALGORITHMIC fp32 FLOPs against the dense fp16 MFMA peak;
     # every algorithmic product is executed as three fp16 MFMA products
@@ -352,7 +370,9 @@ def main():
     workload = ("BASELINE configs[1]: multi-scale 18x32+9x16 (scene 36x64x11), "
                 "batch %d/GPU, fp32 forward-only, beam 1, obs 8 / pred 12%s; gate "
                 "convolution on %s"
-                % (args.batch, ", hipGraph replay" if args.graph else "",
+                % (args.batch, (", hipGraph replay" if args.graph else "") +
+                   (", scene_conv_kernel 1 (dense 1x1 projections on MFMA)"
+                    if args.scene_conv_kernel == 1 else ""),
                    "the fp16 matrix pipe (f16x3 split, fp32-class error)" if
                    args.compute == "f16x3" else
                    "the bf16 matrix pipe (BASELINE configs[4]: bf16 operands, fp32 accumulate; "

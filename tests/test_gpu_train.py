@@ -17,6 +17,7 @@ from multiverse_amd import synth
 from oracle import multiverse_oracle as oracle
 
 pytestmark = pytest.mark.gpu
+_ORACLE_CACHE = {}
 
 
 def _rel(a, b):
@@ -107,8 +108,11 @@ def test_gradients_match_oracle(built_lib, use_grids, N, gnn, mode):
   eng.set_compute_mode(mode)
   eng.train_init()
   loss, wd, pgl = eng.train_forward_backward(feed)
-  oloss, owd, opgl, ograds = oracle.loss_and_grads(params, cfg, feed)
-  _, _, _, ograds64 = oracle.loss_and_grads(params, cfg, feed, dtype=torch.float64)
+  key = (use_grids, N, gnn)            # the f32 and f16x3 runs of a case share the oracle
+  if key not in _ORACLE_CACHE:
+    _ORACLE_CACHE[key] = (oracle.loss_and_grads(params, cfg, feed),
+                          oracle.loss_and_grads(params, cfg, feed, dtype=torch.float64)[3])
+  (oloss, owd, opgl, ograds), ograds64 = _ORACLE_CACHE[key]
   print("loss gpu %.6f oracle %.6f | wd %.6g / %.6g | parts %s / %s"
         % (loss, oloss, wd, owd, pgl, opgl))
   assert abs(loss - oloss) < 1e-4 * max(1.0, abs(oloss))

@@ -29,6 +29,17 @@ OPTIMIZERS = ["momentum", "rmsprop", "adam"]
 SLOTS = {"momentum": 1, "rmsprop": 2, "adam": 2}
 
 
+_ORACLE64 = {}
+
+
+def _oracle64(key, params, cfg, feed):
+  """fp64 oracle gradients, computed once per case (the f32 and f16x3 runs share them:
+  they are 10-20 s of CPU autograd each)."""
+  if key not in _ORACLE64:
+    _ORACLE64[key] = oracle.loss_and_grads(params, cfg, feed, dtype=torch.float64)
+  return _ORACLE64[key]
+
+
 def _rel(a, b):
   a = np.asarray(a, dtype=np.float64)
   b = np.asarray(b, dtype=np.float64)
@@ -50,7 +61,7 @@ def test_loss_and_decoder_switches(built_lib, name, mode):
   print("%s/%s: loss %.6f reference run %.6f parts %s / %s" % (name, mode, loss, ref[0], pgl,
                                                               ref[2:]))
   assert np.allclose([loss, wd] + pgl, ref, rtol=1e-4, atol=1e-5), (loss, ref)
-  _, _, _, og64 = oracle.loss_and_grads(params, cfg, feed, dtype=torch.float64)
+  _, _, _, og64 = _oracle64(name, params, cfg, feed)
   worst = 0.0
   for n, _ in eng.param_specs():
     gr = eng.get_grad(n)
@@ -189,7 +200,7 @@ def test_single_decoder(built_lib, mode):
     print("single decoder/%s step %d: loss %.6f reference run %.6f" % (mode, step, loss, ref[0]))
     assert np.allclose([loss, wd] + pgl, ref, rtol=1e-4, atol=1e-5), (loss, ref)
     if step == 0:
-      _, _, _, og64 = oracle.loss_and_grads(p_before, tcfg, fd, dtype=torch.float64)
+      _, _, _, og64 = _oracle64("single", p_before, tcfg, fd)
       for n, _ in eng.param_specs():
         gr = eng.get_grad(n)
         if n in no_grad:
