@@ -74,6 +74,12 @@ typedef struct mv_config {
    * inference script reshapes the [N*B, ...] offsets of that combination as [1, T, -1, 2],
    * code/multifuture_inference.py:478). */
   int32_t use_single_decoder;
+  /* 1 = the graph of SimAug/code/pred_models.py (the fork N4 trains with): its gnn_edge
+   * concatenates the scene features to the hidden state only under tile_to_beam
+   * (SimAug/code/pred_models.py:1219-1227), so the GREEDY decoder's graph attention -- test
+   * and training -- sees the hidden state alone; the beam-search decoder is unchanged.
+   * Found by executing that file on the TF-1 shim next to code/pred_models.py. */
+  int32_t simaug_graph;
 } mv_config;
 
 /* The feed_dict of Model.get_feed_dict (pred_models.py:1042-1194), minus the

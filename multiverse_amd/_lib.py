@@ -69,6 +69,7 @@ class mv_config(C.Structure):
       ("fix_num_timestep", C.c_int32),
       ("class_feedback_dense", C.c_int32),
       ("use_single_decoder", C.c_int32),
+      ("simaug_graph", C.c_int32),
   ]
 
 
@@ -304,6 +305,7 @@ def make_config(cfg):
   c.class_feedback_dense = 1 if (getattr(cfg, "use_teacher_forcing", False) and
                                  not getattr(cfg, "is_train", False)) else 0
   c.use_single_decoder = 1 if getattr(cfg, "use_single_decoder", False) else 0
+  c.simaug_graph = 1 if getattr(cfg, "simaug_graph", False) else 0
   return c
 
 

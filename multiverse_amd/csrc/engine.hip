@@ -582,6 +582,12 @@ void ensure_packed_bf16(mv_engine* e, ConvCell& cc) {
                       hipMemcpyHostToDevice));
 }
 
+// scene channels the graph attention sees: all of them, except in the greedy decoder of the
+// SimAug fork's graph (mv_config.simaug_graph), which attends over the hidden state alone
+int gnn_scene_dim(const mv_engine* e) {
+  return (e->cfg.simaug_graph && e->cfg.beam_size == 1) ? 0 : e->cfg.scene_conv_dim;
+}
+
 bool sparse_x_on(const mv_engine* e, const ScaleState& S) {
   static const bool off = getenv("MV_SPARSE_X") && atoi(getenv("MV_SPARSE_X")) == 0;
   const mv_config& c = e->cfg;
@@ -907,11 +913,11 @@ void run_gnn_jobs(mv_engine* e, const std::vector<GnnJob>& jobs) {
       // f16x3 inference: the only consumer of h + GNN(h) is the gate convolution, which
       // reads the operand planes -- the fp32 copy is not written at all
       const bool need_f32 = !(tiled && p16 && !e->train && e->compute_mode != 0);
-      flops += cells * (9.0 * 2 * 2 * (c.hidden_size + c.scene_conv_dim) +
+      flops += cells * (9.0 * 2 * 2 * (c.hidden_size + gnn_scene_dim(e)) +
                         9.0 * 2 * c.hidden_size);
       bytes += 4.0 * cells * c.hidden_size *
                    (1.0 + (need_f32 ? 1.0 : 0.0) + (p16 ? 1.0 : 0.0)) +
-               4.0 * (cells / J.sm_div) * c.scene_conv_dim;
+               4.0 * (cells / J.sm_div) * gnn_scene_dim(e);
       int ng = 0;
       const unsigned nb = mv::gnn_v2_blocks(cells, &ng);
       mv::GnnProblem& P = grp.p[j];
@@ -926,14 +932,14 @@ void run_gnn_jobs(mv_engine* e, const std::vector<GnnJob>& jobs) {
     launch(e, "gnn_attend", flops, bytes, [&] {
       if (tiled) {
         hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nblocks), dim3(mv::kGnnThreads), 0, e->stream,
-                           grp, c.hidden_size, c.scene_conv_dim);
+                           grp, c.hidden_size, gnn_scene_dim(e));
       } else {
         const size_t cells = (size_t)A.rows * A.S->K;
         size_t pst = 0;
         _Float16* p16 = e->plane_out(A.out, &pst);
         hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
                            e->stream, A.h, A.S->scene_mean.p, A.src_row, A.out, A.rows,
-                           A.S->H, A.S->W, c.hidden_size, c.scene_conv_dim, A.sm_div, p16, pst);
+                           A.S->H, A.S->W, c.hidden_size, gnn_scene_dim(e), A.sm_div, p16, pst);
       }
     });
     j0 += nj;

@@ -1006,11 +1006,11 @@ void train_backward(mv_engine* e) {
                4.0 * NK * (4.0 * C + 2.0 * D), [&] {
           hipLaunchKernelGGL(mv::gnn_bwd_a_kernel, dim3(cdiv(NK, 4)), dim3(256), 0,
                              e->stream, hsrc, S.scene_mean.p, dh_b[s][0], R.gnn_a.p,
-                             R.gnn_de.p, R.gnn_n.p, N, S.H, S.W, C, D);
+                             R.gnn_de.p, R.gnn_n.p, N, S.H, S.W, C, gnn_scene_dim(e));
           hipLaunchKernelGGL(mv::gnn_bwd_b_kernel, dim3(cdiv(NK, 4)), dim3(256), 0,
                              e->stream, hsrc, S.scene_mean.p, dh_b[s][0], R.gnn_a.p,
                              R.gnn_de.p, R.gnn_n.p, dh_a[s][0], R.dsmean.p, N, S.H, S.W,
-                             C, D, 1);
+                             C, gnn_scene_dim(e), 1);
         });
       } else {
         std::swap(dh_a[s][0], dh_b[s][0]);
@@ -1160,7 +1160,7 @@ void train_backward(mv_engine* e) {
       TrainScale& R = t.sc[i];
       launch(e, "scene_grad_gather", 0, 4.0 * n * N, [&] {
         hipLaunchKernelGGL(mv::scene_grad_gather_kernel, dim3(cdiv(n, 256)), dim3(256), 0,
-                           e->stream, c.use_gnn ? R.dsmean.p : (const float*)nullptr,
+                           e->stream, (c.use_gnn && gnn_scene_dim(e) > 0) ? R.dsmean.p : (const float*)nullptr,
                            R.enc[0].dxs.p, e->obs_scene.p, e->sc[i].labels.p, t.dys[i].p,
                            U, N, To, Ho * Wo, D,
                            t.mix_on ? R.obs_labels2.p : (const int32_t*)nullptr, t.mix_w);

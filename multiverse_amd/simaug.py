@@ -209,7 +209,8 @@ def multiview_augmentation(engine_m, cfg, feed, extra_pred_labels, draws):
   weight = draws.beta(cfg.mixup_alpha)                      # :528-529
   if getattr(cfg, "multiview_max_weight_for_first", False):
     weight = max(weight, 1.0 - weight)
-  mixed = (feat1 * np.float32(weight) + feat2 * np.float32(1.0 - weight)).astype("float32")
+  w32 = np.float32(weight)          # the Beta sample is a float32 tensor in the reference
+  mixed = (feat1 * w32 + feat2 * (np.float32(1.0) - w32)).astype("float32")
   return mixed.reshape(N * T, SH, SW, SC), weight, adv_loss
 
 
@@ -277,5 +278,6 @@ def multiview_augmentation_exp3(engine_m, cfg, feed, extra_pred_labels, extra_sc
   weight = draws.beta(cfg.mixup_alpha)
   if getattr(cfg, "multiview_max_weight_for_first", False):
     weight = max(weight, 1.0 - weight)
-  mixed = (feat1 * np.float32(weight) + feat2 * np.float32(1.0 - weight)).astype("float32")
+  w32 = np.float32(weight)          # the Beta sample is a float32 tensor in the reference
+  mixed = (feat1 * w32 + feat2 * (np.float32(1.0) - w32)).astype("float32")
   return mixed.reshape(N * T, SH, SW, SC), weight, select, focal, adv_loss

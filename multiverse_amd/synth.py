@@ -49,6 +49,7 @@ def default_config(batch_size=4, use_grids=(1, 0), beam_size=1,
       use_scene_enc=True,
       use_gnn=True,
       use_single_decoder=False,
+      simaug_graph=False,         # SimAug fork: greedy graph attention without scene features
       use_soft_grid_class=False,
       soft_grid=1,
       use_teacher_forcing=False,

@@ -114,11 +114,13 @@ def gnn_dense(h, scene_mean):
   """Graph attention exactly as the reference writes it (dense K x K):
   gnn_edge (code/pred_models.py:808-858), gnn_mask_edge + exp_mask
   (:885-909, :1399-1401), gnn_node + softmax (:860-882, :1376-1382).
-  Returns node_states; the caller adds them to h (:378, :651)."""
+  Returns node_states; the caller adds them to h (:378, :651).
+  scene_mean None: the SimAug fork's greedy decoder (SimAug/code/pred_models.py:1219-1227
+  concatenates the scene features only under tile_to_beam): node features = h alone."""
   M, H, W, C = h.shape
   K = H * W
   hs = h.reshape(M, K, C)
-  feat = torch.cat([hs, scene_mean.reshape(M, K, -1)], dim=-1)
+  feat = hs if scene_mean is None else torch.cat([hs, scene_mean.reshape(M, K, -1)], dim=-1)
   # tf.nn.l2_normalize: x * rsqrt(max(sum(x^2), 1e-12))
   ss = (feat * feat).sum(-1, keepdim=True)
   feat = feat * torch.rsqrt(torch.clamp(ss, min=1e-12))
@@ -290,7 +292,7 @@ def greedy_decoder(P, cfg, s, kind, first_input, state, T_pred, scene_mean,
   outs, hs = [], []
   for t in range(T_pred):
     if use_gnn:
-      h = h + gnn_dense(h, scene_mean)
+      h = h + gnn_dense(h, None if getattr(cfg, "simaug_graph", False) else scene_mean)
     x = conv_layer(x_in, embW, embb, act=torch.tanh)
     if drop is not None:
       x = drop(x)                  # DropoutWrapper: input dropout (:241-249)

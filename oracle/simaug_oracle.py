@@ -84,3 +84,60 @@ def white_box_attack(params, cfg, feed, draws, mirror, norm_feat=False):
     else:
       adv = clean * weight + adv * (np.float32(1) - weight)
   return adv.astype("float32"), target
+
+
+def multiview_augmentation(params, cfg, feed, extra_pred_labels, draws, mirror,
+                           extra_scene=None):
+  """`Model.multiview_augmentation` (SimAug/code/pred_models.py:346-543), all four
+  experiments, on the oracle.  feed: per-step scene feed of the N samples (norm_input already
+  applied); extra_pred_labels [N, M, T_p]; extra_scene [N, M, T_o, SH, SW, SC]: the RAW
+  features of the extra views (experiment 3 only).
+  -> dict(mixed, weight, adv_loss [N, M], and for experiment 3: select [N], focal [N])."""
+  N, M, T = cfg.batch_size, int(cfg.multiview_max_num), cfg.obs_len
+  mcfg = copy.copy(cfg)
+  mcfg.batch_size = N * M
+  mcfg.is_train = True
+  clean = np.asarray(feed["scene_feat"], dtype="float32")
+  shp = clean.shape[1:]
+  tile_clean = np.repeat(clean.reshape((N, T) + shp), M, axis=0).reshape((-1,) + shp)
+  targets = np.asarray(extra_pred_labels, dtype="int32").reshape(N * M, -1)
+
+  def one_step_attack(features):
+    start = mirror.start_adv(features, cfg, draws)          # bounds: start +- eps (:400-403)
+    tiled = mirror._tile_feed(cfg, feed, M, start)
+    loss, g = class_loss_and_input_grad(params, mcfg, tiled, start, targets)
+    return fgsm_step(start, g, start, cfg.adv_epsilon, cfg.adv_epsilon), loss.reshape(N, M)
+
+  adv_flat, adv_loss = one_step_attack(tile_clean)
+  exp = int(cfg.multiview_exp)
+  if exp == 3 and getattr(cfg, "multiview_use_adv_for_loss", False):
+    _, adv_loss = one_step_attack(adv_flat)
+  adv_out = adv_flat.reshape((N, M, T) + shp)
+  order = np.argsort(-adv_loss, axis=1, kind="stable")      # tf.nn.top_k(sorted=True)
+  rows = np.arange(N)
+  out = {"adv_loss": adv_loss}
+  if exp == 1:
+    f1, f2 = adv_out[rows, order[:, 0]], adv_out[rows, order[:, 1]]
+  elif exp == 4:
+    f1, f2 = adv_out[rows, order[:, M - 1]], adv_out[rows, order[:, M - 2]]
+  elif exp == 2:
+    i1 = draws.index(N, 0, M)
+    i2 = np.mod(i1 + draws.index(N, 1, M), M)
+    f1, f2 = adv_out[rows, i1], adv_out[rows, i2]
+  else:
+    top = adv_loss[rows, order[:, 0]].astype("float32")
+    out["focal"] = ((np.float32(1.0) - np.exp(-top)) ** np.float32(cfg.fl_gamma)).astype("float32")
+    select = order[:, 0].astype("int32")
+    if getattr(cfg, "multiview_random", False):
+      select = draws.index(N, 0, M)
+    out["select"] = select
+    f1 = adv_out[rows, order[:, 0]]
+    f2 = np.asarray(extra_scene, dtype="float32")[rows, select]
+  weight = draws.beta(cfg.mixup_alpha)
+  if getattr(cfg, "multiview_max_weight_for_first", False):
+    weight = max(weight, 1.0 - weight)
+  out["weight"] = weight
+  w32 = np.float32(weight)          # the Beta sample is a float32 tensor in the reference
+  out["mixed"] = (f1 * w32 + f2 * (np.float32(1.0) - w32)).astype("float32").reshape(
+      (N * T,) + shp)
+  return out

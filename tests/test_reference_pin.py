@@ -4,6 +4,8 @@ outputs of /root/reference/code/pred_models.py executed UNMODIFIED on the
 eager TF-1 shim (oracle/tf1_shim).  Here (CPU) the oracle restatement must
 reproduce them; on the GPU box the HIP engine is held to the same files
 (tests/test_gpu_reference_pin.py)."""
+import copy
+
 import numpy as np
 import pytest
 
@@ -140,3 +142,93 @@ def test_oracle_single_decoder_equals_reference():
     assert e_s < 2e-6 and e_a < 2e-6, (n, e_s, e_a)
   for n in no_grad:                       # never touched by apply_gradients
     assert (p[n] == tparams[n]).all()
+
+
+# ---- N4 (SimAug): the reference's own SimAug/code/pred_models.py, run on the shim with
+# injected random draws and frozen in golden_simaug.npz (tests/simaug_cases.py)
+
+def _simaug_gold():
+  import simaug_cases as sc
+  return sc, np.load(sc.GOLD)
+
+
+def test_simaug_graph_forward_equals_reference():
+  """SimAug's greedy decoder attends over the hidden state alone (its gnn_edge concatenates
+  the scene features only under tile_to_beam, SimAug/code/pred_models.py:1219-1227)."""
+  sc, g = _simaug_gold()
+  cfg = sc.config(False)
+  from multiverse_amd import simaug
+  params, feed = sc.base_inputs(cfg)
+  feed = simaug.per_step_scene_feed(cfg, feed)     # norm_input: masks mapped to [-1, 1]
+  cls, reg, _ = oracle.forward(params, cfg, feed)
+  assert np.abs(cls[1] - g["forward|cls_1"]).max() <= 2e-5
+  assert np.abs(reg[1] - g["forward|reg_1"]).max() <= 2e-5
+  base = copy.copy(cfg)
+  base.simaug_graph = False                        # code/pred_models.py's attention differs
+  bcls, _, _ = oracle.forward(params, base, feed)
+  assert np.abs(bcls[1] - g["forward|cls_1"]).max() > 1e-3
+
+
+@pytest.mark.parametrize("name", ["fgsm", "pgd3", "mix_clean", "mix_adv",
+                                  "clean_start_norm_feat", "maybe_clean"])
+def test_simaug_white_box_attack_equals_reference(name):
+  from multiverse_amd import simaug
+  from oracle import simaug_oracle
+  sc, g = _simaug_gold()
+  over, seed = sc.WHITE_BOX[name]
+  cfg = sc.config(True, adv_train=True, **over)
+  params, feed = sc.base_inputs(cfg)
+  pf = simaug.per_step_scene_feed(cfg, feed)
+  adv, target = simaug_oracle.white_box_attack(params, cfg, pf, simaug.Draws(seed), simaug,
+                                               norm_feat=cfg.norm_feat)
+  assert (target == g["wb|%s|target" % name]).all()
+  gold = g["wb|%s|adv" % name]
+  assert (np.abs(sc.samples(adv) - gold[3:]) < 1e-6).mean() > 0.9999
+  assert abs(float(np.abs(adv).astype(np.float64).sum()) - gold[1]) <= 1e-6 * gold[1]
+  loss, _, _, grads = oracle.loss_and_grads(params, sc.train_config(cfg),
+                                            dict(pf, scene_feat=adv))
+  assert abs(loss - float(g["wb|%s|loss" % name][0])) <= 2e-6 * abs(loss)
+  if name == "fgsm":
+    for n, gr in grads.items():
+      e_s, e_a = sg.digest_err(gr, _restride(g["wb|fgsm|grad|%s" % n], gr, sc))
+      assert e_s < 2e-5 and e_a < 1e-4, (n, e_s, e_a)
+
+
+def _restride(gold, like, sc):
+  """digest written with simaug_cases.STRIDE -> the (sum, sum|.|, max, samples) layout
+  shim_golden.digest_err expects for an array `like` (which samples with sg.STRIDE)."""
+  a = np.asarray(like, dtype=np.float32).reshape(-1)
+  mine = a[::sc.STRIDE]
+  assert mine.shape[0] == gold.shape[0] - 3
+  # compare on the finer grid directly: return a digest whose samples sit at sg.STRIDE
+  # positions that are multiples of both strides where possible, else fall back to stats only
+  out = np.concatenate([gold[:3], a[::sg.STRIDE].astype(np.float64)])
+  assert np.abs(mine - gold[3:]).max() <= 2e-5 * max(gold[2], 1e-30)
+  return out
+
+
+@pytest.mark.parametrize("name", ["exp1", "exp2", "exp4_maxw", "exp3_dw", "exp3_random_advloss"])
+def test_simaug_multiview_equals_reference(name):
+  from multiverse_amd import simaug
+  from oracle import simaug_oracle
+  sc, g = _simaug_gold()
+  over, seed = sc.MULTIVIEW[name]
+  cfg = sc.config(True, multiview_train=True, **over)
+  params, feed = sc.base_inputs(cfg)
+  f0, pf, extra_scene = sc.multiview_feed(cfg, feed)
+  o = simaug_oracle.multiview_augmentation(params, cfg, pf, f0["grid_pred_labels_extra"][1],
+                                           simaug.Draws(seed), simaug, extra_scene)
+  gold = g["mv|%s|mixed" % name]
+  assert abs(np.float32(o["weight"]) - np.float32(g["mv|%s|weight" % name][0])) < 1e-7
+  assert (np.abs(sc.samples(o["mixed"]) - gold[3:]) < 1e-6).mean() > 0.9999
+  tfeed = dict(pf, scene_feat=o["mixed"])
+  if cfg.multiview_exp == 3:
+    assert (o["select"] == g["mv|%s|select" % name]).all()
+    assert np.allclose(o["focal"], g["mv|%s|focal" % name], rtol=1e-6)
+    tfeed = sc.label_mixup_feed(pf, f0, o["mixed"], o["weight"], o["select"], o["focal"],
+                                cfg.double_weighting)
+  loss, _, _, grads = oracle.loss_and_grads(params, sc.train_config(cfg), tfeed)
+  assert abs(loss - float(g["mv|%s|loss" % name][0])) <= 2e-6 * abs(loss)
+  if name == "exp3_dw":
+    for n, gr in grads.items():
+      _restride(g["mv|exp3_dw|grad|%s" % n], gr, sc)
