@@ -6,14 +6,16 @@ Restates `white_box_attack` (SimAug/code/pred_models.py:60-172) and
 network (oracle/multiverse_oracle.py; SimAug's `build_tower` :544 is the same graph as
 code/pred_models.py build_forward), with torch.autograd playing `tf.gradients(loss, input)`.
 
-**parity unpinned**: SimAug/code/pred_models.py is a second 2 100-line TF-1 graph file with
-unseeded random ops; it has not been executed on the TF-1 shim, and the reference ships no
-fixtures for it.  What IS checked: this restatement against the HIP engine under identical,
-injected random draws (tests/test_gpu_simaug.py), and the underlying network / gradients
-against the reference-run goldens of code/pred_models.py.  The label mixup of experiment 3
-(two-hot inputs, mixed targets, focal sample weights) is restated in
-oracle/multiverse_oracle.py (feed keys mix_weight / mix_obs_labels / mix_pred_labels /
-mix_sample_weight), equally unpinned.
+**Pinned to the reference** (round 2): SimAug/code/pred_models.py is executed UNMODIFIED on the
+TF-1 shim (oracle/tf1_shim/run_simaug.py) with its unseeded random ops replayed from the same
+`Draws` object, and frozen in tests/golden/golden_simaug.npz by make_simaug_golden.py: six
+white_box_attack configurations, the four multi-view experiments (experiment 3 twice) and
+SimAug's greedy forward.  tests/test_reference_pin.py holds the functions below to those runs
+(adversarial / mixed features equal element for element, target labels, beta weight, selected
+view, focal weights, the loss of the training step that follows to 2e-6, gradients);
+tests/test_gpu_simaug.py holds the HIP engine + multiverse_amd/simaug.py to the same file.
+That run also showed that SimAug's graph differs from code/pred_models.py in one place: its
+greedy decoder's graph attention sees the hidden state alone (`simaug_graph`).
 """
 from __future__ import annotations
 

@@ -231,3 +231,104 @@ def test_multiview_experiment_3(built_lib):
   print("multiview exp 3: mixed features equal on %.5f of the elements, weight %.4f, focal %s"
         % (same.mean(), weight, np.round(focal, 4)))
   assert abs(w - weight) < 1e-12 and same.mean() > 0.999
+
+
+# ---- against the frozen runs of the reference's own SimAug/code/pred_models.py
+# (tests/golden/golden_simaug.npz, tests/simaug_cases.py): same injected draws, SimAug's graph
+
+def _engine(built_lib, cfg, params, batch=None):
+  c = copy.copy(cfg)
+  if batch is not None:
+    c.batch_size = batch
+  eng = built_lib.Engine(c, device=0)
+  eng.set_params(params)
+  eng.train_init(sc_train_config(c))
+  return eng
+
+
+def sc_train_config(cfg):
+  import simaug_cases as sc
+  return sc.train_config(cfg)
+
+
+def test_simaug_graph_forward_against_reference_run(built_lib):
+  import simaug_cases as sc
+  g = np.load(sc.GOLD)
+  cfg = sc.config(False)
+  params, feed = sc.base_inputs(cfg)
+  feed = simaug.per_step_scene_feed(cfg, feed)
+  for mode in ("f32", "f16x3"):
+    eng = built_lib.Engine(cfg, device=0)
+    eng.set_params(params)
+    eng.set_compute_mode(mode)
+    cls, reg = eng.forward_greedy(feed)
+    eng.close()
+    assert np.abs(cls[1] - g["forward|cls_1"]).max() <= 1e-4
+    assert np.abs(reg[1] - g["forward|reg_1"]).max() <= 1e-4
+    assert (cls[1].reshape(2, 12, -1).argmax(-1) ==
+            g["forward|cls_1"].reshape(2, 12, -1).argmax(-1)).all()
+
+
+@pytest.mark.parametrize("name", ["fgsm", "pgd3", "mix_adv", "clean_start_norm_feat"])
+def test_white_box_attack_against_reference_run(built_lib, name):
+  import simaug_cases as sc
+  g = np.load(sc.GOLD)
+  over, seed = sc.WHITE_BOX[name]
+  cfg = sc.config(True, adv_train=True, **over)
+  params, feed = sc.base_inputs(cfg)
+  pf = simaug.per_step_scene_feed(cfg, feed)
+  eng = _engine(built_lib, cfg, params)
+  adv, target = simaug.white_box_attack(eng, sc.train_config(cfg), pf, simaug.Draws(seed),
+                                        norm_feat=cfg.norm_feat)
+  eng.upload_targets(pf)
+  loss = eng.train_step(None)[0]
+  eng.close()
+  gold = g["wb|%s|adv" % name]
+  same = np.abs(sc.samples(adv) - gold[3:]) < 1e-6
+  print("%s: adversarial features equal to the reference's on %.5f of the sampled elements, "
+        "training loss %.6f (reference %.6f)" % (name, same.mean(), loss, g["wb|%s|loss" % name][0]))
+  assert (target == g["wb|%s|target" % name]).all()
+  assert same.mean() > 0.999
+  assert abs(loss - float(g["wb|%s|loss" % name][0])) <= 1e-4 * abs(loss)
+
+
+@pytest.mark.parametrize("name", ["exp1", "exp2", "exp3_dw", "exp3_random_advloss"])
+def test_multiview_against_reference_run(built_lib, name):
+  import simaug_cases as sc
+  g = np.load(sc.GOLD)
+  over, seed = sc.MULTIVIEW[name]
+  cfg = sc.config(True, multiview_train=True, **over)
+  params, feed = sc.base_inputs(cfg)
+  f0, pf, extra_scene = sc.multiview_feed(cfg, feed)
+  tcfg = sc.train_config(cfg)
+  engm = _engine(built_lib, cfg, params, batch=sc.N * sc.M)
+  if cfg.multiview_exp == 3:
+    mixed, weight, select, focal, _ = simaug.multiview_augmentation_exp3(
+        engm, tcfg, pf, f0["grid_pred_labels_extra"][1], extra_scene, simaug.Draws(seed))
+  else:
+    mixed, weight, _ = simaug.multiview_augmentation(
+        engm, tcfg, pf, f0["grid_pred_labels_extra"][1], simaug.Draws(seed))
+  engm.close()
+  gold = g["mv|%s|mixed" % name]
+  same = np.abs(sc.samples(mixed) - gold[3:]) < 1e-6
+  assert abs(np.float32(weight) - np.float32(g["mv|%s|weight" % name][0])) < 1e-7
+  assert same.mean() > 0.999
+  eng = _engine(built_lib, cfg, params)
+  eng.upload(dict(pf, scene_feat=mixed))
+  eng.upload_targets(pf)
+  if cfg.multiview_exp == 3:
+    assert (select == g["mv|%s|select" % name]).all()
+    assert np.allclose(focal, g["mv|%s|focal" % name], rtol=1e-5)
+    t = sc.label_mixup_feed(pf, f0, mixed, weight, select, focal, cfg.double_weighting)
+    eng.set_label_mixup(t["mix_obs_labels"], t["mix_pred_labels"], weight,
+                        t["mix_sample_weight"])
+  loss = eng.train_forward_backward(None)[0]
+  print("%s: mixed features equal to the reference's on %.5f of the sampled elements, training "
+        "loss %.6f (reference %.6f)" % (name, same.mean(), loss, g["mv|%s|loss" % name][0]))
+  assert abs(loss - float(g["mv|%s|loss" % name][0])) <= 1e-4 * abs(loss)
+  if name == "exp3_dw":
+    for n, _ in eng.param_specs():
+      gd = g["mv|exp3_dw|grad|%s" % n]
+      gr = sc.samples(eng.get_grad(n))
+      assert np.abs(gr - gd[3:]).max() <= 2e-3 * max(gd[2], 1e-30), n
+  eng.close()
