@@ -6,7 +6,8 @@ shim, random ops replayed from multiverse_amd.simaug.Draws) into tests/golden/go
     python oracle/tf1_shim/make_simaug_golden.py          # needs /root/reference
 
 Cases (tests/simaug_cases.py): the greedy Tester forward of SimAug's graph (whose greedy
-graph attention ignores the scene features, SimAug/code/pred_models.py:1219-1227); six
+graph attention ignores the scene features, SimAug/code/pred_models.py:1219-1227) and its
+diverse beam-5 decode (whose attention does see them); six
 white_box_attack configurations; the four multi-view experiments (experiment 3 twice).  Per
 case: the augmented features (digest), target labels / beta weight / selected view / focal
 weights, the training loss of the step that follows, and for two cases every gradient.
@@ -32,6 +33,12 @@ def main():
   params, feed = sc.base_inputs(cfg)
   cls, reg = rs.forward(cfg, params, feed)
   out["forward|cls_1"], out["forward|reg_1"] = cls[1], reg[1]
+  bcfg = sc.beam_config()
+  tf, ref, model = rs.build_model(bcfg, params, feed, is_train=False)
+  out["beam|best"] = rs._np(tf, model.grid_pred_decoded[1])
+  out["beam|reg"] = rs._np(tf, model.grid_pred_reg_decoded[1])
+  out["beam|logits"], out["beam|ids"], out["beam|logprobs"] = [
+      rs._np(tf, t) for t in model.beam_outputs]
   for name, (over, seed) in sc.WHITE_BOX.items():
     cfg = sc.config(True, adv_train=True, **over)
     r = rs.run_white_box(cfg, params, feed, simaug.Draws(seed))

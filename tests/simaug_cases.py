@@ -106,3 +106,11 @@ def train_config(cfg):
   t = copy.copy(cfg)
   t.norm_input = False
   return t
+
+
+def beam_config():
+  """SimAug's beam-search decode (its gnn_edge DOES see the scene features there)."""
+  cfg = config(False)
+  cfg.use_beam_search, cfg.beam_size = True, 5
+  cfg.diverse_beam, cfg.diverse_gamma, cfg.fix_num_timestep = True, 0.01, 1
+  return cfg

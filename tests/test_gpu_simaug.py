@@ -332,3 +332,22 @@ def test_multiview_against_reference_run(built_lib, name):
       gr = sc.samples(eng.get_grad(n))
       assert np.abs(gr - gd[3:]).max() <= 2e-3 * max(gd[2], 1e-30), n
   eng.close()
+
+
+def test_simaug_beam_search_against_reference_run(built_lib):
+  """SimAug's beam decode (attention WITH the scene features, unlike its greedy decoder)."""
+  import simaug_cases as sc
+  g = np.load(sc.GOLD)
+  cfg = sc.beam_config()
+  params, feed = sc.base_inputs(cfg)
+  feed = simaug.per_step_scene_feed(cfg, feed)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode("f16x3")
+  arrs, s = eng.forward_beam(feed)
+  eng.close()
+  assert s == 1
+  assert (np.asarray(arrs["ids"]) == g["beam|ids"]).all()
+  assert np.abs(np.asarray(arrs["logits"]) - g["beam|logits"]).max() <= 1e-4
+  assert np.abs(np.asarray(arrs["logprobs"]) - g["beam|logprobs"]).max() <= 1e-3
+  assert np.abs(np.asarray(arrs["grid_reg"]) - g["beam|reg"]).max() <= 1e-4

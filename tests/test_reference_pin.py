@@ -232,3 +232,19 @@ def test_simaug_multiview_equals_reference(name):
   if name == "exp3_dw":
     for n, gr in grads.items():
       _restride(g["mv|exp3_dw|grad|%s" % n], gr, sc)
+
+
+def test_simaug_beam_search_equals_reference():
+  """SimAug's beam decoder tiles the scene features into its attention (tile_to_beam), its
+  greedy regression decoder has no attention: with simaug_graph the oracle equals the frozen
+  run of SimAug's own file -- ids bit-exact."""
+  from multiverse_amd import simaug
+  sc, g = _simaug_gold()
+  cfg = sc.beam_config()
+  params, feed = sc.base_inputs(cfg)
+  cls, reg, beam = oracle.forward(params, cfg, simaug.per_step_scene_feed(cfg, feed))
+  assert (np.asarray(beam[1]) == g["beam|ids"]).all()
+  assert np.abs(cls[1] - g["beam|best"]).max() <= 2e-5
+  assert np.abs(reg[1] - g["beam|reg"]).max() <= 2e-5
+  assert np.abs(np.asarray(beam[0]) - g["beam|logits"]).max() <= 2e-5
+  assert np.abs(np.asarray(beam[2]) - g["beam|logprobs"]).max() <= 1e-4
