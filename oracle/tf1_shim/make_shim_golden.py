@@ -92,6 +92,8 @@ VARIANT_CASES = [
     ("momentum", dict(optimizer="momentum", init_lr=0.01), 2),
     ("rmsprop", dict(optimizer="rmsprop", init_lr=0.001), 2),
     ("adam", dict(optimizer="adam", init_lr=0.001), 2),
+    # --use_cosine_lr (code/pred_models.py:1646-1654): max_steps = 4, lr 1, 0.854, 0.5 x init
+    ("cosine", dict(use_cosine_lr=True, num_epochs=4, optimizer="momentum", init_lr=0.01), 3),
 ]
 VARIANT_SEED = synth.SEED_BASE + 40
 
@@ -172,8 +174,10 @@ def single_decoder_case():
 def main():
   assert rr.available(), "needs the reference checkout (/root/reference)"
   if len(sys.argv) > 1 and sys.argv[1] == "variants":
+    only = sys.argv[2:] or None
     for name, over, steps in VARIANT_CASES:
-      variant_train_case(name, over, steps)
+      if only is None or name in only:
+        variant_train_case(name, over, steps)
     teacher_test_forward_case()
     return
   if len(sys.argv) > 1 and sys.argv[1] == "single":

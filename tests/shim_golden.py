@@ -81,6 +81,7 @@ VARIANT_CASES = {
     "momentum": (dict(optimizer="momentum", init_lr=0.01), 2),
     "rmsprop": (dict(optimizer="rmsprop", init_lr=0.001), 2),
     "adam": (dict(optimizer="adam", init_lr=0.001), 2),
+    "cosine": (dict(use_cosine_lr=True, num_epochs=4, optimizer="momentum", init_lr=0.01), 3),
 }
 VARIANT_SEED = synth.SEED_BASE + 40
 

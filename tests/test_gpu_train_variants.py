@@ -25,8 +25,8 @@ import shim_golden as sg
 pytestmark = pytest.mark.gpu
 LOSS_VARIANTS = ["soft1", "soft7_mask", "mask", "teacher", "teacher_soft4", "no_onehot",
                  "dropout07"]
-OPTIMIZERS = ["momentum", "rmsprop", "adam"]
-SLOTS = {"momentum": 1, "rmsprop": 2, "adam": 2}
+OPTIMIZERS = ["momentum", "rmsprop", "adam", "cosine"]     # cosine: --use_cosine_lr + momentum
+SLOTS = {"momentum": 1, "rmsprop": 2, "adam": 2, "cosine": 1}
 
 
 _ORACLE64 = {}
