@@ -137,6 +137,9 @@ def main():
                            "RANK" in os.environ)
   if use_dist:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # the host driver only supports dmabuf IPC: without this RCCL's cross-process handles
+    # fail with hipIpcGetMemHandle: invalid argument
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group(backend=backend)  # nccl == RCCL; barrier + max only
 
   beam = args.workload == "beam"

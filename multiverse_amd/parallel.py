@@ -11,9 +11,12 @@ The training step has the path's one real exchange: the batch means in the
 loss (reference code/pred_models.py:995, 1016-1022) couple the samples, so the
 per-rank gradients of the local means are summed over the ranks and scaled by
 1/world.  The engine keeps every parameter gradient in ONE flat device buffer
-(85.4 MB fp32 for both scales) so that is a single all-reduce; xGMI is
-point-to-point, a ring moves 2*(w-1)/w * 85.4 MB per link ~ 1 ms against a
->= 100 ms step, so it is issued once after the backward pass.
+(85.4 MB fp32 for both scales).  On RCCL the reduction runs INSIDE the library
+(`init_engine_comm` -> mv_allreduce_init: one bucket per ConvLSTM kernel on a side
+stream, overlapped with the rest of the backward pass; torch.distributed only
+broadcasts the 128-byte unique id); `allreduce_engine_grads` is the round-1 path --
+one torch all_reduce on the zero-copy view of that buffer -- kept for gloo (the CPU /
+one-GPU tests) and MV_ALLREDUCE=torch.
 """
 
 from __future__ import annotations
