@@ -344,7 +344,7 @@ def main():
       roofline["traffic_unit"] = ("MB HBM per launch, launch-weighted over step / dgrad / wgrad "
                                   "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)")
       roofline["traffic_raw_MB"] = round(raw / n / 1e6, 1)
-      roofline["traffic_source"] = "profiles/r1_train_pmc_*.json"
+      roofline["traffic_source"] = "profiles/r2_train_pmc_*.json"
 
   if beam:
     metric = ("trajectories/sec (8-obs/12-pred, 18x32 grid, diverse beam-%d "
