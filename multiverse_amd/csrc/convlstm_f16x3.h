@@ -212,6 +212,9 @@ static inline unsigned split_planes_blocks(size_t M, int C) {
 #ifndef MV_CONV_WAVES
 #define MV_CONV_WAVES 8
 #endif
+#ifndef MV_BF16_ADIST
+#define MV_BF16_ADIST 1          // bf16 kernel: A operands requested this many k-steps ahead (2: measured -1.5 %)
+#endif
 constexpr int kWaves16 = MV_CONV_WAVES;           // waves per workgroup of the f16x3 kernels
 constexpr int kThreads16 = kWaves16 * 64;
 constexpr int kBlockRows16 = kWaves16 * kWaveRows; // cells per workgroup
@@ -399,6 +402,13 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     bool c_rowok = stage_rowok(st_lo);
     f16x8 fa0, fa1;
     MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 0, fa0, fa1);
+    // bf16 (one MFMA per product): a k-step is 128 matrix-pipe cycles instead of 384; requesting
+    // the operand TWO k-steps ahead (MV_BF16_ADIST=2, 4 more VGPRs) was measured 1.5 % SLOWER
+    // (0.526 vs 0.518 ms per launch): operand latency is not what holds the bf16 kernel at
+    // MFMA busy 0.37 either.
+    constexpr bool kA2 = (NPL == 1) && (MV_BF16_ADIST == 2);
+    f16x8 fb0, fb1;
+    if constexpr (kA2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 1, fb0, fb1);
     __syncthreads();                       // carries the vmcnt(0) of the pending LDS-DMA
     for (int st = st_lo; st < st_hi; ++st) {
       const bool more = st + 1 < st_hi;
@@ -410,8 +420,13 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
         f16x8 fn0, fn1;
+        if constexpr (kA2) {               // the k-step after next
+          if (kk == 0) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 2, fn0, fn1);
+          else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, kk - 1, fn0, fn1);
+        } else {
         if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, fn0, fn1);
         else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 0, fn0, fn1);   // (re-read at the very end)
+        }
         // the DMA of the next stage goes out behind the first k-step's operands (vmcnt
         // retires in order); its target buffer was last read before the previous barrier
         if (kk == 1 && more) stage_dma(st + 1, lds + ((st + 1) & 1) * kBufVec);
@@ -441,7 +456,8 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
                 __builtin_bit_cast(bf16x8, fa0), __builtin_bit_cast(bf16x8, b0[g]), acc[g], 0,
                 0, 0);
         }
-        fa0 = fn0; fa1 = fn1;
+        if constexpr (kA2) { fa0 = fb0; fb0 = fn0; }
+        else { fa0 = fn0; fa1 = fn1; }
       }
       c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
       __syncthreads();
