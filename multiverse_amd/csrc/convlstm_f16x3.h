@@ -212,6 +212,9 @@ static inline unsigned split_planes_blocks(size_t M, int C) {
 #ifndef MV_CONV_WAVES
 #define MV_CONV_WAVES 8
 #endif
+#ifndef MV_BF16_UNITS
+#define MV_BF16_UNITS 2         // bf16 kernel: row units (of 3 k-steps) per LDS stage
+#endif
 #ifndef MV_BF16_ADIST
 #define MV_BF16_ADIST 1          // bf16 kernel: A operands requested this many k-steps ahead (2: measured -1.5 %)
 #endif
@@ -301,15 +304,19 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   // eight v_and.  (The first version spent 8.4 non-MFMA instructions per MFMA --
   // 3.7 VALU + 3.5 SALU -- against ~6 issue slots per 32-cycle MFMA: issue-bound at
   // 49 % MFMA busy, profiles/r1_f16x3_pmc_v2.json.)
-  static_assert(kKpb == 3, "a stage is one stencil row");
-  constexpr int kBufVec = kKpb * NPL * 4 * 64;   // 16-B vectors per LDS stage buffer
+  static_assert(kKpb == 3, "a row unit is one stencil row");
+  // An LDS stage holds R row units (R x 3 k-steps).  f16x3: R = 1 (24 KB).  bf16: one MFMA per
+  // product makes a row unit only 384 matrix-pipe cycles long, so the per-stage barrier and
+  // DMA drain weigh three times as much; R = 2 puts the same 24 KB behind each barrier.
+  constexpr int R = (NPL == 1) ? MV_BF16_UNITS : 1;
+  constexpr int kBufVec = R * kKpb * NPL * 4 * 64;   // 16-B vectors per LDS stage buffer
   const int nxk = p.n_xk;
   const int nsteps = nxk + p.n_hk;
   const int nstages = nsteps / 3;
   const int nxst = nxk / 3;
   const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wp16) +
                       (size_t)cb * p.w_ksteps * (NPL * 4 * 64);
-  constexpr int kSV = 3 * NPL * NG * 64;       // 16-B vectors per stage (NG sub-blocks)
+  constexpr int kSV = R * 3 * NPL * NG * 64;   // 16-B vectors per stage (NG sub-blocks)
   constexpr int kCopy = (kSV + kThreads16 - 1) / kThreads16;     // per thread
   // stage vector v = ((kk*NPL + plane)*NG + g)*64 + lane  ->  its place in the pack,
   // which keeps four sub-block slots per (k-step, plane)
@@ -396,7 +403,9 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
               (__attribute__((address_space(3))) void*)(dstbuf + v0), 16, 0, 0);
       }
     };
-    stage_dma(st_lo, lds + (st_lo & 1) * kBufVec);
+    // LDS stages of R row units each; (st_hi - st_lo) % R == 0 (host-checked for bf16)
+    const int nsg = (st_hi - st_lo) / R;
+    stage_dma(st_lo, lds);
     bool c_isx = stage_isx(st_lo);
     int c_rowoff = stage_rowoff(st_lo), c_cg = stage_cg(st_lo);
     bool c_rowok = stage_rowok(st_lo);
@@ -410,15 +419,19 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     f16x8 fb0, fb1;
     if constexpr (kA2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 1, fb0, fb1);
     __syncthreads();                       // carries the vmcnt(0) of the pending LDS-DMA
-    for (int st = st_lo; st < st_hi; ++st) {
-      const bool more = st + 1 < st_hi;
-      const int stn = more ? st + 1 : st;
+    for (int sg = 0; sg < nsg; ++sg) {
+      const bool more = sg + 1 < nsg;
+      const f16x8* buf = lds + (sg & 1) * kBufVec;
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+      const int st = st_lo + sg * R + u;
+      const int stn = st + 1 < st_hi ? st + 1 : st;
       const bool n_isx = stage_isx(stn);
       const int n_rowoff = stage_rowoff(stn), n_cg = stage_cg(stn);
       const bool n_rowok = stage_rowok(stn);
-      const f16x8* buf = lds + (st & 1) * kBufVec;
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
+        const int kq = u * 3 + kk;         // k-step inside the LDS stage
         f16x8 fn0, fn1;
         if constexpr (kA2) {               // the k-step after next
           if (kk == 0) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 2, fn0, fn1);
@@ -429,13 +442,14 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         }
         // the DMA of the next stage goes out behind the first k-step's operands (vmcnt
         // retires in order); its target buffer was last read before the previous barrier
-        if (kk == 1 && more) stage_dma(st + 1, lds + ((st + 1) & 1) * kBufVec);
+        if (kq == 1 && more)
+          stage_dma(st_lo + (sg + 1) * R, lds + ((sg + 1) & 1) * kBufVec);
         if constexpr (NPL == 2) {
           f16x8 b0[NG], b1[NG];
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
-            b0[g] = buf[((kk * 2 + 0) * NG + g) * 64 + lane];
-            b1[g] = buf[((kk * 2 + 1) * NG + g) * 64 + lane];
+            b0[g] = buf[((kq * 2 + 0) * NG + g) * 64 + lane];
+            b1[g] = buf[((kq * 2 + 1) * NG + g) * 64 + lane];
           }
 #pragma unroll
           for (int g = 0; g < NG; ++g)
@@ -449,7 +463,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         } else {
           f16x8 b0[NG];
 #pragma unroll
-          for (int g = 0; g < NG; ++g) b0[g] = buf[(kk * NG + g) * 64 + lane];
+          for (int g = 0; g < NG; ++g) b0[g] = buf[(kq * NG + g) * 64 + lane];
 #pragma unroll
           for (int g = 0; g < NG; ++g)
             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
@@ -460,6 +474,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         else { fa0 = fn0; fa1 = fn1; }
       }
       c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
+      }
       __syncthreads();
     }
   }
@@ -660,7 +675,7 @@ void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
 // The same step with ONE bf16 plane per operand (compute mode 2, BASELINE configs[4]).
 __global__ __launch_bounds__(kThreads16, MV_CONV_MINWAVES)
 void convlstm_step_bf16_kernel(const ConvLstm16Group g) {
-  __shared__ f16x8 lds[kStageVec];      // 2 buffers x 3 k-steps x 4 KB
+  __shared__ f16x8 lds[MV_BF16_UNITS * kStageVec];   // 2 buffers x (units x 3 k-steps) x 4 KB
   int block = blockIdx.x;
   int pi = 0;
 #pragma unroll

@@ -695,6 +695,10 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     q.n_hk = a.zero_state ? 0 : 9 * (a.C / 16);
     q.w_ksteps = mv::f16x3_xksteps(a.Cx) + 9 * (a.C / 16);
     if (a.x_small) q.w_ksteps = 9 * (a.C / 16);
+    if (bf16)       // an LDS stage of the bf16 kernel holds MV_BF16_UNITS row units of 3 k-steps
+      MV_REQUIRE((q.n_xk / 3) % MV_BF16_UNITS == 0 && (q.n_hk / 3) % MV_BF16_UNITS == 0,
+                 "bf16 mode: %d x / %d h k-steps do not fill whole LDS stages (emb_size and "
+                 "scene_conv_dim must be multiples of 32)", q.n_xk, q.n_hk);
     q.x16 = nullptr; q.h16 = nullptr;
     q.x_plane_stride = q.h_plane_stride = 0;
     // The conv epilogue emits the operand planes of h' (assembled per wave in LDS,
