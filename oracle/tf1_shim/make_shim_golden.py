@@ -94,6 +94,8 @@ VARIANT_CASES = [
     ("adam", dict(optimizer="adam", init_lr=0.001), 2),
     # --use_cosine_lr (code/pred_models.py:1646-1654): max_steps = 4, lr 1, 0.854, 0.5 x init
     ("cosine", dict(use_cosine_lr=True, num_epochs=4, optimizer="momentum", init_lr=0.01), 3),
+    # --scene_conv_kernel 1 (code/train.py:65): the scene stack as two strided 1x1 projections
+    ("sck1", dict(scene_conv_kernel=1), 1),
 ]
 VARIANT_SEED = synth.SEED_BASE + 40
 

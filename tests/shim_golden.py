@@ -82,6 +82,7 @@ VARIANT_CASES = {
     "rmsprop": (dict(optimizer="rmsprop", init_lr=0.001), 2),
     "adam": (dict(optimizer="adam", init_lr=0.001), 2),
     "cosine": (dict(use_cosine_lr=True, num_epochs=4, optimizer="momentum", init_lr=0.01), 3),
+    "sck1": (dict(scene_conv_kernel=1), 1),
 }
 VARIANT_SEED = synth.SEED_BASE + 40
 

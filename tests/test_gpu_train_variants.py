@@ -9,6 +9,8 @@ C ABI, against (a) the frozen runs of the reference's own Trainer on the TF-1 sh
   training without --train_w_onehot                 :285, 427-435 (differentiable feedback)
   --keep_prob < 1 (DropoutWrapper input dropout)    :130-132, 194-202, 241-249
   --optimizer momentum / adam / rmsprop             :1667-1681
+  --use_cosine_lr                                   :1646-1654
+  --scene_conv_kernel 1                             code/train.py:65
 
 Same bars as the published path: losses 1e-4 relative, every gradient tensor within 2e-3
 of its max (measured ~1e-6), parameters after the optimizer step(s).
@@ -24,7 +26,7 @@ import shim_golden as sg
 
 pytestmark = pytest.mark.gpu
 LOSS_VARIANTS = ["soft1", "soft7_mask", "mask", "teacher", "teacher_soft4", "no_onehot",
-                 "dropout07"]
+                 "dropout07", "sck1"]       # sck1: --scene_conv_kernel 1 (1x1 projections on MFMA)
 OPTIMIZERS = ["momentum", "rmsprop", "adam", "cosine"]     # cosine: --use_cosine_lr + momentum
 SLOTS = {"momentum": 1, "rmsprop": 2, "adam": 2, "cosine": 1}
 
