@@ -17,9 +17,13 @@
 //
 // Same tile as the fp32 kernel (convlstm_mfma.h): a wave owns 32 cells x 128
 // columns = the four gates of one block of 32 channels, so the LSTM update still
-// runs in the accumulator registers; operands are register-direct.  One k-step
-// is 16 input channels of one tap: A = 2 planes x 16 B of the lane's cell,
-// B = 2 planes x 4 gates x 16 B in fragment order, 12 MFMAs.
+// runs in the accumulator registers.  One k-step is 16 input channels of one tap:
+// A = 2 planes x 16 B of the lane's cell (register-direct from the tiled operand
+// planes, plane_layout.h), B = 2 planes x 4 gates x 16 B in fragment order, shared by
+// the eight waves of a workgroup through an LDS double buffer filled by LDS-DMA; 12 MFMAs.
+// The same body serves the forward step (LSTM epilogue, optional gate activations for
+// training, optional h' operand planes, optional sparse-x table terms), dgrad (store
+// epilogue, split-K) and, with ONE bf16 plane per operand, the bf16 mode.
 // The regression encoder's 2-channel pixel-offset input (|x| up to 1920, outside
 // the scaled fp16 range) keeps its single fp32 chunk on v_mfma_f32_32x32x2_f32,
 // with weights pre-scaled by 2^16 so that it lands in the same accumulators.
