@@ -182,6 +182,12 @@ def main():
         variant_train_case(name, over, steps)
     teacher_test_forward_case()
     return
+  if len(sys.argv) > 1 and sys.argv[1] == "beam_plain":
+    forward_case("golden_shim_beam_plain_s1.npz",
+                 synth.default_config(batch_size=2, use_grids=(0, 1), beam_size=4,
+                                      diverse_beam=False, fix_num_timestep=0),
+                 synth.SEED_BASE + 9, 3.0, 0.1)
+    return
   if len(sys.argv) > 1 and sys.argv[1] == "single":
     single_decoder_case()
     return

@@ -15,6 +15,9 @@ FORWARD_CASES = {
     "golden_shim_greedy_both.npz": dict(batch_size=2, use_grids=(1, 1)),
     "golden_shim_beam_s1.npz": dict(batch_size=2, use_grids=(0, 1), beam_size=5),
     "golden_shim_beam20_s0.npz": dict(batch_size=1, use_grids=(1, 0), beam_size=20),
+    # plain beam search: no diversity penalty, log-probs accumulated from the first step
+    "golden_shim_beam_plain_s1.npz": dict(batch_size=2, use_grids=(0, 1), beam_size=4,
+                                          diverse_beam=False, fix_num_timestep=0),
 }
 
 

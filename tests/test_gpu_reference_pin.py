@@ -37,7 +37,8 @@ def test_greedy_against_reference_run(built_lib, name):
 
 
 @pytest.mark.parametrize("name,scale", [("golden_shim_beam_s1.npz", 1),
-                                        ("golden_shim_beam20_s0.npz", 0)])
+                                        ("golden_shim_beam20_s0.npz", 0),
+                                        ("golden_shim_beam_plain_s1.npz", 1)])
 def test_beam_against_reference_run(built_lib, name, scale):
   g, cfg, params, feed = sg.forward_case(name)
   eng = built_lib.Engine(cfg, device=0)
