@@ -182,6 +182,11 @@ def main():
         variant_train_case(name, over, steps)
     teacher_test_forward_case()
     return
+  if len(sys.argv) > 1 and sys.argv[1] == "nognn":
+    forward_case("golden_shim_greedy_nognn.npz",
+                 synth.default_config(batch_size=2, use_grids=(1, 1), use_gnn=False),
+                 synth.SEED_BASE + 10, 3.0, 0.1)
+    return
   if len(sys.argv) > 1 and sys.argv[1] == "beam_plain":
     forward_case("golden_shim_beam_plain_s1.npz",
                  synth.default_config(batch_size=2, use_grids=(0, 1), beam_size=4,

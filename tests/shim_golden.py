@@ -15,6 +15,8 @@ FORWARD_CASES = {
     "golden_shim_greedy_both.npz": dict(batch_size=2, use_grids=(1, 1)),
     "golden_shim_beam_s1.npz": dict(batch_size=2, use_grids=(0, 1), beam_size=5),
     "golden_shim_beam20_s0.npz": dict(batch_size=1, use_grids=(1, 0), beam_size=20),
+    # --use_gnn off (the graph attention is optional in the reference, code/train.py)
+    "golden_shim_greedy_nognn.npz": dict(batch_size=2, use_grids=(1, 1), use_gnn=False),
     # plain beam search: no diversity penalty, log-probs accumulated from the first step
     "golden_shim_beam_plain_s1.npz": dict(batch_size=2, use_grids=(0, 1), beam_size=4,
                                           diverse_beam=False, fix_num_timestep=0),

@@ -16,7 +16,8 @@ TOL = 1e-4
 
 
 @pytest.mark.parametrize("name", ["golden_shim_greedy_cfg1.npz",
-                                  "golden_shim_greedy_both.npz"])
+                                  "golden_shim_greedy_both.npz",
+                                  "golden_shim_greedy_nognn.npz"])
 def test_greedy_against_reference_run(built_lib, name):
   g, cfg, params, feed = sg.forward_case(name)
   eng = built_lib.Engine(cfg, device=0)
