@@ -1,35 +1,57 @@
 # coding=utf-8
 """Headline benchmark: trajectories/sec of the Multiverse forward on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
       --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1], SURVEY.md section 8d "config 2"): both grid
-scales (18x32 and 9x16 over 36x64x11 scene maps), batch 64 per GPU, fp32,
-forward only, greedy decode (beam 1): per trajectory 8 observed steps encoded
-by the class + regression ConvLSTM encoders and 12 predicted steps decoded by
-the class (graph attention + argmax feedback) and regression decoders.
-A "step" is one forward over one batch; inputs are resident in HBM when the
-timed region starts (`mv_upload_inputs` before, `mv_run_greedy_resident`
-inside).  Trajectories are independent, so N GPUs run N batch shards with no
-data-path collective ("scaling": "weak").
+With --gpus N > 1 and no launcher (WORLD_SIZE unset) bench.py starts the N ranks itself
+(torch.distributed.run on 127.0.0.1, a free port) and relays rank 0's JSON line.
 
-Extra objects on the JSON line:
-  roofline     -- dominant kernel (convlstm_step, >99 % of FLOPs): algorithmic
-                  FLOPs per launch / average launch duration from hipEvents on
-                  the engine's stream, against the gfx950 fp32 MFMA peak.  The
-                  same sweep as a fraction of the 8 TB/s HBM roofline
-                  (north_star's phrasing) is reported as hbm_frac.
-  cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference graph;
-                  TF1 cannot run here) timed on a bounded sample, rank 0, N=1.
+Headline workload (BASELINE.json configs[1], SURVEY.md section 8d "config 2"): both grid
+scales (18x32 and 9x16 over 36x64x11 scene maps), batch 64 per GPU, fp32-class, forward
+only, greedy decode (beam 1): per trajectory 8 observed steps encoded by the class +
+regression ConvLSTM encoders and 12 predicted steps decoded by the class (graph attention
++ argmax feedback) and regression decoders.  A "step" is one forward over one batch;
+inputs are resident in HBM when the timed region starts (`mv_upload_inputs` before,
+`mv_run_greedy_resident` inside).  Trajectories are independent, so N GPUs run N batch
+shards with no data-path collective ("scaling": "weak").
+
+Beside the headline the same run measures the other BASELINE configs, each as a
+sub-object of the ONE JSON line with its own `value`, `ms_per_step`, `steps` and
+`roofline` (timed the same way: barrier + synchronize on both sides, max over ranks):
+  greedy_b256     north_star's "batch 256" on one GPU (same forward, batch 256)
+  beam_n128_b20   configs[3]: scale 0, diverse beam 20, batch 128, hipGraph replay
+  train_n32       configs[2]: training step, batch 32 per GPU, gradient all-reduce by RCCL
+                  inside the library when ranks > 1 (`rccl_ranks`)
+  bf16            configs[4] (inference half): the headline forward with bf16 operands,
+                  scene-feature 1x1 projections on MFMA -- REDUCED precision
+  train_bf16_n64  configs[4]: training step, batch 64 per GPU, bf16 forward, 1x1 projections
+  host_path       the headline batch through the host boundary (Tester.step, dense and
+                  compact feeds) next to the resident-input rate      [rank 0, N=1 only]
+(`--no-sub` skips them; `--workload beam|train` makes one of them the headline instead.)
+
+Extra objects on the line:
+  roofline     -- dominant kernel (convlstm_step, >99 % of FLOPs): algorithmic FLOPs per
+                  launch / average launch duration from hipEvents on the engine's stream,
+                  against the dense MFMA peak of the arithmetic used.  The same sweep as a
+                  fraction of the 8 TB/s HBM roofline (north_star's phrasing) is hbm_frac.
+                  `traffic` (HBM bytes per launch from PMC passes) is quoted from
+                  profiles/ ONLY when that profile was taken on the kernel sources this
+                  library was built from (source hash match), else null.
+  cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference graph; TF1
+                  cannot run here) timed on a bounded sample, rank 0, N=1.
 """
 
 from __future__ import annotations
 
 import argparse
+import glob
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,6 +62,13 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 (v_mfma_f32_32x32x16_f16)
 PEAK_HBM_GBS = 8000.0
+SUB_TIMED_SECONDS = 1.5         # timed region of every sub-workload
+DEFAULT_TIMED_SECONDS = 3.5     # timed region of the headline when --steps is not given
+
+HBM_KERNELS = ("gnn_attend", "hidden2grid", "decode_tail", "split_planes", "lstm_gate_bwd",
+               "gnn_bwd", "grid_emb_dense", "grid_emb_onehot", "wgrad_transpose",
+               "beam_tile_state", "dgrad_slice_sum", "tanh_bwd", "conv3x3_small_dgrad",
+               "conv3x3_small_wgrad", "gate_bwd_planes", "beam_step")
 
 
 def algorithmic_counts(cfg, beam=1, executed=False, sparse_x=False):
@@ -73,143 +102,133 @@ def algorithmic_counts(cfg, beam=1, executed=False, sparse_x=False):
   return flops, nbytes
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=10)
-  ap.add_argument("--warmup", type=int, default=2)
-  ap.add_argument("--batch", type=int, default=None,
-                  help="trajectories per GPU (default 64 greedy / 128 beam)")
-  ap.add_argument("--workload", choices=("greedy", "beam", "train"), default="greedy",
-                  help="greedy = BASELINE configs[1] (the headline line); beam = "
-                       "configs[3]: scale 0, beam 20, batch 128, hipGraph replay; "
-                       "train = configs[2]: both scales, training step (fwd + loss + "
-                       "bwd + RCCL grad all-reduce + clip + Adadelta), batch 32/GPU")
-  ap.add_argument("--beam", type=int, default=20)
-  ap.add_argument("--graph", type=int, default=None,
-                  help="1: replay the forward as a captured hipGraph "
-                       "(default: 0 greedy, 1 beam)")
-  ap.add_argument("--compute", choices=("f32", "f16x3", "bf16"), default="f16x3",
-                  help="gate-convolution arithmetic of the inference forward: fp32 MFMA, "
-                       "or f16x3 (two scaled fp16 planes per operand, three fp16 MFMAs "
-                       "per product, fp32 accumulate: fp32-class error), or bf16 (BASELINE "
-                       "configs[4]: bf16 operands, one MFMA per product, fp32 accumulate; "
-                       "reduced precision, reported as such)")
-  ap.add_argument("--scene-conv-kernel", type=int, choices=(1, 3), default=3,
-                  help="--scene_conv_kernel of the reference (code/train.py:65): 3 = the published "
-                       "3x3 stride-2 stack; 1 = the dense 1x1 projections, run as MFMA GEMMs "
-                       "(BASELINE configs[4] names it)")
-  ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--cpu-batch", type=int, default=8)
-  args = ap.parse_args()
+def kernel_source_hash():
+  from multiverse_amd import buildinfo
+  return buildinfo.kernel_source_hash()
 
-  # The contract is ONE JSON line on stdout.  RCCL / HIP print banners and warnings on
-  # fd 1 from native code (seen: "RCCL version ..." once the communicator is created), so
-  # fd 1 is pointed at stderr for the whole run and the line goes out through a saved copy.
-  sys.stdout.flush()
-  real_stdout = os.fdopen(os.dup(1), "w")
-  os.dup2(2, 1)
 
-  import torch
-  import torch.distributed as dist
+def committed_traffic(kernel_file_suffix):
+  """HBM bytes per launch of a kernel from the newest committed PMC summary
+  profiles/r*_<suffix> -- only if it was collected on the kernel sources this tree holds
+  (pmc_report.py stores their hash); a stale profile yields (None, reason)."""
+  paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + kernel_file_suffix)),
+                 reverse=True)
+  if not paths:
+    return None, "no PMC summary profiles/r*_%s" % kernel_file_suffix
+  cur = kernel_source_hash()
+  for pth in paths:
+    with open(pth) as f:
+      pmc = json.load(f)
+    hb = pmc.get("hbm_bytes_per_launch")
+    if hb and pmc.get("kernel_source_sha16") == cur:
+      return (hb, os.path.relpath(pth, ROOT)), None
+  return None, ("newest PMC summary %s was taken on other kernel sources (hash %s, built %s): "
+                "not quoted" % (os.path.relpath(paths[0], ROOT),
+                                json.load(open(paths[0])).get("kernel_source_sha16"), cur))
+
+
+class Ctx(object):
+  """Process-group facts every measurement needs."""
+
+  def __init__(self):
+    self.world = int(os.environ.get("WORLD_SIZE", "1"))
+    self.rank = int(os.environ.get("RANK", "0"))
+    self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    self.backend = os.environ.get("MV_BENCH_BACKEND", "nccl")
+    self.use_dist = False
+    self.red_dev = "cuda" if self.backend == "nccl" else "cpu"
+
+  def barrier(self, eng=None):
+    import torch
+    if self.use_dist:
+      import torch.distributed as dist
+      dist.barrier()
+    torch.cuda.synchronize()
+    if eng is not None:
+      eng.synchronize()
+
+  def max_over_ranks(self, seconds):
+    if not self.use_dist:
+      return seconds
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=self.red_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
+            scene_conv_kernel=3, timed_seconds=None, fp32_ref=False, cpu_base=None,
+            cpu_batch=8):
+  """One workload on this rank's GPU: build the engine, upload the batch, W untimed +
+  K timed steps between barriers, then one profiled step for the per-kernel roofline.
+  kind: greedy | beam | train.  steps None -> as many as fill `timed_seconds`."""
   from multiverse_amd import _lib, synth
-
-  world = int(os.environ.get("WORLD_SIZE", "1"))
-  rank = int(os.environ.get("RANK", "0"))
-  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  if args.gpus != world:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks"
-                       % (args.gpus, args.gpus))
-  if not torch.cuda.is_available():
-    raise SystemExit("bench.py needs an MI355X; no HIP device visible "
-                     "(there is no CPU fallback)")
-  # MV_BENCH_BACKEND=gloo lets several ranks share ONE GPU (control-flow check of the
-  # multi-rank path on a single-GPU box; RCCL refuses duplicate devices)
-  backend = os.environ.get("MV_BENCH_BACKEND", "nccl")
-  if backend != "nccl":
-    local_rank = local_rank % torch.cuda.device_count()
-  red_dev = "cuda" if backend == "nccl" else "cpu"
-  torch.cuda.set_device(local_rank)
-  # MV_ALLREDUCE=lib-force: run the multi-rank code path (process group, RCCL bootstrap,
-  # in-library all-reduce) on a world of ONE rank -- the only form a 1-GPU box can check
-  use_dist = world > 1 or (os.environ.get("MV_ALLREDUCE") == "lib-force" and
-                           "RANK" in os.environ)
-  if use_dist:
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    # the host driver only supports dmabuf IPC: without this RCCL's cross-process handles
-    # fail with hipIpcGetMemHandle: invalid argument
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group(backend=backend)  # nccl == RCCL; barrier + max only
-
-  beam = args.workload == "beam"
-  train = args.workload == "train"
-  lib_allreduce = False
-  if args.batch is None:
-    args.batch = 128 if beam else 32 if train else 64
-  if args.graph is None:
-    args.graph = 1 if beam else 0
+  world, rank = ctx.world, ctx.rank
+  beam = kind == "beam"
+  train = kind == "train"
+  if graph is None:
+    graph = 1 if beam else 0
   if beam:
-    cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 0),
-                               beam_size=args.beam, scene_conv_kernel=args.scene_conv_kernel)
+    cfg = synth.default_config(batch_size=batch, use_grids=(1, 0), beam_size=beam_size,
+                               scene_conv_kernel=scene_conv_kernel)
   elif train:
-    cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 1), is_train=True,
-                               scene_conv_kernel=args.scene_conv_kernel)
-    args.graph = 0
+    cfg = synth.default_config(batch_size=batch, use_grids=(1, 1), is_train=True,
+                               scene_conv_kernel=scene_conv_kernel)
+    graph = 0
   else:
-    cfg = synth.default_config(batch_size=args.batch, use_grids=(1, 1),
-                               scene_conv_kernel=args.scene_conv_kernel)
+    cfg = synth.default_config(batch_size=batch, use_grids=(1, 1),
+                               scene_conv_kernel=scene_conv_kernel)
   params = synth.make_params(cfg, seed=synth.SEED_BASE + 2)  # reference initialisers
   feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 2 + 1000 * rank)
-  eng = _lib.Engine(cfg, device=local_rank)
+  eng = _lib.Engine(cfg, device=ctx.local_rank)
   eng.set_params(params)
   eng.upload(feed)          # inputs resident in HBM before the timed region
-  eng.set_graph_mode(bool(args.graph))
-  eng.set_compute_mode(args.compute)
+  eng.set_graph_mode(bool(graph))
+  eng.set_compute_mode(compute)
+  lib_allreduce = False
   if train:
     from multiverse_amd import parallel
     eng.train_init(world=world)
     eng.upload_targets(feed)
     # gradient all-reduce inside the library (RCCL, bucketed, side stream) unless
     # MV_ALLREDUCE=torch or the backend is not RCCL
-    lib_allreduce = use_dist and parallel.init_engine_comm(eng)
+    lib_allreduce = ctx.use_dist and parallel.init_engine_comm(eng)
 
   def one_step():
     if not train:
       eng.run_resident(beam)
       return
     # Trainer.step on the resident batch: forward + loss + backward, all-reduce
-    # (sum) of the flat gradient buffer over the ranks, clip + Adadelta
+    # (sum) of the flat gradient buffer over the ranks, clip + optimizer
     if lib_allreduce:
       eng.train_step(None)       # buckets all-reduced during the backward pass, then 1/world
       return
     eng.train_forward_backward(None)
-    if use_dist:
-      parallel.allreduce_engine_grads(eng, local_rank)
+    if ctx.use_dist:
+      parallel.allreduce_engine_grads(eng, ctx.local_rank)
     eng.train_apply(1.0 / world)
 
-  def barrier():
-    if use_dist:
-      dist.barrier()
-    torch.cuda.synchronize()
-    eng.synchronize()
-
-  for _ in range(args.warmup):
+  for _ in range(warmup):
     one_step()
-  barrier()
+  ctx.barrier(eng)
+  if steps is None:
+    # size the timed region: one probe step (max over ranks so that all agree on K)
+    t0 = time.perf_counter()
+    one_step()
+    eng.synchronize()
+    probe = ctx.max_over_ranks(time.perf_counter() - t0)
+    steps = int(min(400, max(3, math.ceil((timed_seconds or SUB_TIMED_SECONDS) / probe))))
+    ctx.barrier(eng)
   t0 = time.perf_counter()
-  for _ in range(args.steps):
+  for _ in range(steps):
     one_step()
   eng.synchronize()
-  barrier()
-  elapsed = time.perf_counter() - t0
-  if use_dist:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+  ctx.barrier(eng)
+  elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
 
-  ms_per_step = 1e3 * elapsed / args.steps
-  value = world * args.batch * args.steps / elapsed
+  ms_per_step = 1e3 * elapsed / steps
+  value = world * batch * steps / elapsed
 
   # ---- roofline of the dominant kernel, measured live with hipEvents
   eng.set_profiling(True)
@@ -226,18 +245,18 @@ def main():
   conv_s = conv["total_ms"] * 1e-3
   # achieved = algorithmic FLOPs the launches EXECUTED (zero-state steps skip the h half)
   achieved_tf = conv["flops"] / conv_s / 1e12
-  flops_traj, bytes_traj = algorithmic_counts(cfg, args.beam if beam else 1)
-  sparse_x = (not train and args.compute != "f32" and
-              os.environ.get("MV_SPARSE_X", "1") != "0")
-  flops_traj_exec, _ = algorithmic_counts(cfg, args.beam if beam else 1, executed=True,
+  flops_traj, bytes_traj = algorithmic_counts(cfg, beam_size if beam else 1)
+  sparse_x = (not train and compute != "f32" and os.environ.get("MV_SPARSE_X", "1") != "0")
+  flops_traj_exec, _ = algorithmic_counts(cfg, beam_size if beam else 1, executed=True,
                                           sparse_x=sparse_x)
-  flops_traj_exec_dense_x, _ = algorithmic_counts(cfg, args.beam if beam else 1, executed=True)
+  flops_traj_exec_dense_x, _ = algorithmic_counts(cfg, beam_size if beam else 1, executed=True)
   if train:
     flops_traj *= 3.0   # forward + dgrad + wgrad of every gate convolution
     flops_traj_exec *= 3.0
-  f16 = args.compute == "f16x3"
-  bf16 = args.compute == "bf16"
+  f16 = compute == "f16x3"
+  bf16 = compute == "bf16"
   peak = PEAK_FP16_MFMA_TFLOPS if (f16 or bf16) else PEAK_FP32_MFMA_TFLOPS
+  other = {k: v for k, v in stats.items() if k not in mfma_kernels}
   roofline = {
       "kernel": "+".join(mfma_kernels),
       "bound": "mfma",
@@ -245,7 +264,7 @@ def main():
       "peak": peak,
       "unit": "TFLOP/s",
       "frac": round(achieved_tf / peak, 4),
-      "traffic": None,   # filled from the committed PMC profile below, if present
+      "traffic": None,   # filled from a committed PMC profile of THESE kernel sources, if any
       "launches": conv["launches"],
       "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
       "alg_gflop_per_launch_avg": round(conv["flops"] / conv["launches"] / 1e9, 2),
@@ -257,10 +276,8 @@ def main():
       "hbm_achieved_GBs": round(conv["bytes"] / conv_s / 1e9, 1),
       "hbm_frac": round(conv["bytes"] / conv_s / 1e9 / PEAK_HBM_GBS, 4),
       "whole_forward_mfma_frac": round(value / world * flops_traj_exec / 1e12 / peak, 4),
-      "other_kernels_ms": {k: round(v["total_ms"], 3) for k, v in stats.items()
-                           if k not in mfma_kernels},
-      "other_kernels_ms_total": round(sum(v["total_ms"] for k, v in stats.items()
-                                          if k not in mfma_kernels), 3),
+      "other_kernels_ms": {k: round(v["total_ms"], 3) for k, v in other.items()},
+      "other_kernels_ms_total": round(sum(v["total_ms"] for v in other.values()), 3),
       # the HBM-bound members of the path: algorithmic bytes / hipEvent
       # time of their launches against the 8 TB/s HBM roofline
       "hbm_kernels": {
@@ -268,12 +285,8 @@ def main():
               "alg_MB_per_launch": round(v["bytes"] / v["launches"] / 1e6, 2),
               "GBs": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1),
               "frac": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-          for k, v in stats.items()
-          if k not in mfma_kernels and v["bytes"] > 0 and v["total_ms"] > 0 and
-          k in ("gnn_attend", "hidden2grid", "decode_tail", "split_planes", "lstm_gate_bwd",
-                "gnn_bwd", "grid_emb_dense", "grid_emb_onehot", "wgrad_transpose",
-                "beam_tile_state", "dgrad_slice_sum", "tanh_bwd", "conv3x3_small_dgrad",
-                "conv3x3_small_wgrad")},
+          for k, v in other.items()
+          if v["bytes"] > 0 and v["total_ms"] > 0 and k in HBM_KERNELS},
   }
   if "scene_proj1x1_mfma" in stats and stats["scene_proj1x1_mfma"]["total_ms"] > 0:
     # north_star: "MFMA utilisation on the 1x1 projection against gfx950 peak" -- the dense
@@ -302,70 +315,44 @@ def main():
         for n in mfma_kernels}
     roofline["per_kernel_ms"] = {n: round(stats[n]["total_ms"], 3) for n in mfma_kernels}
 
-  # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes
-  # of this same command (FETCH_SIZE and WRITE_SIZE cannot share a pass on
-  # gfx950); bench.py cannot collect PMCs itself, so it quotes the committed
-  # profile when the workload matches, else null.
-  pmc_name = ("r2_greedy_pmc_convlstm_step_f16x3_lds.json" if f16 else
-              "r2_greedy_bf16_pmc_convlstm_step_bf16.json" if bf16 else "r1_convlstm_pmc.json")
-  pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-  if args.batch == 64 and not beam and not train and os.path.exists(pmc_path):
-    with open(pmc_path) as f:
-      pmc = json.load(f)
-    hb = pmc.get("hbm_bytes_per_launch")
-    if hb:
+  # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command
+  # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950); bench.py cannot collect
+  # PMCs itself, so it quotes a committed summary -- only one taken on these sources.
+  if not beam and not train and batch == 64 and scene_conv_kernel == 3:
+    suffix = ("greedy_pmc_convlstm_step_f16x3_lds.json" if f16 else
+              "greedy_bf16_pmc_convlstm_step_bf16.json" if bf16 else
+              "greedy_f32_pmc_convlstm_step_kernel.json")
+    got, why = committed_traffic(suffix)
+    if got:
+      hb, src = got
       roofline["traffic"] = round(hb["total_corrected"] / 1e6, 1)
       roofline["traffic_unit"] = "MB HBM per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
       roofline["traffic_raw_MB"] = round(hb["total_raw"] / 1e6, 1)
-      roofline["traffic_source"] = "profiles/" + pmc_name
+      roofline["traffic_source"] = src
       roofline["alg_MB_per_launch"] = round(conv["bytes"] / conv["launches"] / 1e6, 1)
-
-  if train and f16 and args.batch == 32:
-    # the three matrix kernels of the training step, launch-weighted
-    names = {"convlstm_step": "r2_train_pmc_convlstm_step_f16x3_lds.json",
-             "convlstm_dgrad": "r2_train_pmc_convlstm_dgrad.json",
-             "convlstm_wgrad": "r2_train_pmc_convlstm_wgrad_f16x3.json"}
-    tot, raw, n, ok = 0.0, 0.0, 0, True
-    for k, fn in names.items():
-      pth = os.path.join(ROOT, "profiles", fn)
-      if not os.path.exists(pth):
-        ok = False
-        break
-      with open(pth) as f:
-        hb = json.load(f).get("hbm_bytes_per_launch")
-      if not hb:
-        ok = False
-        break
-      tot += hb["total_corrected"] * stats[k]["launches"]
-      raw += hb["total_raw"] * stats[k]["launches"]
-      n += stats[k]["launches"]
-    if ok and n:
-      roofline["traffic"] = round(tot / n / 1e6, 1)
-      roofline["traffic_unit"] = ("MB HBM per launch, launch-weighted over step / dgrad / wgrad "
-                                  "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)")
-      roofline["traffic_raw_MB"] = round(raw / n / 1e6, 1)
-      roofline["traffic_source"] = "profiles/r2_train_pmc_*.json"
+    else:
+      roofline["traffic_note"] = why
 
   if beam:
     metric = ("trajectories/sec (8-obs/12-pred, 18x32 grid, diverse beam-%d "
-              "multi-future decode)" % args.beam)
+              "multi-future decode)" % beam_size)
     workload = ("BASELINE configs[3]: scale 0 (18x32, scene 36x64x11), beam %d "
                 "(diverse, gamma 0.01, fix_num_timestep 1), batch %d/GPU, fp32, "
-                "obs 8 / pred 12, %s" % (args.beam, args.batch,
-                "hipGraph replay" if args.graph else "stream launches"))
+                "obs 8 / pred 12, %s" % (beam_size, batch,
+                                         "hipGraph replay" if graph else "stream launches"))
   elif train:
     metric = ("trajectories/sec (8-obs/12-pred, multi-scale 18x32+9x16 grid, "
               "training step)")
     workload = ("BASELINE configs[2]: multi-scale 18x32+9x16 (scene 36x64x11), "
                 "batch %d/GPU (global %d), fp32 training step = forward + CE/Huber/wd "
                 "loss + backward + %s + clip + Adadelta; gate convolutions: %s" % (
-                    args.batch, args.batch * world,
+                    batch, batch * world,
                     "RCCL all-reduce of the 21.3M-float gradient buffer" if world > 1
                     else "no all-reduce (1 rank)",
                     "forward, dgrad and wgrad on the fp16 matrix pipe (f16x3 split, "
-                    "fp32-class error)" if args.compute == "f16x3" else
+                    "fp32-class error)" if f16 else
                     "BASELINE configs[4]: forward in bf16 (one MFMA per product, reduced "
-                    "precision), dgrad and wgrad on the f16x3 split" if args.compute == "bf16"
+                    "precision), dgrad and wgrad on the f16x3 split" if bf16
                     else "fp32 matrix pipe"))
   else:
     metric = ("trajectories/sec (8-obs/12-pred, multi-scale 18x32+9x16 grid, "
@@ -373,22 +360,22 @@ def main():
     workload = ("BASELINE configs[1]: multi-scale 18x32+9x16 (scene 36x64x11), "
                 "batch %d/GPU, fp32 forward-only, beam 1, obs 8 / pred 12%s; gate "
                 "convolution on %s"
-                % (args.batch, (", hipGraph replay" if args.graph else "") +
+                % (batch, (", hipGraph replay" if graph else "") +
                    (", scene_conv_kernel 1 (dense 1x1 projections on MFMA)"
-                    if args.scene_conv_kernel == 1 else ""),
-                   "the fp16 matrix pipe (f16x3 split, fp32-class error)" if
-                   args.compute == "f16x3" else
+                    if scene_conv_kernel == 1 else ""),
+                   "the fp16 matrix pipe (f16x3 split, fp32-class error)" if f16 else
                    "the bf16 matrix pipe (BASELINE configs[4]: bf16 operands, fp32 accumulate; "
-                   "REDUCED precision, not the fp32 headline)" if args.compute == "bf16"
+                   "REDUCED precision, not the fp32 headline)" if bf16
                    else "the fp32 matrix pipe"))
   out = {
       "metric": metric,
       "value": round(value, 2),
       "unit": "trajectories/sec",
       "n_gpus": world,
-      "steps": args.steps,
-      "warmup": args.warmup,
+      "steps": steps,
+      "warmup": warmup,
       "ms_per_step": round(ms_per_step, 3),
+      "timed_region_s": round(elapsed, 3),
       "higher_is_better": True,
       "scaling": "weak",
       "vs_baseline": None,
@@ -405,7 +392,7 @@ def main():
       "data": "synthetic (seeded AR(1) trajectories, rectangle scene masks, "
               "random-init weights with the reference's initialisers)",
       "config": {"workload": workload,
-                 "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                 "batch_per_gpu": batch, "global_batch": batch * world,
                  "obs_len": cfg.obs_len, "pred_len": cfg.pred_len,
                  "parallelism": ("data-parallel x%d, gradient all-reduce (RCCL%s)" % (
                                      world, ", in-library: one bucket per ConvLSTM kernel on a "
@@ -421,46 +408,256 @@ def main():
   }
 
   if train:
-    out["rccl_ranks"] = world if use_dist else 0
+    out["rccl_ranks"] = world if (ctx.use_dist and ctx.backend == "nccl") else 0
     ci = eng.comm_info()
     if ci:
       out["allreduce"] = {"where": "libmultiverse_hip (RCCL)",
                           "collectives_per_step": ci["buckets"],
                           "MB_per_step": round(ci["bytes"] / 1e6, 1)}
-  if (f16 or bf16) and not train:
+  if fp32_ref and (f16 or bf16) and not train:
     # the same workload on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), for reference
     eng.set_compute_mode("f32")
     one_step()
-    barrier()
+    ctx.barrier(eng)
     t1 = time.perf_counter()
-    nref = max(2, args.steps // 3)
+    nref = max(2, min(steps // 3, 12))
     for _ in range(nref):
       one_step()
     eng.synchronize()
-    barrier()
-    el = time.perf_counter() - t1
-    if use_dist:
-      tt = torch.tensor([el], dtype=torch.float64, device=red_dev)
-      dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-      el = float(tt.item())
+    ctx.barrier(eng)
+    el = ctx.max_over_ranks(time.perf_counter() - t1)
     out["fp32_mfma_reference"] = {
-        "value": round(world * args.batch * nref / el, 2), "unit": "trajectories/sec",
+        "value": round(world * batch * nref / el, 2), "unit": "trajectories/sec",
         "ms_per_step": round(1e3 * el / nref, 3), "steps": nref,
         # the fp32 path multiplies the dense x operand (no sparse-x tables)
         "mfma_frac_of_fp32_peak": round(
-            args.batch * nref / el * (flops_traj_exec_dense_x * (3.0 if train else 1.0)) /
-            1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
-    eng.set_compute_mode(args.compute)
-
-  if rank == 0 and world == 1 and not args.no_cpu_baseline and not beam:
-    out["cpu_baseline"] = (cpu_baseline_train(min(args.cpu_batch, 4)) if train
-                           else cpu_baseline(args.cpu_batch))
-
+            batch * nref / el * flops_traj_exec_dense_x / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    eng.set_compute_mode(compute)
   eng.close()
-  if use_dist:
+  if cpu_base and rank == 0 and world == 1 and not beam:
+    out["cpu_baseline"] = (cpu_baseline_train(min(cpu_batch, 4)) if train
+                           else cpu_baseline(cpu_batch))
+  return out
+
+
+def compact(sub):
+  """A sub-workload's object: the contract fields + the roofline numbers a reader needs."""
+  r = sub["roofline"]
+  keep = {k: sub[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step",
+                              "timed_region_s", "dtype") if k in sub}
+  keep["workload"] = sub["config"]["workload"]
+  keep["batch_per_gpu"] = sub["config"]["batch_per_gpu"]
+  keep["global_batch"] = sub["config"]["global_batch"]
+  keep["roofline"] = {k: r[k] for k in (
+      "kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms",
+      "executed_mfma_frac", "hbm_frac", "whole_forward_mfma_frac", "other_kernels_ms_total",
+      "per_kernel_ms", "per_kernel_TFLOPs", "scene_proj1x1_mfma") if k in r}
+  keep["roofline"]["hbm_kernels"] = {k: {"ms": v["ms"], "frac": v["frac"]}
+                                     for k, v in r.get("hbm_kernels", {}).items()}
+  for k in ("rccl_ranks", "allreduce"):
+    if k in sub:
+      keep[k] = sub[k]
+  return keep
+
+
+def host_path(compute, batch=64):
+  """The headline batch through the host boundary: mv_forward_greedy with host buffers
+  (dense maps over PCIe, outputs downloaded), the compact upload (labels + (x, y) + uint8
+  masks, maps expanded in HBM), and Tester.step from a Dataset batch (feed construction
+  included), next to the resident-input rate.  One `sess.run` of the reference includes
+  feed and fetch (code/pred_models.py:1761-1790); `value` of the line does not."""
+  from multiverse_amd import _lib, pred_models, pred_utils, synth
+  cfg = synth.default_config(batch_size=batch, use_grids=(1, 1))
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 2)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 2)
+  eng = _lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode(compute)
+
+  def rate(fn, reps=8, warm=2):
+    for _ in range(warm):
+      fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+      fn()
+    return batch * reps / (time.perf_counter() - t0)
+
+  out = {"batch": batch, "unit": "trajectories/sec"}
+  eng.upload(feed)
+
+  def resident():
+    eng.run_resident(False)
+    eng.synchronize()
+  out["resident_inputs"] = round(rate(resident), 1)
+  out["host_buffers_dense"] = round(rate(lambda: eng.forward_greedy(feed)), 1)
+  out["host_buffers_compact"] = round(rate(lambda: eng.forward_greedy_compact(feed)), 1)
+  if hasattr(eng, "forward_greedy_pipelined"):
+    # double-buffered submit / collect: H2D of batch k+1 and D2H of batch k-1 on the copy
+    # stream while batch k computes
+    feeds = [feed] * 10
+    eng.forward_greedy_pipelined(feeds[:3])
+    t0 = time.perf_counter()
+    eng.forward_greedy_pipelined(feeds)
+    out["host_buffers_dense_pipelined"] = round(batch * len(feeds) /
+                                                (time.perf_counter() - t0), 1)
+  eng.close()
+
+  data = synth.make_npz_data(cfg, batch, seed=11, float32_traj=True)
+  ds = pred_utils.dataset_from_npz_dict(data, "test", cfg)
+  b = next(ds.get_batches(batch, full=True, shuffle=False))
+  cfg.compute_mode = compute
+  model = pred_models.get_model(cfg, 0)
+  model.load_params(params)
+  tester = pred_models.Tester(model, cfg)
+  for comp in (False, True):
+    cfg.compact_inputs = comp
+    key = "tester_step_compact" if comp else "tester_step_dense"
+    out[key] = round(rate(lambda: tester.step(None, b), reps=5, warm=1), 1)
+  model.close()
+  h2d = sum(a.nbytes for a in feed["grid_obs_regress"]) + feed["scene_feat"].nbytes
+  out["h2d_MB_dense"] = round(h2d / 1e6, 2)
+  out["h2d_MB_compact"] = round((feed["obs_xy"].nbytes + feed["scene_feat_u8"].nbytes) / 1e6, 3)
+  for k in ("host_buffers_dense", "host_buffers_compact", "tester_step_dense",
+            "tester_step_compact", "host_buffers_dense_pipelined"):
+    if k in out:
+      out[k + "_vs_resident"] = round(out[k] / out["resident_inputs"], 4)
+  return out
+
+
+def free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def spawn_ranks(n, argv):
+  """--gpus N without a launcher: start the N ranks here (one process per GPU, rendezvous
+  on 127.0.0.1) and relay rank 0's line."""
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  env.setdefault("OMP_NUM_THREADS", "4")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+         "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+  return subprocess.call(cmd, env=env)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=None,
+                  help="timed steps of the headline workload (default: as many as fill "
+                       "%.1f s)" % DEFAULT_TIMED_SECONDS)
+  ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--batch", type=int, default=None,
+                  help="trajectories per GPU (default 64 greedy / 128 beam / 32 train)")
+  ap.add_argument("--workload", choices=("greedy", "beam", "train"), default="greedy",
+                  help="the headline: greedy = BASELINE configs[1]; beam = configs[3]: scale "
+                       "0, beam 20, batch 128, hipGraph replay; train = configs[2]: both "
+                       "scales, training step (fwd + loss + bwd + RCCL grad all-reduce + "
+                       "clip + Adadelta), batch 32/GPU")
+  ap.add_argument("--beam", type=int, default=20)
+  ap.add_argument("--graph", type=int, default=None,
+                  help="1: replay the forward as a captured hipGraph "
+                       "(default: 0 greedy, 1 beam)")
+  ap.add_argument("--compute", choices=("f32", "f16x3", "bf16"), default="f16x3",
+                  help="gate-convolution arithmetic of the inference forward: fp32 MFMA, "
+                       "or f16x3 (two scaled fp16 planes per operand, three fp16 MFMAs "
+                       "per product, fp32 accumulate: fp32-class error), or bf16 (BASELINE "
+                       "configs[4]: bf16 operands, one MFMA per product, fp32 accumulate; "
+                       "reduced precision, reported as such)")
+  ap.add_argument("--scene-conv-kernel", type=int, choices=(1, 3), default=3,
+                  help="--scene_conv_kernel of the reference (code/train.py:65): 3 = the published "
+                       "3x3 stride-2 stack; 1 = the dense 1x1 projections, run as MFMA GEMMs "
+                       "(BASELINE configs[4] names it)")
+  ap.add_argument("--no-sub", action="store_true",
+                  help="headline only: skip the sub-workloads and host_path")
+  ap.add_argument("--only-sub", default=None,
+                  help="comma list of sub-workloads to run (default: all)")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-fp32-ref", action="store_true")
+  ap.add_argument("--cpu-batch", type=int, default=8)
+  args = ap.parse_args()
+
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+  # The contract is ONE JSON line on stdout.  RCCL / HIP print banners and warnings on
+  # fd 1 from native code (seen: "RCCL version ..." once the communicator is created), so
+  # fd 1 is pointed at stderr for the whole run and the line goes out through a saved copy.
+  sys.stdout.flush()
+  real_stdout = os.fdopen(os.dup(1), "w")
+  os.dup2(2, 1)
+
+  import torch
+  import torch.distributed as dist
+
+  ctx = Ctx()
+  if args.gpus != ctx.world:
+    raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, ctx.world))
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs an MI355X; no HIP device visible "
+                     "(there is no CPU fallback)")
+  # MV_BENCH_BACKEND=gloo lets several ranks share ONE GPU (control-flow check of the
+  # multi-rank path on a single-GPU box; RCCL refuses duplicate devices)
+  if ctx.backend != "nccl":
+    ctx.local_rank = ctx.local_rank % torch.cuda.device_count()
+  elif ctx.world > torch.cuda.device_count():
+    raise SystemExit("--gpus %d: only %d HIP devices visible (RCCL needs one per rank; "
+                     "MV_BENCH_BACKEND=gloo shares one GPU for control-flow checks)"
+                     % (ctx.world, torch.cuda.device_count()))
+  torch.cuda.set_device(ctx.local_rank)
+  # MV_ALLREDUCE=lib-force: run the multi-rank code path (process group, RCCL bootstrap,
+  # in-library all-reduce) on a world of ONE rank -- the only form a 1-GPU box can check
+  ctx.use_dist = ctx.world > 1 or (os.environ.get("MV_ALLREDUCE") == "lib-force" and
+                                   "RANK" in os.environ)
+  if ctx.use_dist:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # the host driver only supports dmabuf IPC: without this RCCL's cross-process handles
+    # fail with hipIpcGetMemHandle: invalid argument
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend=ctx.backend)  # nccl == RCCL; barrier + max only
+
+  kind = args.workload
+  batch = args.batch or {"greedy": 64, "beam": 128, "train": 32}[kind]
+  head = measure(ctx, kind, batch, args.compute, args.steps, args.warmup,
+                 beam_size=args.beam, graph=args.graph,
+                 scene_conv_kernel=args.scene_conv_kernel,
+                 timed_seconds=DEFAULT_TIMED_SECONDS, fp32_ref=not args.no_fp32_ref,
+                 cpu_base=not args.no_cpu_baseline, cpu_batch=args.cpu_batch)
+  out = head
+
+  subs = []
+  if not args.no_sub and kind == "greedy" and args.batch is None and args.compute == "f16x3":
+    subs = [("train_n32", dict(kind="train", batch=32, compute="f16x3")),
+            ("beam_n128_b20", dict(kind="beam", batch=128, compute="f16x3", beam_size=20)),
+            ("greedy_b256", dict(kind="greedy", batch=256, compute="f16x3")),
+            ("bf16", dict(kind="greedy", batch=64, compute="bf16", scene_conv_kernel=1)),
+            ("train_bf16_n64", dict(kind="train", batch=64, compute="bf16",
+                                    scene_conv_kernel=1))]
+    if args.only_sub is not None:
+      want = set(x for x in args.only_sub.split(",") if x)
+      subs = [s for s in subs if s[0] in want]
+  for name, kw in subs:
+    try:
+      out[name] = compact(measure(ctx, steps=None, warmup=2, **kw))
+    except Exception as ex:  # pylint: disable=broad-except
+      # a sub-workload must not take the headline down; in a multi-rank run every rank
+      # fails or succeeds together (same code, same sizes)
+      out[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+  if (subs and ctx.rank == 0 and ctx.world == 1 and
+      (args.only_sub is None or "host_path" in args.only_sub)):
+    try:
+      out["host_path"] = host_path(args.compute)
+    except Exception as ex:  # pylint: disable=broad-except
+      out["host_path"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
+  if ctx.use_dist:
     dist.barrier()
     dist.destroy_process_group()
-  if rank == 0:
+  if ctx.rank == 0:
     real_stdout.write(json.dumps(out) + "\n")
     real_stdout.flush()
 

@@ -52,6 +52,16 @@ __host__ __device__ __forceinline__ _Float16 bf16_as_half(float v) {
 }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// a pointer the compiler must treat as wave-uniform (SGPR pair): buffer resources built
+// from it then need no waterfall loop
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+
 constexpr int kPlanePad = 16;                       // zero halves in front of every operand plane
 constexpr float kF16Scale = 256.0f;                 // per operand
 constexpr float kF16Unscale = 1.0f / 65536.0f;      // per product
@@ -222,6 +232,22 @@ static inline unsigned split_planes_blocks(size_t M, int C) {
 #ifndef MV_BF16_ADIST
 #define MV_BF16_ADIST 1          // bf16 kernel: A operands requested this many k-steps ahead (2: measured -1.5 %)
 #endif
+// Ablation builds of the gate kernel (tools/ablate_gate_kernel.sh):
+// -DMV_ABL=<bits> removes one ingredient of the main loop at a time so that what each
+// costs the matrix pipe can be read off PMC counters on the real launch geometry.  Results
+// of such a build are garbage by construction; the shipped library is MV_ABL=0.
+//   1  no A operand loads   (the fragments of the first k-step stay in their registers)
+//   2  no B LDS reads       (the fragments of the first k-step stay in their registers)
+//   4  no stage DMA, no per-stage barrier (every stage reads LDS buffer 0, filled once)
+//   8  no epilogue          (accumulators folded into one never-taken store)
+#ifndef MV_ABL
+#define MV_ABL 0
+#endif
+#ifndef MV_SCHED
+#define MV_SCHED 0          // 1: the explicitly software-pipelined stage loop (f16x3 forward)
+#endif
+constexpr bool kAblNoA = (MV_ABL & 1) != 0, kAblNoB = (MV_ABL & 2) != 0,
+               kAblNoDma = (MV_ABL & 4) != 0, kAblNoEpi = (MV_ABL & 8) != 0;
 constexpr int kWaves16 = MV_CONV_WAVES;           // waves per workgroup of the f16x3 kernels
 constexpr int kThreads16 = kWaves16 * 64;
 constexpr int kBlockRows16 = kWaves16 * kWaveRows; // cells per workgroup
@@ -324,13 +350,21 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   constexpr int kCopy = (kSV + kThreads16 - 1) / kThreads16;     // per thread
   // stage vector v = ((kk*NPL + plane)*NG + g)*64 + lane  ->  its place in the pack,
   // which keeps four sub-block slots per (k-step, plane)
-  auto pack_index = [&](int st, int v) -> size_t {
+  // stage vector v = ((kk*NPL + plane)*NG + g)*64 + lane  ->  its place in the stage's
+  // slice of the pack, which keeps four sub-block slots per (k-step, plane); a row unit
+  // (3 k-steps) is 3 * NPL * 256 vectors
+  auto pack_rel = [&](int v) -> uint32_t {
     const int ln = v & 63;
     int t = v >> 6;
     const int g = t % NG; t /= NG;
     const int plane = t % NPL, kk = t / NPL;
-    return ((size_t)(st * 3 + kk) * NPL + plane) * 256 + g * 64 + ln;
+    return (uint32_t)(((kk * NPL + plane) * 256 + g * 64 + ln) * 16);
   };
+  constexpr uint32_t kUnitBytes = 3 * NPL * 256 * 16;
+  // Buffer addressing (V# in SGPRs + one 32-bit VGPR offset + one SGPR offset) for the
+  // weight stream and the operand planes: no 64-bit address arithmetic per lane.
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<f16x8*>(wblk)), 0, 0x7fffffff, 0x00020000);
 
   const bool okx0 = (xpos - 1 >= 0) & (xpos - 1 < W), okx1 = (xpos >= 0) & (xpos < W),
              okx2 = (xpos + 1 >= 0) & (xpos + 1 < W);
@@ -366,20 +400,31 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   const _Float16* const h16 = p.h16;
   const int64_t xps = p.x_plane_stride, hps = p.h_plane_stride;
 
+  // The bases point at the zero pad in FRONT of a plane, so the offset of an out-of-image
+  // tap is simply 0.  Host-checked: a plane pair is shorter than 2 GB.
+  const __amdgpu_buffer_rsrc_t xrs0 = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<_Float16*>(x16 ? x16 - kPlanePad : h16 - kPlanePad)), 0, 0x7fffffff,
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs1 = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<_Float16*>(x16 ? x16 + xps - kPlanePad : h16 - kPlanePad)), 0,
+      0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t hrs0 = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<_Float16*>(h16 - kPlanePad)), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t hrs1 = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<_Float16*>(h16 + hps - kPlanePad)), 0, 0x7fffffff, 0x00020000);
 #define MV_LOAD_A(ISX, ROWOFF, CG, ROWOK, KK, A0, A1)                                  \
   do {                                                                                  \
     const bool ok_ = (ROWOK) & ((KK) == 0 ? okx0 : ((KK) == 1 ? okx1 : okx2));          \
     const int mm_ = (ROWOFF) + ((KK) - 1);                                              \
-    const int off_ = ok_ ? ((mm_ >> 5) * ((ISX) ? KGx : KGh) + (CG)) * 512 + khalf +    \
-                               (mm_ & 31) * 8                                           \
-                         : -kPlanePad;                                                  \
-    if (ISX) {                                                                          \
-      A0 = *reinterpret_cast<const f16x8*>(x16 + off_);                                 \
-      if (NPL == 2) A1 = *reinterpret_cast<const f16x8*>(x16 + xps + off_);             \
-    } else {                                                                            \
-      A0 = *reinterpret_cast<const f16x8*>(h16 + off_);                                 \
-      if (NPL == 2) A1 = *reinterpret_cast<const f16x8*>(h16 + hps + off_);             \
-    }                                                                                   \
+    const int off_ =                                                                    \
+        ok_ ? (((mm_ >> 5) * ((ISX) ? KGx : KGh) + (CG)) * 512 + khalf +                \
+               (mm_ & 31) * 8 + kPlanePad) * 2                                          \
+            : 0;                                                                        \
+    A0 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(               \
+                                       (ISX) ? xrs0 : hrs0, off_, 0, 0));               \
+    if (NPL == 2)                                                                       \
+      A1 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(             \
+                                         (ISX) ? xrs1 : hrs1, off_, 0, 0));             \
   } while (0)
 
   // stage range of this workgroup (split-K: n_kslice equal ranges)
@@ -397,18 +442,128 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   // LDS nor the L2 latency of a single wave is what limits the matrix pipe here.
   if (st_hi > st_lo) {
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    uint32_t dma_voff[kCopy];              // this thread's pieces inside a stage slice
+#pragma unroll
+    for (int i = 0; i < kCopy; ++i) dma_voff[i] = pack_rel((i * kWaves16 + wave_u) * 64 + lane);
     auto stage_dma = [&](int st, f16x8* dstbuf) {
 #pragma unroll
       for (int i = 0; i < kCopy; ++i) {
         const int v0 = (i * kWaves16 + wave_u) * 64;              // wave-uniform piece of 64 vectors
-        if (v0 < kSV)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(wblk + pack_index(st, v0 + lane)),
-              (__attribute__((address_space(3))) void*)(dstbuf + v0), 16, 0, 0);
+        if (kSV % kThreads16 == 0 || v0 < kSV)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              wrs, (__attribute__((address_space(3))) void*)(dstbuf + v0), 16, dma_voff[i],
+              (uint32_t)st * kUnitBytes, 0, 0);
       }
     };
     // LDS stages of R row units each; (st_hi - st_lo) % R == 0 (host-checked for bf16)
     const int nsg = (st_hi - st_lo) / R;
+#if MV_SCHED
+    if constexpr (NPL == 2 && NG == 4 && MV_ABL == 0) {
+      // Explicitly software-pipelined stage loop.  hipcc's own schedule of the loop below
+      // reads the B fragments of a k-step two at a time right in front of the MFMAs that
+      // consume them (every wave parks on lgkmcnt four to six times per k-step) and drains
+      // vmcnt to ZERO at the head of the third k-step because the stage DMA sits in a
+      // conditional.  Here a k-step is three groups of four MFMAs, every operand is
+      // refilled IN PLACE right behind the group that used it last, one to two groups
+      // (128-256 matrix-pipe cycles of this wave, plus the other waves' turns) before its
+      // next use:
+      //     G1  a0 b1[g]     then  b1 <- next k-step
+      //     G2  a0 b0[g]     then  a0 <- next k-step
+      //     G3  a1 b0[g]     then  a1, b0 <- next k-step
+      // 8 B + 2 A fragments of registers, no second register set.  The stage barrier sits
+      // behind G1 of the third k-step (all B reads of the stage have returned by then);
+      // right behind it the DMA of the stage AFTER next goes into the buffer just retired,
+      // a whole stage ahead of its first read, and unconditionally (past the end it
+      // refetches the last stage), so that vmcnt stays countable.
+      static_assert(kSV % kThreads16 == 0 || MV_SCHED == 0, "whole DMA pieces per thread");
+#define MV_A_OFF(ISX, ROWOFF, CG, ROWOK, KK, OFF)                                      \
+  do {                                                                                  \
+    const bool ok_ = (ROWOK) & ((KK) == 0 ? okx0 : ((KK) == 1 ? okx1 : okx2));          \
+    const int mm_ = (ROWOFF) + ((KK) - 1);                                              \
+    OFF = ok_ ? (((mm_ >> 5) * ((ISX) ? KGx : KGh) + (CG)) * 512 + khalf +              \
+                 (mm_ & 31) * 8 + kPlanePad) * 2                                        \
+              : 0;                                                                      \
+  } while (0)
+#define MV_A_LD(ISX, PLANE, OFF)                                                       \
+  __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(                      \
+                                (ISX) ? ((PLANE) ? xrs1 : xrs0) : ((PLANE) ? hrs1 : hrs0), \
+                                OFF, 0, 0))
+      const int st_last = st_hi - 1;
+      stage_dma(st_lo, lds);
+      stage_dma(st_lo + 1 < st_hi ? st_lo + 1 : st_last, lds + kBufVec);
+      bool c_isx = stage_isx(st_lo);
+      int c_rowoff = stage_rowoff(st_lo), c_cg = stage_cg(st_lo);
+      bool c_rowok = stage_rowok(st_lo);
+      f16x8 fa0, fa1;
+      {
+        int o;
+        MV_A_OFF(c_isx, c_rowoff, c_cg, c_rowok, 0, o);
+        fa0 = MV_A_LD(c_isx, 0, o);
+        fa1 = MV_A_LD(c_isx, 1, o);
+      }
+      __syncthreads();
+      f16x8 b0[4], b1[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        b1[g] = lds[(4 + g) * 64 + lane];
+        b0[g] = lds[g * 64 + lane];
+      }
+      for (int sg = 0; sg < nsg; ++sg) {
+        f16x8* buf = lds + (sg & 1) * kBufVec;
+        const f16x8* nbuf = lds + ((sg + 1) & 1) * kBufVec;
+        const int st = st_lo + sg;
+        const int stn = st < st_last ? st + 1 : st_last;
+        const int stnn = st + 2 < st_hi ? st + 2 : st_last;
+        const bool n_isx = stage_isx(stn);
+        const int n_rowoff = stage_rowoff(stn), n_cg = stage_cg(stn);
+        const bool n_rowok = stage_rowok(stn);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b1[g], acc[g], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk < 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b1[g] = buf[(((kk + 1) * 2 + 1) * 4 + g) * 64 + lane];
+          } else {
+            __syncthreads();     // next stage landed; every wave has its B of this stage
+            stage_dma(stnn, buf);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b1[g] = nbuf[(4 + g) * 64 + lane];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          int o;
+          if (kk < 2) MV_A_OFF(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, o);
+          else MV_A_OFF(n_isx, n_rowoff, n_cg, n_rowok, 0, o);
+          fa0 = MV_A_LD(kk < 2 ? c_isx : n_isx, 0, o);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, b0[g], acc[g], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          fa1 = MV_A_LD(kk < 2 ? c_isx : n_isx, 1, o);
+          if (kk < 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b0[g] = buf[(((kk + 1) * 2 + 0) * 4 + g) * 64 + lane];
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b0[g] = nbuf[g * 64 + lane];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
+      }
+#undef MV_A_OFF
+#undef MV_A_LD
+      __syncthreads();           // the epilogue reuses the stage buffers (carries vmcnt(0))
+    } else
+#endif
+    {
     stage_dma(st_lo, lds);
     bool c_isx = stage_isx(st_lo);
     int c_rowoff = stage_rowoff(st_lo), c_cg = stage_cg(st_lo);
@@ -423,9 +578,17 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     f16x8 fb0, fb1;
     if constexpr (kA2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 1, fb0, fb1);
     __syncthreads();                       // carries the vmcnt(0) of the pending LDS-DMA
+    f16x8 ab0[NG], ab1[NG];                // MV_ABL & 2 only
+    if constexpr (kAblNoB) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        ab0[g] = lds[(0 * NG + g) * 64 + lane];
+        ab1[g] = lds[((NPL - 1) * NG + g) * 64 + lane];
+      }
+    }
     for (int sg = 0; sg < nsg; ++sg) {
       const bool more = sg + 1 < nsg;
-      const f16x8* buf = lds + (sg & 1) * kBufVec;
+      const f16x8* buf = lds + (kAblNoDma ? 0 : (sg & 1)) * kBufVec;
 #pragma unroll
       for (int u = 0; u < R; ++u) {
       const int st = st_lo + sg * R + u;
@@ -441,17 +604,19 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
           if (kk == 0) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 2, fn0, fn1);
           else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, kk - 1, fn0, fn1);
         } else {
-        if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, fn0, fn1);
+        if constexpr (kAblNoA) { fn0 = fa0; fn1 = fa1; }
+        else if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, fn0, fn1);
         else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 0, fn0, fn1);   // (re-read at the very end)
         }
         // the DMA of the next stage goes out behind the first k-step's operands (vmcnt
         // retires in order); its target buffer was last read before the previous barrier
-        if (kq == 1 && more)
+        if (kq == 1 && more && !kAblNoDma)
           stage_dma(st_lo + (sg + 1) * R, lds + ((sg + 1) & 1) * kBufVec);
         if constexpr (NPL == 2) {
           f16x8 b0[NG], b1[NG];
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
+            if constexpr (kAblNoB) { b0[g] = ab0[g]; b1[g] = ab1[g]; continue; }
             b0[g] = buf[((kq * 2 + 0) * NG + g) * 64 + lane];
             b1[g] = buf[((kq * 2 + 1) * NG + g) * 64 + lane];
           }
@@ -479,17 +644,32 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       }
       c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
       }
-      __syncthreads();
+      if constexpr (!kAblNoDma) __syncthreads();
+    }
     }
   }
 #undef MV_LOAD_A
   if (!wave_live) return;
+  // The epilogue's per-lane addresses are functions of `lane`; computed from this laundered
+  // copy they cannot be hoisted above the main loop, where they cost it registers (the
+  // stage loop runs at the 128-VGPR edge of two 8-wave workgroups per CU).
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  if constexpr (kAblNoEpi) {               // keep every accumulator live, store nothing
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sum += acc[g][i];
+    if (sum == 12345.678f) a.h_out[0] = sum;
+    return;
+  }
 
   if constexpr (EPI == kEpiStore) {
     const float scale = ldexpf(1.0f, -(8 + (p.g_exp ? p.g_exp[0] : 0)));
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const int col = cb * kBN + g * 32 + (lane & 31);
+      const int col = cb * kBN + g * 32 + (lane_e & 31);
       float* dst = nullptr;
       int stride = 0, cc = col;
       if (col < a.out0_cols) {
@@ -504,14 +684,14 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       if (dst) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane_e >> 5);
           const int m = m_wave + row;
           if (m < M_total) dst[(size_t)m * stride + cc] = acc[g][reg] * scale;
         }
       }
     }
   } else {
-  const int ch = cb * kChBlock + (lane & 31);
+  const int ch = cb * kChBlock + (lane_e & 31);
     // sparse x: the registers hold the INTERIOR class of the bias table
     const float* const b0 = a.sx_bias ? a.sx_bias + (size_t)4 * 4 * C : a.bias;
     const float bi = b0[ch], bj = b0[C + ch], bf = b0[2 * C + ch], bo = b0[3 * C + ch];
@@ -535,7 +715,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     }
   #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane_e >> 5);
       const int m = m_wave + row;
       float hn_keep = 0.f;                 // cells past the end: zero planes
       if (m < M_total) {
@@ -606,7 +786,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         // goes out as 16-byte vectors, 1 KB contiguous per tile and plane.  (Stored
         // straight from the accumulator layout these were 2-byte stores at a 16-byte
         // stride: slower than a separate split pass)
-        const int chl = lane & 31;
+        const int chl = lane_e & 31;
         const int tofs = (chl >> 4) * 512 + ((chl >> 3) & 1) * 256 + (chl & 7) + row * 8;
         if constexpr (NPL == 2) {
           const float sc = hn_keep * kF16Scale;
@@ -623,9 +803,9 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       const size_t tile0 = ((size_t)(m_wave >> 5) * (size_t)(C >> 4) + (size_t)cb * 2) * 512;
 #pragma unroll
       for (int q = 0; q < 2 * NPL; ++q) {  // q = plane * 2 + tile
-        const f16x8 v = *reinterpret_cast<const f16x8*>(tl + q * 512 + lane * 8);
+        const f16x8 v = *reinterpret_cast<const f16x8*>(tl + q * 512 + lane_e * 8);
         *reinterpret_cast<f16x8*>(p.h16_out + (size_t)(q >> 1) * p.h16_out_stride + tile0 +
-                                  (size_t)(q & 1) * 512 + lane * 8) = v;
+                                  (size_t)(q & 1) * 512 + lane_e * 8) = v;
       }
     }
   }

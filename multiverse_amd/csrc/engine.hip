@@ -1847,6 +1847,12 @@ int mv_train_init(mv_handle h, const mv_train_config* tc) {
     if (!h->train) {
       h->train = new mv_train_holder();
       train_alloc(h);
+      // sparse_x_on() turns false once a training state exists (the backward pass needs
+      // the dense x operand), and the graph key does not carry that: a forward captured
+      // before this call would keep replaying the sparse-x launches against tables that
+      // train_apply no longer rebuilds.  Forget the captures and the derived tables.
+      h->drop_graphs();
+      for (int s = 0; s < h->cfg.num_scales; ++s) h->sc[s].wq_valid = h->sc[s].sx_valid = false;
     }
     TrainState& t = h->train->st;
     t.tc = *tc;

@@ -274,3 +274,26 @@ def test_grad_buffer_is_a_torch_view(built_lib):
   finally:
     dist.destroy_process_group()
   eng.close()
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "bf16"])
+def test_graph_forward_after_train_init_replays_current_tables(built_lib, mode):
+  """A forward captured as a hipGraph BEFORE mv_train_init must not be replayed after it:
+  the training state switches the class chains from the sparse-x table terms to the dense
+  x operand, and an optimizer step changes the weights the tables were built from.  The
+  graph-mode forward after train_init + train_step has to equal the eager one bitwise."""
+  cfg, params, feed = _train_case((0, 1), 2, 3)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode(mode)
+  eng.set_graph_mode(True)
+  cls0, reg0 = eng.forward_greedy(feed)        # captures the sparse-x forward
+  eng.train_init()
+  eng.train_step(feed)                         # weights move, tables go stale
+  cls_g, reg_g = eng.forward_greedy(feed)      # graph mode: must re-capture
+  eng.set_graph_mode(False)
+  cls_e, reg_e = eng.forward_greedy(feed)
+  eng.close()
+  s = 1
+  assert np.array_equal(cls_g[s], cls_e[s]) and np.array_equal(reg_g[s], reg_e[s])
+  assert not np.array_equal(cls0[s], cls_e[s])   # the step did change the outputs

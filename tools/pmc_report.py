@@ -9,8 +9,12 @@ FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md (HBM section): on gfx95
 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming
 read, so the read side is quoted raw AND doubled (upper bound)."""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multiverse_amd import buildinfo  # noqa: E402
 
 
 def main(kernel, out, dbs):
@@ -24,7 +28,10 @@ def main(kernel, out, dbs):
     for name, total, n, dur in rows:
       agg[name] = {"total": total, "launches": n, "per_launch": total / n,
                    "avg_launch_us": dur / n / 1e3}
-  res = {"kernel": kernel, "counters": agg}
+  # the sources the profiled library was built from: bench.py quotes roofline.traffic from
+  # this file only while they are the sources of the tree it runs in
+  res = {"kernel": kernel, "counters": agg,
+         "kernel_source_sha16": buildinfo.kernel_source_hash()}
   if "GRBM_GUI_ACTIVE" in agg:
     gui = agg["GRBM_GUI_ACTIVE"]
     cyc = gui["total"] / 8.0                     # summed over the 8 XCDs
