@@ -31,8 +31,20 @@ writer below and (b) `tests/golden/tf_bundle_v2`, a checkpoint hand-assembled by
 byte by an independent script (its own CRC / varint / block / snappy code) from the
 same published descriptions.  `python -m multiverse_amd.tf_checkpoint <ckpt>` prints a
 checkpoint's variable table in the `--check_model` format for diffing against a
-TensorFlow-1.15 listing.  Single-file V1 checkpoints (`*.ckpt` without `.index`,
-accepted by the reference's `initialize`, code/pred_utils.py:196-199) are NOT read.
+TensorFlow-1.15 listing; `--verify` compares it with the variables THIS engine asks
+for (names and shapes from `mv_param_info`), so the first machine that holds the
+published `multiverse-models.tgz` settles whether the inferred variable names are right.
+
+Single-file V1 checkpoints (`*.ckpt` with no `.index` beside it, which the reference's
+`initialize` hands to `saver.restore`, code/pred_utils.py:196-199) are READ
+(`load_checkpoint` dispatches on the file layout; the writer only emits V2, as
+`tf.train.Saver` has since TF 1.0).  A V1 file is ONE SSTable (TF core/util/
+tensor_slice_writer.cc, saved_tensor_slice.proto): key "" -> SavedTensorSlices{meta =
+SavedTensorSliceMeta{tensor: SavedSliceMeta{name, shape, type, slice}...}}, every other
+key (an ordered-code encoding of name + slice, never decoded here) -> SavedTensorSlices{
+data = SavedSlice{name, slice, data = TensorProto}} with the values in the TensorProto's
+typed repeated fields (float_val, ..., packed or not) or in tensor_content.  Pinned by
+`tests/golden/tf_ckpt_v1`, hand-assembled by the same independent script.
 """
 
 from __future__ import annotations
@@ -485,10 +497,129 @@ def resolve_checkpoint(path):
   return path
 
 
+def is_v1_checkpoint(prefix):
+  """A single-file (V1) checkpoint: the prefix itself is a table file and no
+  `<prefix>.index` sits beside it."""
+  return os.path.isfile(prefix) and not os.path.exists(prefix + ".index")
+
+
+# ------------------------------------------------------------------ V1 (single file)
+
+def _decode_slice_is_full(buf):
+  """TensorSliceProto {repeated Extent extent = 1 {start = 1, length = 2}}: full when no
+  extent carries a start or a length (TensorSlice::AsProto omits both for a full dim)."""
+  for f, _, v in _pb_fields(buf):
+    if f == 1 and len(v):
+      return False
+  return True
+
+
+def _decode_tensor_proto(buf, name):
+  """TensorProto -> (dtype enum, shape, flat numpy array)."""
+  dtype, shape, content = None, [], None
+  vals = {5: [], 6: [], 7: [], 10: [], 11: []}     # float, double, int, int64, bool _val
+  wire_np = {5: "<f4", 6: "<f8"}
+  for f, wt, v in _pb_fields(buf):
+    if f == 1:
+      dtype = v
+    elif f == 2:
+      shape = _decode_shape(v)
+    elif f == 4:
+      content = bytes(v)
+    elif f in vals:
+      if wt == 2:                       # packed
+        if f in wire_np:
+          vals[f].append(np.frombuffer(bytes(v), dtype=wire_np[f]))
+        else:
+          pos, out = 0, []
+          while pos < len(v):
+            x, pos = _get_varint(v, pos)
+            out.append(x)
+          vals[f].append(np.asarray(out, dtype=np.uint64))
+      elif wt == 0:                     # one varint element
+        vals[f].append(np.asarray([v], dtype=np.uint64))
+      else:                             # one fixed32 / fixed64 element (already bytes)
+        vals[f].append(np.frombuffer(bytes(v), dtype=wire_np[f]))
+  if dtype not in _NP_OF_DT:
+    raise IOError("variable %s: unsupported dtype %r" % (name, dtype))
+  dt = _NP_OF_DT[dtype]
+  if content is not None:
+    flat = np.frombuffer(content, dtype=dt)
+  else:
+    field = {DT_FLOAT: 5, DT_DOUBLE: 6, DT_INT32: 7, DT_INT64: 10, DT_BOOL: 11}[dtype]
+    parts = vals[field]
+    flat = np.concatenate(parts) if parts else np.zeros((0,), dtype=dt)
+    if flat.dtype == np.uint64:         # varints: two's complement of the signed value
+      flat = flat.astype(np.int64) if dtype != DT_BOOL else flat
+    flat = flat.astype(dt)
+  return dtype, shape, flat
+
+
+def _read_v1(path):
+  """-> ({name: (shape, dtype enum)} from the meta entry, {name: flat array} from the data
+  entries).  Partitioned (sliced) variables are refused like in the V2 reader."""
+  meta, data = {}, {}
+  for key, value in read_table(path):
+    for f, _, v in _pb_fields(value):
+      if f == 1 and not key:            # SavedTensorSliceMeta
+        for f2, _, v2 in _pb_fields(v):
+          if f2 != 1:
+            continue
+          name, shape, dt, full = None, [], None, True
+          for f3, _, v3 in _pb_fields(v2):
+            if f3 == 1:
+              name = bytes(v3).decode()
+            elif f3 == 2:
+              shape = _decode_shape(v3)
+            elif f3 == 3:
+              dt = v3
+            elif f3 == 4:
+              full = full and _decode_slice_is_full(v3)
+          if not full:
+            raise IOError("variable %s is stored as slices (partitioned); not supported" % name)
+          meta[name] = (shape, dt)
+      elif f == 2:                      # SavedSlice
+        name, tp, full = None, None, True
+        for f2, _, v2 in _pb_fields(v):
+          if f2 == 1:
+            name = bytes(v2).decode()
+          elif f2 == 2:
+            full = _decode_slice_is_full(v2)
+          elif f2 == 3:
+            tp = v2
+        if not full:
+          raise IOError("variable %s is stored as slices (partitioned); not supported" % name)
+        data[name] = tp
+  return meta, data
+
+
+def _load_v1(path, keep):
+  meta, data = _read_v1(path)
+  out = {}
+  for name in sorted(meta):
+    if not keep(name):
+      continue
+    shape, dt = meta[name]
+    if name not in data:
+      raise IOError("variable %s: listed in the meta entry, no data entry" % name)
+    dtype, _, flat = _decode_tensor_proto(data[name], name)
+    if dt is not None and dtype != dt:
+      raise IOError("variable %s: dtype %r in the data entry, %r in the meta entry"
+                    % (name, dtype, dt))
+    n = int(np.prod(shape)) if len(shape) else 1
+    if flat.size != n:
+      raise IOError("variable %s: %d values for shape %s" % (name, flat.size, shape))
+    out[name] = flat.reshape(shape).copy()
+  return out
+
+
 def list_variables(path):
   """[(name, shape, numpy dtype)] of a checkpoint."""
   prefix = resolve_checkpoint(path)
   out = []
+  if is_v1_checkpoint(prefix):
+    meta, _ = _read_v1(prefix)
+    return [(n, meta[n][0], _NP_OF_DT.get(meta[n][1])) for n in sorted(meta)]
   for key, value in read_table(prefix + ".index"):
     if not key:
       continue
@@ -502,6 +633,15 @@ def load_checkpoint(path, scope=None, skip_optimizer_slots=True, verify_crc=Fals
   (multifuture_inference.py:287-289: "person_pred"); optimizer slots and
   global_step are dropped like the reference's restore lists."""
   prefix = resolve_checkpoint(path)
+
+  def keep(name):
+    leaf = name.split("/")[-1]
+    if skip_optimizer_slots and (leaf in OPTIMIZER_SLOT_NAMES or "global_step" in name):
+      return False
+    return scope is None or name.split("/")[0] == scope
+
+  if is_v1_checkpoint(prefix):
+    return _load_v1(prefix, keep)
   entries = read_table(prefix + ".index")
   num_shards = 1
   out = {}
@@ -513,10 +653,7 @@ def load_checkpoint(path, scope=None, skip_optimizer_slots=True, verify_crc=Fals
           num_shards = v
       continue
     name = key.decode()
-    leaf = name.split("/")[-1]
-    if skip_optimizer_slots and (leaf in OPTIMIZER_SLOT_NAMES or "global_step" in name):
-      continue
-    if scope is not None and name.split("/")[0] != scope:
+    if not keep(name):
       continue
     e = _decode_entry(value)
     if e["sliced"]:
@@ -547,7 +684,8 @@ def save_checkpoint(prefix, variables, global_step=None, update_state=True,
   only checkpoints written through the same `written` list -- one per Saver
   instance; the process-wide default for bare calls -- count against
   `max_to_keep` and are ever deleted: resuming into a directory never removes the
-  checkpoints of the previous run (they stay listed in the state file).
+  checkpoint FILES of the previous run; the state file lists only this Saver's own
+  checkpoints, as TF rewrites it.
   Returns the checkpoint prefix written."""
   if global_step is not None:
     prefix = "%s-%d" % (prefix, int(global_step))
@@ -588,6 +726,9 @@ def _update_state(prefix, max_to_keep, written):
         if line.startswith("all_model_checkpoint_paths:"):
           allp.append(line.split(":", 1)[1].strip().strip('"'))
   allp = [p for p in allp if p != base] + [base]
+  # tf.train.Saver rewrites the state file from its own _last_checkpoints only: entries of
+  # earlier runs drop out of the LIST (their files stay), the file does not grow per resume
+  allp = [p for p in allp if p in written or p == base]
   if base in written:
     written.remove(base)
   written.append(base)
@@ -606,13 +747,90 @@ def _update_state(prefix, max_to_keep, written):
       f.write('all_model_checkpoint_paths: "%s"\n' % p)
 
 
+def verify_against_engine(path, cfg=None, scope="person_pred", engine_specs=None):
+  """Compare a checkpoint with the variables this engine asks for.
+
+  -> dict(missing=[(name, shape)] the engine needs and the checkpoint lacks,
+          unexpected=[(name, shape)] under `scope` in the checkpoint the engine never reads,
+          shape_mismatch=[(name, ckpt shape, engine shape)], matched=int, ok=bool).
+  The engine side is `mv_param_info` of an engine built for `cfg` when a device is present
+  (`engine_specs` passes a listing in directly), else `synth.param_shapes(cfg)` -- the two
+  are asserted equal by the tests.  Optimizer slots and global_step are ignored, as in the
+  reference's restore lists (code/pred_utils.py:166-174)."""
+  if engine_specs is None:
+    from multiverse_amd import synth
+    if cfg is None:
+      cfg = synth.default_config(batch_size=1, use_grids=(1, 1))
+    engine_specs = None
+    try:
+      import torch
+      if torch.cuda.is_available():
+        from multiverse_amd import _lib
+        eng = _lib.Engine(cfg, device=0)
+        engine_specs = eng.param_specs()
+        eng.close()
+    except Exception:  # pylint: disable=broad-except
+      engine_specs = None
+    if engine_specs is None:
+      engine_specs = sorted(synth.param_shapes(cfg).items())
+  want = {n: tuple(int(d) for d in sh) for n, sh in engine_specs}
+  have = {}
+  for name, shape, _ in list_variables(path):
+    leaf = name.split("/")[-1]
+    if leaf in OPTIMIZER_SLOT_NAMES or "global_step" in name:
+      continue
+    if scope is not None and name.split("/")[0] != scope:
+      continue
+    have[name] = tuple(int(d) for d in shape)
+  res = {"missing": sorted((n, want[n]) for n in want if n not in have),
+         "unexpected": sorted((n, have[n]) for n in have if n not in want),
+         "shape_mismatch": sorted((n, have[n], want[n]) for n in want
+                                  if n in have and have[n] != want[n])}
+  res["matched"] = sum(1 for n in want if n in have and have[n] == want[n])
+  res["ok"] = not (res["missing"] or res["unexpected"] or res["shape_mismatch"])
+  return res
+
+
 def main(argv=None):
-  """`python -m multiverse_amd.tf_checkpoint <checkpoint dir or prefix> [--all]`: one line
-  per variable, `<name>:0 <shape>`, the format of the reference's `train.py --check_model`
-  (code/train.py:154-166), optimizer slots and global_step hidden like there unless
-  --all."""
+  """`python -m multiverse_amd.tf_checkpoint <checkpoint dir, prefix or .ckpt file> [--all]`:
+  one line per variable, `<name>:0 <shape>`, the format of the reference's `train.py
+  --check_model` (code/train.py:154-166), optimizer slots and global_step hidden like there
+  unless --all.
+
+  `--verify [--use_grids 1,0] [--use_single_decoder] [--scene_conv_kernel 1] [--no_gnn]`:
+  report the variables missing from / unexpected in / differently shaped than what this
+  engine asks for (`mv_param_info`); exit status 1 unless they agree.  The names here are
+  inferred from TF-1 scoping rules: run this once on a machine that
+  holds the published multiverse-models.tgz."""
   import sys
   argv = list(sys.argv[1:] if argv is None else argv)
+  if "--verify" in argv:
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m multiverse_amd.tf_checkpoint")
+    ap.add_argument("path")
+    ap.add_argument("--verify", action="store_true")
+    ap.add_argument("--use_grids", default="1,1")
+    ap.add_argument("--use_single_decoder", action="store_true")
+    ap.add_argument("--scene_conv_kernel", type=int, default=3)
+    ap.add_argument("--no_gnn", action="store_true")
+    ap.add_argument("--scope", default="person_pred")
+    a = ap.parse_args(argv)
+    from multiverse_amd import synth
+    cfg = synth.default_config(batch_size=1,
+                               use_grids=tuple(int(x) for x in a.use_grids.split(",")),
+                               use_single_decoder=a.use_single_decoder,
+                               scene_conv_kernel=a.scene_conv_kernel, use_gnn=not a.no_gnn)
+    res = verify_against_engine(a.path, cfg, scope=a.scope or None)
+    for n, sh in res["missing"]:
+      print("MISSING     %s %s   (the engine needs it; not in the checkpoint)" % (n, sh))
+    for n, sh in res["unexpected"]:
+      print("UNEXPECTED  %s %s   (in the checkpoint; the engine never asks for it)" % (n, sh))
+    for n, hs, ws in res["shape_mismatch"]:
+      print("SHAPE       %s checkpoint %s engine %s" % (n, hs, ws))
+    print("# %d variables match, %d missing, %d unexpected, %d shape mismatches -> %s"
+          % (res["matched"], len(res["missing"]), len(res["unexpected"]),
+             len(res["shape_mismatch"]), "OK" if res["ok"] else "MISMATCH"))
+    raise SystemExit(0 if res["ok"] else 1)
   show_all = "--all" in argv
   paths = [a for a in argv if not a.startswith("--")]
   if len(paths) != 1:

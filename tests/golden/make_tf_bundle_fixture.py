@@ -226,5 +226,138 @@ def main():
   print("wrote", OUT, "index", len(file_bytes), "bytes, data", offset, "bytes")
 
 
+# ---------------------------------------------------------------- V1: one SSTable file
+# tensorflow core/util/saved_tensor_slice.proto + tensor_slice_writer.cc (TF 1.x, write_version
+# V1): key "" -> SavedTensorSlices{1 meta = SavedTensorSliceMeta{1 tensor = SavedSliceMeta{1 name,
+# 2 shape, 3 type, 4 slice}..., 2 versions}}; per tensor one key = ordered code of
+# (0, name, rank, (start, length) per dim) -> SavedTensorSlices{2 data = SavedSlice{1 name,
+# 2 slice, 3 data = TensorProto{1 dtype, 2 tensor_shape, 5 float_val / 6 double_val /
+# 7 int_val / 10 int64_val (packed)}}}.  A full dimension is an Extent with neither start
+# nor length.  lib/strings/ordered_code.cc: WriteNumIncreasing(n) = length byte + big-endian
+# bytes (0 -> "\x00"); WriteString escapes \x00 -> \x00\xff, \xff -> \xff\x00 and ends with
+# \x00\x01; WriteSignedNumIncreasing(x) for -64 <= x < 64 is the single byte 0x80 ^ x... the
+# reader never decodes these keys, they only have to sort after "".
+V1_OUT = os.path.join(HERE, "tf_ckpt_v1")
+V1_NAME = "model.ckpt"
+
+
+def oc_num(n):
+  if n == 0:
+    return b"\x00"
+  body = n.to_bytes((n.bit_length() + 7) // 8, "big")
+  return bytes([len(body)]) + body
+
+
+def oc_string(sv):
+  return sv.replace(b"\x00", b"\x00\xff").replace(b"\xff", b"\xff\x00") + b"\x00\x01"
+
+
+def oc_signed_small(x):
+  assert -64 <= x < 64
+  return bytes([(0x80 + x) & 0xff]) if x >= 0 else bytes([0x80 + x])
+
+
+def v1_key(name, rank):
+  k = oc_num(0) + oc_string(name.encode()) + oc_num(rank)
+  for _ in range(rank):
+    k += oc_signed_small(0) + oc_signed_small(-1)     # start 0, length kFullExtent
+  return k
+
+
+def shape_proto(shape):
+  return b"".join(pb_bytes(2, pb_varint(1, d)) for d in shape)
+
+
+def full_slice_proto(rank):
+  return b"".join(pb_bytes(1, b"") for _ in range(rank))       # Extents with nothing set
+
+
+def varint_signed(v):
+  return varint(v & 0xFFFFFFFFFFFFFFFF)                         # two's complement, 10 bytes if < 0
+
+
+def tensor_proto(arr, dt_enum, unpacked=False):
+  msg = pb_varint(1, dt_enum) + pb_bytes(2, shape_proto(arr.shape))
+  flat = np.ascontiguousarray(arr).reshape(-1)
+  if arr.dtype.str == "<f4":
+    if unpacked:            # proto2-style: one fixed32 field per element
+      msg += b"".join(varint((5 << 3) | 5) + struct.pack("<f", float(v)) for v in flat)
+    else:
+      msg += pb_bytes(5, flat.tobytes())
+  elif arr.dtype.str == "<f8":
+    msg += pb_bytes(6, flat.tobytes())
+  elif arr.dtype.str == "<i4":
+    msg += pb_bytes(7, b"".join(varint_signed(int(v)) for v in flat))
+  elif arr.dtype.str == "<i8":
+    msg += pb_bytes(10, b"".join(varint_signed(int(v)) for v in flat))
+  return msg
+
+
+def main_v1():
+  rng = np.random.default_rng(20200615)
+  variables = [
+      ("global_step", np.asarray(1234567, dtype="<i8"), False),
+      ("person_pred/encoder_grid_class_0/enc_grid_0/biases",
+       rng.normal(size=(8,)).astype("<f4"), True),
+      ("person_pred/encoder_grid_class_0/enc_grid_0/kernel",
+       rng.normal(size=(3, 3, 4, 8)).astype("<f4"), False),
+      ("person_pred/encoder_grid_class_0/enc_grid_0/kernel/Adadelta_1",
+       np.ones((3, 3, 4, 8), dtype="<f4"), False),
+      ("person_pred/scene_conv2/W", rng.normal(size=(3, 3, 2, 2)).astype("<f4"), False),
+      ("person_pred/scene_conv2/b", np.asarray([0.5, -0.25], dtype="<f4"), False),
+      ("signed_ints", np.asarray([[-3, 7, 0], [2147483647, -2147483648, 1]], dtype="<i4"), False),
+      ("scalar_double", np.asarray(-1.5, dtype="<f8"), False),
+  ]
+  dt_of = {"<f4": 1, "<f8": 2, "<i4": 3, "<i8": 9}
+  metas = b""
+  items = []
+  for name, arr, unpacked in variables:
+    rank = arr.ndim
+    metas += pb_bytes(1, pb_bytes(1, name.encode()) + pb_bytes(2, shape_proto(arr.shape)) +
+                      pb_varint(3, dt_of[arr.dtype.str]) + pb_bytes(4, full_slice_proto(rank)))
+    saved = (pb_bytes(1, name.encode()) + pb_bytes(2, full_slice_proto(rank)) +
+             pb_bytes(3, tensor_proto(arr, dt_of[arr.dtype.str], unpacked)))
+    items.append((v1_key(name, rank), pb_bytes(2, saved)))
+  meta_msg = pb_bytes(1, metas + pb_bytes(2, pb_varint(1, 1)))          # versions{producer 1}
+  items = [(b"", meta_msg)] + sorted(items)
+  assert all(items[i][0] < items[i + 1][0] for i in range(len(items) - 1))
+  # two data blocks: the first raw (meta + 3 tensors), the second SNAPPY-compressed
+  groups = [items[:4], items[4:]]
+  file_bytes = bytearray()
+  handles = []
+  for gi, grp in enumerate(groups):
+    raw = build_block(grp, 3)
+    if gi == 1:
+      body, _ = snappy_with_copy(raw)
+      btype = 1
+    else:
+      body, btype = raw, 0
+    handles.append((len(file_bytes), len(body)))
+    file_bytes += body + bytes([btype]) + struct.pack(
+        "<I", masked(crc32c_bitwise(body + bytes([btype]))))
+
+  def handle(h):
+    return varint(h[0]) + varint(h[1])
+
+  def add_raw_block(raw):
+    pos = len(file_bytes)
+    file_bytes.extend(raw + b"\x00" + struct.pack("<I", masked(crc32c_bitwise(raw + b"\x00"))))
+    return (pos, len(raw))
+
+  meta = add_raw_block(build_block([], 1))
+  index = add_raw_block(build_block(
+      [(groups[0][-1][0], handle(handles[0])), (groups[1][-1][0] + b"\xff", handle(handles[1]))], 1))
+  footer = handle(meta) + handle(index)
+  footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57)
+  file_bytes += footer
+  os.makedirs(V1_OUT, exist_ok=True)
+  with open(os.path.join(V1_OUT, V1_NAME), "wb") as f:
+    f.write(bytes(file_bytes))
+  np.savez(os.path.join(V1_OUT, "expected.npz"),
+           **{n.replace("/", "|"): a for n, a, _ in variables})
+  print("wrote", V1_OUT, len(file_bytes), "bytes")
+
+
 if __name__ == "__main__":
   main()
+  main_v1()

@@ -320,3 +320,45 @@ def test_compact_inputs_consistency_gate():
                                                dtype="float32") * 0.5
   ok, why = pred_models.compact_inputs_consistent(cfg, batch3)
   assert not ok and "0/1" in why
+
+
+def test_integration_stub_matches_the_header(tmp_path, built_lib):
+  """The ctypes stub printed in INTEGRATION.md section 2 is what a maintainer copies into
+  the reference: it is generated from include/multiverse_hip.h, must not drift from the
+  generator's output, and -- executed as written, against the built library -- must lay
+  mv_config out exactly as gcc does (sizeof and every field offset)."""
+  import importlib.util
+  import shutil
+  import subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location(
+      "gen_stub", os.path.join(root, "tools", "gen_integration_stub.py"))
+  gen = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(gen)
+  block = gen.doc_block()
+  assert block == gen.stub(), ("INTEGRATION.md stub is stale: run "
+                               "python tools/gen_integration_stub.py --write")
+  code = block.strip("`").split("\n", 1)[1].rsplit("```", 1)[0]
+  code = code.replace('C.CDLL("libmultiverse_hip.so")', "C.CDLL(%r)" % built_lib.LIB_PATH)
+  ns = {}
+  exec(compile(code, "INTEGRATION.md:stub", "exec"), ns)    # pylint: disable=exec-used
+  stub_cfg = ns["mv_config"]
+  assert [f[0] for f in stub_cfg._fields_] == [f[0] for f in built_lib.mv_config._fields_]
+  assert ctypes.sizeof(stub_cfg) == ctypes.sizeof(built_lib.mv_config)
+  gcc = shutil.which("gcc")
+  if gcc is None:
+    pytest.skip("no gcc")
+  lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "multiverse_hip.h"',
+           'int main(void) {', '  printf("sizeof %zu\\n", sizeof(mv_config));']
+  for f in stub_cfg._fields_:
+    lines.append('  printf("%s %%zu\\n", offsetof(mv_config, %s));' % (f[0], f[0]))
+  lines += ['  return 0;', '}']
+  src = tmp_path / "stub_layout.c"
+  src.write_text("\n".join(lines))
+  exe = str(tmp_path / "stub_layout")
+  subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                         str(src), "-o", exe])
+  got = dict(l.split() for l in subprocess.check_output([exe]).decode().splitlines())
+  assert int(got["sizeof"]) == ctypes.sizeof(stub_cfg)
+  for f in stub_cfg._fields_:
+    assert int(got[f[0]]) == getattr(stub_cfg, f[0]).offset, f[0]

@@ -118,9 +118,12 @@ def test_resumed_run_never_deletes_the_previous_runs_checkpoints(tmp_path):
   assert idx == ["save-10.index", "save-20.index", "save-40.index", "save-50.index"]
   state = open(os.path.join(d, "checkpoint")).read()
   assert 'model_checkpoint_path: "save-50"' in state
-  for keep in ("save-10", "save-20", "save-40", "save-50"):
+  # the state file is rewritten from the NEW Saver's own list (update_checkpoint_state with
+  # saver.last_checkpoints): the earlier run's entries leave the list, its files stay
+  for keep in ("save-40", "save-50"):
     assert 'all_model_checkpoint_paths: "%s"' % keep in state
-  assert "save-30" not in state
+  for gone in ("save-10", "save-20", "save-30"):
+    assert gone not in state
 
 
 def test_snappy_decoder():
@@ -301,3 +304,78 @@ def test_checkpoint_dump_cli(capsys):
   out = capsys.readouterr().out
   assert "person_pred/scene_conv1/W:0 (3, 3, 11, 2)" in out
   assert "global_step" not in out          # hidden like --check_model hides it
+
+
+V1 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_ckpt_v1")
+
+
+def test_reader_on_a_hand_assembled_v1_checkpoint():
+  """Single-file V1 checkpoints (`*.ckpt`, what the reference's `initialize` passes straight
+  to saver.restore, code/pred_utils.py:196-199).  tests/golden/tf_ckpt_v1/model.ckpt was
+  assembled by make_tf_bundle_fixture.py from saved_tensor_slice.proto / tensor_slice_writer:
+  meta entry under key "", one SavedSlice per tensor under ordered-code keys, values in
+  packed float_val / double_val / int_val / int64_val (one tensor with UNPACKED float_val),
+  negative ints as 10-byte varints, the second data block snappy-compressed."""
+  path = os.path.join(V1, "model.ckpt")
+  assert tc.is_v1_checkpoint(path) and tc.resolve_checkpoint(path) == path
+  exp = np.load(os.path.join(V1, "expected.npz"))
+  listed = {n: (tuple(s), dt) for n, s, dt in tc.list_variables(path)}
+  allv = tc.load_checkpoint(path, skip_optimizer_slots=False)
+  assert len(allv) == len(exp.files) == len(listed) == 8
+  for k in exp.files:
+    n = k.replace("|", "/")
+    assert allv[n].dtype == exp[k].dtype and allv[n].shape == exp[k].shape, n
+    assert np.array_equal(allv[n], exp[k]), n
+    assert listed[n] == (exp[k].shape, exp[k].dtype), n
+  assert allv["signed_ints"].min() == -2147483648 and int(allv["global_step"]) == 1234567
+  w = tc.load_checkpoint(path, scope="person_pred")        # the reference's restore list
+  assert sorted(w) == ["person_pred/encoder_grid_class_0/enc_grid_0/biases",
+                       "person_pred/encoder_grid_class_0/enc_grid_0/kernel",
+                       "person_pred/scene_conv2/W", "person_pred/scene_conv2/b"]
+
+
+def test_v1_checkpoint_loads_into_the_model_protocol(tmp_path):
+  """A V1 file holding exactly the engine's variables passes --verify, and one with a
+  renamed / reshaped / extra variable is reported as such (exit status 1)."""
+  import importlib.util
+  from multiverse_amd import synth
+  spec = importlib.util.spec_from_file_location(
+      "mkfix", os.path.join(os.path.dirname(V1), "make_tf_bundle_fixture.py"))
+  mk = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mk)
+  cfg = synth.default_config(batch_size=1, use_grids=(0, 1))
+  shapes = synth.param_shapes(cfg)
+
+  def write_v1(path, variables):
+    metas, items = b"", []
+    for name, arr in variables:
+      metas += mk.pb_bytes(1, mk.pb_bytes(1, name.encode()) +
+                           mk.pb_bytes(2, mk.shape_proto(arr.shape)) + mk.pb_varint(3, 1) +
+                           mk.pb_bytes(4, mk.full_slice_proto(arr.ndim)))
+      saved = (mk.pb_bytes(1, name.encode()) + mk.pb_bytes(2, mk.full_slice_proto(arr.ndim)) +
+               mk.pb_bytes(3, mk.tensor_proto(arr, 1)))
+      items.append((mk.v1_key(name, arr.ndim), mk.pb_bytes(2, saved)))
+    items = [(b"", mk.pb_bytes(1, metas))] + sorted(items)
+    tc.write_table(path, items)       # the table layer is pinned by the fixtures above
+
+  good = [(n, np.zeros(sh, "<f4")) for n, sh in sorted(shapes.items())]
+  p = str(tmp_path / "good.ckpt")
+  write_v1(p, good)
+  res = tc.verify_against_engine(p, cfg, engine_specs=sorted(shapes.items()))
+  assert res["ok"] and res["matched"] == len(shapes)
+  names = sorted(shapes)
+  bad = [(n if n != names[0] else n + "_renamed", a) for n, a in good]
+  bad[3] = (bad[3][0], np.zeros(bad[3][1].shape + (1,), "<f4"))
+  p2 = str(tmp_path / "bad.ckpt")
+  write_v1(p2, bad)
+  res = tc.verify_against_engine(p2, cfg, engine_specs=sorted(shapes.items()))
+  assert not res["ok"]
+  assert [n for n, _ in res["missing"]] == [names[0]]
+  assert [n for n, _ in res["unexpected"]] == [names[0] + "_renamed"]
+  assert len(res["shape_mismatch"]) == 1
+  with pytest.raises(SystemExit) as ex:
+    tc.main([p2, "--verify", "--use_grids", "0,1"])
+  assert ex.value.code == 1
+  with pytest.raises(SystemExit) as ex:
+    tc.main([p, "--verify", "--use_grids", "0,1"])
+  assert ex.value.code == 0
