@@ -630,7 +630,13 @@ class Engine(object):
     return arrs, s
 
   # ---- training (Trainer.step)
-  def train_init(self, cfg=None, world=1):
+  def train_init(self, cfg=None, world=None):
+    """world None = the world of the previous train_init of this engine (1 for the first):
+    re-initialising with another configuration (the SimAug attacks switch to their loss
+    and back) must not reset the data-parallel LR / decay schedule to a single rank."""
+    if world is None:
+      world = getattr(self, "_train_world", 1)
+    self._train_world = int(world)
     self._tc = make_train_config(cfg or self.cfg, world=world)
     check(self.lib.mv_train_init(self.handle, C.byref(self._tc)), self.handle)
 

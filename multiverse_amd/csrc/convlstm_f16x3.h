@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "convlstm_mfma.h"
 #include "plane_layout.h"
@@ -475,48 +476,55 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       // right behind it the DMA of the stage AFTER next goes into the buffer just retired,
       // a whole stage ahead of its first read, and unconditionally (past the end it
       // refetches the last stage), so that vmcnt stays countable.
+      // The loop body is TWO stages (LDS buffer 0, then 1), so every ds_read is one base
+      // register (lane * 16) + an immediate; a stage names its stencil row j and the
+      // x / h side of its operand once, scalar; the cell index of the lane is one register
+      // (xcell until the x stages are done, then recomputed).
       static_assert(kSV % kThreads16 == 0 || MV_SCHED == 0, "whole DMA pieces per thread");
-#define MV_A_OFF(ISX, ROWOFF, CG, ROWOK, KK, OFF)                                      \
-  do {                                                                                  \
-    const bool ok_ = (ROWOK) & ((KK) == 0 ? okx0 : ((KK) == 1 ? okx1 : okx2));          \
-    const int mm_ = (ROWOFF) + ((KK) - 1);                                              \
-    OFF = ok_ ? (((mm_ >> 5) * ((ISX) ? KGx : KGh) + (CG)) * 512 + khalf +              \
-                 (mm_ & 31) * 8 + kPlanePad) * 2                                        \
-              : 0;                                                                      \
-  } while (0)
-#define MV_A_LD(ISX, PLANE, OFF)                                                       \
-  __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(                      \
-                                (ISX) ? ((PLANE) ? xrs1 : xrs0) : ((PLANE) ? hrs1 : hrs0), \
-                                OFF, 0, 0))
       const int st_last = st_hi - 1;
-      stage_dma(st_lo, lds);
-      stage_dma(st_lo + 1 < st_hi ? st_lo + 1 : st_last, lds + kBufVec);
-      bool c_isx = stage_isx(st_lo);
-      int c_rowoff = stage_rowoff(st_lo), c_cg = stage_cg(st_lo);
-      bool c_rowok = stage_rowok(st_lo);
+      const uint32_t dvoff = (uint32_t)(wave_u * 64 + lane) * 16u;   // piece i: + i * 8 KB
+      auto dma3 = [&](int st, f16x8* dstbuf) {
+#pragma unroll
+        for (int i = 0; i < kSV / kThreads16; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              wrs, (__attribute__((address_space(3))) void*)(dstbuf + (i * kWaves16 + wave_u) * 64),
+              16, dvoff, (uint32_t)st * kUnitBytes + (uint32_t)i * (kThreads16 * 16u), 0, 0);
+      };
+      dma3(st_lo, lds);
+      dma3(st_lo + 1 < st_hi ? st_lo + 1 : st_last, lds + kBufVec);
+      // operand side of the current stage: V# pair, channel groups per tile, lane's cell
+      bool isx = st_lo < nxst;
+      int cellv = isx ? xcell : hcell;                // the one per-lane cell register
+      const int lofs = khalf + kPlanePad;             // per-lane constant of the plane offset
+      auto a_off = [&](bool sx, int cg, int j, int kk) -> int {
+        // tap (j, kk) of the lane's cell: plane byte offset, 0 (the zero pad) when outside
+        const bool ok = (((okymask >> j) & 1) != 0) & (kk == 0 ? okx0 : (kk == 1 ? okx1 : okx2));
+        const int mm = cellv + (j - 1) * W + (kk - 1);
+        return ok ? (((mm >> 5) * (sx ? KGx : KGh) + cg) * 512 + lofs + (mm & 31) * 8) * 2 : 0;
+      };
+      auto stage_j = [&](int st) { const int q = st < nxst ? st : st - nxst; return q - (q / 3) * 3; };
+      int c_j = stage_j(st_lo), c_cg = stage_cg(st_lo);
       f16x8 fa0, fa1;
       {
-        int o;
-        MV_A_OFF(c_isx, c_rowoff, c_cg, c_rowok, 0, o);
-        fa0 = MV_A_LD(c_isx, 0, o);
-        fa1 = MV_A_LD(c_isx, 1, o);
+        const int o = a_off(isx, c_cg, c_j, 0);
+        fa0 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(isx ? xrs0 : hrs0, o, 0, 0));
+        fa1 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(isx ? xrs1 : hrs1, o, 0, 0));
       }
       __syncthreads();
+      const f16x8* const lbase = lds + lane;           // + immediates only
       f16x8 b0[4], b1[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        b1[g] = lds[(4 + g) * 64 + lane];
-        b0[g] = lds[g * 64 + lane];
+        b1[g] = lbase[(4 + g) * 64];
+        b0[g] = lbase[g * 64];
       }
-      for (int sg = 0; sg < nsg; ++sg) {
-        f16x8* buf = lds + (sg & 1) * kBufVec;
-        const f16x8* nbuf = lds + ((sg + 1) & 1) * kBufVec;
-        const int st = st_lo + sg;
+      auto one_stage = [&](auto parity, int st) {
+        constexpr int kP = decltype(parity)::value;
+        constexpr int kCur = kP * kBufVec, kNxt = (1 - kP) * kBufVec;
         const int stn = st < st_last ? st + 1 : st_last;
         const int stnn = st + 2 < st_hi ? st + 2 : st_last;
-        const bool n_isx = stage_isx(stn);
-        const int n_rowoff = stage_rowoff(stn), n_cg = stage_cg(stn);
-        const bool n_rowok = stage_rowok(stn);
+        const bool n_isx = stn < nxst;
+        const int n_j = stage_j(stn), n_cg = stage_cg(stn);
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
 #pragma unroll
@@ -525,41 +533,45 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
           __builtin_amdgcn_sched_barrier(0);
           if (kk < 2) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b1[g] = buf[(((kk + 1) * 2 + 1) * 4 + g) * 64 + lane];
+            for (int g = 0; g < 4; ++g) b1[g] = lbase[kCur + (((kk + 1) * 2 + 1) * 4 + g) * 64];
           } else {
             __syncthreads();     // next stage landed; every wave has its B of this stage
-            stage_dma(stnn, buf);
+            dma3(stnn, lds + kCur);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b1[g] = nbuf[(4 + g) * 64 + lane];
+            for (int g = 0; g < 4; ++g) b1[g] = lbase[kNxt + (4 + g) * 64];
+            if (isx && !n_isx) cellv = hcell;          // the x stages are done (once per tile)
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          int o;
-          if (kk < 2) MV_A_OFF(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, o);
-          else MV_A_OFF(n_isx, n_rowoff, n_cg, n_rowok, 0, o);
-          fa0 = MV_A_LD(kk < 2 ? c_isx : n_isx, 0, o);
+          const bool lx = kk < 2 ? isx : n_isx;
+          const int o = kk < 2 ? a_off(isx, c_cg, c_j, kk + 1) : a_off(n_isx, n_cg, n_j, 0);
+          fa0 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(lx ? xrs0 : hrs0, o, 0, 0));
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, b0[g], acc[g], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          fa1 = MV_A_LD(kk < 2 ? c_isx : n_isx, 1, o);
+          fa1 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(lx ? xrs1 : hrs1, o, 0, 0));
           if (kk < 2) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b0[g] = buf[(((kk + 1) * 2 + 0) * 4 + g) * 64 + lane];
+            for (int g = 0; g < 4; ++g) b0[g] = lbase[kCur + (((kk + 1) * 2 + 0) * 4 + g) * 64];
           } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b0[g] = nbuf[g * 64 + lane];
+            for (int g = 0; g < 4; ++g) b0[g] = lbase[kNxt + g * 64];
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
+        isx = n_isx; c_j = n_j; c_cg = n_cg;
+      };
+      int sg = 0;
+      for (; sg + 1 < nsg; sg += 2) {
+        one_stage(std::integral_constant<int, 0>{}, st_lo + sg);
+        one_stage(std::integral_constant<int, 1>{}, st_lo + sg + 1);
       }
-#undef MV_A_OFF
-#undef MV_A_LD
+      if (sg < nsg) one_stage(std::integral_constant<int, 0>{}, st_lo + sg);
       __syncthreads();           // the epilogue reuses the stage buffers (carries vmcnt(0))
     } else
 #endif
@@ -692,16 +704,17 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     }
   } else {
   const int ch = cb * kChBlock + (lane_e & 31);
+    const int half = lane_e >> 5;
     // sparse x: the registers hold the INTERIOR class of the bias table
     const float* const b0 = a.sx_bias ? a.sx_bias + (size_t)4 * 4 * C : a.bias;
     const float bi = b0[ch], bj = b0[C + ch], bf = b0[2 * C + ch], bo = b0[3 * C + ch];
     _Float16* const tl = reinterpret_cast<_Float16*>(lds) + wave * (1024 * NPL);
-    // (image row, cell) of the wave's 32 cells without a division per register: the tile
-    // starts in image row r0 at cell0 and crosses at most one row boundary (HW >= 32 is
-    // not required: the wrap loop below runs HW-many cells at a time)
+    // The wave's 32 cells start in image r0 at cell0 and cross at most one image boundary
+    // (HW >= 32, host-checked for this kernel): rows >= wrap_at belong to image r0 + 1.
     const int r0 = __builtin_amdgcn_readfirstlane(m_wave / HW);
     const int cell0 = __builtin_amdgcn_readfirstlane(m_wave - r0 * HW);
-    // sparse x: hot cells of the (at most two, for HW >= 32) image rows of the tile
+    const int wrap_at = HW - cell0;
+    // sparse x: hot cells of the two images of the tile
     int hot_y[2] = {0, 0}, hot_x[2] = {0, 0};
     if (a.sx_corr) {
 #pragma unroll
@@ -713,45 +726,75 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         hot_y[k] = (int)(hyx >> 16); hot_x[k] = (int)(hyx & 0xffffu);
       }
     }
+    // ---- pass 1: every state load of the epilogue goes out BEFORE any of its stores.
+    // Written as one loop (load c, update, store c', h' per register) the 16 iterations ran
+    // one after the other -- a load cannot be hoisted over the previous iteration's stores
+    // -- so each waited out its own HBM round trip: the epilogue was 0.29 of the 1.03 ms
+    // launch (profiles/r3_ablation_gate_kernel_s1.md).  Buffer addressing throughout: rows
+    // past M_total fall outside num_records (loads return 0, stores are dropped), so there
+    // is no per-element bounds branch.  The whole byte offset sits in the VGPR operand: the
+    // hardware's range check does not look at the scalar offset.
+    // Source rows of the two images are looked up once, scalar.
+    int sr0 = r0, sr1 = r0 + 1;
+    if (a.src_row_c && !a.zero_state) {
+      sr0 = a.src_row_c[r0 < a.rows ? r0 : a.rows - 1];
+      sr1 = a.src_row_c[r0 + 1 < a.rows ? r0 + 1 : a.rows - 1];
+    }
+    sr0 = __builtin_amdgcn_readfirstlane(sr0);
+    sr1 = __builtin_amdgcn_readfirstlane(sr1);
+    const uint32_t rowb = (uint32_t)C * 4u;                         // bytes per cell
+    const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<float*>(a.zero_state ? a.c_out : a.c)), 0,
+        (uint32_t)M_total * (uint32_t)C * 4u, 0x00020000);
+    const uint32_t c_off0 = ((uint32_t)(sr0 * HW + cell0 + 4 * half) * (uint32_t)C + ch) * 4u;
+    const uint32_t c_wrap = (uint32_t)((sr1 - sr0 - 1) * HW) * rowb;   // added once wrapped
+    float cprev[16];
   #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane_e >> 5);
+      const int rc = (reg & 3) + 8 * (reg >> 2);
+      const bool wrapped = rc + 4 * half >= wrap_at;
+      cprev[reg] = 0.f;
+      if (!a.zero_state)
+        cprev[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            c_rs, (int)(c_off0 + (wrapped ? c_wrap : 0u) + (uint32_t)rc * rowb), 0, 0));
+    }
+    const uint32_t out_bytes = (uint32_t)M_total * rowb;
+    const __amdgpu_buffer_rsrc_t co_rs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(a.c_out), 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ho_rs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(a.h_out), 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t go_rs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(a.gates_out ? a.gates_out : a.h_out), 0, a.gates_out ? 4u * out_bytes : 0u,
+        0x00020000);
+    const uint32_t o_off0 = ((uint32_t)(m_wave + 4 * half) * (uint32_t)C + ch) * 4u;
+    const uint32_t wmagic = 0xFFFFFFFFu / (uint32_t)W + 1u;         // cell / W = umulhi(cell, wmagic)
+  #pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int rc = (reg & 3) + 8 * (reg >> 2);
+      const int row = rc + 4 * half;
       const int m = m_wave + row;
       float hn_keep = 0.f;                 // cells past the end: zero planes
-      if (m < M_total) {
-        int r = r0, cell = cell0 + row;
-        while (cell >= HW) { cell -= HW; ++r; }
-        float cprev = 0.f;
-        if (!a.zero_state) {
-          const int sr = a.src_row_c ? a.src_row_c[r] : r;
-          cprev = a.c[((size_t)sr * HW + cell) * C + ch];
-        }
+      {
         constexpr float kUn = NPL == 2 ? kF16Unscale : 1.0f;   // bf16 operands are unscaled
         float gi = acc[0][reg] * kUn, gj = acc[1][reg] * kUn, gf = acc[2][reg] * kUn,
               go = acc[3][reg] * kUn;
         if (a.sx_corr) {
-          const uint32_t yx = a.sx_cellyx[cell];
-          const int y = (int)(yx >> 16), x = (int)(yx & 0xffffu);
+          const bool wrapped = row >= wrap_at;
+          const int r = wrapped ? r0 + 1 : r0;
+          const int cell = cell0 + row - (wrapped ? HW : 0);
+          const int y = (int)__umulhi((uint32_t)cell, wmagic), x = cell - y * W;
           float ci = bi, cj = bj, cf = bf, co = bo;
           if (a.sx_bias) {
             const int cls = 3 * (y == 0 ? 0 : (y == H - 1 ? 2 : 1)) +
                             (x == 0 ? 0 : (x == W - 1 ? 2 : 1));
-            if (cls != 4) {
+            if (cls != 4 && m < M_total) {
               const float* bt = a.sx_bias + (size_t)cls * 4 * C + ch;
               ci = bt[0]; cj = bt[C]; cf = bt[2 * C]; co = bt[3 * C];
             }
           }
-          int hy, hx;
-          if (r - r0 < 2) {
-            hy = r == r0 ? hot_y[0] : hot_y[1];
-            hx = r == r0 ? hot_x[0] : hot_x[1];
-          } else {                          // HW < 32: more than two image rows in a tile
-            const int hr = a.sx_hot_div > 1 ? r / a.sx_hot_div : r;
-            const uint32_t hyx = a.sx_cellyx[a.sx_hot[(size_t)hr * a.sx_hot_stride]];
-            hy = (int)(hyx >> 16); hx = (int)(hyx & 0xffffu);
-          }
+          const int hy = wrapped ? hot_y[1] : hot_y[0], hx = wrapped ? hot_x[1] : hot_x[0];
           const int dy = y - hy, dx = x - hx, rad = a.sx_rad;
-          if (dy >= -rad && dy <= rad && dx >= -rad && dx <= rad) {
+          if (dy >= -rad && dy <= rad && dx >= -rad && dx <= rad && m < M_total) {
             const int side = 2 * rad + 1;
             const int idx = a.sx_by_class
                                 ? 3 * (hy == 0 ? 0 : (hy == H - 1 ? 2 : 1)) +
@@ -767,15 +810,23 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         }
         const float si = sigm_(gi), tj = tanh_(gj), sf = sigm_(gf + a.forget_bias),
                     so = sigm_(go);
-        float cn = sf * cprev;
+        float cn = sf * cprev[reg];
         cn = cn + si * tj;
         const float hn = tanh_(cn) * so;
-        a.c_out[(size_t)m * C + ch] = cn;
-        a.h_out[(size_t)m * C + ch] = hn;
-        hn_keep = hn;
+        const int o_off = (int)(o_off0 + (uint32_t)rc * rowb);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, cn), co_rs, o_off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hn), ho_rs, o_off, 0, 0);
+        hn_keep = m < M_total ? hn : 0.f;
         if (a.gates_out) {
-          float* gp = a.gates_out + (size_t)m * 4 * C + ch;
-          gp[0] = si; gp[C] = tj; gp[2 * C] = sf; gp[3 * C] = so;
+          const uint32_t g0 = ((uint32_t)(m_wave + row) * 4u * (uint32_t)C + ch) * 4u;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, si), go_rs,
+                                                (int)g0, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, tj), go_rs,
+                                                (int)(g0 + rowb), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, sf), go_rs,
+                                                (int)(g0 + 2 * rowb), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, so), go_rs,
+                                                (int)(g0 + 3 * rowb), 0, 0);
         }
       }
       if (p.h16_out) {

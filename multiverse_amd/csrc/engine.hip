@@ -687,6 +687,11 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     ConvCell* cc = cell_of_pack(e, a.wpack);
     mv::ConvLstm16Args& q = p16[i];
     const bool bf16 = e->compute_mode == 2;
+    // the kernel's epilogue lets a 32-cell wave tile span at most two images
+    MV_REQUIRE(a.H * a.W >= 32, "f16x3 / bf16 compute modes need grids of at least 32 cells "
+               "(%d x %d); use compute mode f32", a.H, a.W);
+    MV_REQUIRE((double)a.rows * a.H * a.W * a.C * 4.0 < 4294967296.0,
+               "f16x3 / bf16 compute modes: state tensor of %d rows exceeds 4 GB", a.rows);
     q.f = a;
     q.wp16 = bf16 ? cc->wpb.p : cc->wp16.p;
     q.wx32 = bf16 ? cc->wx32u.p : cc->wx32.p;

@@ -767,6 +767,9 @@ void comm_reduce_range(mv_engine* e, size_t off, size_t n) {
   mv::Comm* c = e->comm;
   if (!c || n == 0) return;
   TrainState& t = TS(e);
+  // a SimAug attack pass (mv_attack_*) wants d loss / d scene_feat only: the parameter
+  // gradients of that pass are never applied, so there is nothing to exchange
+  if (t.want_dscene) return;
   HIP_CHECK(hipEventRecord(c->ready, e->stream));
   HIP_CHECK(hipStreamWaitEvent(c->stream, c->ready, 0));
   float* p = t.grad.p + off;
@@ -792,7 +795,12 @@ void comm_reduce_rest_and_join(mv_engine* e) {
   mv::Comm* c = e->comm;
   if (!c) return;
   TrainState& t = TS(e);
+  if (t.want_dscene) return;           // attack pass: see comm_reduce_range
   std::vector<char> taken(e->params.size(), 0);
+  // parameters that exist without a gradient (--use_single_decoder: the regression
+  // encoder) are in no bucket and must not ride along in the "rest" group either
+  for (size_t i = 0; i < e->params.size(); ++i)
+    if (e->params[i]->no_grad) taken[i] = 1;
   for (int s = 0; s < e->cfg.num_scales; ++s) {
     ScaleState& S = e->sc[s];
     if (!S.use) continue;

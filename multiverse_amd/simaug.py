@@ -133,8 +133,8 @@ def white_box_attack(engine, cfg, feed, draws, norm_feat=False):
   engine.upload_targets(_attack_feed(feed, s, target))
   engine.attack_begin()                  # bounds come from the CLEAN features (:137-138)
 
-  def attack(start):
-    x0 = _softmax_last(start) if norm_feat else start                      # :143-144
+  def attack(start, normalise=norm_feat):
+    x0 = _softmax_last(start) if normalise else start                      # :143-144
     engine.set_scene_feat(x0)
     if cfg.adv_use_fgsm:                                                   # :146-147
       engine.train_forward_backward(None)
@@ -150,7 +150,8 @@ def white_box_attack(engine, cfg, feed, draws, norm_feat=False):
     if getattr(cfg, "mixup_mix_adv", False):
       assert cfg.adv_use_fgsm and cfg.adv_start_from_clean_prob < 1.0
       adv1 = engine.get_scene_feat()
-      attack(start_adv(clean, cfg, draws))
+      # the second view goes into one_step_attack WITHOUT the softmax (:162-163)
+      attack(start_adv(clean, cfg, draws), normalise=False)
       engine.scene_mix(adv1, 1.0 - weight)      # adv2 * w + adv1 * (1 - w)
     else:
       engine.scene_mix(None, weight)            # clean * w + adv * (1 - w)
