@@ -155,9 +155,22 @@ static inline void pack_convlstm_weights(const float* w, int Cx, int C, float* o
     }
 }
 
-// fp32 tanh / sigmoid from the ocml math library (1-2 ulp).
-__device__ __forceinline__ float tanh_(float v) { return tanhf(v); }
-__device__ __forceinline__ float sigm_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// fp32 sigmoid / tanh of the LSTM update on the hardware transcendentals: v_exp_f32 (2^x)
+// and v_rcp_f32 are 1 ulp each, so sigm_ is good to ~3 ulp and tanh_ to ~2e-7 ABSOLUTE
+// (the (1 - e) difference cancels for |v| << 1; gates and states are O(1) quantities held
+// to a 1e-4 absolute bar).  The ocml tanhf / expf / IEEE division they replace were ~400
+// VALU instructions per (cell, channel): with every workgroup of a round reaching its
+// epilogue at the same time that was 0.25 of the 0.98 ms gate launch
+// (profiles/r3_ablation_gate_kernel_s2.md).  Saturation: 2^(+big) = inf -> rcp = 0.
+__device__ __forceinline__ float sigm_(float v) {
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * v);       // e^-v
+  return __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float tanh_(float v) {
+  const float e = __builtin_amdgcn_exp2f(-2.8853900817779268f * __builtin_fabsf(v));  // e^-2|v|
+  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+  return __builtin_copysignf(t, v);
+}
 
 template <int NG>
 struct ConvFrag {
