@@ -31,7 +31,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include <type_traits>
 
 #include "convlstm_mfma.h"
 #include "plane_layout.h"
@@ -241,14 +240,15 @@ static inline unsigned split_planes_blocks(size_t M, int C) {
 //   2  no B LDS reads       (the fragments of the first k-step stay in their registers)
 //   4  no stage DMA, no per-stage barrier (every stage reads LDS buffer 0, filled once)
 //   8  no epilogue          (accumulators folded into one never-taken store)
+//  16  epilogue without the c state loads          32  without the c' / h' fp32 stores
+//  64  epilogue without the h' operand planes     128  without sigmoid / tanh (mul-adds)
 #ifndef MV_ABL
 #define MV_ABL 0
 #endif
-#ifndef MV_SCHED
-#define MV_SCHED 0          // 1: the explicitly software-pipelined stage loop (f16x3 forward)
-#endif
 constexpr bool kAblNoA = (MV_ABL & 1) != 0, kAblNoB = (MV_ABL & 2) != 0,
-               kAblNoDma = (MV_ABL & 4) != 0, kAblNoEpi = (MV_ABL & 8) != 0;
+               kAblNoDma = (MV_ABL & 4) != 0, kAblNoEpi = (MV_ABL & 8) != 0,
+               kAblNoCLoad = (MV_ABL & 16) != 0, kAblNoStore = (MV_ABL & 32) != 0,
+               kAblNoPlanes = (MV_ABL & 64) != 0, kAblNoMath = (MV_ABL & 128) != 0;
 constexpr int kWaves16 = MV_CONV_WAVES;           // waves per workgroup of the f16x3 kernels
 constexpr int kThreads16 = kWaves16 * 64;
 constexpr int kBlockRows16 = kWaves16 * kWaveRows; // cells per workgroup
@@ -458,123 +458,6 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     };
     // LDS stages of R row units each; (st_hi - st_lo) % R == 0 (host-checked for bf16)
     const int nsg = (st_hi - st_lo) / R;
-#if MV_SCHED
-    if constexpr (NPL == 2 && NG == 4 && MV_ABL == 0) {
-      // Explicitly software-pipelined stage loop.  hipcc's own schedule of the loop below
-      // reads the B fragments of a k-step two at a time right in front of the MFMAs that
-      // consume them (every wave parks on lgkmcnt four to six times per k-step) and drains
-      // vmcnt to ZERO at the head of the third k-step because the stage DMA sits in a
-      // conditional.  Here a k-step is three groups of four MFMAs, every operand is
-      // refilled IN PLACE right behind the group that used it last, one to two groups
-      // (128-256 matrix-pipe cycles of this wave, plus the other waves' turns) before its
-      // next use:
-      //     G1  a0 b1[g]     then  b1 <- next k-step
-      //     G2  a0 b0[g]     then  a0 <- next k-step
-      //     G3  a1 b0[g]     then  a1, b0 <- next k-step
-      // 8 B + 2 A fragments of registers, no second register set.  The stage barrier sits
-      // behind G1 of the third k-step (all B reads of the stage have returned by then);
-      // right behind it the DMA of the stage AFTER next goes into the buffer just retired,
-      // a whole stage ahead of its first read, and unconditionally (past the end it
-      // refetches the last stage), so that vmcnt stays countable.
-      // The loop body is TWO stages (LDS buffer 0, then 1), so every ds_read is one base
-      // register (lane * 16) + an immediate; a stage names its stencil row j and the
-      // x / h side of its operand once, scalar; the cell index of the lane is one register
-      // (xcell until the x stages are done, then recomputed).
-      static_assert(kSV % kThreads16 == 0 || MV_SCHED == 0, "whole DMA pieces per thread");
-      const int st_last = st_hi - 1;
-      const uint32_t dvoff = (uint32_t)(wave_u * 64 + lane) * 16u;   // piece i: + i * 8 KB
-      auto dma3 = [&](int st, f16x8* dstbuf) {
-#pragma unroll
-        for (int i = 0; i < kSV / kThreads16; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(
-              wrs, (__attribute__((address_space(3))) void*)(dstbuf + (i * kWaves16 + wave_u) * 64),
-              16, dvoff, (uint32_t)st * kUnitBytes + (uint32_t)i * (kThreads16 * 16u), 0, 0);
-      };
-      dma3(st_lo, lds);
-      dma3(st_lo + 1 < st_hi ? st_lo + 1 : st_last, lds + kBufVec);
-      // operand side of the current stage: V# pair, channel groups per tile, lane's cell
-      bool isx = st_lo < nxst;
-      int cellv = isx ? xcell : hcell;                // the one per-lane cell register
-      const int lofs = khalf + kPlanePad;             // per-lane constant of the plane offset
-      auto a_off = [&](bool sx, int cg, int j, int kk) -> int {
-        // tap (j, kk) of the lane's cell: plane byte offset, 0 (the zero pad) when outside
-        const bool ok = (((okymask >> j) & 1) != 0) & (kk == 0 ? okx0 : (kk == 1 ? okx1 : okx2));
-        const int mm = cellv + (j - 1) * W + (kk - 1);
-        return ok ? (((mm >> 5) * (sx ? KGx : KGh) + cg) * 512 + lofs + (mm & 31) * 8) * 2 : 0;
-      };
-      auto stage_j = [&](int st) { const int q = st < nxst ? st : st - nxst; return q - (q / 3) * 3; };
-      int c_j = stage_j(st_lo), c_cg = stage_cg(st_lo);
-      f16x8 fa0, fa1;
-      {
-        const int o = a_off(isx, c_cg, c_j, 0);
-        fa0 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(isx ? xrs0 : hrs0, o, 0, 0));
-        fa1 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(isx ? xrs1 : hrs1, o, 0, 0));
-      }
-      __syncthreads();
-      const f16x8* const lbase = lds + lane;           // + immediates only
-      f16x8 b0[4], b1[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        b1[g] = lbase[(4 + g) * 64];
-        b0[g] = lbase[g * 64];
-      }
-      auto one_stage = [&](auto parity, int st) {
-        constexpr int kP = decltype(parity)::value;
-        constexpr int kCur = kP * kBufVec, kNxt = (1 - kP) * kBufVec;
-        const int stn = st < st_last ? st + 1 : st_last;
-        const int stnn = st + 2 < st_hi ? st + 2 : st_last;
-        const bool n_isx = stn < nxst;
-        const int n_j = stage_j(stn), n_cg = stage_cg(stn);
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b1[g], acc[g], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (kk < 2) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b1[g] = lbase[kCur + (((kk + 1) * 2 + 1) * 4 + g) * 64];
-          } else {
-            __syncthreads();     // next stage landed; every wave has its B of this stage
-            dma3(stnn, lds + kCur);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b1[g] = lbase[kNxt + (4 + g) * 64];
-            if (isx && !n_isx) cellv = hcell;          // the x stages are done (once per tile)
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          const bool lx = kk < 2 ? isx : n_isx;
-          const int o = kk < 2 ? a_off(isx, c_cg, c_j, kk + 1) : a_off(n_isx, n_cg, n_j, 0);
-          fa0 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(lx ? xrs0 : hrs0, o, 0, 0));
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, b0[g], acc[g], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          fa1 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(lx ? xrs1 : hrs1, o, 0, 0));
-          if (kk < 2) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b0[g] = lbase[kCur + (((kk + 1) * 2 + 0) * 4 + g) * 64];
-          } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b0[g] = lbase[kNxt + g * 64];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        isx = n_isx; c_j = n_j; c_cg = n_cg;
-      };
-      int sg = 0;
-      for (; sg + 1 < nsg; sg += 2) {
-        one_stage(std::integral_constant<int, 0>{}, st_lo + sg);
-        one_stage(std::integral_constant<int, 1>{}, st_lo + sg + 1);
-      }
-      if (sg < nsg) one_stage(std::integral_constant<int, 0>{}, st_lo + sg);
-      __syncthreads();           // the epilogue reuses the stage buffers (carries vmcnt(0))
-    } else
-#endif
     {
     stage_dma(st_lo, lds);
     bool c_isx = stage_isx(st_lo);
@@ -754,7 +637,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       const int rc = (reg & 3) + 8 * (reg >> 2);
       const bool wrapped = rc + 4 * half >= wrap_at;
       cprev[reg] = 0.f;
-      if (!a.zero_state)
+      if (!a.zero_state && !kAblNoCLoad)
         cprev[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
             c_rs, (int)(c_off0 + (wrapped ? c_wrap : 0u) + (uint32_t)rc * rowb), 0, 0));
     }
@@ -808,14 +691,21 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         } else {
           gi += bi; gj += bj; gf += bf; go += bo;
         }
-        const float si = sigm_(gi), tj = tanh_(gj), sf = sigm_(gf + a.forget_bias),
-                    so = sigm_(go);
+        float si, tj, sf, so;
+        if constexpr (kAblNoMath) {
+          si = gi * 0.25f + 0.5f; tj = gj * 0.5f; sf = gf * 0.25f + 0.5f; so = go * 0.25f + 0.5f;
+        } else {
+          si = sigm_(gi); tj = tanh_(gj); sf = sigm_(gf + a.forget_bias); so = sigm_(go);
+        }
         float cn = sf * cprev[reg];
         cn = cn + si * tj;
-        const float hn = tanh_(cn) * so;
+        const float hn = (kAblNoMath ? cn * 0.5f : tanh_(cn)) * so;
         const int o_off = (int)(o_off0 + (uint32_t)rc * rowb);
+        if (!kAblNoStore || cn == 12345.678f) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, cn), co_rs, o_off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hn), ho_rs, o_off, 0, 0);
+        if (!a.skip_h32)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hn), ho_rs, o_off, 0, 0);
+        }
         hn_keep = m < M_total ? hn : 0.f;
         if (a.gates_out) {
           const uint32_t g0 = ((uint32_t)(m_wave + row) * 4u * (uint32_t)C + ch) * 4u;
@@ -829,7 +719,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
                                                 (int)(g0 + 3 * rowb), 0, 0);
         }
       }
-      if (p.h16_out) {
+      if (p.h16_out && !kAblNoPlanes) {
         // operand planes of h' for the next step: the wave's 32 cells x 32 channels are
         // two plane tiles (32 cells x 16 channels, [k half][cell][8 ch]); a lane holds
         // ONE channel of 16 cells, so the tile is assembled in LDS (the weight stage
@@ -849,7 +739,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         }
       }
     }
-    if (p.h16_out) {
+    if (p.h16_out && !kAblNoPlanes) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS ops of a wave retire in order
       const size_t tile0 = ((size_t)(m_wave >> 5) * (size_t)(C >> 4) + (size_t)cb * 2) * 512;
 #pragma unroll

@@ -81,6 +81,9 @@ struct ConvLstmArgs {
   float forget_bias;
   int32_t want_h16;     // host-side hint (f16x3 mode): the next consumer of h' is a gate
                         // convolution, emit its operand planes from the epilogue
+  int32_t skip_h32;     // f16x3 / bf16 inference: NOTHING reads the fp32 h' of this step (its
+                        // only consumer is the next gate convolution, through the planes):
+                        // the epilogue does not store it (encoder steps)
   // --- sparse x (f16x3 / bf16 inference, class chains).  The x operand of the class
   // encoder is zero except at ONE cell per row, the class decoder's is a constant
   // vector except within one cell of the hot cell: their k-steps (20 % / 11 % of the

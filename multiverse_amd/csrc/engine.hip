@@ -720,6 +720,7 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
         q.h16_out_stride = (int64_t)pst;
       }
     }
+    q.f.skip_h32 = (a.skip_h32 && q.h16_out && !e->train) ? 1 : 0;
     auto ready = [&](const float* src) -> const mv_engine::PlaneBuf* {
       auto it = e->planes.find(src);
       return (it != e->planes.end() && it->second.valid) ? &it->second : nullptr;
@@ -880,6 +881,9 @@ void run_encoders(mv_engine* e, Cursors& cur) {
                                    S.cls_c[cc].p, nullptr, nullptr, S.cls_h[cc ^ 1].p,
                                    S.cls_c[cc ^ 1].p, N, S.H, S.W, t == 0, 0,
                                    /*want_h16=*/t + 1 < T || !c.use_gnn));
+      // the class encoder's h' is read as fp32 only by the graph attention in front of the
+      // first decoder step; the regression encoder's never
+      probs.back().skip_h32 = (t + 1 < T || !c.use_gnn) ? 1 : 0;
       if (sparse) {
         set_sparse_x(e, S, probs.back(), false, S.labels.p + t, T, 1);
         probs.back().sx_corr = S.sx_enc_corr.p + (size_t)t * nc;
@@ -889,6 +893,7 @@ void run_encoders(mv_engine* e, Cursors& cur) {
                                      S.reg_h[cr].p, S.reg_c[cr].p, nullptr, nullptr,
                                      S.reg_h[cr ^ 1].p, S.reg_c[cr ^ 1].p, N, S.H, S.W,
                                      t == 0, (size_t)T * row));
+      if (!c.use_single_decoder) probs.back().skip_h32 = 1;
       cur.cls[s] ^= 1; cur.reg[s] ^= 1;
     }
     run_conv_group(e, probs);

@@ -247,15 +247,28 @@ def test_sparse_x_table_terms_equal_the_dense_x_operand(built_lib, tmp_path):
     eng.close()
     assert "sx_encoder_corr" in stats and "enc_class_input" not in stats
     assert stats["convlstm_step"]["flops"] < 0.93 * stats["convlstm_step"]["flops_dense"]
-    worst = 0.0
+    worst, flipped = 0.0, 0
     for s in range(2):
-      d = float(np.abs(cls[s] - dense["%s_cls%d" % (mode, s)]).max())
-      scale = float(np.abs(dense["%s_cls%d" % (mode, s)]).max())
-      worst = max(worst, d / scale)
-      assert d <= tol * scale, (mode, s, d, scale)
+      ref = dense["%s_cls%d" % (mode, s)]
+      scale = float(np.abs(ref).max())
+      gi = cls[s].reshape(3, cfg.pred_len, -1).argmax(-1)
+      ri = ref.reshape(3, cfg.pred_len, -1).argmax(-1)
+      if mode == "f16x3":
+        assert (gi == ri).all()
+      # bf16 carries ~1e-2 relative noise per logit: where two runs of it pick different cells
+      # the decoder feedback sends the trajectories apart, so a row is compared up to and
+      # including its first differing step (the argmax audit of the mode itself is
+      # tests/test_gpu_bf16.py); at most one of the six rows may branch off
+      for n in range(3):
+        bad = np.nonzero(gi[n] != ri[n])[0]
+        upto = (bad[0] + 1) if bad.size else cfg.pred_len
+        flipped += int(bad.size > 0)
+        d = float(np.abs(cls[s][n, :upto] - ref[n, :upto]).max())
+        worst = max(worst, d / scale)
+        assert d <= tol * scale, (mode, s, n, d, scale)
+      # the regression chain is not fed by the class decoder's choices
       assert np.abs(reg[s] - dense["%s_reg%d" % (mode, s)]).max() <= tol * max(
           1.0, float(np.abs(dense["%s_reg%d" % (mode, s)]).max()))
-      if mode == "f16x3":
-        assert (cls[s].reshape(3, cfg.pred_len, -1).argmax(-1) ==
-                dense["%s_cls%d" % (mode, s)].reshape(3, cfg.pred_len, -1).argmax(-1)).all()
-    print("%s: sparse-x vs dense-x class logits, max rel diff %.2e" % (mode, worst))
+    assert flipped <= (0 if mode == "f16x3" else 1), (mode, flipped)
+    print("%s: sparse-x vs dense-x class logits, max rel diff %.2e, rows branched %d"
+          % (mode, worst, flipped))

@@ -165,3 +165,32 @@ def test_in_library_rccl_allreduce_world1_is_the_identity(built_lib):
     eng.close()
   for n in outs[0]:
     assert (outs[0][n] == outs[1][n]).all(), n
+
+
+def test_bench_spawns_its_own_ranks(built_lib):
+  """`python bench.py --gpus 2` with NO launcher: bench.py starts the two ranks itself
+  (torch.distributed.run on 127.0.0.1) and relays ONE JSON line whose `value` is the
+  whole-job rate and whose training sub-object ran the data-parallel step on both ranks.
+  MV_BENCH_BACKEND=gloo lets the ranks share the single GPU of the test box (RCCL refuses
+  two ranks on one device; on a 2-GPU box the same command runs over RCCL and reports
+  rccl_ranks = 2)."""
+  import json
+  import subprocess
+  env = dict(os.environ, MV_BENCH_BACKEND="gloo")
+  env.pop("WORLD_SIZE", None)
+  env.pop("RANK", None)
+  out = subprocess.check_output(
+      [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+       "--warmup", "1", "--no-fp32-ref", "--only-sub", "train_n32"],
+      env=env, timeout=900)
+  lines = [l for l in out.decode().splitlines() if l.strip()]
+  assert len(lines) == 1, lines
+  d = json.loads(lines[0])
+  assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+  assert d["config"]["global_batch"] == 2 * d["config"]["batch_per_gpu"] == 128
+  assert d["value"] > 0 and abs(d["value"] - 128 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-2 * d["value"]
+  t = d["train_n32"]
+  assert "error" not in t, t
+  assert t["global_batch"] == 64 and t["value"] > 0
+  assert t["rccl_ranks"] == 0          # gloo here; 2 over RCCL on a 2-GPU box
+  assert "host_path" not in d and "cpu_baseline" not in d     # rank 0 at N = 1 only
