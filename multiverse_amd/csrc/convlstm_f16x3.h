@@ -245,6 +245,18 @@ static inline unsigned split_planes_blocks(size_t M, int C) {
 #ifndef MV_ABL
 #define MV_ABL 0
 #endif
+// Cache policy of the three streams (gfx940+ aux bits of the buffer builtins: 1 = sc0,
+// 2 = nt, 16 = sc1): the weight stage DMA, the epilogue's read-once c state and its
+// write-once c' / h' / gate stores.  Tuned per DESIGN.md section 5.
+#ifndef MV_DMA_AUX
+#define MV_DMA_AUX 0
+#endif
+#ifndef MV_EPI_LD_AUX
+#define MV_EPI_LD_AUX 0
+#endif
+#ifndef MV_EPI_ST_AUX
+#define MV_EPI_ST_AUX 0
+#endif
 constexpr bool kAblNoA = (MV_ABL & 1) != 0, kAblNoB = (MV_ABL & 2) != 0,
                kAblNoDma = (MV_ABL & 4) != 0, kAblNoEpi = (MV_ABL & 8) != 0,
                kAblNoCLoad = (MV_ABL & 16) != 0, kAblNoStore = (MV_ABL & 32) != 0,
@@ -262,7 +274,7 @@ constexpr int kStageVec = kKpb * 2 * 4 * 64;     // f16x8 elements per stage (kK
 // 1 = bf16 (ONE bf16 plane of v itself, one v_mfma_f32_32x32x16_bf16 per product, fp32
 // accumulate: the reduced-precision mode of BASELINE.json configs[4]; plane buffers and
 // packs hold bf16 bit patterns in the same 16-bit containers, same tile layout).
-template <int EPI, int NG, int NPL = 2>
+template <int EPI, int NG, int NPL = 2, bool SHIFT = false>
 __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int cb, int mt,
                                                     int kslice, int n_kslice,
                                                     f16x8* lds /* [2][kKpb * NPL * 4 * 64] */) {
@@ -453,7 +465,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         if (kSV % kThreads16 == 0 || v0 < kSV)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(
               wrs, (__attribute__((address_space(3))) void*)(dstbuf + v0), 16, dma_voff[i],
-              (uint32_t)st * kUnitBytes, 0, 0);
+              (uint32_t)st * kUnitBytes, 0, MV_DMA_AUX);
       }
     };
     // LDS stages of R row units each; (st_hi - st_lo) % R == 0 (host-checked for bf16)
@@ -463,15 +475,28 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     bool c_isx = stage_isx(st_lo);
     int c_rowoff = stage_rowoff(st_lo), c_cg = stage_cg(st_lo);
     bool c_rowok = stage_rowok(st_lo);
-    f16x8 fa0, fa1;
-    MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 0, fa0, fa1);
-    // bf16 (one MFMA per product): a k-step is 128 matrix-pipe cycles instead of 384; requesting
-    // the operand TWO k-steps ahead (MV_BF16_ADIST=2, 4 more VGPRs) was measured 1.5 % SLOWER
-    // (0.526 vs 0.518 ms per launch): operand latency is not what holds the bf16 kernel at
-    // MFMA busy 0.37 either.
-    constexpr bool kA2 = (NPL == 1) && (MV_BF16_ADIST == 2);
-    f16x8 fb0, fb1;
-    if constexpr (kA2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 1, fb0, fb1);
+    // A operands.  The three k-steps of a stencil row read the SAME 32 x 16 tile of the lane's
+    // plane shifted by one cell (dx = -1, 0, +1).  SHIFT (every W of the launch divides 32, so
+    // a tile never ends inside an image row: lane 0 / 31 of a k half is x == 0 / W - 1, a
+    // masked tap anyway): only the centre fragment is loaded, one stage ahead; the dx = -/+1
+    // fragments are the centre moved one lane up / down the wave (v_mov_b32_dpp wave_shr:1 /
+    // wave_shl:1) and zeroed where the neighbour is outside the image row -- one third of
+    // the operand requests, issued a whole stage (36 MFMAs) before their use.  Other widths
+    // load every tap, one k-step ahead (cc = the fragments of the NEXT k-step there).
+    auto lane_shift = [&](const f16x8& v, bool up, bool ok) -> f16x8 {
+      const u32x4 w = __builtin_bit_cast(u32x4, v);
+      u32x4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t t = up ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[j], 0x138, 0xf, 0xf, false)
+                              : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[j], 0x130, 0xf, 0xf, false);
+        r[j] = ok ? t : 0u;
+      }
+      return __builtin_bit_cast(f16x8, r);
+    };
+    f16x8 cc0, cc1;                        // SHIFT: centre fragments of the current stage
+    MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, SHIFT ? 1 : 0, cc0, cc1);
+    if constexpr (NPL == 1) cc1 = cc0;
     __syncthreads();                       // carries the vmcnt(0) of the pending LDS-DMA
     f16x8 ab0[NG], ab1[NG];                // MV_ABL & 2 only
     if constexpr (kAblNoB) {
@@ -491,17 +516,29 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       const bool n_isx = stage_isx(stn);
       const int n_rowoff = stage_rowoff(stn), n_cg = stage_cg(stn);
       const bool n_rowok = stage_rowok(stn);
+      f16x8 cn0, cn1;                      // SHIFT: centre fragments of the next stage
+      if constexpr (SHIFT) {
+        if constexpr (kAblNoA) { cn0 = cc0; cn1 = cc1; }
+        else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 1, cn0, cn1);   // (re-read at the very end)
+        if constexpr (NPL == 1) cn1 = cn0;
+      }
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
         const int kq = u * 3 + kk;         // k-step inside the LDS stage
-        f16x8 fn0, fn1;
-        if constexpr (kA2) {               // the k-step after next
-          if (kk == 0) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, 2, fn0, fn1);
-          else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, kk - 1, fn0, fn1);
+        f16x8 fa0, fa1;
+        if constexpr (SHIFT) {
+          if (kk == 1) { fa0 = cc0; fa1 = cc1; }
+          else {
+            const bool okx = kk == 0 ? okx0 : okx2;
+            fa0 = lane_shift(cc0, kk == 0, okx);
+            if constexpr (NPL == 2) fa1 = lane_shift(cc1, kk == 0, okx);
+          }
         } else {
-        if constexpr (kAblNoA) { fn0 = fa0; fn1 = fa1; }
-        else if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, fn0, fn1);
-        else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 0, fn0, fn1);   // (re-read at the very end)
+          fa0 = cc0; fa1 = cc1;            // loaded one k-step ago
+          if constexpr (!kAblNoA) {
+            if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, cc0, cc1);
+            else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 0, cc0, cc1);
+          }
         }
         // the DMA of the next stage goes out behind the first k-step's operands (vmcnt
         // retires in order); its target buffer was last read before the previous barrier
@@ -534,9 +571,8 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
                 __builtin_bit_cast(bf16x8, fa0), __builtin_bit_cast(bf16x8, b0[g]), acc[g], 0,
                 0, 0);
         }
-        if constexpr (kA2) { fa0 = fb0; fb0 = fn0; }
-        else { fa0 = fn0; fa1 = fn1; }
       }
+      if constexpr (SHIFT) { cc0 = cn0; cc1 = cn1; }
       c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
       }
       if constexpr (!kAblNoDma) __syncthreads();
@@ -639,7 +675,8 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       cprev[reg] = 0.f;
       if (!a.zero_state && !kAblNoCLoad)
         cprev[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-            c_rs, (int)(c_off0 + (wrapped ? c_wrap : 0u) + (uint32_t)rc * rowb), 0, 0));
+            c_rs, (int)(c_off0 + (wrapped ? c_wrap : 0u) + (uint32_t)rc * rowb), 0,
+            MV_EPI_LD_AUX));
     }
     const uint32_t out_bytes = (uint32_t)M_total * rowb;
     const __amdgpu_buffer_rsrc_t co_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -702,21 +739,21 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         const float hn = (kAblNoMath ? cn * 0.5f : tanh_(cn)) * so;
         const int o_off = (int)(o_off0 + (uint32_t)rc * rowb);
         if (!kAblNoStore || cn == 12345.678f) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, cn), co_rs, o_off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, cn), co_rs, o_off, 0, MV_EPI_ST_AUX);
         if (!a.skip_h32)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hn), ho_rs, o_off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hn), ho_rs, o_off, 0, MV_EPI_ST_AUX);
         }
         hn_keep = m < M_total ? hn : 0.f;
         if (a.gates_out) {
           const uint32_t g0 = ((uint32_t)(m_wave + row) * 4u * (uint32_t)C + ch) * 4u;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, si), go_rs,
-                                                (int)g0, 0, 0);
+                                                (int)g0, 0, MV_EPI_ST_AUX);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, tj), go_rs,
-                                                (int)(g0 + rowb), 0, 0);
+                                                (int)(g0 + rowb), 0, MV_EPI_ST_AUX);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, sf), go_rs,
-                                                (int)(g0 + 2 * rowb), 0, 0);
+                                                (int)(g0 + 2 * rowb), 0, MV_EPI_ST_AUX);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, so), go_rs,
-                                                (int)(g0 + 3 * rowb), 0, 0);
+                                                (int)(g0 + 3 * rowb), 0, MV_EPI_ST_AUX);
         }
       }
       if (p.h16_out && !kAblNoPlanes) {
@@ -752,6 +789,15 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   }
 }
 
+// SHIFT form of the step kernels: every problem's W divides 32 (MV_CONV_SHIFT=0: never)
+static inline bool conv_group_shift(const ConvLstm16Args* probs, int n) {
+  static const bool off = getenv("MV_CONV_SHIFT") && atoi(getenv("MV_CONV_SHIFT")) == 0;
+  if (off) return false;
+  for (int i = 0; i < n; ++i)
+    if (probs[i].f.W <= 0 || 32 % probs[i].f.W != 0) return false;
+  return true;
+}
+
 // block -> (column block cb, row tile mt) of the forward step.  A workgroup reads the
 // operand planes of its 256 cells and ONE column block's weights.
 //   mode 0  cb = block % 8: a column block per XCD -- its L2 keeps that block's 1.3 MB of
@@ -779,6 +825,7 @@ __device__ __forceinline__ bool step_block_map(const ConvLstmArgs& a, int block,
 #ifndef MV_CONV_MINWAVES
 #define MV_CONV_MINWAVES (MV_CONV_WAVES == 8 ? 4 : 2)
 #endif
+template <bool SHIFT>
 __global__ __launch_bounds__(kThreads16, MV_CONV_MINWAVES)
 void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
   __shared__ f16x8 lds[2 * kStageVec];
@@ -790,14 +837,15 @@ void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
   if (pi > 0) block -= g.block_end[pi - 1];
   int cb, mt;
   switch (pi) {
-    case 0: if (step_block_map(g.p[0].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4>(g.p[0], cb, mt, 0, 1, lds); break;
-    case 1: if (step_block_map(g.p[1].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4>(g.p[1], cb, mt, 0, 1, lds); break;
-    case 2: if (step_block_map(g.p[2].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4>(g.p[2], cb, mt, 0, 1, lds); break;
-    default: if (step_block_map(g.p[3].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4>(g.p[3], cb, mt, 0, 1, lds); break;
+    case 0: if (step_block_map(g.p[0].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 2, SHIFT>(g.p[0], cb, mt, 0, 1, lds); break;
+    case 1: if (step_block_map(g.p[1].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 2, SHIFT>(g.p[1], cb, mt, 0, 1, lds); break;
+    case 2: if (step_block_map(g.p[2].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 2, SHIFT>(g.p[2], cb, mt, 0, 1, lds); break;
+    default: if (step_block_map(g.p[3].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 2, SHIFT>(g.p[3], cb, mt, 0, 1, lds); break;
   }
 }
 
 // The same step with ONE bf16 plane per operand (compute mode 2, BASELINE configs[4]).
+template <bool SHIFT>
 __global__ __launch_bounds__(kThreads16, MV_CONV_MINWAVES)
 void convlstm_step_bf16_kernel(const ConvLstm16Group g) {
   __shared__ f16x8 lds[MV_BF16_UNITS * kStageVec];   // 2 buffers x (units x 3 k-steps) x 4 KB
@@ -809,10 +857,10 @@ void convlstm_step_bf16_kernel(const ConvLstm16Group g) {
   if (pi > 0) block -= g.block_end[pi - 1];
   int cb, mt;
   switch (pi) {
-    case 0: if (step_block_map(g.p[0].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[0], cb, mt, 0, 1, lds); break;
-    case 1: if (step_block_map(g.p[1].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[1], cb, mt, 0, 1, lds); break;
-    case 2: if (step_block_map(g.p[2].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[2], cb, mt, 0, 1, lds); break;
-    default: if (step_block_map(g.p[3].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1>(g.p[3], cb, mt, 0, 1, lds); break;
+    case 0: if (step_block_map(g.p[0].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT>(g.p[0], cb, mt, 0, 1, lds); break;
+    case 1: if (step_block_map(g.p[1].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT>(g.p[1], cb, mt, 0, 1, lds); break;
+    case 2: if (step_block_map(g.p[2].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT>(g.p[2], cb, mt, 0, 1, lds); break;
+    default: if (step_block_map(g.p[3].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT>(g.p[3], cb, mt, 0, 1, lds); break;
   }
 }
 
@@ -867,6 +915,7 @@ static inline void launch_convlstm_bf16_steps(const ConvLstm16Args* probs, int n
 // dgrad on the fp16 matrix pipe: d[h | x] = conv3x3(G, W^T flipped) with G as two
 // fp16 planes under a per-tensor power-of-two scale (split_planes_dyn_kernel) and
 // the transposed, tap-flipped kernel as planes (pack_f16x3_dgrad_kernel).
+template <bool SHIFT>
 __device__ __forceinline__ void convlstm16_dgrad_dispatch(const ConvLstm16Args& p, int block,
                                                           f16x8* lds) {
   // block -> (column block, k slice, row tile).  Full-width column blocks first,
@@ -891,13 +940,14 @@ __device__ __forceinline__ void convlstm16_dgrad_dispatch(const ConvLstm16Args& 
     cb = ncb - 1; ks = b2 % nks; mt = b2 / nks;
   }
   if (cb == ncb - 1 && p.f.ng_last == 1)
-    convlstm16_lds_body<kEpiStore, 1>(p, cb, mt, ks, nks, lds);
+    convlstm16_lds_body<kEpiStore, 1, 2, SHIFT>(p, cb, mt, ks, nks, lds);
   else if (cb == ncb - 1 && p.f.ng_last == 2)
-    convlstm16_lds_body<kEpiStore, 2>(p, cb, mt, ks, nks, lds);
+    convlstm16_lds_body<kEpiStore, 2, 2, SHIFT>(p, cb, mt, ks, nks, lds);
   else
-    convlstm16_lds_body<kEpiStore, 4>(p, cb, mt, ks, nks, lds);
+    convlstm16_lds_body<kEpiStore, 4, 2, SHIFT>(p, cb, mt, ks, nks, lds);
 }
 
+template <bool SHIFT>
 __global__ __launch_bounds__(kThreads16, MV_CONV_MINWAVES)
 void convlstm_dgrad_f16x3_kernel(const ConvLstm16Group g) {
   __shared__ f16x8 lds[2 * kStageVec];
@@ -908,10 +958,10 @@ void convlstm_dgrad_f16x3_kernel(const ConvLstm16Group g) {
     if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
   if (pi > 0) block -= g.block_end[pi - 1];
   switch (pi) {
-    case 0: convlstm16_dgrad_dispatch(g.p[0], block, lds); break;
-    case 1: convlstm16_dgrad_dispatch(g.p[1], block, lds); break;
-    case 2: convlstm16_dgrad_dispatch(g.p[2], block, lds); break;
-    default: convlstm16_dgrad_dispatch(g.p[3], block, lds); break;
+    case 0: convlstm16_dgrad_dispatch<SHIFT>(g.p[0], block, lds); break;
+    case 1: convlstm16_dgrad_dispatch<SHIFT>(g.p[1], block, lds); break;
+    case 2: convlstm16_dgrad_dispatch<SHIFT>(g.p[2], block, lds); break;
+    default: convlstm16_dgrad_dispatch<SHIFT>(g.p[3], block, lds); break;
   }
 }
 
@@ -942,7 +992,10 @@ static inline void launch_convlstm16_dgrads(const ConvLstm16Args* probs, int n,
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
-  hipLaunchKernelGGL(convlstm_dgrad_f16x3_kernel, dim3(total), dim3(kThreads16), 0, stream, g);
+  if (conv_group_shift(probs, n))
+    hipLaunchKernelGGL(convlstm_dgrad_f16x3_kernel<true>, dim3(total), dim3(kThreads16), 0, stream, g);
+  else
+    hipLaunchKernelGGL(convlstm_dgrad_f16x3_kernel<false>, dim3(total), dim3(kThreads16), 0, stream, g);
 }
 
 // out[seg][i] = sum over the k slices (in slice order) of part[seg][s][i]
@@ -1055,7 +1108,10 @@ static inline void launch_convlstm_bf16_steps(const ConvLstm16Args* probs, int n
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
-  hipLaunchKernelGGL(convlstm_step_bf16_kernel, dim3(total), dim3(kThreads16), 0, stream, g);
+  if (conv_group_shift(probs, n))
+    hipLaunchKernelGGL(convlstm_step_bf16_kernel<true>, dim3(total), dim3(kThreads16), 0, stream, g);
+  else
+    hipLaunchKernelGGL(convlstm_step_bf16_kernel<false>, dim3(total), dim3(kThreads16), 0, stream, g);
 }
 
 static inline void launch_convlstm16_steps(const ConvLstm16Args* probs, int n,
@@ -1070,7 +1126,10 @@ static inline void launch_convlstm16_steps(const ConvLstm16Args* probs, int n,
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
-  hipLaunchKernelGGL(convlstm_step_f16x3_lds_kernel, dim3(total), dim3(kThreads16), 0, stream, g);
+  if (conv_group_shift(probs, n))
+    hipLaunchKernelGGL(convlstm_step_f16x3_lds_kernel<true>, dim3(total), dim3(kThreads16), 0, stream, g);
+  else
+    hipLaunchKernelGGL(convlstm_step_f16x3_lds_kernel<false>, dim3(total), dim3(kThreads16), 0, stream, g);
 }
 
 }  // namespace mv
