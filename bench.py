@@ -490,7 +490,9 @@ def host_path(compute, batch=64):
     eng.synchronize()
   out["resident_inputs"] = round(rate(resident), 1)
   out["host_buffers_dense"] = round(rate(lambda: eng.forward_greedy(feed)), 1)
-  out["host_buffers_compact"] = round(rate(lambda: eng.forward_greedy_compact(feed)), 1)
+  # the compact feed carries the scene masks as the npz holds them: uint8 (preprocess.py:831)
+  cfeed = dict(feed, scene_feat=feed["scene_feat_u8"])
+  out["host_buffers_compact"] = round(rate(lambda: eng.forward_greedy_compact(cfeed)), 1)
   if hasattr(eng, "forward_greedy_pipelined"):
     # double-buffered submit / collect: H2D of batch k+1 and D2H of batch k-1 on the copy
     # stream while batch k computes

@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define MV_MAX_SCALES 2
-#define MV_ABI_VERSION 3
+#define MV_ABI_VERSION 4
 
 typedef struct mv_engine* mv_handle;
 
@@ -80,6 +80,12 @@ typedef struct mv_config {
    * and training -- sees the hidden state alone; the beam-search decoder is unchanged.
    * Found by executing that file on the TF-1 shim next to code/pred_models.py. */
   int32_t simaug_graph;
+  /* --activation_func (code/train.py:58-59, code/pred_utils.py:86-94): the activation of
+   * the scene convolutions (code/pred_models.py:155-165) and of grid_emb (:444, :664).
+   * 0 = tanh (published), 1 = relu, 2 = lrelu (tf.nn.leaky_relu, alpha 0.2).  relu / lrelu
+   * outputs are unbounded, so those models run the gate convolutions on the fp32 matrix
+   * pipe: mv_set_compute_mode(1 / 2) is refused for them. */
+  int32_t activation;
 } mv_config;
 
 /* The feed_dict of Model.get_feed_dict (pred_models.py:1042-1194), minus the

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 MV_MAX_SCALES = 2
-MV_ABI_VERSION = 3
+MV_ABI_VERSION = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmultiverse_hip.so")
@@ -70,6 +70,7 @@ class mv_config(C.Structure):
       ("class_feedback_dense", C.c_int32),
       ("use_single_decoder", C.c_int32),
       ("simaug_graph", C.c_int32),
+      ("activation", C.c_int32),
   ]
 
 
@@ -273,6 +274,18 @@ def check(rc, handle=None):
     raise MvError(msg.decode("utf-8", "replace") if msg else "error %d" % rc)
 
 
+ACTIVATIONS = {"tanh": 0, "relu": 1, "lrelu": 2, "leaky_relu": 2}
+
+
+def activation_code(act):
+  """--activation_func (code/pred_utils.py:86-94): a name, or the TF function process_args
+  replaced it with (its __name__: tanh / relu / leaky_relu)."""
+  name = act if isinstance(act, str) else getattr(act, "__name__", None)
+  if name not in ACTIVATIONS:
+    raise MvError("activation_func %r: tanh, relu or lrelu" % (act,))
+  return ACTIVATIONS[name]
+
+
 def make_config(cfg):
   """argparse.Namespace (after process_args) -> mv_config."""
   c = mv_config()
@@ -306,6 +319,7 @@ def make_config(cfg):
                                  not getattr(cfg, "is_train", False)) else 0
   c.use_single_decoder = 1 if getattr(cfg, "use_single_decoder", False) else 0
   c.simaug_graph = 1 if getattr(cfg, "simaug_graph", False) else 0
+  c.activation = activation_code(getattr(cfg, "activation_func", "tanh"))
   return c
 
 

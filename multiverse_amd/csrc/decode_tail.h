@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256)
 void grid_emb_onehot8_kernel(const int32_t* __restrict__ ids, int ids_stride, int ids_div,
                              const float* __restrict__ w, const float* __restrict__ b,
                              float* __restrict__ out, int M, int H, int W, int E,
-                             _Float16* p16, size_t p16_stride) {
+                             _Float16* p16, size_t p16_stride, int act = 0) {
   const int ng = E >> 3;
   const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int K = H * W;
@@ -176,7 +176,7 @@ void grid_emb_onehot8_kernel(const int32_t* __restrict__ ids, int ids_stride, in
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float acc = hot ? wp[j] : 0.f;
-    v[j] = tanhf(acc + b[c8 * 8 + j]);
+    v[j] = act_apply(act, acc + b[c8 * 8 + j]);
   }
   emb_store8(out, p16, p16_stride, mc, c8, E, v);
 }
@@ -193,6 +193,7 @@ struct TailProblem {
   int64_t x16_stride;
   int32_t rows, H, W, P, E;
   int32_t onehot;          // 1: class chain (argmax -> one-hot -> closed-form embedding)
+  int32_t act;             // activation of grid_emb (mv_config.activation)
 };
 struct TailGroup {
   TailProblem p[kTailMax];
@@ -263,7 +264,7 @@ __device__ __forceinline__ void decode_tail_body(const TailProblem& a, int row, 
       const bool in = dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1;
       const float* wp = a.emb_w + (in ? (1 - dy) * 3 + (1 - dx) : 4) * E + c8 * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = tanhf((in ? wp[j] : 0.f) + a.emb_b[c8 * 8 + j]);
+      for (int j = 0; j < 8; ++j) v[j] = act_apply(a.act, (in ? wp[j] : 0.f) + a.emb_b[c8 * 8 + j]);
     } else {
       float acc[8];
 #pragma unroll
@@ -281,7 +282,7 @@ __device__ __forceinline__ void decode_tail_body(const TailProblem& a, int row, 
         }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = tanhf(acc[j] + a.emb_b[c8 * 8 + j]);
+      for (int j = 0; j < 8; ++j) v[j] = act_apply(a.act, acc[j] + a.emb_b[c8 * 8 + j]);
     }
     emb_store8(a.x_out, a.x16, (size_t)a.x16_stride, (size_t)row * K + cell, c8, E, v);
   }

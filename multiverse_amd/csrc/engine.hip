@@ -397,6 +397,8 @@ std::vector<ConvCell*> active_cells(const mv_engine* e, ScaleState& S) {
 void validate_config(const mv_config& c) {
   MV_REQUIRE(c.abi_version == MV_ABI_VERSION, "mv_config.abi_version %d != %d",
              c.abi_version, MV_ABI_VERSION);
+  MV_REQUIRE(c.activation >= 0 && c.activation <= 2, "mv_config.activation %d (0 tanh, 1 relu, "
+             "2 lrelu; reference code/pred_utils.py:86-94)", c.activation);
   MV_REQUIRE(c.batch_size > 0 && c.obs_len > 0 && c.max_pred_len > 0,
              "batch_size/obs_len/max_pred_len must be positive");
   MV_REQUIRE(c.num_scales >= 1 && c.num_scales <= MV_MAX_SCALES,
@@ -622,7 +624,8 @@ void ensure_params(mv_engine* e) {
       hipLaunchKernelGGL(mv::sx_decoder_tables_kernel,
                          dim3(cdiv((size_t)(9 + 9 * 25) * 4 * C, 256)), dim3(256), 0, e->stream,
                          S.dec_cls.kernel->dev.p, S.dec_cls.biases->dev.p, S.emb_cls_W->dev.p,
-                         S.emb_cls_b->dev.p, S.dec_cls.Cx, C, S.sx_dec_bias.p, S.sx_dec_corr.p);
+                         S.emb_cls_b->dev.p, S.dec_cls.Cx, C, S.sx_dec_bias.p, S.sx_dec_corr.p,
+                         e->cfg.activation);
       S.sx_valid = true;
     }
   }
@@ -810,14 +813,14 @@ void run_scene(mv_engine* e) {
       launch(e, "scene_proj1x1_mfma", 2.0 * M * Ci * Co,
              4.0 * (total + (double)M * Ci), [&] {
         hipLaunchKernelGGL(mv::scene_proj1x1_mfma_kernel, dim3(cdiv(M, 128)), dim3(256), 0,
-                           e->stream, in, w, b, out, U, Hi, Wi, Ci, Ho, Wo, Co);
+                           e->stream, in, w, b, out, U, Hi, Wi, Ci, Ho, Wo, Co, c.activation);
       });
     } else {
     launch(e, "scene_conv_s2_tanh", 2.0 * total * k * k * Ci,
            4.0 * (total + (double)U * Hi * Wi * Ci), [&] {
       hipLaunchKernelGGL(mv::scene_conv_s2_tanh_kernel, dim3(cdiv(total, 256)),
                          dim3(256), 0, e->stream, in, w, b, out, U, Hi, Wi, Ci,
-                         Ho, Wo, Co, k, pad_h / 2, pad_w / 2);
+                         Ho, Wo, Co, k, pad_h / 2, pad_w / 2, c.activation);
     });
     }
     in = out; Hi = Ho; Wi = Wo; Ci = Co;
@@ -840,6 +843,13 @@ struct Cursors {                 // which ping-pong buffer holds the live state
   int cls[MV_MAX_SCALES] = {0, 0};
   int reg[MV_MAX_SCALES] = {0, 0};
 };
+
+// MV_BEAM_SHARED_FIRST=0 restores the tiled first beam step for A/B runs (run_decoders_beam)
+static bool beam_shared_first() {
+  static const bool on =
+      !(getenv("MV_BEAM_SHARED_FIRST") && atoi(getenv("MV_BEAM_SHARED_FIRST")) == 0);
+  return on;
+}
 
 // Encoders of every enabled scale (dynamic_rnn from the zero state, T_o steps;
 // code/pred_models.py:212-215, 232-234), all chains advanced in lockstep.
@@ -882,8 +892,10 @@ void run_encoders(mv_engine* e, Cursors& cur) {
                                    S.cls_c[cc ^ 1].p, N, S.H, S.W, t == 0, 0,
                                    /*want_h16=*/t + 1 < T || !c.use_gnn));
       // the class encoder's h' is read as fp32 only by the graph attention in front of the
-      // first decoder step; the regression encoder's never
-      probs.back().skip_h32 = (t + 1 < T || !c.use_gnn) ? 1 : 0;
+      // first decoder step (and by the tiled-first-step A/B path of the beam decoder); the
+      // regression encoder's never
+      probs.back().skip_h32 =
+          (t + 1 < T || (!c.use_gnn && (c.beam_size == 1 || beam_shared_first()))) ? 1 : 0;
       if (sparse) {
         set_sparse_x(e, S, probs.back(), false, S.labels.p + t, T, 1);
         probs.back().sx_corr = S.sx_enc_corr.p + (size_t)t * nc;
@@ -993,11 +1005,11 @@ void run_emb_onehot(mv_engine* e, ScaleState& S, const int32_t* ids, int stride,
     if (tail_v2() && E % 8 == 0)
       hipLaunchKernelGGL(mv::grid_emb_onehot8_kernel, dim3(cdiv(total / 8, 256)), dim3(256), 0,
                          e->stream, ids, stride, ids_div, S.emb_cls_W->dev.p,
-                         S.emb_cls_b->dev.p, out, rows, S.H, S.W, E, p16, pst);
+                         S.emb_cls_b->dev.p, out, rows, S.H, S.W, E, p16, pst, e->cfg.activation);
     else
       hipLaunchKernelGGL(mv::grid_emb_onehot_kernel, dim3(cdiv(total, 256)),
                          dim3(256), 0, e->stream, ids, stride, ids_div, S.emb_cls_W->dev.p,
-                         S.emb_cls_b->dev.p, out, rows, S.H, S.W, E, p16, pst);
+                         S.emb_cls_b->dev.p, out, rows, S.H, S.W, E, p16, pst, e->cfg.activation);
   });
 }
 
@@ -1014,7 +1026,7 @@ void run_emb_dense(mv_engine* e, ScaleState& S, const float* x, size_t row_strid
     _Float16* p16 = e->plane_out(out, &pst);
     hipLaunchKernelGGL(mv::grid_emb_dense_kernel, dim3(cdiv(total, 256)), dim3(256),
                        0, e->stream, x, row_stride, W->dev.p, b->dev.p, out, rows, S.H, S.W,
-                       P, E, p16, pst);
+                       P, E, p16, pst, e->cfg.activation);
   });
 }
 
@@ -1074,6 +1086,7 @@ void run_tail(mv_engine* e, const std::vector<TailPlan>& plans) {
     mv::TailProblem a{};
     a.q = S.q_cls.p; a.out = pl.cls_out; a.out_row_stride = pl.cls_stride;
     a.rows = pl.cls_rows; a.H = S.H; a.W = S.W; a.P = 1; a.E = E; a.onehot = 1;
+    a.act = c.activation;
     tbytes += 4.0 * cc * (9 + 1);
     if (pl.cls_next) {
       a.ids_out = S.ids.p;
@@ -1089,6 +1102,7 @@ void run_tail(mv_engine* e, const std::vector<TailPlan>& plans) {
     mv::TailProblem b{};
     b.q = S.q_reg.p; b.out = pl.reg_out; b.out_row_stride = pl.reg_stride;
     b.rows = N; b.H = S.H; b.W = S.W; b.P = 2; b.E = E; b.onehot = 0;
+    b.act = c.activation;
     tbytes += 4.0 * cr * (18 + 2);
     if (pl.reg_next) {
       size_t pst = 0;
@@ -1267,8 +1281,7 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
   // per sample on the N encoder rows (bit-identical to the tiled computation): its logits
   // are copied to the B beam rows, and the first selection hands out state rows n instead
   // of n * B + parent.  MV_BEAM_SHARED_FIRST=0 restores the tiled first step for A/B runs.
-  static const bool shared_first =
-      !(getenv("MV_BEAM_SHARED_FIRST") && atoi(getenv("MV_BEAM_SHARED_FIRST")) == 0);
+  const bool shared_first = beam_shared_first();
   if (!shared_first) {
     const int cc = cur.cls[s];
     const size_t row4 = (size_t)K * C / 4, total4 = (size_t)R * row4;
@@ -2208,6 +2221,9 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
   return guarded(h, [&] {
     MV_REQUIRE(mode >= 0 && mode <= 2, "compute mode %d (0 = fp32 MFMA, 1 = f16x3, 2 = bf16)",
                mode);
+    MV_REQUIRE(mode == 0 || h->cfg.activation == 0, "compute mode %d needs bounded (tanh) "
+               "embeddings: with --activation_func relu / lrelu the x operand of the gate "
+               "convolutions leaves the scaled fp16 range; use mode 0 (fp32 MFMA)", mode);
     if (mode != 0) {
       // operand-plane scratch per group slot: even slots class-sized (N*B rows),
       // odd slots regression-sized (N rows), largest enabled grid

@@ -1035,10 +1035,11 @@ void train_backward(mv_engine* e) {
           if (t.tc.keep_prob < 1.0f)
             hipLaunchKernelGGL(mv::tanh_bwd_scaled_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
                                e->stream, dx, R.dec[b].xs.p + (size_t)ts * NK * E, dx, total,
-                               t.tc.keep_prob);
+                               t.tc.keep_prob, e->cfg.activation);
           else
             hipLaunchKernelGGL(mv::tanh_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
-                               e->stream, dx, R.dec[b].xs.p + (size_t)ts * NK * E, dx, total);
+                               e->stream, dx, R.dec[b].xs.p + (size_t)ts * NK * E, dx, total,
+                               e->cfg.activation);
         });
       }
       // regression decoder: the step's input was grid_emb(out_reg[t-1]) -> d out_reg[t-1]
@@ -1186,7 +1187,7 @@ void train_backward(mv_engine* e) {
       });
     }
     hipLaunchKernelGGL(mv::tanh_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, e->stream,
-                       t.dys[i].p, e->scene_conv[i].p, t.dpre_sc[i].p, n);
+                       t.dys[i].p, e->scene_conv[i].p, t.dpre_sc[i].p, n, e->cfg.activation);
     const int ph = std::max((Ho - 1) * 2 + k - Hi, 0), pw = std::max((Wo - 1) * 2 + k - Wi, 0);
     const size_t nw = (size_t)k * k * Ci * D;
     const float* in = i == 0 ? e->scene_feat.p : e->scene_conv[i - 1].p;

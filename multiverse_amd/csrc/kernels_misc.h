@@ -38,6 +38,24 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------- activation
+// --activation_func of the reference (code/train.py:58-59 -> code/pred_utils.py:86-94):
+// tanh (published), relu, lrelu = tf.nn.leaky_relu with its default alpha 0.2.  It is the
+// activation of the scene convolutions (code/pred_models.py:155-165) and of grid_emb
+// (:444, :664); the ConvLSTM cells and hidden2grid do not use it.  mv_config.activation.
+constexpr int kActTanh = 0, kActRelu = 1, kActLrelu = 2;
+__device__ __forceinline__ float act_apply(int act, float v) {
+  if (act == kActTanh) return tanhf(v);
+  if (act == kActRelu) return v > 0.f ? v : 0.f;
+  return v > 0.f ? v : 0.2f * v;
+}
+// d act / d pre-activation from the OUTPUT y (lrelu: y > 0 <=> pre-activation > 0)
+__device__ __forceinline__ float act_grad(int act, float y) {
+  if (act == kActTanh) return 1.f - y * y;
+  if (act == kActRelu) return y > 0.f ? 1.f : 0.f;
+  return y > 0.f ? 1.f : 0.2f;
+}
+
 // ---------------------------------------------------------------- scene conv
 // conv k x k, stride 2, SAME, + b, tanh (reference code/pred_models.py:155-160
 // via conv2d :1333-1373) on the U unique frames of the batch; one thread per
@@ -47,7 +65,7 @@ __global__ void scene_conv_s2_tanh_kernel(const float* __restrict__ in,
                                           const float* __restrict__ b,
                                           float* __restrict__ out, int U, int Hi,
                                           int Wi, int Ci, int Ho, int Wo, int Co,
-                                          int k, int pad_t, int pad_l) {
+                                          int k, int pad_t, int pad_l, int act = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)U * Ho * Wo * Co;
   if (idx >= total) return;
@@ -68,7 +86,7 @@ __global__ void scene_conv_s2_tanh_kernel(const float* __restrict__ in,
       for (int ci = 0; ci < Ci; ++ci) acc = fmaf(ip[ci], wp[(size_t)ci * Co], acc);
     }
   }
-  out[idx] = tanhf(acc + b[co]);
+  out[idx] = act_apply(act, acc + b[co]);
 }
 
 // --scene_conv_kernel 1 (code/train.py:65, conv2d code/pred_models.py:155-165): the scene
@@ -82,7 +100,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256)
 void scene_proj1x1_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                const float* __restrict__ b, float* __restrict__ out, int U,
-                               int Hi, int Wi, int Ci, int Ho, int Wo, int Co) {
+                               int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int act = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int M = U * Ho * Wo;
   const int m_wave = (blockIdx.x * 4 + wave) * 32;
@@ -112,8 +130,8 @@ void scene_proj1x1_mfma_kernel(const float* __restrict__ in, const float* __rest
     const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
     const int mm = m_wave + row;
     if (mm >= M) continue;
-    if (col < Co) out[(size_t)mm * Co + col] = tanhf(acc0[reg] + b[col]);
-    if (32 + col < Co) out[(size_t)mm * Co + 32 + col] = tanhf(acc1[reg] + b[32 + col]);
+    if (col < Co) out[(size_t)mm * Co + col] = act_apply(act, acc0[reg] + b[col]);
+    if (32 + col < Co) out[(size_t)mm * Co + 32 + col] = act_apply(act, acc1[reg] + b[32 + col]);
   }
 }
 
@@ -175,7 +193,7 @@ __global__ void grid_emb_dense_kernel(const float* __restrict__ x,
                                       const float* __restrict__ b,
                                       float* __restrict__ out, int M, int H,
                                       int W, int P, int E, _Float16* p16 = nullptr,
-                                      size_t p16_stride = 0) {
+                                      size_t p16_stride = 0, int act = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)M * H * W * E;
   if (idx >= total) return;
@@ -196,7 +214,7 @@ __global__ void grid_emb_dense_kernel(const float* __restrict__ x,
         acc = fmaf(ip[p], w[((ky * 3 + kx) * P + p) * E + e], acc);
     }
   }
-  const float v = tanhf(acc + b[e]);
+  const float v = act_apply(act, acc + b[e]);
   out[idx] = v;
   emit_planes(p16, p16_stride, idx, E, v);
 }
@@ -213,7 +231,7 @@ __global__ void grid_emb_onehot_kernel(const int32_t* __restrict__ ids,
                                        const float* __restrict__ b,
                                        float* __restrict__ out, int M, int H,
                                        int W, int E, _Float16* p16 = nullptr,
-                                       size_t p16_stride = 0) {
+                                       size_t p16_stride = 0, int act = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)M * H * W * E;
   if (idx >= total) return;
@@ -228,7 +246,7 @@ __global__ void grid_emb_onehot_kernel(const int32_t* __restrict__ ids,
   float acc = 0.f;
   if (dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1)
     acc = w[((1 - dy) * 3 + (1 - dx)) * E + e];  // P == 1
-  const float v = tanhf(acc + b[e]);
+  const float v = act_apply(act, acc + b[e]);
   out[idx] = v;
   emit_planes(p16, p16_stride, idx, E, v);
 }

@@ -34,7 +34,7 @@ __global__ void sx_decoder_tables_kernel(const float* __restrict__ w,
                                          const float* __restrict__ emb_w,
                                          const float* __restrict__ emb_b, int Cx, int C,
                                          float* __restrict__ bias_tab,
-                                         float* __restrict__ corr) {
+                                         float* __restrict__ corr, int act = 0) {
   const int N4 = 4 * C, Cin = Cx + C;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int rows = 9 + 9 * 25;
@@ -46,7 +46,7 @@ __global__ void sx_decoder_tables_kernel(const float* __restrict__ w,
     for (int t = 0; t < 9; ++t) {
       if (!sx_inside(cy, t / 3 - 1) || !sx_inside(cx, t % 3 - 1)) continue;
       for (int ch = 0; ch < Cx; ++ch)
-        acc += (double)w[((size_t)t * Cin + ch) * N4 + col] * (double)tanhf(emb_b[ch]);
+        acc += (double)w[((size_t)t * Cin + ch) * N4 + col] * (double)act_apply(act, emb_b[ch]);
     }
     bias_tab[idx] = (float)((double)bias[col] + acc);
     return;
@@ -64,7 +64,7 @@ __global__ void sx_decoder_tables_kernel(const float* __restrict__ w,
     const int t = (dy + 1) * 3 + (dx + 1);
     const float* ew = emb_w + ((1 - ey) * 3 + (1 - ex)) * Cx;
     for (int ch = 0; ch < Cx; ++ch) {
-      const double xd = (double)tanhf(ew[ch] + emb_b[ch]) - (double)tanhf(emb_b[ch]);
+      const double xd = (double)act_apply(act, ew[ch] + emb_b[ch]) - (double)act_apply(act, emb_b[ch]);
       acc += (double)w[((size_t)t * Cin + ch) * N4 + col] * xd;
     }
   }

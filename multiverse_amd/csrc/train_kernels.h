@@ -485,23 +485,23 @@ void h2g_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ do
   }
 }
 
-// dpre = dy * (1 - y^2)   (backward of tanh); in place over dy allowed.
+// dpre = dy * act'(pre) from the output y (tanh: 1 - y^2; relu / lrelu: the slope of y's
+// sign); in place over dy allowed.
 __global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                float* __restrict__ dpre, size_t total) {
+                                float* __restrict__ dpre, size_t total, int act = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const float v = y[idx];
-  dpre[idx] = dy[idx] * (1.f - v * v);
+  dpre[idx] = dy[idx] * act_grad(act, y[idx]);
 }
 
 // the same when y was stored scaled by 1 / keep_prob (dropped input of a cell):
 // dpre = dy * (1 - (y * keep)^2)
 __global__ void tanh_bwd_scaled_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                       float* __restrict__ dpre, size_t total, float keep) {
+                                       float* __restrict__ dpre, size_t total, float keep,
+                                       int act = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const float v = y[idx] * keep;
-  dpre[idx] = dy[idx] * (1.f - v * v);
+  dpre[idx] = dy[idx] * act_grad(act, y[idx] * keep);
 }
 
 // out[s][col] = sum over the rows of slab s of in[row][col]; grid (nslab,

@@ -187,6 +187,11 @@ class Model(object):
     import os
     self.compute_mode = getattr(config, "compute_mode", None) or \
         os.environ.get("MV_COMPUTE", "f16x3")
+    if _lib.activation_code(getattr(config, "activation_func", "tanh")) != 0:
+      # relu / lrelu embeddings are unbounded: outside the scaled fp16 range of the f16x3
+      # operand planes, so those models run on the fp32 matrix pipe (the engine refuses
+      # the other modes for them)
+      self.compute_mode = "f32"
     self.engine.set_compute_mode(self.compute_mode)
     self.global_step = 0
     # names of the fetches, kept for callers that introspect them
@@ -202,10 +207,7 @@ class Model(object):
   def _check_config(config):
     """Same unsupported-combination asserts as the reference graph builder
     (code/pred_models.py:261-262) plus the engine's own scope limits."""
-    act = getattr(config, "activation_func", "tanh")
-    if not (act == "tanh" or getattr(act, "__name__", "") == "tanh"):
-      raise _lib.MvError("activation_func %r: only tanh (the published "
-                         "configuration, TRAINING.md:32-39) is built" % (act,))
+    _lib.activation_code(getattr(config, "activation_func", "tanh"))   # tanh / relu / lrelu
     if not getattr(config, "use_scene_enc", True):
       raise _lib.MvError("only the published --use_scene_enc wiring is built")
     if getattr(config, "use_single_decoder", False) and getattr(config, "use_beam_search", False):

@@ -27,9 +27,11 @@ def process_args(args):
   """Derive the fields the model reads from the CLI flags.  Grid sizes use
   Python round() like the reference (code/pred_utils.py:127-132); the engine
   separately checks they match the stride-2 conv chain."""
-  if getattr(args, "activation_func", "tanh") not in ("tanh",):
-    if not callable(args.activation_func):
-      raise ValueError("activation_func %r: only tanh is built" % args.activation_func)
+  act = getattr(args, "activation_func", "tanh")
+  if not callable(act) and act not in ("tanh", "relu", "lrelu"):
+    # code/pred_utils.py:92-94: "unrecognied activation function, using relu..."
+    print("unrecognied activation function, using relu...")
+    args.activation_func = "relu"
   args.seq_len = args.obs_len + args.pred_len
   if getattr(args, "outbasepath", None) is not None:
     args.outpath = os.path.join(args.outbasepath, args.modelname,

@@ -144,6 +144,21 @@ class Params(object):
     return self.p["person_pred/" + name]
 
 
+def activation_of(cfg):
+  """--activation_func (code/train.py:58-59 -> code/pred_utils.py:86-94): tanh (published),
+  relu, lrelu = tf.nn.leaky_relu (default alpha 0.2).  Used by the scene convolutions
+  (code/pred_models.py:155-165) and grid_emb (:444, :664)."""
+  act = getattr(cfg, "activation_func", "tanh")
+  name = act if isinstance(act, str) else getattr(act, "__name__", "tanh")
+  if name == "tanh":
+    return torch.tanh
+  if name == "relu":
+    return torch.relu
+  if name in ("lrelu", "leaky_relu"):
+    return lambda v: F.leaky_relu(v, negative_slope=0.2)
+  raise ValueError("activation_func %r" % (act,))
+
+
 def scene_stack(P, cfg, scene_feat, obs_scene):
   """code/pred_models.py:146-165: embedding_lookup of the per-frame one-hot
   masks, then `len(strides)` x [conv k, stride 2, SAME, +b, tanh].
@@ -153,7 +168,7 @@ def scene_stack(P, cfg, scene_feat, obs_scene):
   outs = []
   for i, stride in enumerate(cfg.scene_grid_strides):
     x = conv_layer(x, P["scene_conv%d/W" % (i + 1)], P["scene_conv%d/b" % (i + 1)],
-                   stride=2, act=torch.tanh)
+                   stride=2, act=activation_of(cfg))
     outs.append(x.reshape(N, T, x.shape[1], x.shape[2], x.shape[3]))
   return outs
 
@@ -293,7 +308,7 @@ def greedy_decoder(P, cfg, s, kind, first_input, state, T_pred, scene_mean,
   for t in range(T_pred):
     if use_gnn:
       h = h + gnn_dense(h, None if getattr(cfg, "simaug_graph", False) else scene_mean)
-    x = conv_layer(x_in, embW, embb, act=torch.tanh)
+    x = conv_layer(x_in, embW, embb, act=activation_of(cfg))
     if drop is not None:
       x = drop(x)                  # DropoutWrapper: input dropout (:241-249)
     c, h = convlstm_cell(x, c, h, kernel, biases)
@@ -401,7 +416,7 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None):
         break  # raw_rnn stops: state/input of the finished step are unused
     if cfg.use_gnn:
       h = h + gnn_dense(h, sm)                              # :631-654
-    x = conv_layer(x_in, embW, embb, act=torch.tanh)        # :662-666
+    x = conv_layer(x_in, embW, embb, act=activation_of(cfg))   # :662-666
 
   # back-trace (:689-806): walk time backwards following parents
   T = len(all_ids)

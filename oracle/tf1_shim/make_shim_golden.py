@@ -96,6 +96,10 @@ VARIANT_CASES = [
     ("cosine", dict(use_cosine_lr=True, num_epochs=4, optimizer="momentum", init_lr=0.01), 3),
     # --scene_conv_kernel 1 (code/train.py:65): the scene stack as two strided 1x1 projections
     ("sck1", dict(scene_conv_kernel=1), 1),
+    # --activation_func relu / lrelu (code/train.py:58-59, code/pred_utils.py:86-94): the scene
+    # convolutions and grid_emb; tf.nn.leaky_relu's default alpha 0.2
+    ("relu", dict(activation_func="relu"), 1),
+    ("lrelu", dict(activation_func="lrelu"), 1),
 ]
 VARIANT_SEED = synth.SEED_BASE + 40
 

@@ -77,8 +77,9 @@ def batch_from_feed(cfg, feed):
 
 def _activation(tf, cfg):
   # process_args maps the flag to a TF function (code/pred_utils.py:112-121)
-  assert cfg.activation_func in ("tanh",) or callable(cfg.activation_func)
-  return tf.nn.tanh
+  if callable(cfg.activation_func):
+    return cfg.activation_func
+  return {"tanh": tf.nn.tanh, "relu": tf.nn.relu, "lrelu": tf.nn.leaky_relu}[cfg.activation_func]
 
 
 def build_model(cfg, params, feed, is_train=False, opt_slots=None, global_step=0,

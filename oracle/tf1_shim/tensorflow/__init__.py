@@ -781,6 +781,11 @@ class _NN(object):
     return Tensor(torch.relu(_v(x)), name)
 
   @staticmethod
+  def leaky_relu(features, alpha=0.2, name=None):
+    # tf.nn.leaky_relu: max(alpha * x, x) with the default alpha = 0.2
+    return Tensor(torch.nn.functional.leaky_relu(_v(features), negative_slope=alpha), name)
+
+  @staticmethod
   def softmax(x, axis=-1, name=None):
     return Tensor(torch.softmax(_v(x), dim=axis))
 

@@ -88,6 +88,8 @@ VARIANT_CASES = {
     "adam": (dict(optimizer="adam", init_lr=0.001), 2),
     "cosine": (dict(use_cosine_lr=True, num_epochs=4, optimizer="momentum", init_lr=0.01), 3),
     "sck1": (dict(scene_conv_kernel=1), 1),
+    "relu": (dict(activation_func="relu"), 1),
+    "lrelu": (dict(activation_func="lrelu"), 1),
 }
 VARIANT_SEED = synth.SEED_BASE + 40
 

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_struct_layout_matches_header(built_lib):
   # 21 int32/float fields + 3 arrays of MV_MAX_SCALES -> 4-byte packed (offsets: see
   # test_ctypes_structs_match_the_c_header)
-  assert ctypes.sizeof(built_lib.mv_config) == 4 * (21 + 3 * built_lib.MV_MAX_SCALES)
+  assert ctypes.sizeof(built_lib.mv_config) == 4 * (22 + 3 * built_lib.MV_MAX_SCALES)
   assert ctypes.sizeof(built_lib.mv_inputs) == 8 * 2 + 4 * 2 + 8 * 2 * built_lib.MV_MAX_SCALES
   assert ctypes.sizeof(built_lib.mv_outputs) == 8 * 2 * built_lib.MV_MAX_SCALES
   assert ctypes.sizeof(built_lib.mv_beam_outputs) == 8 * 5

@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --no-cpu-baseline $*"
+B="python $ROOT/bench.py --no-cpu-baseline --no-sub --no-fp32-ref $*"
 rocprofv3 --kernel-trace --stats -d $OUT -o kt -- $B --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 python $ROOT/tools/rocpd_summary.py $OUT/kt_results.db > $OUT/kernel_trace_stats.md 2>> $OUT/kt.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $OUT -o pmc1 -- $B --steps 1 --warmup 1 > /dev/null 2> $OUT/pmc1.err
