@@ -110,7 +110,10 @@ typedef struct mv_outputs {
  * of multifuture_inference.py:468-472 for the single active scale. */
 typedef struct mv_beam_outputs {
   float*   best_beam;   /* [N, T, H, W, 1]  == logits[:, 0] */
-  float*   grid_reg;    /* [N, T, H, W, 2]  (regression decoder, un-beamed) */
+  float*   grid_reg;    /* [N, T, H, W, 2]  (regression decoder, un-beamed); with
+                         * use_single_decoder [N*B, T, H, W, 2]: the offsets decoded from the
+                         * class decoder's states traced back along every beam
+                         * (code/pred_models.py:287-296) */
   float*   logits;      /* [N, B, T, H*W] */
   int32_t* ids;         /* [N, B, T] */
   float*   logprobs;    /* [N, B] */

@@ -498,7 +498,9 @@ class Engine(object):
     out = mv_beam_outputs()
     arrs = {
         "best_beam": np.empty((N, Tp, h, w, 1), dtype=np.float32),
-        "grid_reg": np.empty((N, Tp, h, w, 2), dtype=np.float32),
+        # --use_single_decoder: per beam, [N*B, T, h, w, 2] (code/pred_models.py:287-296)
+        "grid_reg": np.empty((N * B if getattr(cfg, "use_single_decoder", False) else N,
+                              Tp, h, w, 2), dtype=np.float32),
         "logits": np.empty((N, B, Tp, h * w), dtype=np.float32),
         "ids": np.empty((N, B, Tp), dtype=np.int32),
         "logprobs": np.empty((N, B), dtype=np.float32),

@@ -266,6 +266,9 @@ constexpr int kThreads16 = kWaves16 * 64;
 constexpr int kBlockRows16 = kWaves16 * kWaveRows; // cells per workgroup
 constexpr int kKpb = MV_F16_KPB;                 // k-steps per LDS stage (2, 3 or 6 divide every k-step count)
 constexpr int kStageVec = kKpb * 2 * 4 * 64;     // f16x8 elements per stage (kKpb x 8 KB)
+// LDS of a step / dgrad workgroup: two stage buffers, and at least the 4 KB per wave the
+// epilogue's h' plane transposes take (16-wave workgroups: 64 KB)
+constexpr int kLdsVec16 = 2 * kStageVec > kWaves16 * 256 ? 2 * kStageVec : kWaves16 * 256;
 
 // EPI = kEpiLstm (forward, NG = 4) or kEpiStore (dgrad: the operand "h" is the gate
 // gradient G with 4C channels, the columns are input channels; NG active 32-column
@@ -828,7 +831,7 @@ __device__ __forceinline__ bool step_block_map(const ConvLstmArgs& a, int block,
 template <bool SHIFT>
 __global__ __launch_bounds__(kThreads16, MV_CONV_MINWAVES)
 void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
-  __shared__ f16x8 lds[2 * kStageVec];
+  __shared__ f16x8 lds[kLdsVec16];
   int block = blockIdx.x;
   int pi = 0;
 #pragma unroll

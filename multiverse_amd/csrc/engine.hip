@@ -184,6 +184,10 @@ struct mv_engine {
   DevBuf<int32_t> bm_ref;          // [N*B] 1 = some surviving beam continues this state row
   DevBuf<int32_t> bm_trace;        // [N, B, T]
   DevBuf<float> bm_out_logits;     // [N, B, T, K]
+  // --use_single_decoder with beam search (code/pred_models.py:274, 287-296): the offsets
+  // are hidden2grid of the class decoder's states traced back along every beam
+  DevBuf<float> bm_reg_steps;      // [T, N*B, K, 2]   per step, in the step's own row order
+  DevBuf<float> bm_out_reg;        // [N*B, T, K, 2]   traced back
   DevBuf<int32_t> bm_out_ids;      // [N, B, T]
   // 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3 split on the fp16 matrix pipe,
   // 2 = bf16 operands / fp32 accumulate (one plane, one MFMA per product)
@@ -414,9 +418,6 @@ void validate_config(const mv_config& c) {
   MV_REQUIRE(c.beam_size >= 1, "beam_size must be >= 1");
   MV_REQUIRE(!(c.class_feedback_dense && c.beam_size > 1), "class_feedback_dense: greedy only "
              "(grid_decoder_beam_search always feeds one-hot ids)");
-  MV_REQUIRE(!(c.use_single_decoder && c.beam_size > 1), "use_single_decoder with beam search is "
-             "not built (the reference's inference script mis-shapes its [N*B,...] offsets, "
-             "code/multifuture_inference.py:478)");
   int hh = c.scene_h, ww = c.scene_w, used = 0;
   for (int s = 0; s < c.num_scales; ++s) {
     hh = (hh + 1) / 2; ww = (ww + 1) / 2;   // stride-2 SAME conv chain
@@ -465,7 +466,8 @@ void alloc_buffers(mv_engine* e) {
     S.out_cls.alloc(N * Tp * K);
     S.out_reg.alloc(N * Tp * K * 2);
     S.ids.alloc(R);
-    S.q_cls.alloc(R * K * 9); S.q_reg.alloc(N * K * 18);
+    // single decoder + beam: the offsets are decoded from all N*B state rows
+    S.q_cls.alloc(R * K * 9); S.q_reg.alloc((c.use_single_decoder ? R : N) * K * 18);
     S.wq_cls.alloc(C * 32); S.wq_reg.alloc(C * 32);
     S.sx_cellyx.alloc(K);
     S.sx_dec_bias.alloc(9 * 4 * C); S.sx_dec_corr.alloc(9 * 25 * 4 * C);
@@ -481,6 +483,10 @@ void alloc_buffers(mv_engine* e) {
       e->bm_trace.alloc(R * Tp);
       e->bm_out_logits.alloc(R * Tp * K);
       e->bm_out_ids.alloc(R * Tp);
+      if (c.use_single_decoder) {
+        e->bm_reg_steps.alloc(Tp * R * K * 2);
+        e->bm_out_reg.alloc(R * Tp * K * 2);
+      }
     }
   }
 }
@@ -1067,6 +1073,7 @@ struct TailPlan {
   const float* cls_h; int cls_rows; float* cls_out; int64_t cls_stride;
   bool cls_next;       // class chain: argmax + embedding of step t+1 (greedy only)
   const float* reg_h; float* reg_out; int64_t reg_stride; bool reg_next;
+  int reg_rows = 0;    // 0: N (the un-beamed regression chain)
 };
 
 void run_tail(mv_engine* e, const std::vector<TailPlan>& plans) {
@@ -1078,7 +1085,8 @@ void run_tail(mv_engine* e, const std::vector<TailPlan>& plans) {
   for (const TailPlan& pl : plans) {
     ScaleState& S = e->sc[pl.s];
     MV_REQUIRE((size_t)S.K * 2 <= 2048 && E == 32, "decode tail: K %d / emb_size %d", S.K, E);
-    const size_t cc = (size_t)pl.cls_rows * S.K, cr = (size_t)N * S.K;
+    const int reg_rows = pl.reg_rows ? pl.reg_rows : N;
+    const size_t cc = (size_t)pl.cls_rows * S.K, cr = (size_t)reg_rows * S.K;
     qp.push_back(mv::H2gQProblem{pl.cls_h, S.wq_cls.p, S.q_cls.p, (int32_t)cc, 1});
     qp.push_back(mv::H2gQProblem{pl.reg_h, S.wq_reg.p, S.q_reg.p, (int32_t)cr, 2});
     qbytes += 4.0 * (cc * (C + 9.0) + cr * (C + 18.0));
@@ -1101,7 +1109,7 @@ void run_tail(mv_engine* e, const std::vector<TailPlan>& plans) {
     tp.push_back(a);
     mv::TailProblem b{};
     b.q = S.q_reg.p; b.out = pl.reg_out; b.out_row_stride = pl.reg_stride;
-    b.rows = N; b.H = S.H; b.W = S.W; b.P = 2; b.E = E; b.onehot = 0;
+    b.rows = reg_rows; b.H = S.H; b.W = S.W; b.P = 2; b.E = E; b.onehot = 0;
     b.act = c.activation;
     tbytes += 4.0 * cr * (18 + 2);
     if (pl.reg_next) {
@@ -1330,9 +1338,14 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
       }
       cur.cls[s] ^= 1;
       const bool v2 = tail_v2();
-      probs.push_back(reg_decoder_problem(e, s, cur, time - 1, Tp, !v2));
+      const bool single = c.use_single_decoder != 0;
+      MV_REQUIRE(!single || v2, "use_single_decoder with beam search needs the v2 decoder tail");
+      if (!single) probs.push_back(reg_decoder_problem(e, s, cur, time - 1, Tp, !v2));
       run_conv_group(e, probs);
       float* logits = e->bm_logits.p + (size_t)(time - 1) * R * K;
+      // single decoder: the offsets of this step, decoded from every state row (traced back
+      // along the beams after the loop)
+      float* regstep = single ? e->bm_reg_steps.p + (size_t)(time - 1) * R * K * 2 : nullptr;
       // one row per sample: the logits land in beam 0's row of each sample
       const size_t lrow = one_per_sample ? (size_t)B * K : (size_t)K;
       if (v2) {
@@ -1340,9 +1353,14 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
         pl.s = s;
         pl.cls_h = S.cls_h[cur.cls[s]].p; pl.cls_rows = rows_now;
         pl.cls_out = logits; pl.cls_stride = lrow; pl.cls_next = false;   // beam_step selects
+        if (single) {
+          pl.reg_h = pl.cls_h; pl.reg_rows = rows_now;
+          pl.reg_out = regstep; pl.reg_stride = (int64_t)lrow * 2; pl.reg_next = false;
+        } else {
         pl.reg_h = S.reg_h[cur.reg[s]].p;
         pl.reg_out = S.out_reg.p + (size_t)(time - 1) * K * 2;
         pl.reg_stride = (int64_t)Tp * K * 2; pl.reg_next = time < Tp;
+        }
         run_tail(e, {pl});
       } else {
         reg_decoder_output(e, s, cur, time - 1, Tp);
@@ -1353,6 +1371,9 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
         const size_t total = (size_t)R * K;
         hipLaunchKernelGGL(tile_beam0_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
                            e->stream, logits, K, B, total);
+        if (single)
+          hipLaunchKernelGGL(tile_beam0_kernel, dim3(cdiv(total * 2, 256)), dim3(256), 0,
+                             e->stream, regstep, K * 2, B, total * 2);
       }
       int32_t* ids = e->bm_ids.p + (size_t)(time - 1) * R;
       int32_t* parents = e->bm_parents.p + (size_t)(time - 1) * R;
@@ -1400,6 +1421,12 @@ void run_decoders_beam(mv_engine* e, int s, Cursors& cur, int Tp) {
   hipLaunchKernelGGL(beam_gather_logits_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
                      e->stream, e->bm_logits.p, e->bm_trace.p, e->bm_out_logits.p,
                      N, B, Tp, K);
+  if (c.use_single_decoder) {       // offsets along every beam: the same gather, 2K per row
+    const size_t tot2 = (size_t)R * Tp * K * 2;
+    hipLaunchKernelGGL(beam_gather_logits_kernel, dim3(cdiv(tot2, 256)), dim3(256), 0,
+                       e->stream, e->bm_reg_steps.p, e->bm_trace.p, e->bm_out_reg.p,
+                       N, B, Tp, K * 2);
+  }
   // final logprobs are in bm_lp[lpi]
   if (lpi != 0)
     HIP_CHECK(hipMemcpyAsync(e->bm_lp[0].p, e->bm_lp[1].p, (size_t)R * sizeof(float),
@@ -1577,9 +1604,15 @@ void download_beam(mv_engine* e, mv_beam_outputs* out) {
   if (out->logprobs)
     HIP_CHECK(hipMemcpyAsync(out->logprobs, e->bm_lp[0].p, N * B * sizeof(float),
                              hipMemcpyDeviceToHost, e->stream));
-  if (out->grid_reg)
+  if (out->grid_reg) {
+    if (c.use_single_decoder)       // per beam: [N*B, T, K, 2]
+      HIP_CHECK(hipMemcpyAsync(out->grid_reg, e->bm_out_reg.p,
+                               N * B * Tp * K * 2 * sizeof(float), hipMemcpyDeviceToHost,
+                               e->stream));
+    else
     HIP_CHECK(hipMemcpyAsync(out->grid_reg, S.out_reg.p, N * Tp * K * 2 * sizeof(float),
                              hipMemcpyDeviceToHost, e->stream));
+  }
   if (out->best_beam)  // logits[:, 0] -> [N, T, K]: rows n*B of [N,B,T,K]
     HIP_CHECK(hipMemcpy2DAsync(out->best_beam, Tp * K * sizeof(float),
                                e->bm_out_logits.p, B * Tp * K * sizeof(float),

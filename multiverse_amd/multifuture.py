@@ -251,11 +251,17 @@ def run_inference(args, model, inputs, traj_ids):
       idxs = group[lo:lo + N]
       feed, n_real = inference_feed(inputs, args, idxs, batch_size=N)
       cls, reg, beam = model.run_forward(feed)
+      # --use_single_decoder with beam search: the offsets come per beam, [N*B, T, H, W, 2]
+      # (code/pred_models.py:287-296); the reference's script reshapes the B rows of its one
+      # sample as [1, T, -1, 2] (code/multifuture_inference.py:478) -- kept as it is
+      rows_per = reg[use_grid_idx].shape[0] // N
       for r in range(n_real):
         i = idxs[r]
         b = None if beam is None else (beam[0][r], beam[1][r], beam[2][r])
+        reg_r = (reg[use_grid_idx][r] if rows_per == 1
+                 else reg[use_grid_idx][r * rows_per:(r + 1) * rows_per])
         output_data[traj_ids[i]] = decode_trajectories(
-            args, cls[use_grid_idx][r], reg[use_grid_idx][r], b, T_pred, use_grid_idx)
+            args, cls[use_grid_idx][r], reg_r, b, T_pred, use_grid_idx)
         if b is not None and getattr(args, "save_prob_file", None) is not None:
           beam_prob[traj_ids[i]] = (b[0][None], b[2][None])
   ordered = {t: output_data[t] for t in traj_ids}

@@ -210,10 +210,6 @@ class Model(object):
     _lib.activation_code(getattr(config, "activation_func", "tanh"))   # tanh / relu / lrelu
     if not getattr(config, "use_scene_enc", True):
       raise _lib.MvError("only the published --use_scene_enc wiring is built")
-    if getattr(config, "use_single_decoder", False) and getattr(config, "use_beam_search", False):
-      raise _lib.MvError("--use_single_decoder with --use_beam_search is not built (the "
-                         "reference's inference script mis-shapes its [N*B,...] offsets, "
-                         "code/multifuture_inference.py:478)")
     if getattr(config, "use_beam_search", False):
       assert not getattr(config, "is_train", False)
       assert sum(config.use_grids) == 1, "only one scale test at a time"

@@ -362,11 +362,13 @@ def topk_stable(x, k):
   return torch.from_numpy(vals), order.astype("int64")
 
 
-def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None):
+def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None,
+                 save_states=False):
   """`Model.grid_decoder_beam_search` (code/pred_models.py:474-806).
 
   Returns (best_beam_logits [N,T,H,W,1], logits [N,B,T,K], ids [N,B,T],
-  logprobs [N,B])."""
+  logprobs [N,B]) and, with save_states (--use_single_decoder, :274), the cell outputs
+  traced back along every beam [N,B,T,H,W,C] (:702-708, 743-746, 778-786)."""
   scope = "decoder_grid_class_%d" % s
   kernel = P["%s/decoder_rnn/dec_grid_%d/kernel" % (scope, s)]
   biases = P["%s/decoder_rnn/dec_grid_%d/biases" % (scope, s)]
@@ -387,10 +389,13 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None):
   sm = tile(scene_mean)  # tile_to_beam (:831-834)
   prev_lp = torch.zeros(N, B, dtype=dt)
   all_ids, all_parents, all_logits, all_prev, all_topvals = [], [], [], [], []
+  all_states = []     # emit_output of raw_rnn: the cell output, in the step's own row order
   # raw_rnn: loop_fn(0) -> [cell -> loop_fn(time)] for time = 1..T_pred
   for time in range(0, T_pred + 1):
     if time > 0:
       c, h = convlstm_cell(x, c, h, kernel, biases)
+      if save_states:
+        all_states.append(h.reshape(N, B, H, W, C))
       logits = conv2d_same(h, outW).reshape(N, B, K)        # :550-555
       lp = log_softmax_tf(logits)                           # :557
       lp = prev_lp.unsqueeze(-1) + lp                       # :560
@@ -425,8 +430,12 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None):
   par = np.tile(np.arange(B)[None], [N, 1])                 # :714-716
   rows = np.arange(N)[:, None]
   out_trace = np.zeros((N, B, T), dtype="int32")
+  out_states = torch.zeros(N, B, T, H, W, C, dtype=dt) if save_states else None
   for t in range(T - 1, -1, -1):
     out_trace[:, :, t] = par
+    if save_states:      # gather_helper(input_states_t, parents) (:743-746)
+      out_states[:, :, t] = all_states[t][torch.from_numpy(rows).long(),
+                                          torch.from_numpy(par).long()]
     out_ids[:, :, t] = all_ids[t][rows, par]
     out_logits[:, :, t] = all_logits[t][torch.from_numpy(rows).long(),
                                         torch.from_numpy(par).long()]
@@ -439,6 +448,8 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None):
     trace["beam_step_topvals"] = all_topvals  # selected scores before zeroing
     trace["beam_trace"] = out_trace           # beam index of each path per step
     trace["beam_step_logits"] = [l.numpy() for l in all_logits]
+  if save_states:
+    return best, out_logits, out_ids, prev_lp, out_states
   return best, out_logits, out_ids, prev_lp
 
 
@@ -496,8 +507,12 @@ def forward_tensors(P, cfg, feed, dtype=torch.float32, trace=None):
       assert not cfg.is_train
       assert sum(cfg.use_grids) == 1, "only one scale test at a time"
       reg_gt = None
-      best, lg, ids, lps = beam_decoder(
-          P, cfg, s, obs_oh[:, -1], enc_c, T_pred, scene_mean, trace)
+      single = getattr(cfg, "use_single_decoder", False)
+      res = beam_decoder(P, cfg, s, obs_oh[:, -1], enc_c, T_pred, scene_mean, trace,
+                         save_states=single)
+      best, lg, ids, lps = res[:4]
+      if single:       # [N, B, T, H, W, C] -> [N*B, T, H, W, C] (:291-294)
+        dec_h = res[4].reshape((-1,) + tuple(res[4].shape[2:]))
       dec_cls = best
       beam_out = [lg, ids, lps]
     else:
@@ -516,7 +531,8 @@ def forward_tensors(P, cfg, feed, dtype=torch.float32, trace=None):
     if getattr(cfg, "use_single_decoder", False):
       # decode the offsets from the class decoder's states (:287-296): one 3x3 conv
       # 256 -> 2, scope "decode_reg" (shared by the scales), no regression decoder
-      assert not cfg.use_beam_search, "single decoder: greedy / training only (DESIGN.md 8)"
+      # with beam search dec_h holds the traced-back states of every beam, [N*B, T, ...]:
+      # the offsets come out per beam, [N*B, T, H, W, 2]
       Nn, Tt = dec_h.shape[0], dec_h.shape[1]
       dec_reg = conv_layer(dec_h.reshape((Nn * Tt,) + tuple(dec_h.shape[2:])),
                            P["decode_reg/out_dec_grid/W"]).reshape(Nn, Tt, H, W, 2)

@@ -177,8 +177,27 @@ def single_decoder_case():
   print("wrote golden_shim_single_decoder.npz")
 
 
+def single_decoder_beam_case():
+  """--use_single_decoder WITH --use_beam_search (code/pred_models.py:274, 287-296): the
+  decoder states are traced back along every beam and the offsets decoded from them per
+  beam, grid_pred_reg_decoded [N * beam, T, H, W, 2]."""
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), use_single_decoder=True,
+                             beam_size=4)
+  params = synth.make_params(cfg, seed=VARIANT_SEED + 4, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=VARIANT_SEED + 4)
+  cls, reg, beam = rr.forward(cfg, params, feed)
+  np.savez_compressed(os.path.join(GOLD, "golden_shim_single_decoder_beam.npz"),
+                      cls_1=np.asarray(cls[1]), reg_1=np.asarray(reg[1]),
+                      beam_logits=np.asarray(beam[0]), beam_ids=np.asarray(beam[1]),
+                      beam_logprobs=np.asarray(beam[2]))
+  print("wrote golden_shim_single_decoder_beam.npz", np.asarray(reg[1]).shape)
+
+
 def main():
   assert rr.available(), "needs the reference checkout (/root/reference)"
+  if len(sys.argv) > 1 and sys.argv[1] == "single_beam":
+    single_decoder_beam_case()
+    return
   if len(sys.argv) > 1 and sys.argv[1] == "variants":
     only = sys.argv[2:] or None
     for name, over, steps in VARIANT_CASES:

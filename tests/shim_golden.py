@@ -128,3 +128,14 @@ def single_decoder_case():
   tparams = synth.make_params(tcfg, seed=VARIANT_SEED + 3, recurrent_gain=2.0, bias_scale=0.1)
   feeds = [synth.make_feed(tcfg, seed=VARIANT_SEED + 103 + s) for s in range(int(g["steps"][0]))]
   return g, (cfg, params, feed), (tcfg, tparams, feeds)
+
+
+def single_decoder_beam_case():
+  """golden_shim_single_decoder_beam.npz: --use_single_decoder with beam search (scale 1,
+  N = 2, beam 4): (fixture, cfg, params, feed)."""
+  g = load("golden_shim_single_decoder_beam.npz")
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), use_single_decoder=True,
+                             beam_size=4)
+  params = synth.make_params(cfg, seed=VARIANT_SEED + 4, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=VARIANT_SEED + 4)
+  return g, cfg, params, feed

@@ -229,7 +229,29 @@ def test_single_decoder(built_lib, mode):
   for n in no_grad:
     assert (eng.get_param(n) == tparams[n]).all()
   eng.close()
-  # refused with beam search
-  bcfg = synth.default_config(batch_size=2, use_grids=(1, 0), use_single_decoder=True, beam_size=5)
-  with pytest.raises(built_lib.MvError, match="use_single_decoder"):
-    built_lib.Engine(bcfg, device=0)
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+def test_single_decoder_with_beam_search(built_lib, mode):
+  """--use_single_decoder + --use_beam_search (code/pred_models.py:274, 287-296): the offsets
+  are hidden2grid of the class decoder's states traced back along every beam,
+  grid_pred_reg_decoded [N * beam, T, H, W, 2].  Against the frozen run of the reference's own
+  graph (golden_shim_single_decoder_beam.npz) and, with hipGraph replay, against itself."""
+  g, cfg, params, feed = sg.single_decoder_beam_case()
+  N, B, Tp = cfg.batch_size, cfg.beam_size, cfg.pred_len
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode(mode)
+  arrs, s = eng.forward_beam(feed)
+  assert s == 1 and arrs["grid_reg"].shape == (N * B, Tp, 9, 16, 2)
+  assert (arrs["ids"] == g["beam_ids"]).all()          # no tied selections in this case
+  assert np.abs(arrs["logits"] - g["beam_logits"]).max() < 1e-4
+  assert np.abs(arrs["logprobs"] - g["beam_logprobs"]).max() < 1e-3
+  assert np.abs(arrs["best_beam"] - g["cls_1"]).max() < 1e-4
+  assert np.abs(arrs["grid_reg"] - g["reg_1"]).max() < 1e-4
+  eng.set_graph_mode(True)
+  again, _ = eng.forward_beam(feed)
+  again, _ = eng.forward_beam(feed)
+  eng.close()
+  for k in arrs:
+    assert (again[k] == arrs[k]).all(), k

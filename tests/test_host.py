@@ -213,9 +213,9 @@ def test_trainer_rejects_unbuilt_switches():
   cfg = synth.default_config(batch_size=2, is_train=True)
   cfg.use_single_decoder = True
   pred_models.Model._check_config(cfg)           # greedy / training: built
-  cfg.use_beam_search = True
-  with pytest.raises(_lib.MvError, match="use_single_decoder"):
-    pred_models.Model._check_config(cfg)
+  bcfg = synth.default_config(batch_size=2, use_grids=(1, 0), use_single_decoder=True,
+                              beam_size=5)
+  pred_models.Model._check_config(bcfg)          # with beam search too (offsets per beam)
   # every published training switch maps onto mv_train_config
   for field, val, attr, want in (("optimizer", "adam", "optimizer", 2),
                                  ("optimizer", "momentum", "optimizer", 1),

@@ -144,6 +144,21 @@ def test_oracle_single_decoder_equals_reference():
     assert (p[n] == tparams[n]).all()
 
 
+def test_oracle_single_decoder_with_beam_search_equals_reference():
+  """--use_single_decoder + --use_beam_search (code/pred_models.py:274, 287-296): the cell
+  outputs are traced back along every beam and the offsets decoded per beam,
+  grid_pred_reg_decoded [N * beam, T, H, W, 2]."""
+  from beam_compare import compare_beams
+  g, cfg, params, feed = sg.single_decoder_beam_case()
+  cls, reg, beam = oracle.forward(params, cfg, feed)
+  N, B = cfg.batch_size, cfg.beam_size
+  assert reg[1].shape == g["reg_1"].shape == (N * B, cfg.pred_len, 9, 16, 2)
+  assert (beam[1] == g["beam_ids"]).all()
+  assert np.abs(beam[0] - g["beam_logits"]).max() <= 2e-5
+  assert np.abs(cls[1] - g["cls_1"]).max() <= 2e-5
+  assert np.abs(reg[1] - g["reg_1"]).max() <= 2e-5
+
+
 # ---- N4 (SimAug): the reference's own SimAug/code/pred_models.py, run on the shim with
 # injected random draws and frozen in golden_simaug.npz (tests/simaug_cases.py)
 
