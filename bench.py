@@ -632,7 +632,9 @@ def main():
   out = head
 
   subs = []
-  if not args.no_sub and kind == "greedy" and args.batch is None and args.compute == "f16x3":
+  with_subs = (not args.no_sub and kind == "greedy" and args.batch is None and
+               args.compute == "f16x3")
+  if with_subs:
     subs = [("train_n32", dict(kind="train", batch=32, compute="f16x3")),
             ("beam_n128_b20", dict(kind="beam", batch=128, compute="f16x3", beam_size=20)),
             ("greedy_b256", dict(kind="greedy", batch=256, compute="f16x3")),
@@ -649,8 +651,8 @@ def main():
       # a sub-workload must not take the headline down; in a multi-rank run every rank
       # fails or succeeds together (same code, same sizes)
       out[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-  if (subs and ctx.rank == 0 and ctx.world == 1 and
-      (args.only_sub is None or "host_path" in args.only_sub)):
+  if (with_subs and ctx.rank == 0 and ctx.world == 1 and
+      (args.only_sub is None or "host_path" in args.only_sub.split(","))):
     try:
       out["host_path"] = host_path(args.compute)
     except Exception as ex:  # pylint: disable=broad-except

@@ -224,6 +224,17 @@ typedef struct mv_targets_compact {
 int  mv_set_grid_centers(mv_handle h, int32_t scale, const double* centers /* [H, W, 2] */);
 int  mv_upload_inputs_compact(mv_handle h, const mv_inputs_compact* in);
 int  mv_upload_targets_compact(mv_handle h, const mv_targets_compact* tg);
+/* Pipelined greedy forward.  One sess.run of the reference is feed + compute + fetch in turn
+ * (code/pred_models.py:1761-1790); an evaluation loop (code/pred_utils.py:415) knows its next
+ * batch while the current one computes.  mv_submit_greedy copies the caller's buffers (free
+ * again on return) into one of `depth` pinned slots and queues H2D -> forward -> D2H on the
+ * engine's copy and compute streams; mv_collect_greedy blocks for the OLDEST submission and
+ * fills `out` (sized for that submission's pred_len, returned through *pred_len when not
+ * NULL).  At most `depth` submissions may be outstanding.  Results are bitwise those of
+ * mv_forward_greedy. */
+int  mv_pipeline_create(mv_handle h, int32_t depth);
+int  mv_submit_greedy(mv_handle h, const mv_inputs* in);
+int  mv_collect_greedy(mv_handle h, mv_outputs* out, int32_t* pred_len);
 int  mv_run_greedy_resident(mv_handle h);   /* enqueue on the handle's stream */
 int  mv_run_beam_resident(mv_handle h);
 int  mv_synchronize(mv_handle h);

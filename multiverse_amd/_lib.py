@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = [
     "mv_set_label_mixup", "mv_clear_label_mixup",
     "mv_op_convlstm_bwd", "mv_op_gnn_bwd",
     "mv_set_grid_centers", "mv_upload_inputs_compact", "mv_upload_targets_compact",
+    "mv_pipeline_create", "mv_submit_greedy", "mv_collect_greedy",
 ]
 
 
@@ -189,6 +190,9 @@ def load():
   lib.mv_forward_beam.argtypes = [h, C.POINTER(mv_inputs),
                                   C.POINTER(mv_beam_outputs)]
   lib.mv_upload_inputs.argtypes = [h, C.POINTER(mv_inputs)]
+  lib.mv_pipeline_create.argtypes = [h, C.c_int32]
+  lib.mv_submit_greedy.argtypes = [h, C.POINTER(mv_inputs)]
+  lib.mv_collect_greedy.argtypes = [h, C.POINTER(mv_outputs), C.POINTER(C.c_int32)]
   lib.mv_set_grid_centers.argtypes = [h, C.c_int32, _dp]
   lib.mv_upload_inputs_compact.argtypes = [h, C.POINTER(mv_inputs_compact)]
   lib.mv_upload_targets_compact.argtypes = [h, C.POINTER(mv_targets_compact)]
@@ -607,6 +611,37 @@ class Engine(object):
         tg.grid_pred_labels[s] = iptr(lab)
       check(self.lib.mv_upload_targets_compact(self.handle, C.byref(tg)), self.handle)
     del keep      # both calls copy synchronously
+
+  # ---- pipelined greedy forward: feed of batch k+1 / fetch of batch k-1 under batch k
+  def submit_greedy(self, feed, depth=2):
+    """Queue one batch (H2D -> forward -> D2H on the engine's streams) and return; the
+    caller's arrays are free again on return.  At most `depth` batches outstanding."""
+    if not getattr(self, "_pipe_depth", 0):
+      check(self.lib.mv_pipeline_create(self.handle, int(depth)), self.handle)
+      self._pipe_depth = int(depth)
+    inp = self._inputs(feed)
+    check(self.lib.mv_submit_greedy(self.handle, C.byref(inp)), self.handle)
+    self._pipe_lens = getattr(self, "_pipe_lens", []) + [inp.pred_len]
+
+  def collect_greedy(self):
+    """-> (cls, reg) of the OLDEST submitted batch (blocks until it is on the host)."""
+    Tp = self._pipe_lens.pop(0)
+    out, cls, reg = self._alloc_outputs(Tp)
+    check(self.lib.mv_collect_greedy(self.handle, C.byref(out), None), self.handle)
+    return cls, reg
+
+  def forward_greedy_pipelined(self, feeds, depth=2):
+    """[(cls, reg)] of a sequence of batches, bitwise those of forward_greedy on each; batch
+    k+1 is submitted before batch k is collected."""
+    feeds = list(feeds)
+    outs = []
+    for k, feed in enumerate(feeds):
+      if k >= depth:
+        outs.append(self.collect_greedy())
+      self.submit_greedy(feed, depth)
+    while len(outs) < len(feeds):
+      outs.append(self.collect_greedy())
+    return outs
 
   def forward_greedy_compact(self, feed):
     self.upload_compact(feed)

@@ -218,6 +218,19 @@ struct mv_engine {
     for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
     graphs.clear();
   }
+  // pipelined greedy forward (mv_submit_greedy / mv_collect_greedy): feed of batch k+1 and
+  // fetch of batch k-1 on a copy stream while batch k computes
+  struct PipeSlot {
+    void* pin = nullptr;            // pinned host: inputs, then outputs
+    char* dev = nullptr;            // device staging, same layout
+    size_t in_bytes = 0, out_bytes = 0;
+    hipEvent_t h2d = nullptr, done = nullptr, d2h = nullptr;
+    int num_frames = 0, pred_len = 0;
+    bool busy = false;
+  };
+  std::vector<PipeSlot> pipe;
+  hipStream_t copy_stream = nullptr;
+  size_t pipe_head = 0, pipe_tail = 0;      // next slot to submit into / to collect from
   // in-library gradient all-reduce (mv_allreduce_init, comm.h); null: single device
   mv::Comm* comm = nullptr;
   // training state (mv_train_init)
@@ -1588,6 +1601,169 @@ void download_outputs(mv_engine* e, mv_outputs* out) {
   HIP_CHECK(hipStreamSynchronize(e->stream));
 }
 
+// ---- pipelined greedy forward.  One `sess.run` of the reference is feed + compute + fetch,
+// strictly in turn (code/pred_models.py:1761-1790).  An evaluation loop knows its next batch
+// while the current one computes: mv_submit_greedy copies the caller's buffers into a pinned
+// slot and queues H2D (copy stream) -> device staging -> [compute stream: D2D into the live
+// input buffers, the forward, D2D of the outputs into the slot] -> D2H (copy stream) and
+// returns; mv_collect_greedy waits for the OLDEST submission and hands its outputs over.
+// With two slots the PCIe traffic of batches k+1 and k-1 runs under the kernels of batch k.
+// Layout of a slot: obs_scene | scene_feat (N*T frames max) | per used scale labels,
+// obs_regress || per used scale out_cls, out_reg (max_pred_len).
+struct PipeLayout {
+  size_t obs_scene = 0, scene_feat = 0, labels[MV_MAX_SCALES] = {0, 0},
+         obs_reg[MV_MAX_SCALES] = {0, 0}, in_bytes = 0;
+  size_t out_cls[MV_MAX_SCALES] = {0, 0}, out_reg[MV_MAX_SCALES] = {0, 0}, out_bytes = 0;
+};
+static PipeLayout pipe_layout(const mv_engine* e) {
+  const mv_config& c = e->cfg;
+  const size_t N = c.batch_size, T = c.obs_len, Tp = c.max_pred_len;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  PipeLayout L;
+  size_t o = 0;
+  L.obs_scene = o; o = al(o + N * T * sizeof(int32_t));
+  L.scene_feat = o; o = al(o + N * T * c.scene_h * c.scene_w * c.scene_class * sizeof(float));
+  for (int s = 0; s < c.num_scales; ++s) {
+    if (!e->sc[s].use) continue;
+    const size_t K = e->sc[s].K;
+    L.labels[s] = o; o = al(o + N * T * sizeof(int32_t));
+    L.obs_reg[s] = o; o = al(o + N * T * K * 2 * sizeof(float));
+  }
+  L.in_bytes = o;
+  for (int s = 0; s < c.num_scales; ++s) {
+    if (!e->sc[s].use) continue;
+    const size_t K = e->sc[s].K;
+    L.out_cls[s] = o; o = al(o + N * Tp * K * sizeof(float));
+    L.out_reg[s] = o; o = al(o + N * Tp * K * 2 * sizeof(float));
+  }
+  L.out_bytes = o - L.in_bytes;
+  return L;
+}
+
+void pipeline_create(mv_engine* e, int depth) {
+  MV_REQUIRE(depth >= 1 && depth <= 8, "pipeline depth %d not in [1, 8]", depth);
+  MV_REQUIRE(e->cfg.beam_size == 1, "the pipelined forward is the greedy one");
+  MV_REQUIRE(e->pipe.empty(), "pipeline already created");
+  const PipeLayout L = pipe_layout(e);
+  HIP_CHECK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  e->pipe.resize(depth);
+  for (auto& sl : e->pipe) {
+    sl.in_bytes = L.in_bytes; sl.out_bytes = L.out_bytes;
+    HIP_CHECK(hipHostMalloc(&sl.pin, L.in_bytes + L.out_bytes, hipHostMallocDefault));
+    HIP_CHECK(hipMalloc((void**)&sl.dev, L.in_bytes + L.out_bytes));
+    HIP_CHECK(hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&sl.d2h, hipEventDisableTiming));
+  }
+  e->pipe_head = e->pipe_tail = 0;
+}
+
+void pipeline_destroy(mv_engine* e) {
+  for (auto& sl : e->pipe) {
+    if (sl.pin) (void)hipHostFree(sl.pin);
+    if (sl.dev) (void)hipFree(sl.dev);
+    if (sl.h2d) (void)hipEventDestroy(sl.h2d);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.d2h) (void)hipEventDestroy(sl.d2h);
+  }
+  e->pipe.clear();
+  if (e->copy_stream) { (void)hipStreamDestroy(e->copy_stream); e->copy_stream = nullptr; }
+}
+
+void pipeline_submit(mv_engine* e, const mv_inputs* in) {
+  const mv_config& c = e->cfg;
+  const size_t N = c.batch_size, T = c.obs_len;
+  MV_REQUIRE(!e->pipe.empty(), "mv_pipeline_create has not been called");
+  mv_engine::PipeSlot& sl = e->pipe[e->pipe_head % e->pipe.size()];
+  MV_REQUIRE(!sl.busy, "pipeline full: %zu submissions not collected (mv_collect_greedy)",
+             e->pipe.size());
+  MV_REQUIRE(in->obs_scene && in->scene_feat, "obs_scene / scene_feat is NULL");
+  MV_REQUIRE(in->num_scene_frames >= 1 && (size_t)in->num_scene_frames <= N * T,
+             "num_scene_frames %d not in [1, N*T_o=%zu]", in->num_scene_frames, N * T);
+  MV_REQUIRE(in->pred_len >= 1 && in->pred_len <= c.max_pred_len,
+             "pred_len %d not in [1, max_pred_len=%d]", in->pred_len, c.max_pred_len);
+  for (size_t i = 0; i < N * T; ++i)
+    MV_REQUIRE(in->obs_scene[i] >= 0 && in->obs_scene[i] < in->num_scene_frames,
+               "obs_scene[%zu] = %d out of range [0,%d)", i, in->obs_scene[i],
+               in->num_scene_frames);
+  const PipeLayout L = pipe_layout(e);
+  char* pin = static_cast<char*>(sl.pin);
+  const size_t sf_bytes = (size_t)in->num_scene_frames * c.scene_h * c.scene_w *
+                          c.scene_class * sizeof(float);
+  memcpy(pin + L.obs_scene, in->obs_scene, N * T * sizeof(int32_t));
+  memcpy(pin + L.scene_feat, in->scene_feat, sf_bytes);
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    MV_REQUIRE(in->grid_obs_labels[s] && in->grid_obs_regress[s],
+               "grid_obs_labels/grid_obs_regress[%d] is NULL for an enabled scale", s);
+    for (size_t i = 0; i < N * T; ++i)
+      MV_REQUIRE(in->grid_obs_labels[s][i] >= 0 && in->grid_obs_labels[s][i] < S.K,
+                 "grid_obs_labels[%d][%zu] = %d out of range [0,%d)", s, i,
+                 in->grid_obs_labels[s][i], S.K);
+    memcpy(pin + L.labels[s], in->grid_obs_labels[s], N * T * sizeof(int32_t));
+    memcpy(pin + L.obs_reg[s], in->grid_obs_regress[s], N * T * S.K * 2 * sizeof(float));
+  }
+  sl.num_frames = in->num_scene_frames; sl.pred_len = in->pred_len;
+  // copy stream: the whole input block in one transfer (it must not start before the
+  // slot's previous fetch has left the same pinned / staging buffers: collect waited d2h)
+  HIP_CHECK(hipMemcpyAsync(sl.dev, sl.pin, L.in_bytes, hipMemcpyHostToDevice, e->copy_stream));
+  HIP_CHECK(hipEventRecord(sl.h2d, e->copy_stream));
+  // compute stream: staging -> live inputs, forward, outputs -> staging
+  HIP_CHECK(hipStreamWaitEvent(e->stream, sl.h2d, 0));
+  auto d2d = [&](void* dst, const void* src, size_t n) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, e->stream));
+  };
+  d2d(e->obs_scene.p, sl.dev + L.obs_scene, N * T * sizeof(int32_t));
+  d2d(e->scene_feat.p, sl.dev + L.scene_feat, sf_bytes);
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    d2d(S.labels.p, sl.dev + L.labels[s], N * T * sizeof(int32_t));
+    d2d(S.obs_reg.p, sl.dev + L.obs_reg[s], N * T * S.K * 2 * sizeof(float));
+  }
+  e->num_frames = sl.num_frames;
+  e->pred_len = sl.pred_len;
+  e->inputs_ready = true;
+  run_forward(e, false);
+  const size_t Tp = sl.pred_len;
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    d2d(sl.dev + L.out_cls[s], S.out_cls.p, N * Tp * S.K * sizeof(float));
+    d2d(sl.dev + L.out_reg[s], S.out_reg.p, N * Tp * S.K * 2 * sizeof(float));
+  }
+  HIP_CHECK(hipEventRecord(sl.done, e->stream));
+  // copy stream: fetch
+  HIP_CHECK(hipStreamWaitEvent(e->copy_stream, sl.done, 0));
+  HIP_CHECK(hipMemcpyAsync(pin + L.in_bytes, sl.dev + L.in_bytes, L.out_bytes,
+                           hipMemcpyDeviceToHost, e->copy_stream));
+  HIP_CHECK(hipEventRecord(sl.d2h, e->copy_stream));
+  sl.busy = true;
+  e->pipe_head += 1;
+}
+
+void pipeline_collect(mv_engine* e, mv_outputs* out) {
+  const mv_config& c = e->cfg;
+  MV_REQUIRE(!e->pipe.empty(), "mv_pipeline_create has not been called");
+  mv_engine::PipeSlot& sl = e->pipe[e->pipe_tail % e->pipe.size()];
+  MV_REQUIRE(sl.busy, "mv_collect_greedy: nothing submitted");
+  HIP_CHECK(hipEventSynchronize(sl.d2h));
+  const PipeLayout L = pipe_layout(e);
+  const char* pin = static_cast<const char*>(sl.pin);
+  const size_t N = c.batch_size, Tp = sl.pred_len;
+  for (int s = 0; s < c.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    if (!S.use) continue;
+    if (out->grid_pred_class[s])
+      memcpy(out->grid_pred_class[s], pin + L.out_cls[s], N * Tp * S.K * sizeof(float));
+    if (out->grid_pred_reg[s])
+      memcpy(out->grid_pred_reg[s], pin + L.out_reg[s], N * Tp * S.K * 2 * sizeof(float));
+  }
+  sl.busy = false;
+  e->pipe_tail += 1;
+}
+
 void download_beam(mv_engine* e, mv_beam_outputs* out) {
   const mv_config& c = e->cfg;
   const size_t N = c.batch_size, Tp = e->pred_len, B = c.beam_size;
@@ -1712,6 +1888,8 @@ int mv_destroy(mv_handle h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+  pipeline_destroy(h);
   h->drop_graphs();
   if (h->comm) {
     if (h->comm->stream) (void)hipStreamSynchronize(h->comm->stream);
@@ -1863,6 +2041,30 @@ int mv_forward_greedy(mv_handle h, const mv_inputs* in, mv_outputs* out) {
     upload_inputs(h, in);
     run_forward(h, false);
     download_outputs(h, out);
+    drain_events(h);
+  });
+}
+
+int mv_pipeline_create(mv_handle h, int32_t depth) {
+  if (!h) return 1;
+  return guarded(h, [&] { pipeline_create(h, depth); });
+}
+
+int mv_submit_greedy(mv_handle h, const mv_inputs* in) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(in, "mv_submit_greedy: NULL argument");
+    pipeline_submit(h, in);
+  });
+}
+
+int mv_collect_greedy(mv_handle h, mv_outputs* out, int32_t* pred_len) {
+  if (!h) return 1;
+  return guarded(h, [&] {
+    MV_REQUIRE(out, "mv_collect_greedy: NULL argument");
+    if (pred_len && !h->pipe.empty())
+      *pred_len = h->pipe[h->pipe_tail % h->pipe.size()].pred_len;
+    pipeline_collect(h, out);
     drain_events(h);
   });
 }

@@ -278,6 +278,39 @@ class Tester(object):
     feed = self.model.get_feed_dict(batch_data, is_train=False)
     return self.model.run_forward(feed)
 
+  def steps(self, sess, batches, depth=2):
+    """Yield (batch, step(sess, batch)) for every batch of an iterable -- what the loop of
+    `evaluate` (code/pred_utils.py:415) computes, with the feed of batch k+1 and the fetch
+    of batch k-1 overlapped with the kernels of batch k (mv_submit_greedy /
+    mv_collect_greedy; greedy decode with the dense feed, else plain `step`).  Results are
+    bitwise those of `step`."""
+    cfg = self.config
+    if getattr(cfg, "use_beam_search", False) or getattr(cfg, "no_pipeline", False):
+      for batch in batches:
+        yield batch, self.step(sess, batch)
+      return
+    pending = []
+    eng = self.model.engine
+    for batch in batches:
+      feed = self.model.get_feed_dict(batch[1], is_train=False)
+      if feed.get("compact", False):          # compact feeds take the blocking path
+        while pending:
+          b0 = pending.pop(0)
+          cls, reg = eng.collect_greedy()
+          yield b0, (cls, reg, None)
+        yield batch, self.model.run_forward(feed)
+        continue
+      if len(pending) >= depth:
+        b0 = pending.pop(0)
+        cls, reg = eng.collect_greedy()
+        yield b0, (cls, reg, None)
+      eng.submit_greedy(feed, depth)
+      pending.append(batch)
+    while pending:
+      b0 = pending.pop(0)
+      cls, reg = eng.collect_greedy()
+      yield b0, (cls, reg, None)
+
 
 class Trainer(object):
   """code/pred_models.py:1636-1742: learning-rate schedule, Adadelta,

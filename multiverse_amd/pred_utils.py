@@ -310,8 +310,12 @@ def evaluate(dataset, config, sess, tester):
     if getattr(config, "use_beam_search", False):
       out_data["beam_grid_ids"] = []
       out_data["beam_logprobs"] = []
-  for evalbatch in dataset.get_batches(config.batch_size, full=True, shuffle=False):
-    grid_pred_class, grid_pred_reg, beam_outputs = tester.step(sess, evalbatch)
+  # tester.steps == tester.step per batch, with the next batch's feed and the previous
+  # batch's fetch overlapped with the current batch's kernels when the tester offers it
+  batches = dataset.get_batches(config.batch_size, full=True, shuffle=False)
+  stepper = (tester.steps(sess, batches) if hasattr(tester, "steps")
+             else ((b, tester.step(sess, b)) for b in batches))
+  for evalbatch, (grid_pred_class, grid_pred_reg, beam_outputs) in stepper:
     _, batch = evalbatch
     N = batch.data["original_batch_size"]
     if getattr(config, "use_beam_search", False):
