@@ -229,7 +229,10 @@ struct mv_engine {
     bool busy = false;
   };
   std::vector<PipeSlot> pipe;
-  hipStream_t copy_stream = nullptr;
+  hipStream_t copy_stream = nullptr;     // H2D (feeds)
+  hipStream_t fetch_stream = nullptr;    // D2H (fetches): its own queue, else the feed of
+                                         // batch k+1 would sit behind the fetch of batch k,
+                                         // which waits for batch k's kernels
   size_t pipe_head = 0, pipe_tail = 0;      // next slot to submit into / to collect from
   // in-library gradient all-reduce (mv_allreduce_init, comm.h); null: single device
   mv::Comm* comm = nullptr;
@@ -1646,6 +1649,7 @@ void pipeline_create(mv_engine* e, int depth) {
   MV_REQUIRE(e->pipe.empty(), "pipeline already created");
   const PipeLayout L = pipe_layout(e);
   HIP_CHECK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&e->fetch_stream, hipStreamNonBlocking));
   e->pipe.resize(depth);
   for (auto& sl : e->pipe) {
     sl.in_bytes = L.in_bytes; sl.out_bytes = L.out_bytes;
@@ -1668,6 +1672,7 @@ void pipeline_destroy(mv_engine* e) {
   }
   e->pipe.clear();
   if (e->copy_stream) { (void)hipStreamDestroy(e->copy_stream); e->copy_stream = nullptr; }
+  if (e->fetch_stream) { (void)hipStreamDestroy(e->fetch_stream); e->fetch_stream = nullptr; }
 }
 
 void pipeline_submit(mv_engine* e, const mv_inputs* in) {
@@ -1734,11 +1739,11 @@ void pipeline_submit(mv_engine* e, const mv_inputs* in) {
     d2d(sl.dev + L.out_reg[s], S.out_reg.p, N * Tp * S.K * 2 * sizeof(float));
   }
   HIP_CHECK(hipEventRecord(sl.done, e->stream));
-  // copy stream: fetch
-  HIP_CHECK(hipStreamWaitEvent(e->copy_stream, sl.done, 0));
+  // fetch stream
+  HIP_CHECK(hipStreamWaitEvent(e->fetch_stream, sl.done, 0));
   HIP_CHECK(hipMemcpyAsync(pin + L.in_bytes, sl.dev + L.in_bytes, L.out_bytes,
-                           hipMemcpyDeviceToHost, e->copy_stream));
-  HIP_CHECK(hipEventRecord(sl.d2h, e->copy_stream));
+                           hipMemcpyDeviceToHost, e->fetch_stream));
+  HIP_CHECK(hipEventRecord(sl.d2h, e->fetch_stream));
   sl.busy = true;
   e->pipe_head += 1;
 }
@@ -1889,6 +1894,7 @@ int mv_destroy(mv_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+  if (h->fetch_stream) (void)hipStreamSynchronize(h->fetch_stream);
   pipeline_destroy(h);
   h->drop_graphs();
   if (h->comm) {
