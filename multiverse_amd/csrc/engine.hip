@@ -1090,6 +1090,10 @@ struct TailPlan {
   bool cls_next;       // class chain: argmax + embedding of step t+1 (greedy only)
   const float* reg_h; float* reg_out; int64_t reg_stride; bool reg_next;
   int reg_rows = 0;    // 0: N (the un-beamed regression chain)
+  // training forward: where the argmax ids and the next step's embeddings go (null: the
+  // inference buffers S.ids / S.xbuf_cls / S.xbuf_reg with their operand planes)
+  int32_t* cls_ids_out = nullptr; float* cls_x_out = nullptr; float* reg_x_out = nullptr;
+  bool cls_embed = true;   // false: ids only (the embedding is made elsewhere)
 };
 
 void run_tail(mv_engine* e, const std::vector<TailPlan>& plans) {
@@ -1113,8 +1117,14 @@ void run_tail(mv_engine* e, const std::vector<TailPlan>& plans) {
     a.act = c.activation;
     tbytes += 4.0 * cc * (9 + 1);
     if (pl.cls_next) {
-      a.ids_out = S.ids.p;
-      if (!sparse_x_on(e, S)) {     // sparse x: the next step needs the id, not the embedding
+      a.ids_out = pl.cls_ids_out ? pl.cls_ids_out : S.ids.p;
+      if (pl.cls_x_out) {           // training: fp32 embedding into the time-major x buffer
+        if (pl.cls_embed) {
+          a.emb_w = S.emb_cls_W->dev.p; a.emb_b = S.emb_cls_b->dev.p;
+          a.x_out = pl.cls_x_out;
+          tbytes += 4.0 * cc * E;
+        }
+      } else if (!sparse_x_on(e, S)) {     // sparse x: the next step needs the id, not the embedding
         size_t pst = 0;
         a.emb_w = S.emb_cls_W->dev.p; a.emb_b = S.emb_cls_b->dev.p;
         a.x_out = S.xbuf_cls.p;
@@ -1131,9 +1141,14 @@ void run_tail(mv_engine* e, const std::vector<TailPlan>& plans) {
     if (pl.reg_next) {
       size_t pst = 0;
       b.emb_w = S.emb_reg_W->dev.p; b.emb_b = S.emb_reg_b->dev.p;
+      if (pl.reg_x_out) {
+        b.x_out = pl.reg_x_out;
+        tbytes += 4.0 * cr * E;
+      } else {
       b.x_out = S.xbuf_reg.p;
       b.x16 = e->plane_out(S.xbuf_reg.p, &pst); b.x16_stride = (int64_t)pst;
       tbytes += 4.0 * cr * E * (b.x16 ? 2 : 1);
+      }
     }
     tp.push_back(b);
   }

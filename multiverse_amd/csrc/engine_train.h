@@ -517,6 +517,7 @@ void train_forward(mv_engine* e) {
     run_conv_group(e, probs);
   }
   // decoders (grid_decoder under raw_rnn, input_onehot for the class decoder)
+  bool tail_embedded = false;      // the previous step's tail wrote this step's embeddings
   for (int ts = 0; ts < Tp; ++ts) {
     std::vector<ConvLstmArgs> probs;
     for (int s = 0; s < c.num_scales; ++s) {
@@ -541,7 +542,9 @@ void train_forward(mv_engine* e) {
                            R.onehot.p, 1, N, S.K);
         run_emb_dense(e, S, R.onehot.p, (size_t)S.K, xc, N, S.emb_cls_W, S.emb_cls_b, 1);
       } else if (ts == 0) run_emb_onehot(e, S, S.labels.p + (To - 1), To, xc, N);
-      else if (cls_fb == 0) run_emb_onehot(e, S, R.ids.p + (size_t)ts * N, 1, xc, N);
+      else if (cls_fb == 0) {
+        if (!tail_embedded) run_emb_onehot(e, S, R.ids.p + (size_t)ts * N, 1, xc, N);
+      }
       else   // dense input map: the previous step's logits, or the step's ground truth
         run_emb_dense(e, S, cls_fb == 1 ? R.logits.p + (size_t)(ts - 1) * NK
                                         : R.gt_cls.p + (size_t)ts * NK,
@@ -564,7 +567,7 @@ void train_forward(mv_engine* e) {
       }
       if (reg_tf && ts > 0)       // teacher forcing: grid_pred_regress[:, ts] (:398)
         run_emb_dense(e, S, R.reg_in.p + (size_t)ts * NK * 2, (size_t)S.K * 2, xr, N);
-      else
+      else if (!(tail_embedded && ts > 0))
         run_emb_dense(e, S, R.regio.p + (size_t)ts * NK * 2, (size_t)S.K * 2, xr, N);
       run_dropout(e, xr, NK * E, s, 3, ts);
       probs.push_back(train_problem(e, R.dec[1], xr, R.hs[1].p + slot * NKC,
@@ -574,6 +577,40 @@ void train_forward(mv_engine* e) {
                                     false));
     }
     run_conv_group(e, probs);
+    // Decoder tail of the step on the inference kernels (round 3): hidden2grid of every chain
+    // as ONE grouped GEMM launch (h2g_q) + one gather / argmax / next-embedding kernel
+    // (decode_tail) instead of two hidden2grid convolutions, an argmax and two embedding
+    // launches per scale.  The embeddings of step ts+1 land in the time-major x buffers the
+    // backward pass reads; dense class feedback and teacher forcing keep their own embedding
+    // launches at the head of the next iteration.  MV_TRAIN_TAIL=v1 restores the old launches.
+    static const bool tail2 = tail_v2() &&
+        !(getenv("MV_TRAIN_TAIL") && strcmp(getenv("MV_TRAIN_TAIL"), "v1") == 0);
+    if (tail2 && E == 32) {
+      std::vector<TailPlan> plans;
+      for (int s = 0; s < c.num_scales; ++s) {
+        ScaleState& S = e->sc[s];
+        if (!S.use) continue;
+        TrainScale& R = t.sc[s];
+        const size_t NK = (size_t)N * S.K, NKC = NK * C;
+        const int slot = To + ts + 1;
+        const bool more = ts + 1 < Tp;
+        TailPlan pl{};
+        pl.s = s;
+        pl.cls_h = R.hs[0].p + slot * NKC; pl.cls_rows = N;
+        pl.cls_out = R.logits.p + (size_t)ts * NK; pl.cls_stride = (int64_t)S.K;
+        pl.cls_next = more && cls_fb == 0;
+        pl.cls_ids_out = R.ids.p + (size_t)(ts + 1) * N;
+        pl.cls_x_out = R.dec[0].xs.p + (size_t)(ts + 1) * NK * E;
+        pl.reg_h = R.hs[nb - 1].p + slot * NKC;
+        pl.reg_out = R.regio.p + (size_t)(ts + 1) * NK * 2; pl.reg_stride = (int64_t)S.K * 2;
+        pl.reg_next = more && nb == 2 && !reg_tf;
+        pl.reg_x_out = nb == 2 ? R.dec[1].xs.p + (size_t)(ts + 1) * NK * E : nullptr;
+        plans.push_back(pl);
+      }
+      run_tail(e, plans);
+      tail_embedded = true;
+      continue;
+    }
     for (int s = 0; s < c.num_scales; ++s) {
       ScaleState& S = e->sc[s];
       if (!S.use) continue;

@@ -272,3 +272,26 @@ def test_sparse_x_table_terms_equal_the_dense_x_operand(built_lib, tmp_path):
     assert flipped <= (0 if mode == "f16x3" else 1), (mode, flipped)
     print("%s: sparse-x vs dense-x class logits, max rel diff %.2e, rows branched %d"
           % (mode, worst, flipped))
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+def test_literal_baseline_grids_36x18_and_18x9(built_lib, mode):
+  """BASELINE.json words the grids as 36x18 / 18x9 (648 / 162 cells over 72x36 scene maps);
+  the reference's own are 18x32 / 9x16.  W = 18 and 9 do not divide 32:
+  the gate kernels run their generic (every-tap-loaded) template instance, image rows end
+  inside the 32-cell operand tiles, the attention falls to 1-D groups that straddle rows.
+  Same bars as everywhere: argmax exact, 1e-4."""
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1), scene_h=72, scene_w=36,
+                             scene_grids=[(36, 18), (18, 9)])
+  params = synth.make_params(cfg, recurrent_gain=2.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 5)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode(mode)
+  cls, reg = eng.forward_greedy(feed)
+  eng.close()
+  ocls, oreg, _ = oracle.forward(params, cfg, feed)
+  for s in range(2):
+    assert cls[s].shape == ocls[s].shape
+    assert (cls[s].reshape(2, 12, -1).argmax(-1) == ocls[s].reshape(2, 12, -1).argmax(-1)).all()
+    assert np.abs(cls[s] - ocls[s]).max() < 1e-4 and np.abs(reg[s] - oreg[s]).max() < 1e-4
