@@ -50,6 +50,7 @@ void transpose_split_kernel(const float* __restrict__ in, _Float16* __restrict__
                             float* __restrict__ colsum_out) {
   __shared__ float tile[64][65];
   const int e = exp_ptr ? exp_ptr[0] : exp_const;
+  const float sc2e = __int_as_float((127 + e) << 23);     // 2^e, |e| <= 100 (one multiply = ldexpf)
   const long long m0 = (long long)blockIdx.x * 64;
   const int c0 = blockIdx.y * 64;
   const int tid = threadIdx.x;
@@ -82,7 +83,7 @@ void transpose_split_kernel(const float* __restrict__ in, _Float16* __restrict__
     f16x8 p0, p1;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const float s = ldexpf(tile[grp * 8 + q][ch], e);
+      const float s = tile[grp * 8 + q][ch] * sc2e;
       const _Float16 h0 = (_Float16)s;
       p0[q] = h0;
       p1[q] = (_Float16)(s - (float)h0);
@@ -100,6 +101,7 @@ void transpose_split_narrow_kernel(const float* __restrict__ in, _Float16* __res
                                    const int32_t* __restrict__ exp_ptr) {
   __shared__ float tile[64][65];
   const int exp_const = exp_ptr[0];
+  const float sc2e = __int_as_float((127 + exp_const) << 23);
   const long long m0 = (long long)blockIdx.x * 64;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < 64 * Cc; idx += 256) {
@@ -116,7 +118,7 @@ void transpose_split_narrow_kernel(const float* __restrict__ in, _Float16* __res
     f16x8 p0, p1;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const float s = ldexpf(tile[grp * 8 + q][ch], exp_const);
+      const float s = tile[grp * 8 + q][ch] * sc2e;
       const _Float16 h0 = (_Float16)s;
       p0[q] = h0;
       p1[q] = (_Float16)(s - (float)h0);
