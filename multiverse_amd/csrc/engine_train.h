@@ -167,7 +167,7 @@ void train_alloc(mv_engine* e) {
     max_partial = std::max(max_partial, (size_t)4096 * 9 * 512);
     max_partial = std::max(max_partial, (size_t)64 * c.scene_conv_kernel * c.scene_conv_kernel * std::max<size_t>(D, c.scene_class) * D);
     // bias column sums: slabs x 4C
-    max_partial = std::max(max_partial, (size_t)1024 * 4 * C);
+    max_partial = std::max(max_partial, (size_t)1088 * 4 * C);   // run_colsum: 1024 + 32 fold rows
     (void)E;
   }
   for (int i = 0; i < c.num_scales; ++i) {
@@ -196,9 +196,13 @@ void train_alloc(mv_engine* e) {
   t.losses.alloc(64);
 }
 
-// deterministic column sum of X [rows, ncols] into out [ncols]
+// deterministic column sum of X [rows, ncols] into out [ncols]: slabs of rows are summed in
+// parallel, then the partial rows are folded 32 at a time until one is left (a fixed tree:
+// the result does not depend on timing).  Round 3: the fold of up to 1 024 partial rows used
+// to be ONE serial loop per column in a single workgroup per 256 columns (240 us per bias
+// gradient, 2 ms per training step); now every pass is at most 32 dependent adds.
 void run_colsum(mv_engine* e, const float* x, size_t rows, size_t ncols, float* out,
-                float* tmp /* >= 1024*ncols */) {
+                float* tmp /* >= 1056*ncols */) {
   size_t nslab = std::min<size_t>(1024, (rows + 63) / 64);
   if (nslab < 1) nslab = 1;
   const size_t rps = (rows + nslab - 1) / nslab;
@@ -209,17 +213,25 @@ void run_colsum(mv_engine* e, const float* x, size_t rows, size_t ncols, float* 
                        rows, ncols, rows);
     return;
   }
-  if (ncols <= 128 && 256 % ncols == 0) {     // narrow: all 256 threads on 1 KB runs
+  if (ncols <= 128 && 256 % ncols == 0)       // narrow: all 256 threads on 1 KB runs
     hipLaunchKernelGGL(mv::colsum_narrow_kernel, dim3((unsigned)nslab), dim3(256), 0,
                        e->stream, x, tmp, rows, (int)ncols, rps);
-    hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, gy), dim3(256), 0, e->stream, tmp, out,
-                       nslab, ncols, nslab);
-    return;
+  else
+    hipLaunchKernelGGL(mv::colsum_kernel, dim3((unsigned)nslab, gy), dim3(256), 0,
+                       e->stream, x, tmp, rows, ncols, rps);
+  // fold the nslab partial rows: tmp rows [0, nslab) -> rows [1024, 1024 + ceil(nslab/32))
+  const float* cur = tmp;
+  size_t n = nslab;
+  float* nxt = tmp + (size_t)1024 * ncols;
+  while (n > 32) {
+    const size_t m = (n + 31) / 32;
+    hipLaunchKernelGGL(mv::colsum_kernel, dim3((unsigned)m, gy), dim3(256), 0, e->stream, cur,
+                       nxt, n, ncols, (size_t)32);
+    cur = nxt; n = m;
+    nxt = (cur == tmp) ? tmp + (size_t)1024 * ncols : tmp;   // m <= 32 rows: fits either end
   }
-  hipLaunchKernelGGL(mv::colsum_kernel, dim3((unsigned)nslab, gy), dim3(256), 0,
-                     e->stream, x, tmp, rows, ncols, rps);
-  hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, gy), dim3(256), 0, e->stream, tmp, out,
-                     nslab, ncols, nslab);
+  hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, gy), dim3(256), 0, e->stream, cur, out, n,
+                     ncols, n);
 }
 
 void run_small_dgrad(mv_engine* e, const float* dout, size_t dout_rs, const float* w,

@@ -278,12 +278,23 @@ __global__ void conv3x3_small_dgrad_kernel(const float* __restrict__ dout,
   const int yy = r % H;
   const int m = r / H;
   float acc = 0.f;
+  const bool vec4 = (Co % 4 == 0) && (dout_row_stride % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(w)) % 16 == 0);
   for (int t = 0; t < 9; ++t) {
     const int sy = yy - (t / 3 - 1), sx = xx - (t % 3 - 1);
     if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
     const float* dp = dout + (size_t)m * dout_row_stride + ((size_t)sy * W + sx) * Co;
     const float* wp = w + ((size_t)t * Ci + ci) * Co;
+    if (vec4) {          // 16-byte loads (Co = emb_size = 32: eight per tap instead of 32)
+      for (int co = 0; co < Co; co += 4) {
+        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dp + co);
+        const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(wp + co);
+        acc = fmaf(d4[0], w4[0], acc); acc = fmaf(d4[1], w4[1], acc);
+        acc = fmaf(d4[2], w4[2], acc); acc = fmaf(d4[3], w4[3], acc);
+      }
+    } else {
     for (int co = 0; co < Co; ++co) acc = fmaf(dp[co], wp[co], acc);
+    }
   }
   float* o = din + (size_t)m * din_row_stride + ((size_t)yy * W + xx) * Ci + ci;
   *o = accumulate ? *o + acc : acc;
