@@ -362,3 +362,46 @@ def test_integration_stub_matches_the_header(tmp_path, built_lib):
   assert int(got["sizeof"]) == ctypes.sizeof(stub_cfg)
   for f in stub_cfg._fields_:
     assert int(got[f[0]]) == getattr(stub_cfg, f[0]).offset, f[0]
+
+
+def test_bench_traffic_is_quoted_only_from_profiles_of_these_sources(tmp_path, monkeypatch):
+  """bench.py quotes roofline.traffic from a committed PMC summary ONLY when that summary
+  carries the hash of the kernel sources of this tree (tools/pmc_report.py stores it); a
+  summary of other sources yields (None, reason) -- never a stale number."""
+  import json
+  import bench
+  from multiverse_amd import buildinfo
+  cur = buildinfo.kernel_source_hash()
+  assert len(cur) == 16 and cur == buildinfo.kernel_source_hash()
+  prof = tmp_path / "profiles"
+  prof.mkdir()
+  monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+  hb = {"total_corrected": 1.2e9, "total_raw": 7.0e8}
+  (prof / "r3_greedy_pmc_x.json").write_text(json.dumps(
+      {"kernel_source_sha16": "0123456789abcdef", "hbm_bytes_per_launch": hb}))
+  got, why = bench.committed_traffic("greedy_pmc_x.json")
+  assert got is None and "other kernel sources" in why
+  (prof / "r4_greedy_pmc_x.json").write_text(json.dumps(
+      {"kernel_source_sha16": cur, "hbm_bytes_per_launch": hb}))
+  got, why = bench.committed_traffic("greedy_pmc_x.json")
+  assert why is None and got[0] == hb and got[1].endswith("r4_greedy_pmc_x.json")
+  got, why = bench.committed_traffic("greedy_pmc_missing.json")
+  assert got is None and "no PMC summary" in why
+
+
+def test_bench_algorithmic_counts_match_the_survey():
+  """SURVEY.md section 8d, the ConvLSTM sweep alone (what roofline.achieved counts): per step
+  2*K*9*(Cx+C)*4C = 3.397 / 2.739 / 3.058 GFLOP (class encoder / regression encoder / decoders)
+  at 18x32 -> 8*(3.397 + 2.739) + 24*3.058 = 122.5 GFLOP per trajectory at scale 0, 153.1 for
+  both scales, 819.6 with a 20-beam class decoder (the survey's 127.2 / 158.2 / 912 add the
+  dense graph attention, hidden2grid and the scene convolutions)."""
+  import bench
+  from multiverse_amd import synth
+  f0, _ = bench.algorithmic_counts(synth.default_config(batch_size=1, use_grids=(1, 0)))
+  fb, _ = bench.algorithmic_counts(synth.default_config(batch_size=1, use_grids=(1, 1)))
+  f20, _ = bench.algorithmic_counts(synth.default_config(batch_size=1, use_grids=(1, 0)), beam=20)
+  assert abs(f0 / 1e9 - (8 * (3.397 + 2.739) + 24 * 3.058)) < 0.05
+  assert abs(fb / 1e9 - 153.09) < 0.05 and abs(f20 / 1e9 - 819.6) < 0.1
+  fe, _ = bench.algorithmic_counts(synth.default_config(batch_size=1, use_grids=(1, 1)),
+                                   executed=True, sparse_x=True)
+  assert fe < fb          # zero-state first steps and the sparse x k-steps are not counted
