@@ -937,6 +937,15 @@ void run_encoders(mv_engine* e, Cursors& cur) {
 // One attention pass per job; the LDS-tiled kernel takes up to two jobs per launch (the
 // two grid scales of a greedy step are 62 + 22 us back to back, one round of workgroups
 // each: together they fill the chip better).
+// MV_GNN = v1 (one wave per cell) / v2 (LDS-tiled, one cell per thread) select the earlier
+// kernels for A/B runs; default: the register-blocked third version.
+static int gnn_version() {
+  const char* v = getenv("MV_GNN");
+  if (v && strcmp(v, "v1") == 0) return 1;
+  if (v && strcmp(v, "v2") == 0) return 2;
+  return 3;
+}
+
 struct GnnJob {
   ScaleState* S; const float* h; const int32_t* src_row; float* out; int rows, sm_div;
   const int32_t* row_ref = nullptr;
@@ -944,12 +953,21 @@ struct GnnJob {
 
 void run_gnn_jobs(mv_engine* e, const std::vector<GnnJob>& jobs) {
   const mv_config& c = e->cfg;
-  static const bool v2 = !(getenv("MV_GNN") && strcmp(getenv("MV_GNN"), "v1") == 0);
+  static const int env_ver = gnn_version();
+  // The third version addresses h, the scene means and nothing else through 32-bit byte
+  // offsets and takes the scene channels in one 64-channel chunk; anything else runs on
+  // the second.
+  const size_t max_rows = (size_t)c.batch_size * (size_t)std::max(1, c.beam_size);
+  auto v3_ok = [&](const GnnJob& J) {
+    return (gnn_scene_dim(e) == 0 || gnn_scene_dim(e) == 64) &&
+           max_rows * J.S->K * c.hidden_size * 4 < ((size_t)1 << 32);
+  };
   for (size_t j0 = 0; j0 < jobs.size();) {
     const GnnJob& A = jobs[j0];
-    const bool tiled = v2 && A.S->W <= 32 && c.hidden_size == 256 && c.scene_conv_dim <= 64;
+    const bool tiled = env_ver >= 2 && A.S->W <= 32 && c.hidden_size == 256 && c.scene_conv_dim <= 64;
     size_t nj = 1;
     if (tiled && j0 + 1 < jobs.size() && jobs[j0 + 1].S->W <= 32) nj = 2;
+    const int ver = env_ver >= 3 && !(v3_ok(A) && (nj == 1 || v3_ok(jobs[j0 + 1]))) ? 2 : env_ver;
     mv::GnnGroup grp{};
     double flops = 0, bytes = 0;
     unsigned nblocks = 0;
@@ -967,7 +985,7 @@ void run_gnn_jobs(mv_engine* e, const std::vector<GnnJob>& jobs) {
                    (1.0 + (need_f32 ? 1.0 : 0.0) + (p16 ? 1.0 : 0.0)) +
                4.0 * (cells / J.sm_div) * gnn_scene_dim(e);
       int ng = 0;
-      const unsigned nb = mv::gnn_v2_blocks(cells, &ng);
+      const unsigned nb = ver >= 3 ? mv::gnn_v3_blocks(cells, &ng) : mv::gnn_v2_blocks(cells, &ng);
       mv::GnnProblem& P = grp.p[j];
       P.h = J.h; P.scene_mean = J.S->scene_mean.p; P.src_row = J.src_row;
       P.out = need_f32 ? J.out : nullptr; P.p16 = p16; P.p16_stride = pst;
@@ -978,7 +996,10 @@ void run_gnn_jobs(mv_engine* e, const std::vector<GnnJob>& jobs) {
     }
     if (nj == 1) grp.nblocks0 = nblocks;
     launch(e, "gnn_attend", flops, bytes, [&] {
-      if (tiled) {
+      if (tiled && ver >= 3) {
+        hipLaunchKernelGGL(mv::gnn_attend_v3_kernel, dim3(nblocks), dim3(mv::kGnn3Threads), 0,
+                           e->stream, grp, c.hidden_size, gnn_scene_dim(e));
+      } else if (tiled) {
         hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nblocks), dim3(mv::kGnnThreads), 0, e->stream,
                            grp, c.hidden_size, gnn_scene_dim(e));
       } else {
@@ -2630,14 +2651,20 @@ int mv_op_gnn(int device, const float* h, const float* scene_mean, int32_t M,
     ctx.up(dh, h, cells * C);
     ctx.up(ds, scene_mean, cells * D);
     dout.alloc(cells * C);
-    if (!(getenv("MV_GNN") && strcmp(getenv("MV_GNN"), "v1") == 0) && W <= 32) {
+    int ver = gnn_version();              // read per call: the kernel test runs every version
+    if (ver >= 3 && !((D == 0 || D == 64) && cells * C * 4 < ((size_t)1 << 32))) ver = 2;
+    if (ver >= 2 && W <= 32) {
       int ng = 0;
-      const unsigned nb = mv::gnn_v2_blocks(cells, &ng);
+      const unsigned nb = ver >= 3 ? mv::gnn_v3_blocks(cells, &ng) : mv::gnn_v2_blocks(cells, &ng);
       mv::GnnGroup grp{};
       grp.p[0] = mv::GnnProblem{dh.p, ds.p, nullptr, dout.p, nullptr, 0, M, H, W, 1, ng, nullptr};
       grp.nblocks0 = nb;
-      hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nb), dim3(mv::kGnnThreads), 0, ctx.stream, grp,
-                         C, D);
+      if (ver >= 3)
+        hipLaunchKernelGGL(mv::gnn_attend_v3_kernel, dim3(nb), dim3(mv::kGnn3Threads), 0, ctx.stream,
+                           grp, C, D);
+      else
+        hipLaunchKernelGGL(mv::gnn_attend_v2_kernel, dim3(nb), dim3(mv::kGnnThreads), 0, ctx.stream,
+                           grp, C, D);
     } else {
       hipLaunchKernelGGL(mv::gnn_attend_kernel, dim3(cdiv(cells, 4)), dim3(256), 0,
                          ctx.stream, dh.p, ds.p, (const int32_t*)nullptr, dout.p, M, H,

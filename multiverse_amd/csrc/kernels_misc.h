@@ -624,6 +624,370 @@ static inline unsigned gnn_v2_blocks(size_t cells, int* ngroups) {
   return (unsigned)(((g + 7) / 8) * 8);
 }
 
+// ---- graph attention, third version: the same two-pass scheme, register-blocked, with the
+// staging done by the LDS-DMA.
+// The second version is bound by its LDS reads, not by memory: every thread owns ONE cell
+// and reads ten staged vectors (itself + 9 neighbours) for 72 FMAs -- 26.9 KB of LDS reads
+// per cell over the two passes plus 7 KB of staging writes -- and a chunk travels global ->
+// registers -> LDS, 28 registers per thread that live across the whole compute phase.
+// Here a workgroup of 256 threads owns 64 consecutive cells of the flat index (<= 128
+// staged) and a thread owns several ADJACENT cells, so a row of staged vectors is shared:
+//   pass 1  thread = (4 cells, 4 channels of the 64-channel chunk): 18 16-byte LDS reads
+//           feed the 36 dot products of the quad (v2: 40 reads of twice the channels); the
+//           16 channel slices of a cell are 16 consecutive lanes, folded once, after the
+//           last chunk, with four DPP adds per value.  |u|^2 of an owned cell is its self
+//           dot product; the <= 64 halo cells get theirs from four more reads per thread,
+//           computed exactly the way their owner computes it (same chain, same fold);
+//   pass 2  thread = (2 cells, 8 channels): 24 reads for 144 FMAs, 16-byte plane stores.
+// 13 KB of LDS reads per cell and no staging writes by the waves: chunk q + 1 is copied
+// global -> LDS by the DMA (16 bytes per lane, lane-linear destination) into the second
+// of two tiles while the waves compute on chunk q; one barrier per chunk.
+// LDS tile: 128 cells x 256 bytes, no pad.  Pass 1: part p of staged cell l at l*256 + p*16:
+// its readers (16 consecutive lanes = the 16 parts of one cell) are conflict-free and every
+// read is one of three row bases + an immediate; a window may reach one cell past its tile
+// -- the other tile, or the small arrays behind them -- where it reads garbage that only
+// ever feeds dot products of out-of-image neighbours, which nothing uses.  Pass 2: the lane that fills slot p of cell l fetches part
+// p ^ ((l >> 1) & 15) instead, which makes the pass-2 pattern (16 consecutive lanes = 16
+// consecutive cell pairs, same part) hit 16 different bank groups; reads are clamped into
+// the tile, every slot of which holds a real cell (indices are clamped into the tensor): an
+// out-of-image neighbour is a finite value times a weight of exactly 0.
+// Arithmetic per cell depends only on the cell's data, not on where the cell sits in its
+// workgroup (the engine's A/B tests compare layouts bit for bit).
+constexpr int kGnn3Cells = 64;
+constexpr int kGnn3Threads = 256;
+constexpr int kGnn3Stage = kGnn3Cells + 2 * 32;       // halo: W (+ 1 unless W divides 64) per side
+constexpr int kGnn3It = kGnn3Stage * 16 / kGnn3Threads;   // 8 DMA pieces per thread and chunk
+constexpr int kGnn3Tile = kGnn3Stage * 64;            // floats per chunk tile
+constexpr int kGnn3Small = 1024;                      // floats behind the tiles: e_ij / weights, |u|^2, row maps
+static_assert(kGnn3Stage * 16 % kGnn3Threads == 0, "the DMA pieces cover the tile exactly");
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// Sum over the 16 lanes of a DPP row; every lane of the row ends with the total.  All 16
+// lanes must be active.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_lane_f<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_lane_f<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_lane_f<0x141>(v);    // row_half_mirror: lane i <- lane 7 - i of its half row
+  v += dpp_lane_f<0x140>(v);    // row_mirror:      lane i <- lane 15 - i
+  return v;
+}
+__device__ __forceinline__ float dot4_acc(const f32x4_t a, const f32x4_t b, float acc) {
+  acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc);
+  acc = fmaf(a[2], b[2], acc); acc = fmaf(a[3], b[3], acc);
+  return acc;
+}
+
+__global__ __launch_bounds__(kGnn3Threads, 2)
+void gnn_attend_v3_kernel(const GnnGroup grp, int C, int D) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  // The two tiles come first: every LDS-DMA destination then lies below 64 KB.
+  __shared__ __attribute__((aligned(16))) float smem[2 * kGnn3Tile + kGnn3Small];
+  float* const buf0 = smem;                                 // tiles: buf0, buf0 + kGnn3Tile
+  float* const ea = smem + 2 * kGnn3Tile;                   // [64][9] e_ij, then the softmax weights
+  float* const ssq = ea + kGnn3Cells * 9;                   // [128]
+  int* const hsrc = reinterpret_cast<int*>(ssq + kGnn3Stage);      // [128]
+  int* const ssrc = hsrc + kGnn3Stage;                             // [128]
+  static_assert(kGnn3Cells * 9 + 3 * kGnn3Stage <= kGnn3Small, "small arrays");
+  const bool second = blockIdx.x >= grp.nblocks0;
+  const GnnProblem& pr = grp.p[second ? 1 : 0];
+  const unsigned blk = second ? blockIdx.x - grp.nblocks0 : blockIdx.x;
+  const float* __restrict__ h = pr.h;
+  const float* __restrict__ scene_mean = pr.scene_mean;
+  const int32_t* __restrict__ src_row = pr.src_row;
+  float* __restrict__ out = pr.out;
+  _Float16* p16 = pr.p16;
+  const size_t p16_stride = pr.p16_stride;
+  const int M = pr.M, H = pr.H, W = pr.W, sm_div = pr.sm_div, ngroups = pr.ngroups;
+  const int per = (ngroups + 7) >> 3;
+  const int g = (blk & 7) * per + (blk >> 3);
+  if (g >= ngroups) return;
+  const int tid = threadIdx.x;
+  const int K = H * W;
+  const long long Mtot = (long long)M * K;
+  const long long m0 = (long long)g * kGnn3Cells;
+  if (pr.row_ref) {     // beam decode: skip the rows no surviving beam descends from
+    const long long mlast = m0 + kGnn3Cells - 1 < Mtot ? m0 + kGnn3Cells - 1 : Mtot - 1;
+    bool any = false;
+    for (long long r = m0 / K; r <= mlast / K; ++r) any |= pr.row_ref[r] != 0;
+    if (!any) return;
+  }
+  // When W divides 64 the group starts at x == 0 and ends at x == W - 1: the corner
+  // neighbours m0 - W - 1 and m0 + 64 + W are out of the image and need no staging.
+  // Tile slot l holds cell s0 + l, clamped into the tensor (the first and the last group:
+  // cells that do not exist are nobody's in-image neighbour); the owned cells are slots
+  // own0 .. own0 + 63.
+  const int own0 = kGnn3Cells % W == 0 ? W : W + 1;
+  const long long s0 = m0 - own0;
+  if (tid < kGnn3Stage) {
+    long long m = s0 + tid;
+    m = m < 0 ? 0 : (m > Mtot - 1 ? Mtot - 1 : m);
+    const int r = (int)(m / K), c = (int)(m - (long long)r * K);
+    hsrc[tid] = (src_row ? src_row[r] : r) * K + c;
+    ssrc[tid] = (r / sm_div) * K + c;
+  }
+  __syncthreads();
+
+  // DMA role: slot (tid & 15) of staged cells (tid >> 4) + 16 k.  A wave's 64 lanes fill 64
+  // consecutive 16-byte slots of the tile.
+  // Buffer addressing: one uniform descriptor per tensor + a 32-bit lane offset (rows of h
+  // and of the scene means lie below 4 GB: host-checked).
+  const int part = tid & 15, ls0 = tid >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<float*>(h)), 0, 0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sm_rs = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<float*>(scene_mean)), 0, 0xffffffffu, 0x00020000);
+  uint32_t goff[kGnn3It];                     // byte offset of the cell's row in h
+#pragma unroll
+  for (int k = 0; k < kGnn3It; ++k) {
+    goff[k] = (uint32_t)hsrc[ls0 + 16 * k] * (uint32_t)(C * 4);
+  }
+  // (ls >> 1) & 15 of cell ls0 + 16 k is (ls0 >> 1) + 8 (k & 1)
+  const uint32_t p_plain = part * 16;
+  const uint32_t p_swz0 = (part ^ (ls0 >> 1)) * 16, p_swz1 = (part ^ ((ls0 >> 1) + 8)) * 16;
+  auto dma_h = [&](int q, float* tile, bool swizzled) {     // channels q*64 .. q*64+63 of h
+#pragma unroll
+    for (int k = 0; k < kGnn3It; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          h_rs, (lds_void*)(tile + (wave * 64 + k * kGnn3Threads) * 4), 16,
+          goff[k] + (swizzled ? ((k & 1) ? p_swz1 : p_swz0) : p_plain), q * 256, 0, 0);
+  };
+  auto dma_scene = [&](float* tile) {         // the 64 scene-mean channels (D is 0 or 64: host-checked)
+#pragma unroll
+    for (int k = 0; k < kGnn3It; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          sm_rs, (lds_void*)(tile + (wave * 64 + k * kGnn3Threads) * 4), 16,
+          (uint32_t)ssrc[ls0 + 16 * k] * 256u + p_plain, 0, 0, 0);
+  };
+
+  // ---- pass 1: thread = (quad of cells 4 cp .. 4 cp + 3, channel slice sl); plain layout
+  const int cp = tid >> 4, sl = tid & 15;
+  const int lq = own0 + cp * 4;
+  float pd[4][9], hq[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    hq[k] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) pd[k][t] = 0.f;
+  }
+  const int o0 = (lq - 1) * 64 + sl * 4;      // row dy = 0, window cell j: + j * 64 (floats)
+  // The window of row dy = -1 starts at slot own0 - 1 - W + 4 cp >= -1: slot -1 (quad 0 when
+  // W divides 64) is the out-of-image corner and is read from slot 0 instead.  Windows end
+  // at slot 128 at most: one cell past a tile is the other tile or the small arrays.
+  const int om = o0 - W * 64, om0 = om < 0 ? sl * 4 : om;
+  // halo cells of this thread: the i-th is staged cell hc, hc = cp + 16 i below the owned
+  // range, + 64 above it
+  int ho[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int hc = cp + 16 * i;
+    ho[i] = (hc < own0 ? hc : hc + kGnn3Cells) * 64 + sl * 4;
+  }
+  auto dots1 = [&](const float* tile) {
+    f32x4_t own[4], r[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) r[j] = *reinterpret_cast<const f32x4_t*>(tile + o0 + j * 64);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      own[k] = r[k + 1];
+      pd[k][3] = dot4_acc(own[k], r[k], pd[k][3]);
+      pd[k][4] = dot4_acc(own[k], own[k], pd[k][4]);
+      pd[k][5] = dot4_acc(own[k], r[k + 2], pd[k][5]);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      r[j] = *reinterpret_cast<const f32x4_t*>(tile + (j == 0 ? om0 : om + j * 64));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pd[k][0] = dot4_acc(own[k], r[k], pd[k][0]);
+      pd[k][1] = dot4_acc(own[k], r[k + 1], pd[k][1]);
+      pd[k][2] = dot4_acc(own[k], r[k + 2], pd[k][2]);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) r[j] = *reinterpret_cast<const f32x4_t*>(tile + o0 + W * 64 + j * 64);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pd[k][6] = dot4_acc(own[k], r[k], pd[k][6]);
+      pd[k][7] = dot4_acc(own[k], r[k + 1], pd[k][7]);
+      pd[k][8] = dot4_acc(own[k], r[k + 2], pd[k][8]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(tile + ho[i]);
+      hq[i] = dot4_acc(v, v, hq[i]);
+    }
+  };
+  // Chunk c of the kernel's nchunk + 4 lands in tile c & 1.  The barrier at the top of a
+  // step carries the vmcnt(0) of this wave's pending DMA pieces and closes the reads of
+  // the tile the next DMA overwrites.
+  const int nchunk = D > 0 ? 5 : 4;
+  dma_h(0, buf0, false);
+#pragma unroll 1
+  for (int c = 0; c < nchunk; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of chunk c
+    __syncthreads();
+    float* const next = buf0 + ((c + 1) & 1) * kGnn3Tile;
+    if (c + 1 < 4) dma_h(c + 1, next, false);
+    else if (c + 1 < nchunk) dma_scene(next);
+    else dma_h(0, next, true);                // pass 2's first chunk
+    dots1(buf0 + (c & 1) * kGnn3Tile);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float v = row16_sum(pd[k][t]);
+      if (sl == 0) {
+        ea[(cp * 4 + k) * 9 + t] = v;
+        if (t == 4) ssq[lq + k] = v;
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = row16_sum(hq[i]);
+    const int hc = cp + 16 * i;
+    const int l = hc < own0 ? hc : hc + kGnn3Cells;
+    if (sl == 0) ssq[l] = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pass 2's first chunk
+  __syncthreads();
+
+  auto cell_mask = [&](long long m) {
+    int mask = 0;
+    if (m < Mtot) {
+      const int c = (int)(m % K);
+      const int y = c / W, x = c - y * W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) mask |= 1 << t;
+      }
+    }
+    return mask;
+  };
+  if (tid < kGnn3Cells) {              // softmax over the in-image neighbours of cell tid
+    const int mask = cell_mask(m0 + tid);
+    const int li = own0 + tid;
+    float e[9];
+    float emax = -INFINITY;
+    const float invi = mask ? rsqrtf(fmaxf(ssq[li], 1e-12f)) : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      e[t] = 0.f;
+      if ((mask >> t) & 1) {
+        const int lj = li + (t / 3 - 1) * W + (t % 3 - 1);
+        e[t] = ea[tid * 9 + t] * invi * rsqrtf(fmaxf(ssq[lj], 1e-12f));
+        emax = fmaxf(emax, e[t]);
+      }
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      e[t] = ((mask >> t) & 1) ? expf(e[t] - emax) : 0.f;
+      den += e[t];
+    }
+    const float inv = mask ? 1.0f / den : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) ea[tid * 9 + t] = e[t] * inv;
+  }
+  __syncthreads();                     // weights visible; pass 2's first chunk has landed
+
+  // ---- pass 2: thread = (pair of cells 2 pi, 2 pi + 1, channels c8*8 .. +7 of the chunk);
+  // swizzled layout, reads clamped into the tile
+  const int pi = tid & 31, c8 = tid >> 5;
+  const int lp = own0 + pi * 2;
+  const long long m2 = m0 + pi * 2;
+  // h_i + sum_t a_t h_t = sum_t (a_t + [t == 4]) h_t: the residual rides on the self weight
+  float al[2][9];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) al[k][t] = ea[(pi * 2 + k) * 9 + t] + (t == 4 ? 1.0f : 0.f);
+  // The stores of chunk q are issued at the top of step q + 1, in front of that step's DMA:
+  // the vmcnt(0) in front of a barrier then only waits for requests that are a whole compute
+  // phase old (vmcnt counts loads and stores alike).
+  auto store_pair = [&](const float (&o2)[2][8], int ch) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (m2 + k < Mtot) {
+        const float* o = o2[k];
+        if (out) {
+          f32x4_t* dst = reinterpret_cast<f32x4_t*>(out + (size_t)(m2 + k) * C + ch);
+          dst[0] = f32x4_t{o[0], o[1], o[2], o[3]};
+          dst[1] = f32x4_t{o[4], o[5], o[6], o[7]};
+        }
+        if (p16) {
+          typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+          h8 pa, pb;
+          const size_t idx = plane_index(m2 + k, ch, C);
+          if (p16_stride == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pa[j] = bf16_half_bits(o[j]);
+            *reinterpret_cast<h8*>(p16 + idx) = pa;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float sc = o[j] * 256.0f;
+              const _Float16 h0h = (_Float16)sc;
+              pa[j] = h0h;
+              pb[j] = (_Float16)(sc - (float)h0h);
+            }
+            *reinterpret_cast<h8*>(p16 + idx) = pa;
+            *reinterpret_cast<h8*>(p16 + p16_stride + idx) = pb;
+          }
+        }
+      }
+    }
+  };
+  float node[2][8];
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    const int c = nchunk + q;
+    if (q > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of chunk c
+      __syncthreads();
+      store_pair(node, (q - 1) * 64 + c8 * 8);
+    }
+    if (q < 3) dma_h(q + 1, buf0 + ((c + 1) & 1) * kGnn3Tile, true);
+    const float* const tile = buf0 + (c & 1) * kGnn3Tile;
+    auto staged = [&](int l, int p) -> f32x4_t {
+      l = l < 0 ? 0 : (l > kGnn3Stage - 1 ? kGnn3Stage - 1 : l);
+      return *reinterpret_cast<const f32x4_t*>(&tile[l * 64 + ((p ^ ((l >> 1) & 15)) << 2)]);
+    };
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) node[k][j] = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        f32x4_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = staged(lp - 1 + j + dy * W, c8 * 2 + half);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const float a = al[k][(dy + 1) * 3 + dx + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              node[k][half * 4 + j] = fmaf(a, r[k + 1 + dx][j], node[k][half * 4 + j]);
+          }
+      }
+    }
+  }
+  store_pair(node, 3 * 64 + c8 * 8);
+}
+static inline unsigned gnn_v3_blocks(size_t cells, int* ngroups) {
+  const size_t g = (cells + kGnn3Cells - 1) / kGnn3Cells;
+  *ngroups = (int)g;
+  return (unsigned)(((g + 7) / 8) * 8);
+}
+
 // ---------------------------------------------------------------- hidden2grid
 // conv3x3 SAME, no bias, identity, C -> P (P in {1,2}); hidden2grid,
 // code/pred_models.py:925-959.  One wave per cell, lane l holds channels

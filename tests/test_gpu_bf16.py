@@ -105,7 +105,10 @@ def test_bf16_argmax_flip_audit_256_trajectories(built_lib):
         assert worst < 2 * BF16_TOL
       else:
         assert nflip == 0 or float(margin[first_flip].max()) < 1e-4 / rng
-  assert flips_total[("f16x3", 0)] <= 1 and flips_total[("f16x3", 1)] <= 1
+  # f16x3: every flip sits under an oracle margin below north_star's 1e-4 (asserted above);
+  # how many of the ~20 such near-ties of this input flip depends on the last bits of the
+  # fp32 sums (2 of 19 with the register-blocked graph attention, 1 with the one before)
+  assert flips_total[("f16x3", 0)] <= 3 and flips_total[("f16x3", 1)] <= 3
 
 
 def test_bf16_training_step_and_beam_run(built_lib):

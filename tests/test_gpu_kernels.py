@@ -70,7 +70,10 @@ def test_convlstm_step_transpose_detecting(built_lib):
   assert np.abs(hg - ho).max() < 1e-6
 
 
-@pytest.mark.parametrize("M,H,W", [(2, 18, 32), (3, 9, 16), (1, 4, 5)])
+# 36x18 / 18x9: BASELINE.json's literal grids (a quad of cells straddles image rows there);
+# 3x31, 2x7: widths that divide nothing; M chosen so that the last 64-cell group is partial
+@pytest.mark.parametrize("M,H,W", [(2, 18, 32), (3, 9, 16), (1, 4, 5), (2, 36, 18), (3, 18, 9),
+                                   (1, 3, 31), (5, 2, 7)])
 def test_gnn(built_lib, M, H, W):
   rng = _rng(H)
   h = np.tanh(rng.normal(size=(M, H, W, 256))).astype("f4")
@@ -81,6 +84,30 @@ def test_gnn(built_lib, M, H, W):
   if H * W <= 20:
     twin = naive_twin.gnn_stencil_naive(h, sm)
     assert np.abs(out - twin).max() < 2e-6
+
+
+def test_gnn_kernel_versions_and_position_independence(built_lib, monkeypatch):
+  """The three kernels of the graph attention (MV_GNN=v1 one wave per cell, v2 LDS-tiled,
+  default: register-blocked + LDS-DMA) against the oracle on the same input; and the
+  default one gives a row the same bits wherever the row sits in its 64-cell groups
+  (the engine's layout A/B tests rely on that)."""
+  rng = _rng(77)
+  M, H, W = 9, 9, 16                    # K = 144 = 2.25 groups: every row is aligned differently
+  h = np.tanh(rng.normal(size=(M, H, W, 256))).astype("f4")
+  sm = np.tanh(rng.normal(size=(M, H, W, 64))).astype("f4")
+  ref = oracle.gnn_np(h, sm)
+  outs = {}
+  for ver in ("v1", "v2", ""):
+    if ver:
+      monkeypatch.setenv("MV_GNN", ver)
+    else:
+      monkeypatch.delenv("MV_GNN", raising=False)
+    outs[ver] = built_lib.op_gnn(h, sm)
+    assert np.abs(outs[ver] - ref).max() < 2e-6, ver
+  assert np.abs(outs[""] - outs["v2"]).max() < 1e-6
+  for lo in (1, 2, 3):
+    part = built_lib.op_gnn(h[lo:], sm[lo:])
+    assert (part == outs[""][lo:]).all(), lo
 
 
 @pytest.mark.parametrize("P", [1, 2])
