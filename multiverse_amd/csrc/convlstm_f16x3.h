@@ -172,9 +172,10 @@ __global__ void scale_xchunk_kernel(const float* __restrict__ wpack, float* __re
 // kernels_misc.h): tiles of 32 cells x 16 channels in MFMA A-fragment order.  One
 // thread per (cell, 8 channels), cells fastest inside a tile: 16-byte stores,
 // contiguous over the 32 cells of a tile half.
-__global__ void split_planes_kernel(const float* __restrict__ in, _Float16* __restrict__ p0,
-                                    _Float16* __restrict__ p1, int M, int C) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void split_planes_item(const float* __restrict__ in,
+                                                  _Float16* __restrict__ p0,
+                                                  _Float16* __restrict__ p1, int M, int C,
+                                                  size_t i) {
   const int c8n = C >> 3;
   const size_t per_tile = (size_t)32 * c8n;
   const size_t mb = i / per_tile;
@@ -202,8 +203,30 @@ __global__ void split_planes_kernel(const float* __restrict__ in, _Float16* __re
   *reinterpret_cast<f16x8*>(p0 + o) = a;
   *reinterpret_cast<f16x8*>(p1 + o) = b;
 }
+__global__ void split_planes_kernel(const float* __restrict__ in, _Float16* __restrict__ p0,
+                                    _Float16* __restrict__ p1, int M, int C) {
+  split_planes_item(in, p0, p1, M, C, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
 static inline unsigned split_planes_blocks(size_t M, int C) {
   return (unsigned)((((M + 31) / 32) * 32 * (size_t)(C >> 3) + 255) / 256);
+}
+// The x and h operands of up to four grouped ConvLSTM problems in ONE launch (a training
+// forward step issued up to eight of these 4-6 us launches in front of every gate kernel).
+constexpr int kSplitGroup = 8;
+struct SplitGroup {
+  const float* in[kSplitGroup];
+  _Float16* p0[kSplitGroup];
+  _Float16* p1[kSplitGroup];
+  int M[kSplitGroup], C[kSplitGroup];
+  unsigned blk_end[kSplitGroup];      // running block count: item j owns [blk_end[j-1], blk_end[j])
+  int n;
+};
+__global__ void split_planes_group_kernel(const SplitGroup g) {
+  int j = 0;
+  while (j + 1 < g.n && blockIdx.x >= g.blk_end[j]) ++j;
+  const unsigned b0 = j ? g.blk_end[j - 1] : 0u;
+  split_planes_item(g.in[j], g.p0[j], g.p1[j], g.M[j], g.C[j],
+                    (size_t)(blockIdx.x - b0) * blockDim.x + threadIdx.x);
 }
 
 // ---------------------------------------------------------------- v2: B through LDS

@@ -707,11 +707,13 @@ ConvCell* cell_of_pack(mv_engine* e, const float* wpack) {
 void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
                           double flops, double bytes, double dense) {
   std::vector<mv::ConvLstm16Args> p16(probs.size());
+  struct SplitItem { const float* in; _Float16* p0; _Float16* p1; int cells, C; };
+  std::vector<SplitItem> splits;
+  const bool bf16 = e->compute_mode == 2;
   for (size_t i = 0; i < probs.size(); ++i) {
     const ConvLstmArgs& a = probs[i];
     ConvCell* cc = cell_of_pack(e, a.wpack);
     mv::ConvLstm16Args& q = p16[i];
-    const bool bf16 = e->compute_mode == 2;
     // the kernel's epilogue lets a 32-cell wave tile span at most two images
     MV_REQUIRE(a.H * a.W >= 32, "f16x3 / bf16 compute modes need grids of at least 32 cells "
                "(%d x %d); use compute mode f32", a.H, a.W);
@@ -761,11 +763,7 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       MV_REQUIRE(e->px16[i].n >= 2 * pst, "internal: f16x3 x plane scratch");
       _Float16* p0 = e->px16[i].p + mv::kPlanePad;
       q.x16 = p0; q.x_plane_stride = (int64_t)pst;
-      launch(e, "split_planes", 0, (bf16 ? 6.0 : 8.0) * n, [&] {
-        hipLaunchKernelGGL(mv::split_planes_kernel, dim3(mv::split_planes_blocks(cells, a.Cx)),
-                           dim3(256), 0, e->stream, a.x, p0, bf16 ? (_Float16*)nullptr : p0 + pst,
-                           (int)cells, a.Cx);
-      });
+      splits.push_back(SplitItem{a.x, p0, bf16 ? (_Float16*)nullptr : p0 + pst, (int)cells, a.Cx});
       }
     }
     if (!a.zero_state) {
@@ -777,13 +775,26 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       MV_REQUIRE(e->ph16[i].n >= 2 * pst, "internal: f16x3 h plane scratch");
       _Float16* p0 = e->ph16[i].p + mv::kPlanePad;
       q.h16 = p0; q.h_plane_stride = (int64_t)pst;
-      launch(e, "split_planes", 0, (bf16 ? 6.0 : 8.0) * n, [&] {
-        hipLaunchKernelGGL(mv::split_planes_kernel, dim3(mv::split_planes_blocks(cells, a.C)),
-                           dim3(256), 0, e->stream, a.h, p0, bf16 ? (_Float16*)nullptr : p0 + pst,
-                           (int)cells, a.C);
-      });
+      splits.push_back(SplitItem{a.h, p0, bf16 ? (_Float16*)nullptr : p0 + pst, (int)cells, a.C});
       }
     }
+  }
+  // operands no producer left as planes: one grouped split launch in front of the gate kernel
+  for (size_t s0 = 0; s0 < splits.size(); s0 += mv::kSplitGroup) {
+    mv::SplitGroup g{};
+    double sbytes = 0;
+    unsigned nb = 0;
+    g.n = (int)std::min<size_t>(mv::kSplitGroup, splits.size() - s0);
+    for (int j = 0; j < g.n; ++j) {
+      const SplitItem& it = splits[s0 + j];
+      g.in[j] = it.in; g.p0[j] = it.p0; g.p1[j] = it.p1; g.M[j] = it.cells; g.C[j] = it.C;
+      nb += mv::split_planes_blocks((size_t)it.cells, it.C);
+      g.blk_end[j] = nb;
+      sbytes += (bf16 ? 6.0 : 8.0) * (double)it.cells * it.C;
+    }
+    launch(e, "split_planes", 0, sbytes, [&] {
+      hipLaunchKernelGGL(mv::split_planes_group_kernel, dim3(nb), dim3(256), 0, e->stream, g);
+    });
   }
   launch(e, "convlstm_step", flops, bytes, [&] {
     if (e->compute_mode == 2)

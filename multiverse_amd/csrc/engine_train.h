@@ -1273,10 +1273,12 @@ void train_backward(mv_engine* e) {
       if (nm.size() < 2 || nm.compare(nm.size() - 2, 2, "/W") != 0) continue;
       MV_REQUIRE(base + 1 + nW < 64, "too many W tensors");
       const size_t n = p->elems();
-      hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream, p->dev.p,
-                         n, t.losses.p + base + 1 + nW, 0.5f * t.tc.wd, 1);
-      hipLaunchKernelGGL(mv::add_scaled_kernel, dim3(cdiv(n, 256)), dim3(256), 0,
-                         e->stream, grad_of(e, p.get()), p->dev.p, t.tc.wd, n);
+      const size_t nblk = cdiv(n, mv::kWdChunk);
+      MV_REQUIRE(nblk <= t.partial.n, "internal: weight-decay partial sums");
+      hipLaunchKernelGGL(mv::add_scaled_sumsq_kernel, dim3(nblk), dim3(256), 0, e->stream,
+                         grad_of(e, p.get()), p->dev.p, t.tc.wd, n, t.partial.p);
+      hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream, t.partial.p,
+                         nblk, t.losses.p + base + 1 + nW, 0.5f * t.tc.wd, 0);
       ++nW;
     }
     hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream,

@@ -917,6 +917,35 @@ __global__ void add_scaled_kernel(float* __restrict__ g, const float* __restrict
   if (i < n) g[i] = g[i] + s * w[i];
 }
 
+// The same with the weight-decay cost's sum of squares taken from the pass (the parameter is
+// read once per step instead of twice: a one-workgroup reduce_sum over a 20 MB kernel took
+// 100-430 us).  A workgroup owns 4 096 consecutive elements: thread-strided partial sums in a
+// fixed order, LDS tree, partial[blockIdx.x]; reduce_sum_kernel folds the partials.
+constexpr int kWdChunk = 4096;
+__global__ __launch_bounds__(256)
+void add_scaled_sumsq_kernel(float* __restrict__ g, const float* __restrict__ w, float s,
+                             size_t n, float* __restrict__ partial) {
+  __shared__ float red[256];
+  const size_t base = (size_t)blockIdx.x * kWdChunk;
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < kWdChunk / 256; ++j) {
+    const size_t i = base + (size_t)j * 256 + threadIdx.x;
+    if (i < n) {
+      const float wv = w[i];
+      g[i] = g[i] + s * wv;
+      acc += wv * wv;
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // clip_by_value (code/pred_models.py:1700-1705) + TF ApplyAdadelta
 // (AdadeltaOptimizer(lr, rho=0.95, epsilon=1e-8), :1671-1672):
 //   accum = rho accum + (1-rho) g^2

@@ -15,7 +15,7 @@ if [ $rc -ne 0 ]; then tail -80 $O/gnn_tests.log; exit 1; fi
 timeout 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; rc=$?
 echo "gpu tests rc $rc"; tail -4 $O/gpu_tests.log
 if [ $rc -ne 0 ]; then grep -E "^(FAILED|ERROR)" $O/gpu_tests.log; fi     # measurements follow either way
-for v in v2 v3; do
+for v in ${AB_GNN:-v2 v3}; do      # AB_GNN=" " skips the A/B
   MV_GNN=$v timeout 200 python bench.py --workload beam --no-sub --no-cpu-baseline --no-fp32-ref \
     > $O/beam_gnn_$v.json 2> $O/beam_gnn_$v.err
   MV_GNN=$v timeout 200 python bench.py --no-sub --no-cpu-baseline --no-fp32-ref \
