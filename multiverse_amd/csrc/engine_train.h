@@ -196,6 +196,23 @@ void train_alloc(mv_engine* e) {
   t.losses.alloc(64);
 }
 
+// out[0] = scale * sum(in[0 .. n)), fixed order: long inputs go through per-chunk workgroups
+// first (train_kernels.h chunk_sum_kernel), the partials through the one-workgroup kernel.
+void run_long_sum(mv_engine* e, TrainState& t, const float* in, size_t n, float* out,
+                  float scale) {
+  if (n <= 4 * (size_t)mv::kSumChunk) {
+    hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream, in, n, out,
+                       scale, 0);
+    return;
+  }
+  const size_t nblk = cdiv(n, mv::kSumChunk);
+  MV_REQUIRE(nblk <= t.partial.n, "internal: long-sum partials");
+  hipLaunchKernelGGL(mv::chunk_sum_kernel, dim3(nblk), dim3(256), 0, e->stream, in, n,
+                     t.partial.p);
+  hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream, t.partial.p, nblk,
+                     out, scale, 0);
+}
+
 // deterministic column sum of X [rows, ncols] into out [ncols]: slabs of rows are summed in
 // parallel, then the partial rows are folded 32 at a time until one is left (a fixed tree:
 // the result does not depend on timing).  Round 3: the fold of up to 1 024 partial rows used
@@ -687,8 +704,7 @@ void train_losses(mv_engine* e) {
                            e->stream, R.regio.p + NK * 2, R.pred_reg.p, R.gt_cls.p,
                            R.fg_count.p, R.loss_elem.p, R.dreg.p, Tp, N, S.K,
                            t.tc.grid_reg_loss_weight);
-        hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream,
-                           R.loss_elem.p, nel, t.scratch.p, 1.0f, 0);
+        run_long_sum(e, t, R.loss_elem.p, nel, t.scratch.p, 1.0f);
         hipLaunchKernelGGL(mv::masked_mean_kernel, dim3(1), dim3(64), 0, e->stream,
                            t.scratch.p, R.fg_count.p, t.losses.p + li + 1,
                            t.tc.grid_reg_loss_weight);
@@ -696,8 +712,7 @@ void train_losses(mv_engine* e) {
         hipLaunchKernelGGL(mv::huber_loss_kernel, dim3(cdiv(nel, 256)), dim3(256), 0,
                            e->stream, R.regio.p + NK * 2, R.pred_reg.p, R.loss_elem.p,
                            R.dreg.p, Tp, N, S.K * 2, rs);
-        hipLaunchKernelGGL(mv::reduce_sum_kernel, dim3(1), dim3(256), 0, e->stream,
-                           R.loss_elem.p, nel, t.losses.p + li + 1, rs, 0);
+        run_long_sum(e, t, R.loss_elem.p, nel, t.losses.p + li + 1, rs);
       }
     });
     li += 2;
