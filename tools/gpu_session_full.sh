@@ -24,7 +24,7 @@ done
 python - <<PY
 import json
 for w in ("beam", "greedy"):
-  for v in ("v2", "v3"):
+  for v in "${AB_GNN:-v2 v3}".split():
     try:
       d = json.load(open("$O/%s_gnn_%s.json" % (w, v)))
       r = d["roofline"]
