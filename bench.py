@@ -531,12 +531,26 @@ def host_path(compute, batch=64):
     cfg.compact_inputs = comp
     key = "tester_step_compact" if comp else "tester_step_dense"
     out[key] = round(rate(lambda: tester.step(None, b), reps=5, warm=1, rounds=2), 1)
+  # Tester.steps over a stream of Dataset batches: what `evaluate` runs (feed construction
+  # included; feed of batch k+1 and fetch of batch k-1 under the kernels of batch k)
+  cfg.compact_inputs = False
+  if hasattr(tester, "steps"):
+    many = [b] * 12
+    for _ in tester.steps(None, many[:3]):
+      pass
+    best = 0.0
+    for _ in range(3):
+      t0 = time.perf_counter()
+      for _ in tester.steps(None, many):
+        pass
+      best = max(best, batch * len(many) / (time.perf_counter() - t0))
+    out["tester_steps_pipelined"] = round(best, 1)
   model.close()
   h2d = sum(a.nbytes for a in feed["grid_obs_regress"]) + feed["scene_feat"].nbytes
   out["h2d_MB_dense"] = round(h2d / 1e6, 2)
   out["h2d_MB_compact"] = round((feed["obs_xy"].nbytes + feed["scene_feat_u8"].nbytes) / 1e6, 3)
   for k in ("host_buffers_dense", "host_buffers_compact", "tester_step_dense",
-            "tester_step_compact", "host_buffers_dense_pipelined"):
+            "tester_step_compact", "host_buffers_dense_pipelined", "tester_steps_pipelined"):
     if k in out:
       out[k + "_vs_resident"] = round(out[k] / out["resident_inputs"], 4)
   return out
