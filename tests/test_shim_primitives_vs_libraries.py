@@ -170,3 +170,41 @@ def test_top_k_order_and_ties():
   assert np.array_equal(vals.numpy(), np.take_along_axis(a, np.array(want), 1))
   tv, ti = torch.topk(torch.from_numpy(a[0]), 4)                   # same values as torch's
   assert np.array_equal(vals.numpy()[0], tv.numpy())
+
+
+def test_convlstm_cell_on_one_pixel_is_torch_lstm_cell():
+  """tf.contrib.rnn.ConvLSTMCell with a 1x1 kernel on a 1x1 image is an LSTM cell.  Against
+  torch.nn.LSTMCell: TF orders the gate blocks (i, j, f, o) and adds forget_bias = 1 to f
+  (contrib/rnn/python/ops/rnn_cell.py, restated from the source: no library shares that
+  layout); torch orders them (i, f, g, o).  With the blocks permuted and the forget bias
+  moved into the bias vector the two cells must agree -- the update c' = sig(f) c + sig(i)
+  tanh(j), h' = sig(o) tanh(c') is the part a library can pin."""
+  rng = np.random.default_rng(9)
+  N, Cx, C = 5, 7, 6
+  kernel = rng.normal(size=(1, 1, Cx + C, 4 * C)) * 0.5
+  biases = rng.normal(size=(4 * C,)) * 0.3
+  x = rng.normal(size=(N, 1, 1, Cx))
+  c0 = rng.normal(size=(N, 1, 1, C))
+  h0 = np.tanh(rng.normal(size=(N, 1, 1, C)))
+  tf.reset_default_graph(params={"cell/kernel": kernel, "cell/biases": biases})
+  cell = tf.contrib.rnn.ConvLSTMCell(conv_ndims=2, input_shape=[1, 1, Cx], output_channels=C,
+                                     kernel_shape=[1, 1], name="cell")
+  out, (c1, h1) = cell(tf.constant(x, dtype=tf.float64),
+                       tf.nn.rnn_cell.LSTMStateTuple(tf.constant(c0, dtype=tf.float64),
+                                                     tf.constant(h0, dtype=tf.float64)))
+  ref = torch.nn.LSTMCell(Cx, C).double()
+  W = kernel[0, 0]                                       # [Cx + C, 4C], TF blocks i j f o
+  perm = np.concatenate([np.arange(0, C), np.arange(2 * C, 3 * C), np.arange(C, 2 * C),
+                         np.arange(3 * C, 4 * C)])       # -> torch blocks i f g o
+  b = biases.copy()
+  b[2 * C:3 * C] += 1.0                                  # forget_bias
+  with torch.no_grad():
+    ref.weight_ih.copy_(torch.from_numpy(W[:Cx, perm].T.copy()))
+    ref.weight_hh.copy_(torch.from_numpy(W[Cx:, perm].T.copy()))
+    ref.bias_ih.copy_(torch.from_numpy(b[perm]))
+    ref.bias_hh.zero_()
+    rh, rc = ref(torch.from_numpy(x.reshape(N, Cx)),
+                 (torch.from_numpy(h0.reshape(N, C)), torch.from_numpy(c0.reshape(N, C))))
+  assert np.abs(c1.numpy().reshape(N, C) - rc.numpy()).max() < 1e-12
+  assert np.abs(h1.numpy().reshape(N, C) - rh.numpy()).max() < 1e-12
+  assert np.abs(out.numpy() - h1.numpy()).max() == 0.0
