@@ -379,3 +379,62 @@ def test_v1_checkpoint_loads_into_the_model_protocol(tmp_path):
   with pytest.raises(SystemExit) as ex:
     tc.main([p, "--verify", "--use_grids", "0,1"])
   assert ex.value.code == 0
+
+
+def test_bundle_entry_codec_against_the_protobuf_library():
+  """The hand-written protobuf reader / writer of tf_checkpoint.py (BundleEntryProto,
+  TensorShapeProto: tensorflow/core/protobuf/tensor_bundle.proto, framework/
+  tensor_shape.proto -- field numbers restated here as there) against google.protobuf
+  building and parsing the same messages: wire format in both directions."""
+  from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+  fd = descriptor_pb2.FileDescriptorProto(name="mv_bundle_test.proto", package="mvtest",
+                                          syntax="proto3")
+  dim = descriptor_pb2.DescriptorProto(name="Dim")
+  dim.field.add(name="size", number=1, type=3, label=1)                 # int64
+  dim.field.add(name="name", number=2, type=9, label=1)                 # string
+  shp = descriptor_pb2.DescriptorProto(name="TensorShapeProto")
+  shp.field.add(name="dim", number=2, type=11, label=3, type_name=".mvtest.Dim")
+  shp.field.add(name="unknown_rank", number=3, type=8, label=1)
+  ent = descriptor_pb2.DescriptorProto(name="BundleEntryProto")
+  ent.field.add(name="dtype", number=1, type=5, label=1)                # enum DataType as int32
+  ent.field.add(name="shape", number=2, type=11, label=1, type_name=".mvtest.TensorShapeProto")
+  ent.field.add(name="shard_id", number=3, type=5, label=1)
+  ent.field.add(name="offset", number=4, type=3, label=1)
+  ent.field.add(name="size", number=5, type=3, label=1)
+  ent.field.add(name="crc32c", number=6, type=7, label=1)               # fixed32
+  fd.message_type.extend([dim, shp, ent])
+  pool = descriptor_pool.DescriptorPool()
+  pool.Add(fd)
+  get = getattr(message_factory, "GetMessageClass", None)
+  Entry = get(pool.FindMessageTypeByName("mvtest.BundleEntryProto")) if get else \
+      message_factory.MessageFactory(pool).GetPrototype(
+          pool.FindMessageTypeByName("mvtest.BundleEntryProto"))
+  for dtype, shape, offset, size, crc in ((1, (3, 3, 320, 1024), 0, 11796480, 0xdeadbeef),
+                                          (1, (), 4096, 4, 1), (3, (1024,), 2 ** 33 + 5, 4096, 0xffffffff)):
+    mine = tc._encode_entry(dtype, shape, offset, size, crc)
+    m = Entry()
+    m.ParseFromString(mine)                              # library reads what we write
+    assert (m.dtype, tuple(d.size for d in m.shape.dim), m.offset, m.size, m.crc32c) == \
+        (dtype, shape, offset, size, crc)
+    m2 = Entry(dtype=dtype, shard_id=0, offset=offset, size=size, crc32c=crc)
+    for d in shape:
+      m2.shape.dim.add(size=d)
+    back = tc._decode_entry(m2.SerializeToString())      # we read what the library writes
+    assert (back["dtype"], back["shape"], back["offset"], back["size"], back["crc32c"]) == \
+        (dtype, shape, offset, size, crc)
+
+
+def test_snappy_decoder_against_pyarrow_snappy():
+  """Table blocks of a TF checkpoint may be snappy-compressed (leveldb table format); the
+  decoder in tf_checkpoint.py against blocks compressed by the snappy library pyarrow ships."""
+  import pyarrow as pa
+  if "snappy" not in [c for c in ("snappy",) if pa.Codec.is_available(c)]:
+    import pytest
+    pytest.skip("pyarrow built without snappy")
+  rng = np.random.default_rng(4)
+  cases = [b"", b"a", b"abc" * 1000, bytes(rng.integers(0, 256, size=70000, dtype=np.uint8)),
+           (b"person_pred/enc_cell_0/kernel\x00" * 300) + bytes(rng.integers(0, 4, size=5000, dtype=np.uint8)),
+           bytes(200000)]
+  for data in cases:
+    comp = pa.compress(data, codec="snappy", asbytes=True)
+    assert bytes(tc._snappy_decompress(comp)) == data
