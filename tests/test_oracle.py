@@ -180,3 +180,31 @@ def test_greedy_is_batch_independent():
   cls2, reg2, _ = oracle.forward(params, cfg2, sub)
   assert np.abs(cls4[1][2:4] - cls2[1]).max() < 1e-5
   assert np.abs(reg4[1][2:4] - reg2[1]).max() < 1e-5
+
+
+def test_gnn_against_scikit_learn_and_scipy():
+  """The graph attention (code/pred_models.py:808-909) written with third-party pieces:
+  cosine similarity from scikit-learn, the neighbourhood mask as the reference builds it --
+  a one-hot image convolved with 3x3 ones (:890-902) -- through scipy.signal.convolve2d,
+  softmax from scipy.special; against the oracle's torch restatement."""
+  import scipy.signal
+  import scipy.special
+  from sklearn.metrics.pairwise import cosine_similarity
+  rng = np.random.default_rng(21)
+  M, H, W, C, D = 2, 5, 7, 256, 64
+  h = np.tanh(rng.normal(size=(M, H, W, C)))
+  sm = np.tanh(rng.normal(size=(M, H, W, D)))
+  K = H * W
+  mask = np.zeros((K, K))
+  for k in range(K):
+    one = np.zeros((H, W)); one.flat[k] = 1.0
+    mask[k] = scipy.signal.convolve2d(one, np.ones((3, 3)), mode="same").reshape(K)
+  want = np.empty_like(h)
+  for m in range(M):
+    feat = np.concatenate([h[m].reshape(K, C), sm[m].reshape(K, D)], -1)
+    e = cosine_similarity(feat)
+    e = np.where(mask > 0, e, -1e30)                      # exp_mask, :1399-1401
+    a = scipy.special.softmax(e, axis=-1)
+    want[m] = (h[m].reshape(K, C) + a @ h[m].reshape(K, C)).reshape(H, W, C)
+  got = oracle.gnn_np(h, sm, dtype=torch.float64)
+  assert np.abs(got - want).max() < 1e-12
