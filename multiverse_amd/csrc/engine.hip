@@ -719,6 +719,11 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
                "(%d x %d); use compute mode f32", a.H, a.W);
     MV_REQUIRE((double)a.rows * a.H * a.W * a.C * 4.0 < 4294967296.0,
                "f16x3 / bf16 compute modes: state tensor of %d rows exceeds 4 GB", a.rows);
+    // the training forward stores the four gate activations [M][4C] through a buffer
+    // resource with 32-bit byte offsets (convlstm_f16x3.h epilogue: num_records = 16 M C)
+    MV_REQUIRE(!a.gates_out || (double)a.rows * a.H * a.W * a.C * 16.0 < 4294967296.0,
+               "f16x3 / bf16 training forward: gate tensor of %d rows exceeds 4 GB "
+               "(lower the per-GPU batch or use compute mode f32)", a.rows);
     q.f = a;
     q.wp16 = bf16 ? cc->wpb.p : cc->wp16.p;
     q.wx32 = bf16 ? cc->wx32u.p : cc->wx32.p;

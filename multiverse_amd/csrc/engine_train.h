@@ -289,8 +289,11 @@ void run_small_wgrad(mv_engine* e, const float* in, const float* dout, float* dw
   const size_t lds = G > 1 ? (size_t)G * 9 * P * sizeof(float) : 0;
   MV_REQUIRE((size_t)nblk * ncols <= t.partial.n && 64 * ncols <= t.scratch.n,
              "internal: small wgrad partial buffer");
+  // algorithmic bytes: the input and the output gradient are each read ONCE (the nine taps
+  // re-read the same cells from LDS / L1), plus the per-block partial tiles written and
+  // folded.  (Rounds 1-3 counted the input nine times: a "roofline fraction" of 1.05.)
   launch(e, "conv3x3_small_wgrad", 2.0 * cells * 9 * Ci * Co,
-         4.0 * cells * (9.0 * Ci + Co), [&] {
+         4.0 * cells * ((double)Ci + Co) + 8.0 * (double)nblk * ncols, [&] {
     const size_t lds2 = ((size_t)(cpb + 2 * W + 2) * Co + cpb) * sizeof(float);
     if (Ci > Co && Ci <= 256 && (Co == 1 || Co == 2) && G == 1 && lds2 <= 48 * 1024) {
       if (Co == 1)
@@ -614,7 +617,10 @@ void train_forward(mv_engine* e) {
     // launches at the head of the next iteration.  MV_TRAIN_TAIL=v1 restores the old launches.
     static const bool tail2 = tail_v2() &&
         !(getenv("MV_TRAIN_TAIL") && strcmp(getenv("MV_TRAIN_TAIL"), "v1") == 0);
-    if (tail2 && E == 32) {
+    bool tail_fits = E == 32;               // run_tail's own limits (decode_tail LDS layout)
+    for (int s = 0; s < c.num_scales; ++s)
+      if (e->sc[s].use && (size_t)e->sc[s].K * 2 > 2048) tail_fits = false;
+    if (tail2 && tail_fits) {
       std::vector<TailPlan> plans;
       for (int s = 0; s < c.num_scales; ++s) {
         ScaleState& S = e->sc[s];

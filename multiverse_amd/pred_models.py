@@ -192,6 +192,11 @@ class Model(object):
       # operand planes, so those models run on the fp32 matrix pipe (the engine refuses
       # the other modes for them)
       self.compute_mode = "f32"
+    if any(use and h * w < 32 for (h, w), use in zip(config.scene_grids, config.use_grids)):
+      # the fp16-pipe kernels' epilogue lets a 32-cell wave tile span at most two images
+      # (engine.hip run_conv_group_f16x3 refuses smaller grids); such toy grids run on the
+      # fp32 matrix pipe, whose kernel wraps over any number of images
+      self.compute_mode = "f32"
     self.engine.set_compute_mode(self.compute_mode)
     self.global_step = 0
     # names of the fetches, kept for callers that introspect them
@@ -291,25 +296,32 @@ class Tester(object):
       return
     pending = []
     eng = self.model.engine
-    for batch in batches:
-      feed = self.model.get_feed_dict(batch[1], is_train=False)
-      if feed.get("compact", False):          # compact feeds take the blocking path
-        while pending:
+    try:
+      for batch in batches:
+        feed = self.model.get_feed_dict(batch[1], is_train=False)
+        if feed.get("compact", False):          # compact feeds take the blocking path
+          while pending:
+            b0 = pending.pop(0)
+            cls, reg = eng.collect_greedy()
+            yield b0, (cls, reg, None)
+          yield batch, self.model.run_forward(feed)
+          continue
+        if len(pending) >= depth:
           b0 = pending.pop(0)
           cls, reg = eng.collect_greedy()
           yield b0, (cls, reg, None)
-        yield batch, self.model.run_forward(feed)
-        continue
-      if len(pending) >= depth:
+        eng.submit_greedy(feed, depth)
+        pending.append(batch)
+      while pending:
         b0 = pending.pop(0)
         cls, reg = eng.collect_greedy()
         yield b0, (cls, reg, None)
-      eng.submit_greedy(feed, depth)
-      pending.append(batch)
-    while pending:
-      b0 = pending.pop(0)
-      cls, reg = eng.collect_greedy()
-      yield b0, (cls, reg, None)
+    finally:
+      # a consumer that stops early (break, an exception in its loop body) must not leave
+      # submissions in the engine's pipeline: the next caller would collect THEIR outputs
+      while pending:
+        pending.pop(0)
+        eng.collect_greedy()
 
 
 class Trainer(object):

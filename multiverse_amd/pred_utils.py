@@ -299,6 +299,11 @@ def evaluate(dataset, config, sess, tester):
   l2 = [[] for _ in range(n_scale)]
   l2_center = [[] for _ in range(n_scale)]
   hits = [[] for _ in range(n_scale)]
+  per_scene = bool(getattr(config, "per_scene_eval", False))
+  if per_scene:       # code/pred_utils.py:374-378 (the ActEV cameras)
+    assert sum(config.use_grids) == 1, "per scene eval is for one grid only"
+    scenes = ["0000", "0002", "0400", "0401", "0500"]
+    l2_scenes = [[] for _ in scenes]
   out_data = None
   if getattr(config, "save_output", None) is not None:
     out_data = {"obs_list": [], "pred_gt_list": [], "seq_ids": []}
@@ -340,6 +345,8 @@ def evaluate(dataset, config, sess, tester):
         gt_traj = np.asarray(batch.data["pred_traj"][i])
         l2[j].append(np.sqrt(np.sum((gt_traj - traj) ** 2, axis=1)))
         l2_center[j].append(np.sqrt(np.sum((gt_traj - this_center) ** 2, axis=1)))
+        if per_scene:   # :514-517; a camera outside the list raises, as scenes.index does
+          l2_scenes[scenes.index(get_scene(batch.data["traj_key"][i]))].append(l2[j][-1])
         if out_data is not None:
           if j == 0 and "traj_key" in batch.data:
             out_data["seq_ids"].append(batch.data["traj_key"][i])
@@ -366,10 +373,20 @@ def evaluate(dataset, config, sess, tester):
     dc = np.array(l2_center[j])
     p["grid%d_traj_centerOnly_ade" % j] = np.mean(dc)
     p["grid%d_traj_centerOnly_fde" % j] = np.mean(dc[:, -1])
+  if per_scene:         # :569-578
+    for scene, diffs in zip(scenes, l2_scenes):
+      p["%s_ade" % scene] = np.mean([t for l in diffs for t in l]) if diffs else 0.0
+      p["%s_fde" % scene] = np.mean([l[-1] for l in diffs]) if diffs else 0.0
   if out_data is not None:
     with open(config.save_output, "wb") as f:
       pickle.dump(out_data, f)
   return p
+
+
+def get_scene(videoname_):
+  """The scene camera of an ActEV video name, e.g. `VIRAT_S_040003_02_...` -> "0400"
+  (code/pred_utils.py:303-307)."""
+  return videoname_.split("_S_")[-1].split("_")[0][:4]
 
 
 def relative_to_abs(rel_traj, start_pos):

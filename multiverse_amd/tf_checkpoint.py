@@ -514,8 +514,14 @@ def _decode_slice_is_full(buf):
   return True
 
 
-def _decode_tensor_proto(buf, name):
-  """TensorProto -> (dtype enum, shape, flat numpy array)."""
+def _decode_tensor_proto(buf, name, meta_dtype=None):
+  """TensorProto -> (dtype enum, shape, flat numpy array).
+
+  TensorFlow's TensorSliceWriter (core/util/tensor_slice_writer.cc: SaveData -> Fill) sets
+  ONLY the repeated `*_val` field of a data entry's TensorProto -- neither `dtype` nor
+  `tensor_shape`; its reader takes both from the SavedSliceMeta.  So the type of the meta
+  entry (`meta_dtype`) is used when the proto carries none, and a proto that does carry one
+  must agree with it."""
   dtype, shape, content = None, [], None
   vals = {5: [], 6: [], 7: [], 10: [], 11: []}     # float, double, int, int64, bool _val
   wire_np = {5: "<f4", 6: "<f8"}
@@ -540,6 +546,11 @@ def _decode_tensor_proto(buf, name):
         vals[f].append(np.asarray([v], dtype=np.uint64))
       else:                             # one fixed32 / fixed64 element (already bytes)
         vals[f].append(np.frombuffer(bytes(v), dtype=wire_np[f]))
+  if dtype is None:
+    dtype = meta_dtype
+  elif meta_dtype is not None and dtype != meta_dtype:
+    raise IOError("variable %s: dtype %r in the data entry, %r in the meta entry"
+                  % (name, dtype, meta_dtype))
   if dtype not in _NP_OF_DT:
     raise IOError("variable %s: unsupported dtype %r" % (name, dtype))
   dt = _NP_OF_DT[dtype]
@@ -602,10 +613,7 @@ def _load_v1(path, keep):
     shape, dt = meta[name]
     if name not in data:
       raise IOError("variable %s: listed in the meta entry, no data entry" % name)
-    dtype, _, flat = _decode_tensor_proto(data[name], name)
-    if dt is not None and dtype != dt:
-      raise IOError("variable %s: dtype %r in the data entry, %r in the meta entry"
-                    % (name, dtype, dt))
+    _, _, flat = _decode_tensor_proto(data[name], name, meta_dtype=dt)
     n = int(np.prod(shape)) if len(shape) else 1
     if flat.size != n:
       raise IOError("variable %s: %d values for shape %s" % (name, flat.size, shape))

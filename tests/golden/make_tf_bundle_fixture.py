@@ -276,8 +276,12 @@ def varint_signed(v):
   return varint(v & 0xFFFFFFFFFFFFFFFF)                         # two's complement, 10 bytes if < 0
 
 
-def tensor_proto(arr, dt_enum, unpacked=False):
-  msg = pb_varint(1, dt_enum) + pb_bytes(2, shape_proto(arr.shape))
+def tensor_proto(arr, dt_enum, unpacked=False, with_type=False):
+  """The data entry's TensorProto.  TensorSliceWriter::SaveData -> Fill writes ONLY the
+  repeated *_val field (no dtype, no tensor_shape: the reader takes both from the
+  SavedSliceMeta), so that is the default here; with_type adds the two fields a
+  hand-written or foreign writer might set."""
+  msg = pb_varint(1, dt_enum) + pb_bytes(2, shape_proto(arr.shape)) if with_type else b""
   flat = np.ascontiguousarray(arr).reshape(-1)
   if arr.dtype.str == "<f4":
     if unpacked:            # proto2-style: one fixed32 field per element
@@ -308,6 +312,7 @@ def main_v1():
       ("signed_ints", np.asarray([[-3, 7, 0], [2147483647, -2147483648, 1]], dtype="<i4"), False),
       ("scalar_double", np.asarray(-1.5, dtype="<f8"), False),
   ]
+  typed = {"person_pred/scene_conv2/b"}       # ONE entry that also carries dtype + shape
   dt_of = {"<f4": 1, "<f8": 2, "<i4": 3, "<i8": 9}
   metas = b""
   items = []
@@ -316,7 +321,8 @@ def main_v1():
     metas += pb_bytes(1, pb_bytes(1, name.encode()) + pb_bytes(2, shape_proto(arr.shape)) +
                       pb_varint(3, dt_of[arr.dtype.str]) + pb_bytes(4, full_slice_proto(rank)))
     saved = (pb_bytes(1, name.encode()) + pb_bytes(2, full_slice_proto(rank)) +
-             pb_bytes(3, tensor_proto(arr, dt_of[arr.dtype.str], unpacked)))
+             pb_bytes(3, tensor_proto(arr, dt_of[arr.dtype.str], unpacked,
+                                      with_type=name in typed)))
     items.append((v1_key(name, rank), pb_bytes(2, saved)))
   meta_msg = pb_bytes(1, metas + pb_bytes(2, pb_varint(1, 1)))          # versions{producer 1}
   items = [(b"", meta_msg)] + sorted(items)

@@ -82,6 +82,57 @@ def test_tester_step_and_evaluate_through_the_boundary(built_lib):
   model.close()
 
 
+def test_abandoned_steps_generator_leaves_no_stale_batches(built_lib):
+  """Tester.steps pipelines feed / kernels / fetch over the engine's submit / collect slots.
+  A consumer that stops early (break, an exception in its loop body) must not leave
+  submissions behind: the next pass over the data would collect THOSE outputs and pair
+  them with the wrong batch (or die with `pipeline full`)."""
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1))
+  data = synth.make_npz_data(cfg, 8, seed=11)
+  ds = pred_utils.dataset_from_npz_dict(data, "test", cfg)
+  model = pred_models.get_model(cfg, 0)
+  model.load_params(synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1))
+  tester = pred_models.Tester(model, cfg, sess=None)
+  batches = list(ds.get_batches(2, full=True, shuffle=False))
+  assert len(batches) == 4
+  want = [tester.step(None, bt) for bt in batches]
+  gen = tester.steps(None, batches[::-1], depth=2)       # reversed order, abandoned after one
+  first = next(gen)
+  assert first[0] is batches[-1]
+  gen.close()                                            # GeneratorExit -> drains the pipeline
+  with pytest.raises(RuntimeError, match="consumer"):
+    for _ in tester.steps(None, batches, depth=2):
+      raise RuntimeError("consumer failed")
+  got = list(tester.steps(None, batches, depth=2))
+  assert len(got) == 4
+  for (bt, (cls, reg, beam)), w, b0 in zip(got, want, batches):
+    assert bt is b0 and beam is None
+    for s in (0, 1):
+      assert (cls[s] == w[0][s]).all() and (reg[s] == w[1][s]).all()
+  model.close()
+
+
+def test_toy_grids_select_the_fp32_pipe(built_lib):
+  """Grids of fewer than 32 cells cannot run the fp16-pipe kernels (a 32-cell wave tile would
+  span more than two images); Model picks the fp32 MFMA path for them instead of failing at
+  the first forward, the C ABI keeps refusing an explicit f16x3 request."""
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), scene_h=12, scene_w=20,
+                             scene_grids=[(6, 10), (3, 5)])     # scale 1: 15 cells
+  model = pred_models.get_model(cfg, 0)
+  assert model.compute_mode == "f32"
+  params = synth.make_params(cfg, recurrent_gain=3.0, bias_scale=0.1)
+  model.load_params(params)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 3)
+  cls, reg = model.engine.forward_greedy(feed)
+  from oracle import multiverse_oracle as oracle
+  ocls, oreg, _ = oracle.forward(params, cfg, feed)
+  assert np.abs(cls[1] - ocls[1]).max() < 1e-4 and np.abs(reg[1] - oreg[1]).max() < 1e-4
+  model.engine.set_compute_mode("f16x3")
+  with pytest.raises(built_lib.MvError, match="at least 32 cells"):
+    model.engine.forward_greedy(feed)
+  model.close()
+
+
 def test_full_size_properties_batch64(built_lib):
   """BASELINE configs[1] size (N=64, both scales): the oracle would take
   minutes, so check size-independent properties: (a) batch independence -- a

@@ -315,7 +315,10 @@ def test_reader_on_a_hand_assembled_v1_checkpoint():
   assembled by make_tf_bundle_fixture.py from saved_tensor_slice.proto / tensor_slice_writer:
   meta entry under key "", one SavedSlice per tensor under ordered-code keys, values in
   packed float_val / double_val / int_val / int64_val (one tensor with UNPACKED float_val),
-  negative ints as 10-byte varints, the second data block snappy-compressed."""
+  negative ints as 10-byte varints, the second data block snappy-compressed.  As in the files
+  TensorFlow writes (tensor_slice_writer.cc SaveData -> Fill), the data entries' TensorProtos
+  hold ONLY the *_val field: dtype and shape come from the meta entry (one entry carries
+  both as well, to keep that spelling readable too)."""
   path = os.path.join(V1, "model.ckpt")
   assert tc.is_v1_checkpoint(path) and tc.resolve_checkpoint(path) == path
   exp = np.load(os.path.join(V1, "expected.npz"))
@@ -332,6 +335,30 @@ def test_reader_on_a_hand_assembled_v1_checkpoint():
   assert sorted(w) == ["person_pred/encoder_grid_class_0/enc_grid_0/biases",
                        "person_pred/encoder_grid_class_0/enc_grid_0/kernel",
                        "person_pred/scene_conv2/W", "person_pred/scene_conv2/b"]
+
+
+def test_v1_data_entry_type_comes_from_the_meta_entry():
+  """_decode_tensor_proto: a TensorProto without dtype takes the meta entry's; one whose own
+  dtype contradicts the meta entry is refused; without either it is an error."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location(
+      "mkfix2", os.path.join(os.path.dirname(V1), "make_tf_bundle_fixture.py"))
+  mk = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mk)
+  arr = np.asarray([1.5, -2.0, 3.25], "<f4")
+  bare = mk.tensor_proto(arr, 1)
+  assert bare[:1] == bytes([(5 << 3) | 2])          # nothing in front of float_val
+  dt, shape, flat = tc._decode_tensor_proto(bare, "v", meta_dtype=1)
+  assert dt == 1 and tuple(shape) == () and np.array_equal(flat, arr) and flat.dtype == np.float32
+  dt, shape, flat = tc._decode_tensor_proto(mk.tensor_proto(arr, 1, with_type=True), "v", 1)
+  assert dt == 1 and tuple(shape) == (3,) and np.array_equal(flat, arr)
+  with pytest.raises(IOError, match="meta entry"):
+    tc._decode_tensor_proto(mk.tensor_proto(arr, 1, with_type=True), "v", meta_dtype=2)
+  with pytest.raises(IOError, match="unsupported dtype"):
+    tc._decode_tensor_proto(bare, "v")
+  ints = np.asarray([-5, 7], "<i8")
+  _, _, flat = tc._decode_tensor_proto(mk.tensor_proto(ints, 9), "g", meta_dtype=9)
+  assert np.array_equal(flat, ints) and flat.dtype == np.int64
 
 
 def test_v1_checkpoint_loads_into_the_model_protocol(tmp_path):

@@ -112,3 +112,39 @@ def test_read_data_batcher_and_evaluate_match_the_reference(tmp_path, use_grids)
     assert my_p[k] == pytest.approx(ref_p[k], rel=1e-6, abs=1e-9), k
   acc = [v for k, v in ref_p.items() if k.endswith("_acc")]
   assert acc and all(0.05 < a < 1.0 for a in acc)      # the noise made it non-trivial
+
+
+def test_per_scene_eval_matches_the_reference(tmp_path):
+  """--per_scene_eval (code/pred_utils.py:374-378, 514-517, 569-578): ADE / FDE per ActEV
+  camera, keyed by the scene part of the trajectory key; a camera without samples reports 0."""
+  ref_pu = _reference_pred_utils()
+  assert pred_utils.get_scene("VIRAT_S_040003_02_000197_000552_F_00001234_P_12") == \
+      ref_pu.get_scene("VIRAT_S_040003_02_000197_000552_F_00001234_P_12") == "0400"
+  cfg = _config(tmp_path, (0, 1), batch_size=4)
+  cfg.per_scene_eval = True
+  data = synth.make_npz_data(cfg, 10, seed=23, float32_traj=True)
+  cams = ["0000", "0002", "0400", "0401"]                      # "0500" stays empty
+  keys = ["VIRAT_S_%s0%d_0%d_000197_000552_F_%08d_P_%d" % (cams[i % 4], i % 7, i % 3, 100 + i, i)
+          for i in range(10)]
+  n = len(data["obs_traj"])
+  data["obs_boxid"] = np.arange(n * cfg.obs_len, dtype="int64").reshape(n, cfg.obs_len)
+  data["person_boxid2key"] = {int(data["obs_boxid"][i][0]): keys[i] for i in range(n)}
+  np.savez(os.path.join(str(tmp_path), "data_test.npz"), **data)
+  ref_ds = ref_pu.read_data(cfg, "test")
+  my_ds = pred_utils.read_data(cfg, "test")
+  assert list(my_ds.data["traj_key"]) == list(ref_ds.data["traj_key"]) == keys
+  tester = _NoisyGtTester(cfg)
+  ref_p = ref_pu.evaluate(ref_ds, cfg, None, tester)
+  my_p = pred_utils.evaluate(my_ds, cfg, None, tester)
+  assert sorted(ref_p) == sorted(my_p)
+  for cam in cams + ["0500"]:
+    for m in ("ade", "fde"):
+      k = "%s_%s" % (cam, m)
+      print("%-10s reference %.10g  here %.10g" % (k, ref_p[k], my_p[k]))
+      assert my_p[k] == pytest.approx(ref_p[k], rel=1e-6, abs=1e-9), k
+  assert my_p["0500_ade"] == 0.0 and my_p["0000_ade"] > 0 and my_p["0401_fde"] > 0
+  both = synth.default_config(batch_size=4, use_grids=(1, 1))
+  both.per_scene_eval = True
+  both.save_output = None
+  with pytest.raises(AssertionError, match="one grid only"):
+    pred_utils.evaluate(my_ds, both, None, tester)

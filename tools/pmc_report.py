@@ -35,7 +35,13 @@ def main(kernel, out, dbs):
   if "GRBM_GUI_ACTIVE" in agg:
     gui = agg["GRBM_GUI_ACTIVE"]
     cyc = gui["total"] / 8.0                     # summed over the 8 XCDs
-    res["effective_clock_GHz"] = cyc / (gui["avg_launch_us"] * 1e3 * gui["launches"])
+    # GRBM_GUI_ACTIVE also counts the front-end's launch / drain cycles around a dispatch:
+    # for launches shorter than ~50 us the quotient exceeds the 2.4 GHz maximum clock, so
+    # the field is only reported where it means something
+    if gui["avg_launch_us"] >= 50.0:
+      res["effective_clock_GHz"] = cyc / (gui["avg_launch_us"] * 1e3 * gui["launches"])
+    else:
+      res["effective_clock_note"] = "launches < 50 us: GRBM_GUI_ACTIVE / duration is not a clock"
     if "SQ_VALU_MFMA_BUSY_CYCLES" in agg:
       res["mfma_busy_frac"] = agg["SQ_VALU_MFMA_BUSY_CYCLES"]["total"] / (cyc * 1024)
     if "SQ_WAVE_CYCLES" in agg:
