@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define MV_MAX_SCALES 2
-#define MV_ABI_VERSION 4
+#define MV_ABI_VERSION 5
 
 typedef struct mv_engine* mv_handle;
 
@@ -371,6 +371,14 @@ int  mv_op_convlstm_step(int device, const float* x, const float* c,
                          const float* h, const float* kernel,
                          const float* biases, int32_t M, int32_t H, int32_t W,
                          int32_t Cx, int32_t C, float* c_out, float* h_out);
+/* The same step on the fp16 matrix pipe at fp32 accuracy (f16x3 operand planes):
+ * variant 1 = direct 3x3 form, 2 = Winograd F(2,3) over image rows (W must divide 32).
+ * h16_out (optional) [M,H,W,C]: the h' OPERAND PLANES the kernel emitted for the next
+ * step, decoded back to fp32 ((hi + lo) / 256), so that a test sees the plane layout. */
+int  mv_op_convlstm_step16(int device, int32_t variant, const float* x, const float* c,
+                           const float* h, const float* kernel, const float* biases,
+                           int32_t M, int32_t H, int32_t W, int32_t Cx, int32_t C,
+                           float* c_out, float* h_out, float* h16_out);
 /* h + GNN(h): gnn_edge/gnn_mask_edge/gnn_node (pred_models.py:808-909);
  * h [M,H,W,C], scene_mean [M,H,W,D]. */
 int  mv_op_gnn(int device, const float* h, const float* scene_mean, int32_t M,

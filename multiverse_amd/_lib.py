@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 MV_MAX_SCALES = 2
-MV_ABI_VERSION = 4
+MV_ABI_VERSION = 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmultiverse_hip.so")
@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "mv_set_graph_mode", "mv_set_compute_mode", "mv_set_profiling", "mv_reset_kernel_stats", "mv_num_kernel_stats",
     "mv_kernel_stat", "mv_kernel_stat_dense_flops", "mv_time_greedy_resident",
     "mv_time_beam_resident",
-    "mv_op_convlstm_step", "mv_op_gnn", "mv_op_hidden2grid", "mv_op_beam_step",
+    "mv_op_convlstm_step", "mv_op_convlstm_step16", "mv_op_gnn", "mv_op_hidden2grid", "mv_op_beam_step",
     "mv_train_init", "mv_train_step", "mv_train_forward_backward",
     "mv_upload_targets", "mv_grad_buffer", "mv_train_apply", "mv_get_grad", "mv_get_global_step",
     "mv_set_global_step", "mv_get_opt_slot", "mv_set_opt_slot",
@@ -214,6 +214,8 @@ def load():
   lib.mv_time_beam_resident.argtypes = [h, C.c_int32, _fp]
   lib.mv_op_convlstm_step.argtypes = [C.c_int, _fp, _fp, _fp, _fp, _fp] + \
       [C.c_int32] * 5 + [_fp, _fp]
+  lib.mv_op_convlstm_step16.argtypes = [C.c_int, C.c_int32, _fp, _fp, _fp, _fp, _fp] + \
+      [C.c_int32] * 5 + [_fp, _fp, _fp]
   lib.mv_op_gnn.argtypes = [C.c_int, _fp, _fp] + [C.c_int32] * 5 + [_fp]
   lib.mv_op_hidden2grid.argtypes = [C.c_int, _fp, _fp] + [C.c_int32] * 5 + [_fp]
   lib.mv_op_beam_step.argtypes = [C.c_int, _fp, _fp, C.c_int32, C.c_int32,
@@ -916,6 +918,28 @@ def op_convlstm_step(x, c, h, kernel, biases, device=0):
   check(lib.mv_op_convlstm_step(device, fptr(x), cp, hp, fptr(kernel), fptr(biases),
                                 M, H, W, Cx, Cc, fptr(c_out), fptr(h_out)))
   return c_out, h_out
+
+
+def op_convlstm_step16(x, c, h, kernel, biases, variant, device=0):
+  """The step on the fp16 matrix pipe (f16x3 planes): variant 1 = direct form, 2 = Winograd
+  F(2,3) over image rows.  Returns c', h' and the h' operand planes decoded to fp32."""
+  lib = load()
+  x = f32(x)
+  M, H, W, Cx = x.shape
+  Cc = int(kernel.shape[3]) // 4
+  kernel, biases = f32(kernel), f32(biases)
+  c_out = np.empty((M, H, W, Cc), dtype=np.float32)
+  h_out = np.empty((M, H, W, Cc), dtype=np.float32)
+  h16 = np.empty((M, H, W, Cc), dtype=np.float32)
+  if c is None:
+    cp, hp = _fp(), _fp()
+  else:
+    c, h = f32(c), f32(h)
+    cp, hp = fptr(c), fptr(h)
+  check(lib.mv_op_convlstm_step16(device, int(variant), fptr(x), cp, hp, fptr(kernel),
+                                  fptr(biases), M, H, W, Cx, Cc, fptr(c_out), fptr(h_out),
+                                  fptr(h16)))
+  return c_out, h_out, h16
 
 
 def op_gnn(h, scene_mean, device=0):

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // types and enums only; entry points come from dlsym
 
+#include <stdlib.h>
+
 #include <string>
 
 namespace mv {
@@ -40,6 +42,15 @@ inline RcclApi& rccl() {
     // an RCCL already in the process first (NOLOAD matches by SONAME), then ROCm's
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
                            "/opt/rocm/lib/librccl.so"};
+    // MV_RCCL_LIB=<path>: exactly that library and no other (the single-GPU tests put a
+    // shared-memory stand-in there, tests/fake_rccl, so that the bucketed all-reduce can run
+    // with two ranks on one device -- real RCCL refuses duplicate devices)
+    if (const char* forced = getenv("MV_RCCL_LIB")) {
+      h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+      if (!h) { a.error = std::string("MV_RCCL_LIB: ") + dlerror(); return a; }
+      a.where = std::string(forced) + " (MV_RCCL_LIB)";
+    }
+    if (!h)
     for (const char* n : names)
       if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) { a.where = std::string(n) + " (already loaded)"; break; }
     if (!h)

@@ -1,0 +1,532 @@
+// ConvLSTM step, f16x3 arithmetic, with the 3x3 gate convolution in Winograd F(2,3) form
+// along the image's ROW axis: two thirds of the matrix-pipe work of convlstm_f16x3.h for
+// the same pre-activations.
+//
+// Why: the direct f16x3 gate kernel runs at the package
+// power cap (MFMA busy 0.78 at 1.64-1.75 GHz), so scheduling work no longer pays; what is
+// left is energy per result, i.e. MFMAs per product.  For a pair of output rows (2t, 2t+1)
+// at column x and the three kernel rows g0, g1, g2 of one stencil column dx,
+//     y(2t)   = M0 + M1 + M2        M0 = (d(2t-1) - d(2t+1)) g0
+//     y(2t+1) = M1 - M2 - M3        M1 = (d(2t)   + d(2t+1)) (g0 + g1 + g2) / 2
+//                                   M2 = (d(2t+1) - d(2t)  ) (g0 - g1 + g2) / 2
+//                                   M3 = (d(2t)   - d(2t+2)) g2
+// four products instead of six, each still summed over (dx, input channel): four
+// independent GEMMs  M_c[pair-cell][column] = sum_{dx, ci} V_c[pair-cell + dx][ci] U_c[dx][ci][column].
+// Rows, not columns, are paired so that the dx taps stay what they are in the direct
+// kernel: ONE operand fragment per (component, 16 channels) moved one lane up / down the
+// wave by DPP (a wave's 32 pair-cells are consecutive x of whole image rows; every W of
+// the launch divides 32).
+//
+// Operands.  U_c is formed from the fp32 kernel in fp64 and stored, like every f16x3
+// operand, as two fp16 planes of 256 U (pack_wino_kernel).  V_c is formed IN the kernel
+// from the ordinary operand planes the producers already write (plane_layout.h; no
+// producer changes, beam row indirection as before): with d = hi + lo per row,
+//     V = (a_hi +- b_hi) + (a_lo +- b_lo)
+// is evaluated in packed fp16 with an error-free TwoSum of the high planes (hi' = fl(a_hi
+// +- b_hi), lo' = err + (a_lo +- b_lo)): |V - hi' - lo'| <= ~2^-21 max(|a|, |b|), the
+// class of the plane residuals themselves.  32 packed fp16 instructions per component and 16 channels
+// against 18 MFMAs (576 matrix-pipe cycles).
+//
+// Tile.  The matrix roles are swapped against the direct kernel: the weights are the A
+// operand (rows = 4 gates x 8 channels), the activations the B operand (columns = 32
+// pair-cells), so a lane's accumulator registers hold i, j, f, o of FOUR consecutive
+// channels of ONE pair-cell: the LSTM update stays in registers, state loads / stores
+// are 16-byte vectors, and the h' operand planes leave the registers as 8-byte stores that
+// a wave lays down as contiguous 512-byte runs (no LDS transpose).  A wave owns 32
+// pair-cells (64 cells) x 16 channels x 4 gates x 4 Winograd components = 128
+// accumulator registers; a workgroup = 8 waves = 256 pair-cells of one 16-channel column
+// block, sharing that block's weight stage (24 KB = 2 components x 3 dx x 2 planes x 2
+// row blocks) through a double LDS buffer filled by LDS-DMA; 36 MFMAs per wave and stage.
+// One workgroup per CU (2 waves per SIMD, <= 256 registers).
+//
+// The regression encoder's 2-channel pixel-offset input keeps its fp32 chunk
+// (v_mfma_f32_32x32x2_f32, weights x 2^16 read straight from the HWIO kernel): direct
+// form, row 2t into M0 and row 2t+1, negated, into M3.
+#pragma once
+#include "convlstm_f16x3.h"
+
+namespace mv {
+
+constexpr int kWnWaves = 8;
+constexpr int kWnThreads = kWnWaves * 64;
+constexpr int kWnPairs = kWnWaves * 32;              // pair-cells per workgroup
+constexpr int kWnCh = 16;                            // output channels per workgroup
+constexpr int kWnStageVec = 2 * 3 * 2 * 2 * 64;      // 16-byte vectors per LDS stage (24 KB)
+constexpr uint32_t kWnStageBytes = kWnStageVec * 16;
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct ConvLstmWinoArgs {
+  ConvLstm16Args b;        // geometry, operand planes, outputs (wp16 / wx32 unused)
+  const _Float16* wpw;     // [cb16][stage][comp in stage 2][dx 3][plane 2][row block 2][lane 64][8]
+  const float* w_hwio;     // the fp32 kernel [3,3,Cx+C,4C] (x_small chunk)
+  int32_t n_xc;            // 16-channel x chunks present in the pack (0 when x_small)
+  int32_t pad_;
+};
+
+struct ConvLstmWinoGroup {
+  ConvLstmWinoArgs p[kMaxGroup];
+  int32_t block_end[kMaxGroup];
+  int32_t n;
+};
+
+static inline size_t wino_wpack_elems(int Cx16, int C) {   // in halves
+  return (size_t)(C / kWnCh) * 2 * (size_t)(Cx16 / 16 + C / 16) * kWnStageVec * 8;
+}
+
+// The pack, from the CURRENT device weights: one thread per (cb16, stage, comp, dx, row
+// block, lane, element), both planes.  Element e of lane l: A-operand row l & 31 = gate
+// (row >> 3), channel cb16*16 + rb*8 + (row & 7); k = 8 (l >> 5) + e = input channel of the
+// chunk.  Stage s = 2 * chunk + (comp >> 1); chunks = x groups of 16 first, then h groups.
+__global__ void pack_wino_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
+                                 int Cx_total, int Cx16, int C, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx & 7;
+  const int l = (idx >> 3) & 63;
+  const int rb = (idx >> 9) & 1;
+  size_t t = idx >> 10;                           // ((cb16 * nst + s) * 2 + ci) * 3 + dx
+  const int dx = (int)(t % 3); t /= 3;
+  const int ci = (int)(t & 1); t >>= 1;
+  const int nxc = Cx16 / 16, nst = 2 * (nxc + C / 16);
+  const int s = (int)(t % nst), cb16 = (int)(t / nst);
+  const int chunk = s >> 1, comp = (s & 1) * 2 + ci;
+  const bool is_x = chunk < nxc;
+  const int cg = is_x ? chunk : chunk - nxc;
+  const int k = 8 * (l >> 5) + e;
+  const int cin = (is_x ? 0 : Cx_total) + cg * 16 + k;
+  const int row = l & 31;
+  const int n = (row >> 3) * C + cb16 * kWnCh + rb * 8 + (row & 7);
+  const int Cin = Cx_total + C, N4 = 4 * C;
+  const double g0 = w[((size_t)(0 * 3 + dx) * Cin + cin) * N4 + n];
+  const double g1 = w[((size_t)(1 * 3 + dx) * Cin + cin) * N4 + n];
+  const double g2 = w[((size_t)(2 * 3 + dx) * Cin + cin) * N4 + n];
+  const double u = comp == 0 ? g0 : (comp == 1 ? 0.5 * (g0 + g1 + g2)
+                                               : (comp == 2 ? 0.5 * (g0 - g1 + g2) : g2));
+  const double sv = u * 256.0;
+  const _Float16 v0 = (_Float16)sv;
+  const _Float16 v1 = (_Float16)(sv - (double)v0);
+  const size_t base = ((((size_t)cb16 * nst + s) * 2 + ci) * 3 + dx) * (2 * 2 * 64 * 8);
+  out[base + ((size_t)(0 * 2 + rb) * 64 + l) * 8 + e] = v0;
+  out[base + ((size_t)(1 * 2 + rb) * 64 + l) * 8 + e] = v1;
+}
+
+// a - b on packed halves as ONE v_pk_fma_f16 (b * -1 + a, exactly rounded like the
+// subtraction).  Written as a - b, hipcc scalarises a <8 x half> subtraction into v_sub_f16 /
+// SDWA / v_pack triples (there is no v_pk_sub_f16 and the fsub lowering does not use the neg
+// modifiers); m1 = (-1, -1) comes from a laundered SGPR so that the fma is not folded back.
+__device__ __forceinline__ f16x8 wn_sub(const f16x8 a, const f16x8 b, const f16x8 m1) {
+  return __builtin_elementwise_fma(b, m1, a);
+}
+// (a_hi + a_lo) +- (b_hi + b_lo) as a plane pair: error-free TwoSum of the high planes
+// (s + err == a_hi +- b_hi exactly), everything else into the low plane.  8 packed
+// instructions per register.
+template <bool SUB>
+__device__ __forceinline__ void wn_combine(const f16x8 a_hi, const f16x8 a_lo, const f16x8 b_hi,
+                                           const f16x8 b_lo, const f16x8 m1, f16x8& hi,
+                                           f16x8& lo) {
+  const f16x8 s = SUB ? wn_sub(a_hi, b_hi, m1) : a_hi + b_hi;
+  const f16x8 bb = wn_sub(s, a_hi, m1);              // the part of +-b_hi that arrived in s
+  const f16x8 t = wn_sub(s, bb, m1);                 // the part of a_hi that arrived
+  const f16x8 e1 = wn_sub(a_hi, t, m1);
+  const f16x8 e2 = SUB ? wn_sub(-bb, b_hi, m1) : wn_sub(b_hi, bb, m1);   // (+-b_hi) - bb
+  hi = s;
+  lo = (e1 + e2) + (SUB ? wn_sub(a_lo, b_lo, m1) : a_lo + b_lo);
+}
+
+// the fragment moved one lane up (dx = -1: lane l takes lane l - 1) or down the wave
+__device__ __forceinline__ f16x8 wn_lane_shift(const f16x8& v, bool up, bool ok) {
+  const u32x4 w = __builtin_bit_cast(u32x4, v);
+  u32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t t =
+        up ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[j], 0x138, 0xf, 0xf, true)
+           : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[j], 0x130, 0xf, 0xf, true);
+    r[j] = ok ? t : 0u;
+  }
+  return __builtin_bit_cast(f16x8, r);
+}
+
+__device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, int cb16, int mt,
+                                                   f16x8* lds /* [2][kWnStageVec] */) {
+  const ConvLstm16Args& q = p.b;
+  const ConvLstmArgs& a = q.f;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int H = a.H, W = a.W, HW = H * W, C = a.C, Cx = a.Cx;
+  const int Hp = (H + 1) >> 1, Kp = Hp * W;
+  const int Q_total = a.rows * Kp;
+  const int q_wave = mt * kWnPairs + wave * 32;
+  const bool wave_live = q_wave < Q_total;       // dead waves still copy and hit barriers
+  const int col = lane & 31, half = lane >> 5;
+
+  int r = 0, y0 = 0, xpos = 0;
+  bool valid;
+  {
+    const int qq = q_wave + col;
+    valid = qq < Q_total;
+    if (valid) {
+      r = qq / Kp;
+      const int pc = qq - r * Kp;
+      const int t = pc / W;
+      y0 = 2 * t;
+      xpos = pc - t * W;
+    }
+  }
+  const int srh = (valid && a.src_row_h) ? a.src_row_h[r] : r;
+  const bool okx0 = valid & (xpos > 0), okx2 = valid & (xpos + 1 < W);
+
+  // operand rows y0 - 1 .. y0 + 2 of the lane's column: byte offsets of the lane's 16-byte
+  // vector in channel group 0 of the tiled planes (from the zero pad in front of a plane,
+  // so that offset 0 reads zeros); an out-of-image row reads offset 0
+  bool rok[4];
+  uint32_t roffx[4], roffh[4];
+  {
+    const int KGx = Cx >> 4, KGh = C >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rho = y0 - 1 + i;
+      rok[i] = valid & (rho >= 0) & (rho < H);
+      const int cx = r * HW + rho * W + xpos, chh = srh * HW + rho * W + xpos;
+      roffx[i] = (uint32_t)((((cx >> 5) * KGx) * 512 + half * 256 + (cx & 31) * 8 + kPlanePad) * 2);
+      roffh[i] = (uint32_t)((((chh >> 5) * KGh) * 512 + half * 256 + (chh & 31) * 8 + kPlanePad) * 2);
+    }
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[c][rb][i] = 0.f;
+
+  // ---- the 2-channel fp32 x chunk (regression encoder), direct form
+  if (a.x_small && wave_live) {
+    const int Cin = Cx + C, N4 = 4 * C;
+    const int nk = 9 * Cx;
+    const int n0 = (col >> 3) * C + cb16 * kWnCh + (col & 7);
+    for (int k2 = 0; 2 * k2 < nk; ++k2) {
+      const int k = 2 * k2 + half;
+      const bool kok = k < nk;
+      const int tap = kok ? k / Cx : 0, chn = kok ? k - tap * Cx : 0;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      float wv[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const float tw = p.w_hwio[((size_t)tap * Cin + chn) * N4 + n0 + rb * 8];
+        wv[rb] = kok ? tw * 65536.0f : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int yy = y0 + e + dy, xx = xpos + dx;
+        const bool ok = kok & valid & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+        const int off = ok ? r * a.x_row_stride + (yy * W + xx) * Cx + chn : 0;
+        const float tv = a.x[off];
+        const float v = ok ? (e ? -tv : tv) : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          acc[e ? 3 : 0][rb] =
+              __builtin_amdgcn_mfma_f32_32x32x2f32(wv[rb], v, acc[e ? 3 : 0][rb], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- f16 chunks of 16 input channels: x chunks first, then h chunks
+  const int nxc = p.n_xc;
+  const int ck_lo = a.sx_corr ? nxc : 0;                    // sparse x: table terms instead
+  const int ck_hi = a.zero_state ? nxc : nxc + (C >> 4);
+  if (ck_hi > ck_lo) {
+    const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wpw) +
+                        (size_t)cb16 * 2 * (nxc + (C >> 4)) * kWnStageVec;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<f16x8*>(wblk)), 0, 0x7fffffff, 0x00020000);
+    const _Float16* const x16 = q.x16 ? q.x16 : q.h16;
+    const int64_t xps = q.x16 ? q.x_plane_stride : 0;
+    const _Float16* const h16 = q.h16 ? q.h16 : q.x16;
+    const int64_t hps = q.h16 ? q.h_plane_stride : 0;
+    const __amdgpu_buffer_rsrc_t xrs0 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<_Float16*>(x16 - kPlanePad)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs1 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<_Float16*>(x16 + xps - kPlanePad)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrs0 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<_Float16*>(h16 - kPlanePad)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrs1 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<_Float16*>(h16 + hps - kPlanePad)), 0, 0x7fffffff, 0x00020000);
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // stage copy: the pack IS the LDS image; 24 pieces of 64 vectors, three per wave
+    auto stage_dma = [&](int s, f16x8* dstbuf) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int v0 = (i * kWnWaves + wave_u) * 64;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            wrs, (__attribute__((address_space(3))) void*)(dstbuf + v0), 16,
+            (uint32_t)(v0 + lane) * 16u, (uint32_t)s * kWnStageBytes, 0, MV_DMA_AUX);
+      }
+    };
+    f16x8 raw[4][2];
+    auto load_raw = [&](int ck) {
+      const bool is_x = ck < nxc;
+      const uint32_t cgo = (uint32_t)(is_x ? ck : ck - nxc) * 1024u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t o = (is_x ? roffx[i] : roffh[i]) + cgo;
+        const int off = rok[i] ? (int)o : 0;
+        raw[i][0] = __builtin_bit_cast(
+            f16x8, __builtin_amdgcn_raw_buffer_load_b128(is_x ? xrs0 : hrs0, off, 0, 0));
+        raw[i][1] = __builtin_bit_cast(
+            f16x8, __builtin_amdgcn_raw_buffer_load_b128(is_x ? xrs1 : hrs1, off, 0, 0));
+      }
+    };
+    // one component: 3 dx x 2 row blocks x 3 MFMAs from stage buffer `buf`, slot ci
+#define MV_WN_COMP(COMP, CI, VHI, VLO, BUF)                                                   \
+  do {                                                                                        \
+    _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                        \
+      const f16x8 b0 = dx == 1 ? (VHI) : wn_lane_shift((VHI), dx == 0, dx == 0 ? okx0 : okx2); \
+      const f16x8 b1 = dx == 1 ? (VLO) : wn_lane_shift((VLO), dx == 0, dx == 0 ? okx0 : okx2); \
+      f16x8 w0[2], w1[2];                                                                     \
+      _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) {                                      \
+        w0[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 0) * 2 + rb) * 64 + lane];                     \
+        w1[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 1) * 2 + rb) * 64 + lane];                     \
+      }                                                                                       \
+      _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                        \
+        acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[rb], b0, acc[COMP][rb], 0, 0, 0); \
+      _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                        \
+        acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b1, acc[COMP][rb], 0, 0, 0); \
+      _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                        \
+        acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b0, acc[COMP][rb], 0, 0, 0); \
+    }                                                                                         \
+  } while (0)
+
+    uint32_t mone = 0xBC00BC00u;              // (-1, -1) as packed halves, opaque to hipcc
+    asm volatile("" : "+s"(mone));
+    const f16x8 m1 = __builtin_bit_cast(f16x8, u32x4{mone, mone, mone, mone});
+    f16x8* const bufA = lds;
+    f16x8* const bufB = lds + kWnStageVec;
+    load_raw(ck_lo);
+    stage_dma(2 * ck_lo, bufA);
+    __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
+    for (int ck = ck_lo; ck < ck_hi; ++ck) {
+      const bool more = ck + 1 < ck_hi;
+      f16x8 vh0, vl0, vh1, vl1;
+      // stage A: components 0, 1
+      stage_dma(2 * ck + 1, bufB);           // its buffer was last read before the barrier
+      wn_combine<true>(raw[0][0], raw[0][1], raw[2][0], raw[2][1], m1, vh0, vl0);   // d(-1) - d(+1)
+      wn_combine<false>(raw[1][0], raw[1][1], raw[2][0], raw[2][1], m1, vh1, vl1);  // d(0) + d(+1)
+      MV_WN_COMP(0, 0, vh0, vl0, bufA);
+      MV_WN_COMP(1, 1, vh1, vl1, bufA);
+      __syncthreads();
+      // stage B: components 2, 3
+      wn_combine<true>(raw[2][0], raw[2][1], raw[1][0], raw[1][1], m1, vh0, vl0);   // d(+1) - d(0)
+      wn_combine<true>(raw[1][0], raw[1][1], raw[3][0], raw[3][1], m1, vh1, vl1);   // d(0) - d(+2)
+      if (more) {
+        stage_dma(2 * ck + 2, bufA);
+        load_raw(ck + 1);                    // a whole stage (36 MFMAs) ahead of its use
+      }
+      MV_WN_COMP(2, 0, vh0, vl0, bufB);
+      MV_WN_COMP(3, 1, vh1, vl1, bufB);
+      __syncthreads();
+    }
+#undef MV_WN_COMP
+  }
+  if (!wave_live) return;
+
+  // ---------------------------------------------------------------- epilogue
+  // registers of acc[c][rb]: gate = reg >> 2, channel = cb16*16 + rb*8 + 4*half + (reg & 3);
+  // the lane's pair-cell gives rows y0 (e = 0) and y0 + 1 (e = 1).
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));          // keep the address arithmetic below the loop
+  const int half_e = lane_e >> 5;
+  const int ch0 = cb16 * kWnCh + 4 * half_e;                 // + rb * 8
+  const uint32_t rowb = (uint32_t)C * 4u;                    // bytes per cell
+  const uint32_t out_bytes = (uint32_t)(a.rows * HW) * rowb;
+  const int src_c = (valid && a.src_row_c && !a.zero_state) ? a.src_row_c[r] : r;
+  const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<float*>(a.zero_state ? a.c_out : a.c)), 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t co_rs = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.c_out), 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ho_rs = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.h_out), 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t go_rs = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.gates_out ? a.gates_out : a.h_out), 0, a.gates_out ? 4u * out_bytes : 0u,
+      0x00020000);
+  bool okc[2];
+  int cell[2];                                // cell index inside its image
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    okc[e] = valid & (y0 + e < H);
+    cell[e] = (y0 + e) * W + xpos;
+  }
+  // pass 1: every state load goes out before any store
+  f32x4 cprev[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      cprev[e][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!a.zero_state) {
+        // lanes that own no cell read offset 0 (the value is never used)
+        const uint32_t off = okc[e] ? ((uint32_t)(src_c * HW + cell[e]) * (uint32_t)C +
+                                       (uint32_t)(ch0 + rb * 8)) * 4u
+                                    : 0u;
+        cprev[e][rb] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_rs, (int)off, 0, MV_EPI_LD_AUX));
+      }
+    }
+  // sparse x: hot cell of the lane's image
+  int hot_y = 0, hot_x = 0;
+  if (a.sx_corr) {
+    const int hr = a.sx_hot_div > 1 ? r / a.sx_hot_div : r;
+    const uint32_t hyx = a.sx_cellyx[a.sx_hot[(size_t)hr * a.sx_hot_stride]];
+    hot_y = (int)(hyx >> 16); hot_x = (int)(hyx & 0xffffu);
+  }
+  const float un = kF16Unscale;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int y = y0 + e;
+    const uint32_t mcell = (uint32_t)(r * HW + cell[e]);     // output cell, flat
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int ch = ch0 + rb * 8;
+      // per-gate additive terms (4 channels each)
+      f32x4 add[4];
+      {
+        const float* bsrc = a.bias;
+        if (a.sx_corr && a.sx_bias) {
+          const int cls = 3 * (y == 0 ? 0 : (y == H - 1 ? 2 : 1)) +
+                          (xpos == 0 ? 0 : (xpos == W - 1 ? 2 : 1));
+          bsrc = a.sx_bias + (size_t)(okc[e] ? cls : 4) * 4 * C;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          add[g] = *reinterpret_cast<const f32x4*>(bsrc + g * C + ch);
+        if (a.sx_corr) {
+          const int dy = y - hot_y, dxh = xpos - hot_x, rad = a.sx_rad;
+          if (okc[e] && dy >= -rad && dy <= rad && dxh >= -rad && dxh <= rad) {
+            const int side = 2 * rad + 1;
+            const int idx = a.sx_by_class
+                                ? 3 * (hot_y == 0 ? 0 : (hot_y == H - 1 ? 2 : 1)) +
+                                      (hot_x == 0 ? 0 : (hot_x == W - 1 ? 2 : 1))
+                                : r;
+            const float* ct = a.sx_corr +
+                ((size_t)idx * side * side + (dy + rad) * side + (dxh + rad)) * 4 * C + ch;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 cv = *reinterpret_cast<const f32x4*>(ct + g * C);
+              add[g][0] += cv[0]; add[g][1] += cv[1]; add[g][2] += cv[2]; add[g][3] += cv[3];
+            }
+          }
+        }
+      }
+      f32x4 cn4, hn4, si4, tj4, sf4, so4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int reg = g * 4 + j;
+          const float m0 = acc[0][rb][reg], m1 = acc[1][rb][reg], m2 = acc[2][rb][reg],
+                      m3 = acc[3][rb][reg];
+          const float yv = e == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
+          pre[g] = yv * un + add[g][j];
+        }
+        const float si = sigm_(pre[0]), tj = tanh_(pre[1]), sf = sigm_(pre[2] + a.forget_bias),
+                    so = sigm_(pre[3]);
+        float cn = sf * cprev[e][rb][j];
+        cn = cn + si * tj;
+        const float hn = tanh_(cn) * so;
+        cn4[j] = cn; hn4[j] = hn; si4[j] = si; tj4[j] = tj; sf4[j] = sf; so4[j] = so;
+      }
+      if (okc[e]) {
+        const uint32_t o_off = (mcell * (uint32_t)C + (uint32_t)ch) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cn4), co_rs, (int)o_off,
+                                               0, MV_EPI_ST_AUX);
+        if (!a.skip_h32)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hn4), ho_rs,
+                                                 (int)o_off, 0, MV_EPI_ST_AUX);
+        if (a.gates_out) {
+          const uint32_t g0 = (mcell * 4u * (uint32_t)C + (uint32_t)ch) * 4u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, si4), go_rs, (int)g0,
+                                                 0, MV_EPI_ST_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tj4), go_rs,
+                                                 (int)(g0 + rowb), 0, MV_EPI_ST_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sf4), go_rs,
+                                                 (int)(g0 + 2 * rowb), 0, MV_EPI_ST_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, so4), go_rs,
+                                                 (int)(g0 + 3 * rowb), 0, MV_EPI_ST_AUX);
+        }
+      }
+      if (q.h16_out && okc[e]) {
+        // operand planes of h' for the next gate convolution: tile (m >> 5, cb16), k half
+        // rb, the lane's 4 of the 8 channels -- the 64 lanes of the store lay down one
+        // contiguous 512-byte run per plane (lanes 0-31: first 8 bytes of 32 consecutive
+        // cells, lanes 32-63: the second 8)
+        f16x4 p0, p1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sc = hn4[j] * kF16Scale;
+          const _Float16 h0 = (_Float16)sc;
+          p0[j] = h0;
+          p1[j] = (_Float16)(sc - (float)h0);
+        }
+        const size_t o = ((size_t)(mcell >> 5) * (size_t)(C >> 4) + (size_t)cb16) * 512 +
+                         (size_t)(rb * 256 + (int)(mcell & 31u) * 8 + 4 * half_e);
+        *reinterpret_cast<f16x4*>(q.h16_out + o) = p0;
+        *reinterpret_cast<f16x4*>(q.h16_out + q.h16_out_stride + o) = p1;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kWnThreads, 2)
+void convlstm_step_wino_kernel(const ConvLstmWinoGroup g) {
+  __shared__ f16x8 lds[2 * kWnStageVec];
+  int block = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxGroup - 1; ++i)
+    if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
+  if (pi > 0) block -= g.block_end[pi - 1];
+  switch (pi) {
+    case 0: { const int ncb = g.p[0].b.f.C / kWnCh; convlstm_wino_body(g.p[0], block % ncb, block / ncb, lds); break; }
+    case 1: { const int ncb = g.p[1].b.f.C / kWnCh; convlstm_wino_body(g.p[1], block % ncb, block / ncb, lds); break; }
+    case 2: { const int ncb = g.p[2].b.f.C / kWnCh; convlstm_wino_body(g.p[2], block % ncb, block / ncb, lds); break; }
+    default: { const int ncb = g.p[3].b.f.C / kWnCh; convlstm_wino_body(g.p[3], block % ncb, block / ncb, lds); break; }
+  }
+}
+
+static inline unsigned convlstm_wino_blocks(const ConvLstmArgs& a) {
+  const size_t Q = (size_t)a.rows * ((a.H + 1) / 2) * a.W;
+  return (unsigned)((Q + kWnPairs - 1) / kWnPairs) * (unsigned)(a.C / kWnCh);
+}
+
+// The Winograd form serves a group when every problem's W divides 32 (the DPP column shift)
+// and C is a multiple of 16.  MV_WINO=0 keeps the direct kernel (A/B runs).
+static inline bool wino_enabled() {
+  static const bool off = getenv("MV_WINO") && atoi(getenv("MV_WINO")) == 0;
+  return !off;
+}
+static inline bool wino_geometry_ok(const ConvLstmArgs& a) {
+  return a.W > 0 && 32 % a.W == 0 && a.C % kWnCh == 0 && (a.Cx % 16 == 0 || a.x_small) &&
+         a.H >= 2;
+}
+
+static inline void launch_convlstm_wino_steps(const ConvLstmWinoArgs* probs, int n,
+                                              hipStream_t stream) {
+  ConvLstmWinoGroup g{};
+  g.n = n;
+  unsigned total = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = probs[i];
+    total += convlstm_wino_blocks(probs[i].b.f);
+    g.block_end[i] = (int32_t)total;
+  }
+  for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
+  hipLaunchKernelGGL(convlstm_step_wino_kernel, dim3(total), dim3(kWnThreads), 0, stream, g);
+}
+
+}  // namespace mv

@@ -24,6 +24,7 @@
 #include "convlstm_mfma.h"
 #include "convlstm_wgrad.h"
 #include "convlstm_f16x3.h"
+#include "convlstm_wino.h"
 #include "convlstm_wgrad_f16x3.h"
 #include "kernels_misc.h"
 #include "decode_tail.h"
@@ -108,6 +109,7 @@ struct ConvCell {           // one ConvLSTMCell: packed kernel + biases
   DevBuf<float> wx32;       // f16x3, Cx <= 3: the fp32 x chunk scaled by 2^16
   DevBuf<_Float16> wpb;     // bf16 compute mode: one unscaled bf16 plane, fragment order
   DevBuf<float> wx32u;      // bf16, Cx <= 3: the fp32 x chunk, unscaled
+  DevBuf<_Float16> wpw;     // f16x3, Winograd F(2,3) form of the kernel (convlstm_wino.h)
   bool host_stale = false;  // device copy was updated by the optimizer
   int Cx = 0;
 };
@@ -566,6 +568,27 @@ void ensure_packed16(mv_engine* e, ConvCell& cc) {
                       hipMemcpyHostToDevice));
 }
 
+static bool C_multiple_ok(const mv_engine* e, const ConvCell& cc) {
+  return e->cfg.hidden_size % mv::kWnCh == 0 &&
+         (cc.Cx % 16 == 0 || (cc.Cx > 0 && 9 * cc.Cx <= mv::kBK));
+}
+// Winograd F(2,3) pack of the f16x3 forward (convlstm_wino.h), from the CURRENT device
+// weights; the transform of the kernel rows runs in fp64 on the device.
+void pack_wino(mv_engine* e, ConvCell& cc) {
+  const int C = e->cfg.hidden_size;
+  const bool small = cc.Cx > 0 && 9 * cc.Cx <= mv::kBK;
+  const int Cx16 = small ? 0 : cc.Cx;
+  const size_t halves = mv::wino_wpack_elems(Cx16, C);
+  cc.wpw.alloc(halves);
+  const size_t threads = halves / 2;
+  hipLaunchKernelGGL(mv::pack_wino_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, e->stream,
+                     cc.kernel->dev.p, cc.wpw.p, cc.Cx, Cx16, C, threads);
+}
+void ensure_packed_wino(mv_engine* e, ConvCell& cc) {
+  if (cc.wpw.p) return;
+  if (C_multiple_ok(e, cc)) pack_wino(e, cc);
+}
+
 // bf16 packs (one unscaled plane; the 2-channel regression-encoder input keeps its fp32
 // chunk), from the CURRENT weights.
 void ensure_packed_bf16(mv_engine* e, ConvCell& cc) {
@@ -629,6 +652,8 @@ void ensure_params(mv_engine* e) {
     for (ConvCell* cc : active_cells(e, S)) ensure_packed(e, *cc);
     if (e->compute_mode == 1)
       for (ConvCell* cc : active_cells(e, S)) ensure_packed16(e, *cc);
+    if (e->compute_mode == 1 && mv::wino_enabled())
+      for (ConvCell* cc : active_cells(e, S)) ensure_packed_wino(e, *cc);
     if (e->compute_mode == 2)
       for (ConvCell* cc : active_cells(e, S)) ensure_packed_bf16(e, *cc);
     if (!S.wq_valid) {     // hidden2grid tap packs, from the CURRENT device weights
@@ -801,9 +826,26 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       hipLaunchKernelGGL(mv::split_planes_group_kernel, dim3(nb), dim3(256), 0, e->stream, g);
     });
   }
+  // f16x3: the Winograd F(2,3) form of the same step (two thirds of the MFMAs,
+  // convlstm_wino.h) whenever every problem of the group fits its tiling
+  bool wino = e->compute_mode == 1 && mv::wino_enabled();
+  std::vector<mv::ConvLstmWinoArgs> pw;
+  if (wino) {
+    pw.resize(p16.size());
+    for (size_t i = 0; i < p16.size() && wino; ++i) {
+      ConvCell* cc = cell_of_pack(e, probs[i].wpack);
+      if (!mv::wino_geometry_ok(p16[i].f) || !cc->wpw.p) { wino = false; break; }
+      pw[i].b = p16[i];
+      pw[i].wpw = cc->wpw.p;
+      pw[i].w_hwio = cc->kernel->dev.p;
+      pw[i].n_xc = p16[i].f.x_small ? 0 : p16[i].f.Cx / 16;
+    }
+  }
   launch(e, "convlstm_step", flops, bytes, [&] {
     if (e->compute_mode == 2)
       mv::launch_convlstm_bf16_steps(p16.data(), (int)p16.size(), e->stream);
+    else if (wino)
+      mv::launch_convlstm_wino_steps(pw.data(), (int)pw.size(), e->stream);
     else
       mv::launch_convlstm16_steps(p16.data(), (int)p16.size(), e->stream);
   }, dense);
@@ -2005,7 +2047,7 @@ int mv_set_param(mv_handle h, const char* tf_name, const float* data,
       for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
         if (cc->kernel == p) {
           cc->wpack.release(); cc->wp16.release(); cc->wx32.release();
-          cc->wpb.release(); cc->wx32u.release();
+          cc->wpb.release(); cc->wx32u.release(); cc->wpw.release();
           cc->host_stale = false;
         }
     }
@@ -2652,6 +2694,120 @@ int mv_op_convlstm_step(int device, const float* x, const float* c, const float*
     mv::convlstm_finish_args(a, zero);
     mv::launch_convlstm_steps(&a, 1, ctx.stream);
     HIP_CHECK(hipGetLastError());
+    ctx.down(c_out, dco, cells * C);
+    ctx.down(h_out, dho, cells * C);
+  });
+}
+
+namespace {
+// planes (hi + lo) / 256 of an [M][C] tensor in the tiled operand layout -> fp32 [M][C]
+__global__ void decode_planes_kernel(const _Float16* __restrict__ p0,
+                                     const _Float16* __restrict__ p1, float* __restrict__ out,
+                                     size_t M, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * (size_t)C) return;
+  const size_t m = i / C;
+  const int ch = (int)(i - m * C);
+  const size_t o = mv::plane_index((long long)m, ch, C);
+  out[i] = ((float)p0[o] + (float)p1[o]) * (1.0f / 256.0f);
+}
+}  // namespace
+
+int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const float* c,
+                          const float* h, const float* kernel, const float* biases,
+                          int32_t M, int32_t H, int32_t W, int32_t Cx, int32_t C,
+                          float* c_out, float* h_out, float* h16_out) {
+  return guarded(nullptr, [&] {
+    MV_REQUIRE(variant == 1 || variant == 2, "variant %d: 1 = direct f16x3, 2 = Winograd", variant);
+    MV_REQUIRE(C % mv::kChBlock == 0 && C % mv::kBK == 0, "C %d must be a multiple of 32", C);
+    MV_REQUIRE(mv::f16x3_cx_supported(Cx), "Cx %d unsupported (multiple of 16, or <= 3)", Cx);
+    MV_REQUIRE(H * W >= 32, "grids of at least 32 cells");
+    OpCtx ctx(device);
+    const size_t cells = (size_t)M * H * W;
+    const bool small = Cx > 0 && 9 * Cx <= mv::kBK;
+    const int Cx16 = small ? 0 : Cx;
+    const int Cin = Cx + C, N4 = 4 * C;
+    DevBuf<float> dx, dc, dh, dw, db, dco, dho, dk, dwx, dplanes;
+    DevBuf<_Float16> px, ph, pho, wp;
+    ctx.up(dx, x, cells * Cx);
+    ctx.up(db, biases, (size_t)4 * C);
+    ctx.up(dk, kernel, (size_t)9 * Cin * N4);
+    std::vector<float> packed(mv::convlstm_wpack_elems(Cx, C));
+    mv::pack_convlstm_weights(kernel, Cx, C, packed.data());
+    ctx.up(dw, packed.data(), packed.size());
+    const bool zero = (c == nullptr && h == nullptr);
+    if (!zero) {
+      MV_REQUIRE(c && h, "c and h must both be given or both be NULL");
+      ctx.up(dc, c, cells * C);
+      ctx.up(dh, h, cells * C);
+    }
+    dco.alloc(cells * C); dho.alloc(cells * C);
+    // operand planes: [pad | plane 0 | slack][pad | plane 1 | slack], zero-filled
+    auto make_planes = [&](DevBuf<_Float16>& buf, const float* src, int Cc, size_t* stride) {
+      const size_t pst = cells * Cc + mv::kPlaneSlack + mv::kPlanePad;
+      buf.alloc(2 * pst + mv::kPlanePad);
+      HIP_CHECK(hipMemsetAsync(buf.p, 0, (2 * pst + mv::kPlanePad) * sizeof(_Float16), ctx.stream));
+      _Float16* p0 = buf.p + mv::kPlanePad;
+      if (src)
+        hipLaunchKernelGGL(mv::split_planes_kernel, dim3(mv::split_planes_blocks(cells, Cc)),
+                           dim3(256), 0, ctx.stream, src, p0, p0 + pst, (int)cells, Cc);
+      *stride = pst;
+      return p0;
+    };
+    mv::ConvLstm16Args q{};
+    mv::ConvLstmArgs& a = q.f;
+    a.x = dx.p; a.h = dh.p; a.c = dc.p; a.wpack = dw.p; a.bias = db.p;
+    a.h_out = dho.p; a.c_out = dco.p;
+    a.rows = M; a.H = H; a.W = W; a.Cx = Cx; a.C = C;
+    mv::convlstm_finish_args(a, zero);
+    size_t xst = 0, hst = 0, ost = 0;
+    if (Cx16 > 0) { q.x16 = make_planes(px, dx.p, Cx16, &xst); q.x_plane_stride = (int64_t)xst; }
+    if (!zero) { q.h16 = make_planes(ph, dh.p, C, &hst); q.h_plane_stride = (int64_t)hst; }
+    q.h16_out = make_planes(pho, nullptr, C, &ost);
+    q.h16_out_stride = (int64_t)ost;
+    q.n_xk = small ? 0 : mv::f16x3_xksteps(Cx);
+    q.n_hk = zero ? 0 : 9 * (C / 16);
+    q.w_ksteps = small ? 9 * (C / 16) : mv::f16x3_xksteps(Cx) + 9 * (C / 16);
+    if (variant == 1) {
+      std::vector<_Float16> p16(mv::f16x3_wpack_elems(Cx16, C));
+      if (small) {
+        std::vector<float> wh((size_t)9 * C * N4);
+        for (int t = 0; t < 9; ++t)
+          memcpy(&wh[(size_t)t * C * N4], &kernel[((size_t)t * Cin + Cx) * N4],
+                 (size_t)C * N4 * sizeof(float));
+        mv::pack_f16x3_weights(wh.data(), 0, C, p16.data());
+        const int nch = mv::convlstm_xchunks(Cx) + 9 * (C / mv::kBK);
+        std::vector<float> wx((size_t)(C / mv::kChBlock) * mv::kBN * mv::kBK);
+        for (int cb = 0; cb < C / mv::kChBlock; ++cb)
+          for (int i = 0; i < mv::kBN * mv::kBK; ++i)
+            wx[(size_t)cb * mv::kBN * mv::kBK + i] =
+                packed[((size_t)cb * nch + 0) * mv::kBN * mv::kBK + i] * 65536.0f;
+        ctx.up(dwx, wx.data(), wx.size());
+        q.wx32 = dwx.p;
+      } else {
+        mv::pack_f16x3_weights(kernel, Cx, C, p16.data());
+      }
+      ctx.up(wp, p16.data(), p16.size());
+      q.wp16 = wp.p;
+      mv::launch_convlstm16_steps(&q, 1, ctx.stream);
+    } else {
+      MV_REQUIRE(mv::wino_geometry_ok(a), "Winograd form: W %d must divide 32, H >= 2", W);
+      const size_t halves = mv::wino_wpack_elems(Cx16, C);
+      wp.alloc(halves);
+      hipLaunchKernelGGL(mv::pack_wino_kernel, dim3(cdiv(halves / 2, 256)), dim3(256), 0,
+                         ctx.stream, dk.p, wp.p, Cx, Cx16, C, halves / 2);
+      mv::ConvLstmWinoArgs wq{};
+      wq.b = q; wq.wpw = wp.p; wq.w_hwio = dk.p; wq.n_xc = Cx16 / 16;
+      mv::launch_convlstm_wino_steps(&wq, 1, ctx.stream);
+    }
+    HIP_CHECK(hipGetLastError());
+    if (h16_out) {
+      dplanes.alloc(cells * C);
+      hipLaunchKernelGGL(decode_planes_kernel, dim3(cdiv(cells * C, 256)), dim3(256), 0,
+                         ctx.stream, q.h16_out, q.h16_out + ost, dplanes.p, cells, C);
+      HIP_CHECK(hipGetLastError());
+      ctx.down(h16_out, dplanes, cells * C);
+    }
     ctx.down(c_out, dco, cells * C);
     ctx.down(h_out, dho, cells * C);
   });

@@ -346,13 +346,14 @@ void run_pack(mv_engine* e, TrainChain& ch) {
       const size_t threads = halves / 2;
       hipLaunchKernelGGL(mv::pack_f16x3_kernel, dim3(cdiv(threads, 256)), dim3(256), 0,
                          e->stream, cc.kernel->dev.p, cc.wp16.p, Cx, Cx16, C, threads);
+      if (mv::wino_enabled() && C_multiple_ok(e, cc)) pack_wino(e, cc);
       cc.wpb.release(); cc.wx32u.release();
     } else {                    // bf16 forward; dgrad / wgrad stay on the f16x3 split
       const size_t halves = mv::bf16_wpack_elems(Cx16, C);
       cc.wpb.alloc(halves);
       hipLaunchKernelGGL(mv::pack_bf16_kernel, dim3(cdiv(halves, 256)), dim3(256), 0,
                          e->stream, cc.kernel->dev.p, cc.wpb.p, Cx, Cx16, C, halves);
-      cc.wp16.release(); cc.wx32.release();
+      cc.wp16.release(); cc.wx32.release(); cc.wpw.release();
     }
     {
       const size_t dh = mv::f16x3_dgrad_wpack_elems(Cx, C);
@@ -370,7 +371,7 @@ void run_pack(mv_engine* e, TrainChain& ch) {
     }
   } else {
     cc.wp16.release(); cc.wx32.release();   // rebuilt lazily if the mode is switched on
-    cc.wpb.release(); cc.wx32u.release();
+    cc.wpb.release(); cc.wx32u.release(); cc.wpw.release();
   }
 }
 

@@ -167,6 +167,139 @@ def test_in_library_rccl_allreduce_world1_is_the_identity(built_lib):
     assert (outs[0][n] == outs[1][n]).all(), n
 
 
+FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
+
+
+def _lib_worker(rank, world, outdir):
+  """One rank of the IN-LIBRARY data-parallel step: mv_allreduce_init + the bucketed
+  side-stream all-reduce inside mv_train_forward_backward / mv_train_step, over the
+  shared-memory RCCL stand-in (MV_RCCL_LIB), both ranks on GPU 0."""
+  sys.path.insert(0, ROOT)
+  os.environ["MV_RCCL_LIB"] = FAKE_RCCL
+  os.environ["MV_FAKE_RCCL_LOG"] = os.path.join(outdir, "rccl_rank%d.log" % rank)
+  os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  import time
+  from multiverse_amd import _lib, parallel, synth
+  idfile = os.path.join(outdir, "unique_id.bin")
+  if rank == 0:
+    uid = _lib.comm_unique_id()
+    with open(idfile + ".tmp", "wb") as f:
+      f.write(bytes(uid))
+    os.rename(idfile + ".tmp", idfile)
+  else:
+    t0 = time.time()
+    while not os.path.exists(idfile):
+      assert time.time() - t0 < 120, "rank 0 never published the unique id"
+      time.sleep(0.05)
+    uid = open(idfile, "rb").read()
+  gcfg = _cfg(N_GLOBAL, synth, True)
+  params = synth.make_params(gcfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0,
+                             bias_scale=0.1)
+  lo, hi = parallel.shard_range(N_GLOBAL, rank, world)
+  eng = _lib.Engine(_cfg(hi - lo, synth, True), device=0)
+  eng.set_params(params)
+  eng.set_compute_mode("f16x3")
+  eng.train_init(world=world)
+  eng.comm_init(rank, world, bytes(uid))
+  _, nelem = eng.grad_buffer()
+  out, losses, infos = {}, [], []
+  for step in range(STEPS):
+    feed = synth.make_feed(gcfg, seed=synth.SEED_BASE + 200 + step)
+    shard, _ = parallel.shard_feed(feed, rank, world, N_GLOBAL)
+    if step == 0:     # the split form: the gradients in the buffer are the SUM over the ranks
+      loss, wd, pgl = eng.train_forward_backward(shard)
+      for n, _ in eng.param_specs():
+        out["grad|" + n] = eng.get_grad(n)
+      eng.train_apply(1.0 / world)
+    else:             # the one-call form: reduce + 1/world + clip + optimizer inside
+      loss, wd, pgl = eng.train_step(shard)
+    losses.append([loss, wd] + list(pgl))
+    infos.append(eng.comm_info())
+  assert eng.global_step == STEPS
+  for info in infos:
+    assert info["world"] == world and info["rank"] == rank
+    assert info["buckets"] == 8 + 1 + 4 and info["bytes"] == 4.0 * nelem, info
+  out.update({n: eng.get_param(n) for n, _ in eng.param_specs()})
+  out.update({"slot0|" + n: eng.get_opt_slot(n, 0) for n, _ in eng.param_specs()})
+  out["losses"] = np.asarray(losses)
+  out["nelem"] = np.asarray([nelem])
+  eng.close()
+  np.savez(os.path.join(outdir, "lib_rank%d.npz" % rank), **out)
+
+
+def test_in_library_allreduce_two_ranks_one_gpu(built_lib, tmp_path):
+  """The library's own bucketed all-reduce (comm.h, engine_train.h comm_reduce_*) with TWO
+  ranks: bucket order, event hand-offs between the main and the side stream, the 1 / world
+  scale and clip-after-reduce -- against one process on the global batch.  RCCL refuses two
+  ranks on one GPU, so the ranks load the shared-memory stand-in tests/fake_rccl through
+  MV_RCCL_LIB (test infrastructure: same entry points, sum in rank order on the host); what
+  is under test is everything on THIS side of ncclAllReduce."""
+  from multiverse_amd import synth
+  if not os.path.exists(FAKE_RCCL):
+    pytest.skip("tests/fake_rccl/libfakerccl.so not built (__graft_entry__.build())")
+  world = 2
+  mp.spawn(_lib_worker, args=(world, str(tmp_path)), nprocs=world, join=True)
+  r = [np.load(os.path.join(str(tmp_path), "lib_rank%d.npz" % k)) for k in range(world)]
+  nelem = int(r[0]["nelem"][0])
+  # what the stand-in saw: per step 13 collectives per rank, the same sizes in the same order
+  # on both ranks, covering the gradient buffer exactly once; the last group inside
+  # ncclGroupStart / End
+  calls = []
+  for k in range(world):
+    lines = open(os.path.join(str(tmp_path), "rccl_rank%d.log" % k)).read().split("\n")
+    calls.append([(int(l.split()[6]), int(l.split()[8])) for l in lines if l.strip()])
+  assert calls[0] == calls[1] and len(calls[0]) == STEPS * 13
+  for st in range(STEPS):
+    step_calls = calls[0][st * 13:(st + 1) * 13]
+    assert sum(c for c, _ in step_calls) == nelem
+    assert [g for _, g in step_calls[:8]] == [0] * 8            # ConvLSTM buckets, one by one
+    assert all(g == 1 for _, g in step_calls[8:])               # the rest as one group
+    assert min(c for c, _ in step_calls[:8]) > 2_000_000        # a kernel + its biases each
+  # both ranks hold the same model afterwards, bit for bit
+  gcfg = _cfg(N_GLOBAL, synth, True)
+  params = synth.make_params(gcfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0,
+                             bias_scale=0.1)
+  for n in params:
+    assert (r[0][n] == r[1][n]).all(), n
+    assert (r[0]["grad|" + n] == r[1]["grad|" + n]).all(), n
+  # ... and it is the model one process makes of the global batch
+  eng = built_lib.Engine(gcfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode("f16x3")
+  eng.train_init()
+  for step in range(STEPS):
+    feed = synth.make_feed(gcfg, seed=synth.SEED_BASE + 200 + step)
+    if step == 0:
+      loss, wd, pgl = eng.train_forward_backward(feed)
+      worst_g = 0.0
+      for n, _ in eng.param_specs():
+        g = eng.get_grad(n)                  # gradient of the GLOBAL batch mean
+        gs = r[0]["grad|" + n] / world       # sum over ranks of the shard means / world
+        scale = max(float(np.abs(g).max()), 1e-30)
+        worst_g = max(worst_g, float(np.abs(gs - g).max()) / scale)
+        assert np.abs(gs - g).max() <= 2e-4 * scale, (n, np.abs(gs - g).max(), scale)
+      print("reduced gradients vs the global batch: worst %.2e of max|g|" % worst_g)
+      eng.train_apply(1.0)
+    else:
+      loss, wd, pgl = eng.train_step(feed)
+    ref = np.asarray([loss, wd] + list(pgl))
+    mean = 0.5 * (r[0]["losses"][step] + r[1]["losses"][step])
+    print("step %d: single-process %s | 2 ranks (mean) %s" % (step, ref, mean))
+    assert np.allclose(mean, ref, rtol=2e-6, atol=1e-7)
+  worst = 0.0
+  for n, _ in eng.param_specs():
+    ref = eng.get_param(n)
+    upd = max(float(np.abs(ref - params[n]).max()), 1e-12)
+    d = float(np.abs(r[0][n] - ref).max())
+    worst = max(worst, d / max(1.0, float(np.abs(ref).max())))
+    assert d <= 1e-6 * max(1.0, float(np.abs(ref).max())) and d <= 2e-3 * upd, (n, d, upd)
+    s_ref = eng.get_opt_slot(n, 0)
+    assert np.abs(r[0]["slot0|" + n] - s_ref).max() <= 1e-4 * max(np.abs(s_ref).max(), 1e-30)
+  eng.close()
+  print("parameters after %d in-library data-parallel steps: max |2 ranks - 1 process| = %.2e"
+        % (STEPS, worst))
+
+
 def test_bench_spawns_its_own_ranks(built_lib):
   """`python bench.py --gpus 2` with NO launcher: bench.py starts the two ranks itself
   (torch.distributed.run on 127.0.0.1) and relays ONE JSON line whose `value` is the

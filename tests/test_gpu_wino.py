@@ -1,0 +1,142 @@
+# coding=utf-8
+"""GPU: the Winograd F(2,3) form of the f16x3 ConvLSTM step (csrc/convlstm_wino.h) -- the
+default gate kernel of the f16x3 compute mode whenever the grid widths divide 32 -- against
+the CPU oracle, the direct f16x3 form and its own emitted operand planes, kernel by kernel
+through the C ABI (mv_op_convlstm_step16).  The end-to-end parity tests (forward, beam,
+training, at-size) run through the same kernel inside the engine.
+
+Tolerance: 2e-5 absolute on O(1) gate sums -- the bar of the fp32-MFMA kernel test
+(tests/test_gpu_kernels.py); measured errors are printed."""
+
+import numpy as np
+import pytest
+
+from oracle import multiverse_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(M, H, W, Cx, zero, seed):
+  rng = np.random.default_rng(seed)
+  C = 256
+  x = rng.normal(size=(M, H, W, Cx)).astype("f4")
+  if Cx > 3:
+    x = np.tanh(x)                # f16x3 operand range: embeddings / scene features are in [-1, 1]
+  else:
+    x = (x * 300.0).astype("f4")  # pixel offsets of the regression encoder
+  lim = np.sqrt(6.0 / (9 * (Cx + C) + 9 * 4 * C)) * 3.0
+  kernel = rng.uniform(-lim, lim, size=(3, 3, Cx + C, 4 * C)).astype("f4")
+  if Cx <= 3:
+    kernel[:, :, :Cx, :] *= 1.0 / 300.0
+  biases = (0.1 * rng.normal(size=4 * C)).astype("f4")
+  if zero:
+    c = h = None
+    c0 = h0 = np.zeros((M, H, W, C), "f4")
+  else:
+    c = c0 = rng.normal(size=(M, H, W, C)).astype("f4")
+    h = h0 = np.tanh(rng.normal(size=(M, H, W, C))).astype("f4")
+  co, ho = oracle.convlstm_step_np(x, c0, h0, kernel, biases)
+  return x, c, h, kernel, biases, co, ho
+
+
+def _where(err, name):
+  """Localise a mismatch: max error by image, row parity, row, column, channel mod 16 and
+  channel block -- a wrong lane / register / tile map shows up as a pattern here."""
+  M, H, W, C = err.shape
+  lines = ["%s: max %.3g at %s" % (name, err.max(), np.unravel_index(err.argmax(), err.shape))]
+  lines.append("  by image      " + " ".join("%.1e" % err[m].max() for m in range(M)))
+  lines.append("  by row        " + " ".join("%.1e" % err[:, y].max() for y in range(H)))
+  lines.append("  by column     " + " ".join("%.1e" % err[:, :, xx].max() for xx in range(W)))
+  lines.append("  by ch mod 16  " + " ".join("%.1e" % err[..., k::16].max() for k in range(16)))
+  lines.append("  by ch block16 " + " ".join("%.1e" % err[..., b * 16:(b + 1) * 16].max()
+                                            for b in range(C // 16)))
+  return "\n".join(lines)
+
+
+SHAPES = [
+    (2, 18, 32, 64, False),   # class encoder, dense x (training form)
+    (2, 18, 32, 2, False),    # regression encoder: fp32 x chunk
+    (3, 9, 16, 32, False),    # decoders, scale 1: odd H (last row pair half empty), 80 pairs/image
+    (2, 9, 16, 64, True),     # first encoder step: zero state, x only
+    (2, 9, 16, 2, True),      # zero state + fp32 x chunk only
+    (5, 9, 16, 16, False),    # a wave tile straddles three images' worth of pairs
+    (1, 6, 8, 32, False),     # W = 8: four row pairs per wave tile, partial workgroup
+    (3, 18, 32, 32, False),   # M tiles not a multiple of the workgroup
+]
+
+
+@pytest.mark.parametrize("M,H,W,Cx,zero", SHAPES)
+def test_wino_step_vs_oracle(built_lib, M, H, W, Cx, zero):
+  x, c, h, kernel, biases, co, ho = _case(M, H, W, Cx, zero, M * 1000 + H * 10 + Cx)
+  cg, hg, h16 = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=2)
+  ec, eh = np.abs(cg - co), np.abs(hg - ho)
+  print("winograd  M=%d %dx%d Cx=%d zero=%s: max|dc| %.3g max|dh| %.3g, planes vs h' %.3g"
+        % (M, H, W, Cx, zero, ec.max(), eh.max(), np.abs(h16 - hg).max()))
+  assert ec.max() < 2e-5, _where(ec, "c'")
+  assert eh.max() < 2e-5, _where(eh, "h'")
+  # the operand planes the epilogue emitted for the next step ARE h' (two fp16 planes of
+  # 256 h': 22 bits)
+  ep = np.abs(h16 - hg)
+  assert ep.max() < 1e-6, _where(ep, "h' planes")
+
+
+@pytest.mark.parametrize("M,H,W,Cx,zero", SHAPES[:4])
+def test_wino_agrees_with_direct_form(built_lib, M, H, W, Cx, zero):
+  """Same operands, same planes: the two forms differ by fp32 summation order and the
+  ~2^-21 of the in-kernel input transform."""
+  x, c, h, kernel, biases, co, ho = _case(M, H, W, Cx, zero, 77 + M + Cx)
+  c1, h1, p1 = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=1)
+  c2, h2, p2 = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=2)
+  d1, d2 = np.abs(c1 - co).max(), np.abs(c2 - co).max()
+  print("direct f16x3 max|dc| %.3g, winograd %.3g, between them %.3g"
+        % (d1, d2, np.abs(c1 - c2).max()))
+  assert d1 < 2e-5 and d2 < 2e-5
+  assert np.abs(c1 - c2).max() < 1e-5 and np.abs(h1 - h2).max() < 1e-5
+  assert np.abs(p1 - p2).max() < 1e-5
+
+
+def test_wino_transpose_detecting(built_lib):
+  """One hot input cell / one hot weight tap per case: tap orientation, row-pair parity and
+  row <-> column swaps that symmetric data would hide.  Every (ky, kx) tap, an even and an
+  odd source row."""
+  M, H, W, Cx, C = 1, 6, 8, 32, 256
+  for ky in range(3):
+    for kx in range(3):
+      for (sy, sx) in ((2, 5), (3, 2)):
+        x = np.zeros((M, H, W, Cx), "f4")
+        x[0, sy, sx, 3] = 1.0
+        kernel = np.zeros((3, 3, Cx + C, 4 * C), "f4")
+        kernel[ky, kx, 3, 1 * C + 17] = 2.0      # gate j, channel 17
+        biases = np.zeros(4 * C, "f4")
+        biases[0 * C:1 * C] = 5.0                # input gate ~ open
+        c = np.zeros((M, H, W, C), "f4")
+        h = np.zeros((M, H, W, C), "f4")
+        co, ho = oracle.convlstm_step_np(x, c, h, kernel, biases)
+        cg, hg, _ = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=2)
+        oy, ox = sy - (ky - 1), sx - (kx - 1)      # out(y,x) sees in(y+ky-1, x+kx-1)
+        assert abs(co[0, oy, ox, 17]) > 0.5
+        err = np.abs(cg - co)
+        assert err.max() < 1e-6, "tap (%d,%d) source (%d,%d)\n%s" % (ky, kx, sy, sx,
+                                                                    _where(err, "c'"))
+        assert np.abs(hg - ho).max() < 1e-6
+
+
+def test_wino_dynamic_range(built_lib):
+  """Operands at the edges of the scaled fp16 range: |h| up to 1 next to |h| ~ 1e-3 (whose low
+  plane is subnormal), weights of mixed magnitude -- the TwoSum of the input transform and the
+  fp64 weight transform must hold the f16x3 error class."""
+  M, H, W, Cx, C = 2, 8, 16, 32, 256
+  rng = np.random.default_rng(5)
+  x = np.tanh(rng.normal(size=(M, H, W, Cx)) * 3.0).astype("f4")
+  h = np.tanh(rng.normal(size=(M, H, W, C)) * 3.0).astype("f4")
+  h[:, ::2] *= 1e-3                                  # alternate rows tiny: cancellation in V
+  cst = rng.normal(size=(M, H, W, C)).astype("f4")
+  kernel = (rng.normal(size=(3, 3, Cx + C, 4 * C)) * 0.02).astype("f4")
+  kernel[..., ::7] *= 8.0
+  biases = np.zeros(4 * C, "f4")
+  co, ho = oracle.convlstm_step_np(x, cst, h, kernel, biases)
+  c1, h1, _ = built_lib.op_convlstm_step16(x, cst, h, kernel, biases, variant=1)
+  c2, h2, _ = built_lib.op_convlstm_step16(x, cst, h, kernel, biases, variant=2)
+  print("dynamic range: direct %.3g, winograd %.3g" % (np.abs(c1 - co).max(),
+                                                      np.abs(c2 - co).max()))
+  assert np.abs(c2 - co).max() < 2e-5 and np.abs(h2 - ho).max() < 2e-5
