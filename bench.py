@@ -247,7 +247,7 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
   if train and "convlstm_wgrad_x" in stats:      # f16x3: the x rows are a launch of their own
     mfma_kernels.append("convlstm_wgrad_x")
   conv = {k: sum(stats[n][k] for n in mfma_kernels)
-          for k in ("launches", "total_ms", "flops", "bytes", "flops_dense")}
+          for k in ("launches", "total_ms", "flops", "bytes", "flops_dense", "flops_mfma")}
   conv_s = conv["total_ms"] * 1e-3
   # achieved = algorithmic FLOPs the launches EXECUTED (zero-state steps skip the h half)
   achieved_tf = conv["flops"] / conv_s / 1e12
@@ -309,11 +309,21 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
   if f16:
     # achieved / frac count ALGORITHMIC fp32 FLOPs against the dense fp16 MFMA peak;
     # every algorithmic product is executed as three fp16 MFMA products
-    roofline["note"] = ("f16x3: each fp32 product = 3 fp16 MFMA products (two pre-scaled "
-                        "fp16 planes per operand, fp32 accumulate); ceiling of the method "
-                        "= peak / 3")
-    roofline["executed_mfma_TFLOPs"] = round(3 * achieved_tf, 1)
-    roofline["executed_mfma_frac"] = round(3 * achieved_tf / peak, 4)
+    # the engine reports what its launches issued to the matrix pipe (mv_kernel_stat_mfma_flops):
+    # 3 fp16 MFMA products per fp32 product in the direct form, 2 in the Winograd F(2,3) form
+    # of the forward step (csrc/convlstm_wino.h: four products per two output rows and tap
+    # column instead of six)
+    per_product = conv["flops_mfma"] / conv["flops"] if conv["flops"] else 3.0
+    step_pp = (stats["convlstm_step"]["flops_mfma"] / stats["convlstm_step"]["flops"]
+               if stats["convlstm_step"]["flops"] else 3.0)
+    roofline["gate_kernel_form"] = ("winograd F(2,3) over image rows, 2 fp16 MFMA products per "
+                                    "fp32 product" if step_pp < 2.5 else
+                                    "direct 3x3, 3 fp16 MFMA products per fp32 product")
+    roofline["note"] = ("f16x3: fp32 operands as two pre-scaled fp16 planes, fp32 accumulate; "
+                        "%.2f fp16 MFMA products issued per algorithmic fp32 product over these "
+                        "launches; ceiling of the method = peak / that" % per_product)
+    roofline["executed_mfma_TFLOPs"] = round(per_product * achieved_tf, 1)
+    roofline["executed_mfma_frac"] = round(per_product * achieved_tf / peak, 4)
     roofline["vs_fp32_mfma_peak"] = round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 3)
   if train:
     roofline["per_kernel_TFLOPs"] = {
@@ -325,7 +335,9 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
   # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950); bench.py cannot collect
   # PMCs itself, so it quotes a committed summary -- only one taken on these sources.
   if not beam and not train and batch == 64 and scene_conv_kernel == 3:
-    suffix = ("greedy_pmc_convlstm_step_f16x3_lds.json" if f16 else
+    wino = f16 and stats["convlstm_step"]["flops_mfma"] < 2.5 * stats["convlstm_step"]["flops"]
+    suffix = ("greedy_pmc_convlstm_step_wino.json" if wino else
+              "greedy_pmc_convlstm_step_f16x3_lds.json" if f16 else
               "greedy_bf16_pmc_convlstm_step_bf16.json" if bf16 else
               "greedy_f32_pmc_convlstm_step_kernel.json")
     got, why = committed_traffic(suffix)

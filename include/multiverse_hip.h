@@ -360,6 +360,10 @@ int  mv_kernel_stat(mv_handle h, int32_t i, char* name_out, int32_t name_cap,
  * them as achieved FLOPs"); this returns the same steps counted densely, as the
  * reference computes them: 2 M 9 (Cx + C) 4C per ConvLSTM step. */
 int  mv_kernel_stat_dense_flops(mv_handle h, int32_t i, double* flops_dense);
+/* FLOPs the launches ISSUED to the matrix pipe: the executed algorithmic count x 3 for the
+ * direct f16x3 gate kernel (three fp16 MFMAs per fp32 product), x 2 for its Winograd F(2,3)
+ * form, x 1 on the fp32 / bf16 pipes; 0 for kernels that carry no such figure. */
+int  mv_kernel_stat_mfma_flops(mv_handle h, int32_t i, double* flops_mfma);
 /* elapsed ms between two events recorded around fn on the engine's stream */
 int  mv_time_greedy_resident(mv_handle h, int32_t iters, float* ms_out);
 int  mv_time_beam_resident(mv_handle h, int32_t iters, float* ms_out);

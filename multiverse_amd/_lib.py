@@ -27,7 +27,8 @@ EXPORTED_SYMBOLS = [
     "mv_upload_inputs", "mv_run_greedy_resident", "mv_run_beam_resident",
     "mv_synchronize", "mv_download_outputs", "mv_download_beam_outputs",
     "mv_set_graph_mode", "mv_set_compute_mode", "mv_set_profiling", "mv_reset_kernel_stats", "mv_num_kernel_stats",
-    "mv_kernel_stat", "mv_kernel_stat_dense_flops", "mv_time_greedy_resident",
+    "mv_kernel_stat", "mv_kernel_stat_dense_flops", "mv_kernel_stat_mfma_flops",
+    "mv_time_greedy_resident",
     "mv_time_beam_resident",
     "mv_op_convlstm_step", "mv_op_convlstm_step16", "mv_op_gnn", "mv_op_hidden2grid", "mv_op_beam_step",
     "mv_train_init", "mv_train_step", "mv_train_forward_backward",
@@ -210,6 +211,7 @@ def load():
                                  C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]
   lib.mv_kernel_stat_dense_flops.argtypes = [h, C.c_int32, C.POINTER(C.c_double)]
+  lib.mv_kernel_stat_mfma_flops.argtypes = [h, C.c_int32, C.POINTER(C.c_double)]
   lib.mv_time_greedy_resident.argtypes = [h, C.c_int32, _fp]
   lib.mv_time_beam_resident.argtypes = [h, C.c_int32, _fp]
   lib.mv_op_convlstm_step.argtypes = [C.c_int, _fp, _fp, _fp, _fp, _fp] + \
@@ -888,15 +890,19 @@ class Engine(object):
     out = {}
     name = C.create_string_buffer(256)
     n, ms, fl, by, dn = C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    mf = C.c_double()
     for i in range(self.lib.mv_num_kernel_stats(self.handle)):
       self.lib.mv_kernel_stat(self.handle, i, name, 256, C.byref(n), C.byref(ms),
                               C.byref(fl), C.byref(by))
       self.lib.mv_kernel_stat_dense_flops(self.handle, i, C.byref(dn))
+      self.lib.mv_kernel_stat_mfma_flops(self.handle, i, C.byref(mf))
       # flops: algorithmic FLOPs the launches executed; flops_dense: the same steps as
-      # the reference computes them (a zero-state encoder step still multiplies h = 0)
+      # the reference computes them (a zero-state encoder step still multiplies h = 0);
+      # flops_mfma: FLOPs issued to the matrix pipe (f16x3: 3 MFMAs per product in the
+      # direct form, 2 in the Winograd form)
       out[name.value.decode()] = {"launches": int(n.value), "total_ms": ms.value,
                                   "flops": fl.value, "bytes": by.value,
-                                  "flops_dense": dn.value}
+                                  "flops_dense": dn.value, "flops_mfma": mf.value}
     return out
 
 

@@ -73,6 +73,10 @@ struct ConvLstm16Args {
   const _Float16* wp16;        // [cb][kstep][plane][gate][lane][8]
   const float* wx32;           // x_small: fp32 fragment-order chunk [cb][4][4][64][4], x 2^16
   const int32_t* g_exp;        // dgrad: exponent e of the G planes' scale 2^e
+  const int32_t* x_exp;        // forward, unbounded activations (relu / lrelu): the x planes hold
+                               // 2^e x with a per-tensor e (split_planes_dyn_kernel) instead of
+                               // 256 x; the accumulators are rescaled by 2^(8 - e) once the x
+                               // k-steps are done (they come first).  null: e = 8
   _Float16* h16_out;           // optional: planes of h' for the next step's h operand
   int64_t h16_out_stride;
   int64_t x_plane_stride;      // elements between the two planes
@@ -600,6 +604,15 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       }
       if constexpr (SHIFT) { cc0 = cn0; cc1 = cn1; }
       c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
+      if constexpr (EPI == kEpiLstm && NPL == 2) {
+        if (p.x_exp && st == nxst - 1) {       // x planes at 2^e: bring the sums to 2^16
+          const float f = __int_as_float((127 + 8 - p.x_exp[0]) << 23);
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[g][i] *= f;
+        }
+      }
       }
       if constexpr (!kAblNoDma) __syncthreads();
     }

@@ -47,9 +47,9 @@
 
 namespace mv {
 
-constexpr int kWnWaves = 8;
-constexpr int kWnThreads = kWnWaves * 64;
-constexpr int kWnPairs = kWnWaves * 32;              // pair-cells per workgroup
+// Waves per workgroup (template parameter WAVES): 8 waves = 256 pair-cells share one weight
+// stage, ONE workgroup per CU; 4 waves = 128 pair-cells, TWO workgroups per CU whose
+// barriers and transform phases de-phase each other at twice the stage traffic from L2.
 constexpr int kWnCh = 16;                            // output channels per workgroup
 constexpr int kWnStageVec = 2 * 3 * 2 * 2 * 64;      // 16-byte vectors per LDS stage (24 KB)
 constexpr uint32_t kWnStageBytes = kWnStageVec * 16;
@@ -62,13 +62,17 @@ struct ConvLstmWinoArgs {
   const _Float16* wpw;     // [cb16][stage][comp in stage 2][dx 3][plane 2][row block 2][lane 64][8]
   const float* w_hwio;     // the fp32 kernel [3,3,Cx+C,4C] (x_small chunk)
   int32_t n_xc;            // 16-channel x chunks present in the pack (0 when x_small)
-  int32_t pad_;
+  int32_t abl;             // MV_WINO_ABL (timing ablations, results are garbage): 1 = no main
+                           // loop, 2 = no epilogue (accumulators folded into a never-taken
+                           // store), 4 = no c loads, 8 = no c' / h' / gate stores, 16 = no h'
+                           // plane stores, 32 = sigmoid / tanh replaced by mul-adds
 };
 
 struct ConvLstmWinoGroup {
   ConvLstmWinoArgs p[kMaxGroup];
   int32_t block_end[kMaxGroup];
   int32_t n;
+  int32_t map_mode;          // 1: adjacent 16-channel blocks (one 128-byte state line) per XCD
 };
 
 static inline size_t wino_wpack_elems(int Cx16, int C) {   // in halves
@@ -149,8 +153,10 @@ __device__ __forceinline__ f16x8 wn_lane_shift(const f16x8& v, bool up, bool ok)
   return __builtin_bit_cast(f16x8, r);
 }
 
+template <int WAVES>
 __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, int cb16, int mt,
                                                    f16x8* lds /* [2][kWnStageVec] */) {
+  constexpr int kWnPairs = WAVES * 32;             // pair-cells per workgroup
   const ConvLstm16Args& q = p.b;
   const ConvLstmArgs& a = q.f;
   const int tid = threadIdx.x;
@@ -238,7 +244,7 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
   // ---- f16 chunks of 16 input channels: x chunks first, then h chunks
   const int nxc = p.n_xc;
   const int ck_lo = a.sx_corr ? nxc : 0;                    // sparse x: table terms instead
-  const int ck_hi = a.zero_state ? nxc : nxc + (C >> 4);
+  const int ck_hi = (p.abl & 1) ? ck_lo : (a.zero_state ? nxc : nxc + (C >> 4));
   if (ck_hi > ck_lo) {
     const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wpw) +
                         (size_t)cb16 * 2 * (nxc + (C >> 4)) * kWnStageVec;
@@ -258,11 +264,11 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
         uniform_ptr(const_cast<_Float16*>(h16 + hps - kPlanePad)), 0, 0x7fffffff, 0x00020000);
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // stage copy: the pack IS the LDS image; 24 pieces of 64 vectors, three per wave
+    // stage copy: the pack IS the LDS image; 24 pieces of 64 vectors, 24 / WAVES per wave
     auto stage_dma = [&](int s, f16x8* dstbuf) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int v0 = (i * kWnWaves + wave_u) * 64;
+      for (int i = 0; i < 24 / WAVES; ++i) {
+        const int v0 = (i * WAVES + wave_u) * 64;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             wrs, (__attribute__((address_space(3))) void*)(dstbuf + v0), 16,
             (uint32_t)(v0 + lane) * 16u, (uint32_t)s * kWnStageBytes, 0, MV_DMA_AUX);
@@ -310,6 +316,7 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
     load_raw(ck_lo);
     stage_dma(2 * ck_lo, bufA);
     __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
+    {
     for (int ck = ck_lo; ck < ck_hi; ++ck) {
       const bool more = ck + 1 < ck_hi;
       f16x8 vh0, vl0, vh1, vl1;
@@ -329,11 +336,32 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
       }
       MV_WN_COMP(2, 0, vh0, vl0, bufB);
       MV_WN_COMP(3, 1, vh1, vl1, bufB);
+      if (q.x_exp && ck == nxc - 1) {        // x planes at 2^e (relu / lrelu): sums to 2^16
+        const float f = __int_as_float((127 + 8 - q.x_exp[0]) << 23);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[c][rb][i] *= f;
+      }
       __syncthreads();
+    }
     }
 #undef MV_WN_COMP
   }
   if (!wave_live) return;
+  if (p.abl & 2) {                          // keep every accumulator live, store nothing
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += acc[c][rb][i];
+    if (sum == 12345.678f) a.h_out[0] = sum;
+    return;
+  }
 
   // ---------------------------------------------------------------- epilogue
   // registers of acc[c][rb]: gate = reg >> 2, channel = cb16*16 + rb*8 + 4*half + (reg & 3);
@@ -361,22 +389,58 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
     okc[e] = valid & (y0 + e < H);
     cell[e] = (y0 + e) * W + xpos;
   }
+  // ---- state I/O through LDS.  A lane owns 4 + 4 channels of the two cells of its pair-cell:
+  // stored from the accumulator layout, every lane of a wave instruction would touch its own
+  // cache line (16 bytes at a stride of C floats).  Instead the wave's tile of a state tensor
+  // -- 64 cells x 16 channels fp32, rows = cells (e * 32 + column) -- passes through a
+  // wave-private 4 KB LDS tile (the weight stages are dead after the last barrier) and is
+  // moved to / from memory with lane l on cell row (l >> 2) + 16 k, 16-byte piece l & 3:
+  // four lanes cover the 64 contiguous bytes the workgroup's 16 channels have in a cell.
+  // Row r of the tile belongs to lane (r & 31)'s pair-cell: its offsets come by ds_bpermute.
+  float* const tl0 = reinterpret_cast<float*>(lds) + wave * 2048;     // two tiles per wave
+  float* const tl1 = tl0 + 1024;
+  constexpr uint32_t kNone = 0xffffffffu;
+  const uint32_t colb = (uint32_t)(cb16 * kWnCh) * 4u;       // the workgroup's first channel
+  uint32_t coff[2], ooff[2];                  // byte offsets of the lane's cells: c source, outputs
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    coff[e] = okc[e] ? (uint32_t)(src_c * HW + cell[e]) * rowb : kNone;
+    ooff[e] = okc[e] ? (uint32_t)(r * HW + cell[e]) * rowb : kNone;
+  }
+  const int piece = lane_e & 3;
+  uint32_t rcoff[4], rooff[4];                // the same for the four transposed rows of the lane
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int srcl = ((lane_e >> 2) + 16 * (k & 1)) * 4;
+    rcoff[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)coff[k >> 1]);
+    rooff[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)ooff[k >> 1]);
+  }
+  const int wr_idx = (lane_e & 31) * 16 + half_e * 4;        // + e * 512 + rb * 8 (floats)
+  const int rd_idx = (lane_e >> 2) * 16 + piece * 4;         // + k * 256
   // pass 1: every state load goes out before any store
   f32x4 cprev[2][2];
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      cprev[e][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!a.zero_state) {
-        // lanes that own no cell read offset 0 (the value is never used)
-        const uint32_t off = okc[e] ? ((uint32_t)(src_c * HW + cell[e]) * (uint32_t)C +
-                                       (uint32_t)(ch0 + rb * 8)) * 4u
-                                    : 0u;
-        cprev[e][rb] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_rs, (int)off, 0, MV_EPI_LD_AUX));
-      }
+    for (int rb = 0; rb < 2; ++rb) cprev[e][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!a.zero_state && !(p.abl & 4)) {
+    u32x4 cl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // rows that own no cell read offset 0 (the value is never used)
+      const uint32_t off = rcoff[k] != kNone ? rcoff[k] + colb + (uint32_t)piece * 16u : 0u;
+      cl[k] = __builtin_amdgcn_raw_buffer_load_b128(c_rs, (int)off, 0, MV_EPI_LD_AUX);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      *reinterpret_cast<u32x4*>(tl0 + rd_idx + k * 256) = cl[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS ops of a wave retire in order
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+        cprev[e][rb] = *reinterpret_cast<const f32x4*>(tl0 + wr_idx + e * 512 + rb * 8);
+  }
   // sparse x: hot cell of the lane's image
   int hot_y = 0, hot_x = 0;
   if (a.sx_corr) {
@@ -385,6 +449,8 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
     hot_y = (int)(hyx >> 16); hot_x = (int)(hyx & 0xffffu);
   }
   const float un = kF16Unscale;
+  const bool planes = q.h16_out != nullptr;
+  u32x2 ph[2][2], pl[2][2];                   // h' as plane halves (hi, lo), [e][rb]
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int y = y0 + e;
@@ -432,39 +498,37 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
           const float m0 = acc[0][rb][reg], m1 = acc[1][rb][reg], m2 = acc[2][rb][reg],
                       m3 = acc[3][rb][reg];
           const float yv = e == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
-          pre[g] = yv * un + add[g][j];
+          pre[g] = __builtin_fmaf(yv, un, add[g][j]);   // un = 2^-16: the product is exact
         }
-        const float si = sigm_(pre[0]), tj = tanh_(pre[1]), sf = sigm_(pre[2] + a.forget_bias),
-                    so = sigm_(pre[3]);
+        float si, tj, sf, so;
+        if (p.abl & 32) {
+          si = pre[0] * 0.25f + 0.5f; tj = pre[1] * 0.5f; sf = pre[2] * 0.25f + 0.5f;
+          so = pre[3] * 0.25f + 0.5f;
+        } else {
+          si = sigm_(pre[0]); tj = tanh_(pre[1]); sf = sigm_(pre[2] + a.forget_bias);
+          so = sigm_(pre[3]);
+        }
         float cn = sf * cprev[e][rb][j];
         cn = cn + si * tj;
-        const float hn = tanh_(cn) * so;
+        const float hn = ((p.abl & 32) ? cn * 0.5f : tanh_(cn)) * so;
         cn4[j] = cn; hn4[j] = hn; si4[j] = si; tj4[j] = tj; sf4[j] = sf; so4[j] = so;
       }
-      if (okc[e]) {
-        const uint32_t o_off = (mcell * (uint32_t)C + (uint32_t)ch) * 4u;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cn4), co_rs, (int)o_off,
+      // c' and h' into the wave's two LDS tiles (the c tile was read into cprev above)
+      *reinterpret_cast<f32x4*>(tl0 + wr_idx + e * 512 + rb * 8) = cn4;
+      if (!a.skip_h32) *reinterpret_cast<f32x4*>(tl1 + wr_idx + e * 512 + rb * 8) = hn4;
+      if (a.gates_out && okc[e] && !(p.abl & 8)) {
+        // training forward: the four gate activations [m][4][C] (stored from the lane)
+        const uint32_t g0 = (mcell * 4u * (uint32_t)C + (uint32_t)ch) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, si4), go_rs, (int)g0,
                                                0, MV_EPI_ST_AUX);
-        if (!a.skip_h32)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hn4), ho_rs,
-                                                 (int)o_off, 0, MV_EPI_ST_AUX);
-        if (a.gates_out) {
-          const uint32_t g0 = (mcell * 4u * (uint32_t)C + (uint32_t)ch) * 4u;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, si4), go_rs, (int)g0,
-                                                 0, MV_EPI_ST_AUX);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tj4), go_rs,
-                                                 (int)(g0 + rowb), 0, MV_EPI_ST_AUX);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sf4), go_rs,
-                                                 (int)(g0 + 2 * rowb), 0, MV_EPI_ST_AUX);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, so4), go_rs,
-                                                 (int)(g0 + 3 * rowb), 0, MV_EPI_ST_AUX);
-        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tj4), go_rs,
+                                               (int)(g0 + rowb), 0, MV_EPI_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sf4), go_rs,
+                                               (int)(g0 + 2 * rowb), 0, MV_EPI_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, so4), go_rs,
+                                               (int)(g0 + 3 * rowb), 0, MV_EPI_ST_AUX);
       }
-      if (q.h16_out && okc[e]) {
-        // operand planes of h' for the next gate convolution: tile (m >> 5, cb16), k half
-        // rb, the lane's 4 of the 8 channels -- the 64 lanes of the store lay down one
-        // contiguous 512-byte run per plane (lanes 0-31: first 8 bytes of 32 consecutive
-        // cells, lanes 32-63: the second 8)
+      if (planes) {
         f16x4 p0, p1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -473,35 +537,94 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
           p0[j] = h0;
           p1[j] = (_Float16)(sc - (float)h0);
         }
-        const size_t o = ((size_t)(mcell >> 5) * (size_t)(C >> 4) + (size_t)cb16) * 512 +
-                         (size_t)(rb * 256 + (int)(mcell & 31u) * 8 + 4 * half_e);
-        *reinterpret_cast<f16x4*>(q.h16_out + o) = p0;
-        *reinterpret_cast<f16x4*>(q.h16_out + q.h16_out_stride + o) = p1;
+        ph[e][rb] = __builtin_bit_cast(u32x2, p0);
+        pl[e][rb] = __builtin_bit_cast(u32x2, p1);
       }
     }
   }
+  // ---- c' / h' out: four lanes per cell, 64 contiguous bytes each
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (!(p.abl & 8)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32x4 cv = *reinterpret_cast<const u32x4*>(tl0 + rd_idx + k * 256);
+      u32x4 hv = cv;
+      if (!a.skip_h32) hv = *reinterpret_cast<const u32x4*>(tl1 + rd_idx + k * 256);
+      if (rooff[k] != kNone) {
+        const int off = (int)(rooff[k] + colb + (uint32_t)piece * 16u);
+        __builtin_amdgcn_raw_buffer_store_b128(cv, co_rs, off, 0, MV_EPI_ST_AUX);
+        if (!a.skip_h32) __builtin_amdgcn_raw_buffer_store_b128(hv, ho_rs, off, 0, MV_EPI_ST_AUX);
+      }
+    }
+  }
+  // ---- operand planes of h' for the next gate convolution: tile (m >> 5, cb16), k half rb,
+  // 8 channels = one 16-byte vector per cell.  A lane holds 4 of them for each of its two
+  // cells; v_permlane32_swap hands the lower half-wave the complete vectors of the e = 0 cells
+  // and the upper half-wave those of the e = 1 cells: every store is 16 bytes per lane, the 32
+  // lanes of a half-wave one contiguous 512-byte run per plane.
+  if (planes && !(p.abl & 16)) {
+    const uint32_t mc = (uint32_t)(r * HW + (half_e ? cell[1] : cell[0]));
+    const bool okp = half_e ? okc[1] : okc[0];
+    const size_t o0 = ((size_t)(mc >> 5) * (size_t)(C >> 4) + (size_t)cb16) * 512 +
+                      (size_t)((int)(mc & 31u) * 8);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int pn = 0; pn < 2; ++pn) {
+        const u32x2 A = pn ? pl[0][rb] : ph[0][rb], B = pn ? pl[1][rb] : ph[1][rb];
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A[0], B[0], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(A[1], B[1], false, false);
+        // lower lanes: (own A | partner's A) = e 0, channels 0-3 | 4-7; upper lanes:
+        // (partner's B | own B) = e 1, channels 0-3 | 4-7
+        const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+        if (okp)
+          *reinterpret_cast<u32x4*>(q.h16_out + (size_t)pn * q.h16_out_stride + o0 + rb * 256) = v;
+      }
+  }
 }
 
-__global__ __launch_bounds__(kWnThreads, 2)
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2)
 void convlstm_step_wino_kernel(const ConvLstmWinoGroup g) {
-  __shared__ f16x8 lds[2 * kWnStageVec];
+  // two weight stage buffers; the epilogue reuses them as two 4 KB state tiles per wave
+  __shared__ f16x8 lds[(2 * kWnStageVec > WAVES * 512) ? 2 * kWnStageVec : WAVES * 512];
   int block = blockIdx.x;
   int pi = 0;
 #pragma unroll
   for (int i = 0; i < kMaxGroup - 1; ++i)
     if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
   if (pi > 0) block -= g.block_end[pi - 1];
+  // block -> (16-channel column block, row tile).  Mode 0: cb16 = block % 16 (XCD = block % 8
+  // holds blocks x and x + 8); mode 1: XCD x holds the ADJACENT blocks 2x, 2x + 1 -- the two
+  // halves of every 128-byte line of the state tensors, fetched and written through one L2
+  auto cbmap = [&](int ncb, int& cb16, int& mt) {
+    if (g.map_mode == 1 && (ncb & 15) == 0) {
+      const int grp = block / 16, w16 = block - grp * 16;      // 16 consecutive blocks
+      cb16 = (grp % (ncb / 16)) * 16 + 2 * (w16 & 7) + (w16 >> 3);
+      mt = grp / (ncb / 16);
+    } else {
+      cb16 = block % ncb; mt = block / ncb;
+    }
+  };
+  int cb16, mt;
   switch (pi) {
-    case 0: { const int ncb = g.p[0].b.f.C / kWnCh; convlstm_wino_body(g.p[0], block % ncb, block / ncb, lds); break; }
-    case 1: { const int ncb = g.p[1].b.f.C / kWnCh; convlstm_wino_body(g.p[1], block % ncb, block / ncb, lds); break; }
-    case 2: { const int ncb = g.p[2].b.f.C / kWnCh; convlstm_wino_body(g.p[2], block % ncb, block / ncb, lds); break; }
-    default: { const int ncb = g.p[3].b.f.C / kWnCh; convlstm_wino_body(g.p[3], block % ncb, block / ncb, lds); break; }
+    case 0: cbmap(g.p[0].b.f.C / kWnCh, cb16, mt); convlstm_wino_body<WAVES>(g.p[0], cb16, mt, lds); break;
+    case 1: cbmap(g.p[1].b.f.C / kWnCh, cb16, mt); convlstm_wino_body<WAVES>(g.p[1], cb16, mt, lds); break;
+    case 2: cbmap(g.p[2].b.f.C / kWnCh, cb16, mt); convlstm_wino_body<WAVES>(g.p[2], cb16, mt, lds); break;
+    default: cbmap(g.p[3].b.f.C / kWnCh, cb16, mt); convlstm_wino_body<WAVES>(g.p[3], cb16, mt, lds); break;
   }
 }
 
-static inline unsigned convlstm_wino_blocks(const ConvLstmArgs& a) {
+// MV_WINO_WAVES = 8 | 4: waves per workgroup (A/B runs)
+static inline int wino_waves() {
+  static const int w = getenv("MV_WINO_WAVES") ? atoi(getenv("MV_WINO_WAVES")) : 8;
+  return w == 4 ? 4 : 8;
+}
+
+static inline unsigned convlstm_wino_blocks(const ConvLstmArgs& a, int waves) {
   const size_t Q = (size_t)a.rows * ((a.H + 1) / 2) * a.W;
-  return (unsigned)((Q + kWnPairs - 1) / kWnPairs) * (unsigned)(a.C / kWnCh);
+  const size_t pairs = (size_t)waves * 32;
+  return (unsigned)((Q + pairs - 1) / pairs) * (unsigned)(a.C / kWnCh);
 }
 
 // The Winograd form serves a group when every problem's W divides 32 (the DPP column shift)
@@ -519,14 +642,24 @@ static inline void launch_convlstm_wino_steps(const ConvLstmWinoArgs* probs, int
                                               hipStream_t stream) {
   ConvLstmWinoGroup g{};
   g.n = n;
+  const int waves = wino_waves();
+  static const int abl = getenv("MV_WINO_ABL") ? atoi(getenv("MV_WINO_ABL")) : 0;
+  // MV_WINO_MAP: block -> column block map (1, default: the two halves of a 128-byte state
+  // line on one XCD)
+  static const int map_mode = getenv("MV_WINO_MAP") ? atoi(getenv("MV_WINO_MAP")) : 1;
+  g.map_mode = map_mode;
   unsigned total = 0;
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
-    total += convlstm_wino_blocks(probs[i].b.f);
+    g.p[i].abl = abl;
+    total += convlstm_wino_blocks(probs[i].b.f, waves);
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
-  hipLaunchKernelGGL(convlstm_step_wino_kernel, dim3(total), dim3(kWnThreads), 0, stream, g);
+  if (waves == 8)
+    hipLaunchKernelGGL(convlstm_step_wino_kernel<8>, dim3(total), dim3(512), 0, stream, g);
+  else
+    hipLaunchKernelGGL(convlstm_step_wino_kernel<4>, dim3(total), dim3(256), 0, stream, g);
 }
 
 }  // namespace mv

@@ -123,7 +123,7 @@ static inline void launch_h2g_q(const H2gQProblem* probs, int n, int C, hipStrea
 }
 
 // ---- grid_emb with 16-byte plane stores.  item = (cell, group of 8 output channels);
-// the fp32 row [E] of a cell is 4 x 32 B (E == 32), the planes one 16-byte vector per
+// the fp32 row [E] of a cell is E / 8 x 32 B, the planes one 16-byte vector per
 // item and plane (plane_index: tile (cell>>5, c8>>1), k half c8&1).
 __device__ __forceinline__ void emb_store8(float* __restrict__ x, _Float16* p16, size_t pst,
                                            size_t m, int c8, int E, const float (&v)[8]) {
@@ -153,7 +153,7 @@ __device__ __forceinline__ void emb_store8(float* __restrict__ x, _Float16* p16,
 }
 
 // grid_emb(one_hot(id)) in closed form (kernels_misc.h grid_emb_onehot_kernel), rows x K
-// cells, E = 32; row m reads ids[(m / ids_div) * ids_stride].
+// cells, E % 8 == 0; row m reads ids[(m / ids_div) * ids_stride].
 __global__ __launch_bounds__(256)
 void grid_emb_onehot8_kernel(const int32_t* __restrict__ ids, int ids_stride, int ids_div,
                              const float* __restrict__ w, const float* __restrict__ b,
@@ -207,7 +207,7 @@ __device__ __forceinline__ void decode_tail_body(const TailProblem& a, int row, 
   const int H = a.H, W = a.W, K = H * W, P = a.P, E = a.E, QS = 9 * P;
   float* vals = sm;                         // [K * P]
   float* wl = sm + 2 * 1024;                // [9 * P * E] (K * 2 <= 2048 host-checked)
-  float* red = wl + 9 * 2 * 32;             // [16] + [16] ints
+  float* red = wl + 9 * 2 * E;              // [16] + [16] ints
   int* redi = reinterpret_cast<int*>(red + 16);
   const float* qrow = a.q + (size_t)row * K * QS;
   if (a.emb_w && !a.onehot)
@@ -288,7 +288,11 @@ __device__ __forceinline__ void decode_tail_body(const TailProblem& a, int row, 
   }
 }
 
-constexpr size_t kTailLdsBytes = (2 * 1024 + 9 * 2 * 32 + 32) * sizeof(float);
+// dynamic LDS of a decode-tail workgroup: the gathered values, the embedding kernel of the
+// regression chain [9][2][E] and the argmax scratch; E = the largest emb_size of the launch
+static inline size_t tail_lds_bytes(int E) {
+  return ((size_t)2 * 1024 + (size_t)9 * 2 * E + 32) * sizeof(float);
+}
 constexpr int kTailThreads = 1024;    // one workgroup per (chain, row): rows are few, wide WGs
 
 __global__ __launch_bounds__(kTailThreads)
@@ -318,8 +322,10 @@ static inline void launch_decode_tail(const TailProblem* probs, int n, hipStream
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kTailMax; ++i) g.block_end[i] = (int32_t)total;
-  hipLaunchKernelGGL(decode_tail_kernel, dim3(total), dim3(kTailThreads), kTailLdsBytes, stream,
-                     g);
+  int emax = 32;
+  for (int i = 0; i < n; ++i) emax = probs[i].E > emax ? probs[i].E : emax;
+  hipLaunchKernelGGL(decode_tail_kernel, dim3(total), dim3(kTailThreads), tail_lds_bytes(emax),
+                     stream, g);
 }
 
 }  // namespace mv

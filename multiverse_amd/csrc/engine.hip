@@ -17,6 +17,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -121,6 +122,10 @@ struct KernelStat {
   // half of the gate convolution); flops_dense: the same steps as the reference
   // computes them (dense 2*M*9*(Cx+C)*4C).  bytes: algorithmic HBM bytes.
   double total_ms = 0, flops = 0, bytes = 0, flops_dense = 0;
+  // FLOPs the launches ISSUED to the matrix pipe (0 for non-MFMA kernels): the algorithmic
+  // count x 3 for the direct f16x3 form (three fp16 MFMAs per product), x 2 for its Winograd
+  // F(2,3) form (two thirds of them), x 1 for the fp32 and bf16 pipes
+  double flops_mfma = 0;
 };
 
 struct PendingEvent {
@@ -195,6 +200,12 @@ struct mv_engine {
   // 2 = bf16 operands / fp32 accumulate (one plane, one MFMA per product)
   int compute_mode = 0;
   DevBuf<_Float16> px16[mv::kMaxGroup], ph16[mv::kMaxGroup];   // fallback plane scratch per slot
+  // relu / lrelu models in f16x3 mode: the x operands of the gate convolutions are unbounded,
+  // so their planes carry a per-tensor exponent (max |x| as float bits [64] | exponent [1])
+  // instead of the fixed 2^8; the producers do not emit planes for these buffers
+  DevBuf<int32_t> xexp[mv::kMaxGroup];
+  std::set<const float*> xbufs;
+  bool dyn_x() const { return compute_mode == 1 && cfg.activation != 0; }
   // planes that travel with an fp32 operand buffer: producers (conv epilogue, graph
   // attention, embeddings) emit them, the next conv launch consumes them
   struct PlaneBuf { _Float16* p; size_t n; bool valid; };
@@ -203,6 +214,7 @@ struct mv_engine {
   // producer side; stride 0 tells the producer kernels to write ONE bf16 plane
   _Float16* plane_out(const float* dst, size_t* stride) {
     if (compute_mode == 0) return nullptr;
+    if (dyn_x() && xbufs.count(dst)) return nullptr;
     auto it = planes.find(dst);
     if (it == planes.end()) return nullptr;
     it->second.valid = true;
@@ -321,7 +333,7 @@ void launch_beam_step(hipStream_t stream, const float* logits, const float* prev
 // Launch wrapper: optional hipEvent bracket per launch for the roofline figure.
 template <typename F>
 void launch(mv_engine* e, const char* name, double flops, double bytes, F&& fn,
-            double flops_dense = -1.0) {
+            double flops_dense = -1.0, double mfma_factor = 0.0) {
   if (!e->profiling) {
     fn();
     return;
@@ -336,6 +348,7 @@ void launch(mv_engine* e, const char* name, double flops, double bytes, F&& fn,
   e->stats[si].launches += 1;
   e->stats[si].flops += flops;
   e->stats[si].flops_dense += flops_dense >= 0 ? flops_dense : flops;
+  e->stats[si].flops_mfma += mfma_factor * flops;
   e->stats[si].bytes += bytes;
   e->pending.push_back(pe);
 }
@@ -432,7 +445,11 @@ void validate_config(const mv_config& c) {
   MV_REQUIRE(c.scene_conv_dim > 0 && c.scene_conv_dim <= 64 &&
              mv::convlstm_cx_supported(c.scene_conv_dim),
              "scene_conv_dim %d unsupported", c.scene_conv_dim);
-  MV_REQUIRE(mv::convlstm_cx_supported(c.emb_size), "emb_size %d unsupported", c.emb_size);
+  // the decoders' x operand: whole 32-channel chunks of the gate GEMM, 16-byte plane vectors
+  // and the decode tail's LDS (decode_tail.h) -- checked here, not at the first decode step
+  MV_REQUIRE(c.emb_size >= 32 && c.emb_size % 32 == 0 && c.emb_size <= 512 &&
+             mv::convlstm_cx_supported(c.emb_size),
+             "emb_size %d unsupported (a multiple of 32 up to 512)", c.emb_size);
   MV_REQUIRE(c.beam_size >= 1, "beam_size must be >= 1");
   MV_REQUIRE(!(c.class_feedback_dense && c.beam_size > 1), "class_feedback_dense: greedy only "
              "(grid_decoder_beam_search always feeds one-hot ids)");
@@ -734,6 +751,8 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
   std::vector<mv::ConvLstm16Args> p16(probs.size());
   struct SplitItem { const float* in; _Float16* p0; _Float16* p1; int cells, C; };
   std::vector<SplitItem> splits;
+  struct DynItem { const float* in; _Float16* p0; _Float16* p1; int cells, C; int32_t* bits; };
+  std::vector<DynItem> dyn_splits;
   const bool bf16 = e->compute_mode == 2;
   for (size_t i = 0; i < probs.size(); ++i) {
     const ConvLstmArgs& a = probs[i];
@@ -793,7 +812,13 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       MV_REQUIRE(e->px16[i].n >= 2 * pst, "internal: f16x3 x plane scratch");
       _Float16* p0 = e->px16[i].p + mv::kPlanePad;
       q.x16 = p0; q.x_plane_stride = (int64_t)pst;
+      if (e->dyn_x()) {       // unbounded activations: planes of 2^e x, e from max |x|
+        MV_REQUIRE(e->xexp[i].p, "internal: x exponent scratch");
+        q.x_exp = e->xexp[i].p + 64;
+        dyn_splits.push_back(DynItem{a.x, p0, p0 + pst, (int)cells, a.Cx, e->xexp[i].p});
+      } else {
       splits.push_back(SplitItem{a.x, p0, bf16 ? (_Float16*)nullptr : p0 + pst, (int)cells, a.Cx});
+      }
       }
     }
     if (!a.zero_state) {
@@ -808,6 +833,16 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       splits.push_back(SplitItem{a.h, p0, bf16 ? (_Float16*)nullptr : p0 + pst, (int)cells, a.C});
       }
     }
+  }
+  for (const DynItem& it : dyn_splits) {
+    launch(e, "split_planes", 0, 12.0 * (double)it.cells * it.C, [&] {
+      HIP_CHECK(hipMemsetAsync(it.bits, 0, 64 * sizeof(int32_t), e->stream));
+      hipLaunchKernelGGL(mv::absmax_bits_kernel, dim3(256), dim3(256), 0, e->stream, it.in,
+                         (size_t)it.cells * it.C, it.bits);
+      hipLaunchKernelGGL(mv::split_planes_dyn_kernel,
+                         dim3(mv::split_planes_blocks((size_t)it.cells, it.C)), dim3(256), 0,
+                         e->stream, it.in, it.p0, it.p1, it.cells, it.C, it.bits, it.bits + 64);
+    });
   }
   // operands no producer left as planes: one grouped split launch in front of the gate kernel
   for (size_t s0 = 0; s0 < splits.size(); s0 += mv::kSplitGroup) {
@@ -848,7 +883,7 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       mv::launch_convlstm_wino_steps(pw.data(), (int)pw.size(), e->stream);
     else
       mv::launch_convlstm16_steps(p16.data(), (int)p16.size(), e->stream);
-  }, dense);
+  }, dense, e->compute_mode == 2 ? 1.0 : (wino ? 2.0 : 3.0));
 }
 
 // One launch for up to four independent ConvLSTM steps (class / regression
@@ -872,7 +907,7 @@ void run_conv_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs) {
   }
   launch(e, "convlstm_step", flops, bytes, [&] {
     mv::launch_convlstm_steps(probs.data(), (int)probs.size(), e->stream);
-  }, dense);
+  }, dense, 1.0);
 }
 
 void run_scene(mv_engine* e) {
@@ -1183,7 +1218,8 @@ void run_tail(mv_engine* e, const std::vector<TailPlan>& plans) {
   double qbytes = 0, qflops = 0, tbytes = 0;
   for (const TailPlan& pl : plans) {
     ScaleState& S = e->sc[pl.s];
-    MV_REQUIRE((size_t)S.K * 2 <= 2048 && E == 32, "decode tail: K %d / emb_size %d", S.K, E);
+    MV_REQUIRE((size_t)S.K * 2 <= 2048 && E % 16 == 0 && E <= 512,
+               "decode tail: K %d / emb_size %d", S.K, E);
     const int reg_rows = pl.reg_rows ? pl.reg_rows : N;
     const size_t cc = (size_t)pl.cls_rows * S.K, cr = (size_t)reg_rows * S.K;
     qp.push_back(mv::H2gQProblem{pl.cls_h, S.wq_cls.p, S.q_cls.p, (int32_t)cc, 1});
@@ -2556,9 +2592,6 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
   return guarded(h, [&] {
     MV_REQUIRE(mode >= 0 && mode <= 2, "compute mode %d (0 = fp32 MFMA, 1 = f16x3, 2 = bf16)",
                mode);
-    MV_REQUIRE(mode == 0 || h->cfg.activation == 0, "compute mode %d needs bounded (tanh) "
-               "embeddings: with --activation_func relu / lrelu the x operand of the gate "
-               "convolutions leaves the scaled fp16 range; use mode 0 (fp32 MFMA)", mode);
     if (mode != 0) {
       // operand-plane scratch per group slot: even slots class-sized (N*B rows),
       // odd slots regression-sized (N rows), largest enabled grid
@@ -2573,6 +2606,7 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
         h->px16[i].alloc(2 * (rows * K * xc + mv::kPlaneSlack + mv::kPlanePad));
         h->ph16[i].alloc(2 * (rows * K * c.hidden_size + mv::kPlaneSlack + mv::kPlanePad));
         HIP_CHECK(hipMemset(h->px16[i].p, 0, h->px16[i].n * sizeof(_Float16)));
+        if (c.activation != 0) h->xexp[i].alloc(65);    // never inside a graph capture
         HIP_CHECK(hipMemset(h->ph16[i].p, 0, h->ph16[i].n * sizeof(_Float16)));
       }
     }
@@ -2591,6 +2625,7 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
           // pad in front of plane 1 as well (slack: the last partial 32-cell tile row)
           h->planes[b->p] = mv_engine::PlaneBuf{pb.p + mv::kPlanePad,
                                                 b->n + mv::kPlaneSlack + mv::kPlanePad, false};
+          if (b == &S.xbuf_cls || b == &S.xbuf_reg) h->xbufs.insert(b->p);
         }
       }
     }
@@ -2620,6 +2655,12 @@ int mv_num_kernel_stats(mv_handle h) { return h ? (int)h->stats.size() : -1; }
 int mv_kernel_stat_dense_flops(mv_handle h, int32_t i, double* flops_dense) {
   if (!h || i < 0 || i >= (int)h->stats.size() || !flops_dense) return 1;
   *flops_dense = h->stats[i].flops_dense;
+  return 0;
+}
+
+int mv_kernel_stat_mfma_flops(mv_handle h, int32_t i, double* flops_mfma) {
+  if (!h || i < 0 || i >= (int)h->stats.size() || !flops_mfma) return 1;
+  *flops_mfma = h->stats[i].flops_mfma;
   return 0;
 }
 

@@ -618,7 +618,7 @@ void train_forward(mv_engine* e) {
     // launches at the head of the next iteration.  MV_TRAIN_TAIL=v1 restores the old launches.
     static const bool tail2 = tail_v2() &&
         !(getenv("MV_TRAIN_TAIL") && strcmp(getenv("MV_TRAIN_TAIL"), "v1") == 0);
-    bool tail_fits = E == 32;               // run_tail's own limits (decode_tail LDS layout)
+    bool tail_fits = E % 16 == 0 && E <= 512;   // run_tail's own limits (decode_tail LDS)
     for (int s = 0; s < c.num_scales; ++s)
       if (e->sc[s].use && (size_t)e->sc[s].K * 2 > 2048) tail_fits = false;
     if (tail2 && tail_fits) {
@@ -784,7 +784,7 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
   }
   launch(e, "convlstm_dgrad", fl, by, [&] {
     mv::launch_convlstm16_dgrads(p16.data(), (int)p16.size(), e->stream);
-  });
+  }, -1.0, 3.0);
   mv::SumSlicesArgs sa{};
   unsigned blocks = 0;
   double sbytes = 0;
@@ -828,7 +828,7 @@ void run_dgrad_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
   }
   launch(e, "convlstm_dgrad", fl, by, [&] {
     mv::launch_convlstm_dgrads(probs.data(), (int)probs.size(), e->stream);
-  });
+  }, -1.0, 1.0);
 }
 
 // In-library gradient all-reduce (comm.h): the elements [off, off + n) of the flat
@@ -928,8 +928,10 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
     t.bias_part.alloc(t.mrow_max / 64 * 4 * C);
     for (int d = 0; d < 3; ++d) t.at16[d].alloc((size_t)2 * C * t.mrow_max);
     if (Cx)
-      for (int d = 0; d < 3; ++d) t.xt16[d].alloc((size_t)2 * 64 * t.mrow_max);
-    MV_REQUIRE(Cx <= 64, "internal: f16x3 wgrad x operand wider than 64 channels");
+      for (int d = 0; d < 3; ++d) t.xt16[d].alloc((size_t)2 * std::max(64, Cx) * t.mrow_max);
+    // x rows: any width up to 64 (narrow transpose), or whole 64-channel column groups
+    // (--emb_size 128: the transpose of the h operand, one grid row per group)
+    MV_REQUIRE(Cx <= 64 || Cx % 64 == 0, "internal: f16x3 wgrad x operand of %d channels", Cx);
     if (!t.wgrad16_attr) {
       HIP_CHECK(hipFuncSetAttribute(
           reinterpret_cast<const void*>(mv::convlstm_wgrad_f16x3_kernel<false>),
@@ -957,8 +959,8 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
                            t.chain_exp.p + 64, 1, 64, t.chain_exp.p + 2);
       }
       for (int d = 0; d < 3 && Cx; ++d) {
-        if (Cx == 64)
-          hipLaunchKernelGGL(mv::transpose_split_kernel, dim3((unsigned)(Mrow / 64), 1),
+        if (Cx % 64 == 0)
+          hipLaunchKernelGGL(mv::transpose_split_kernel, dim3((unsigned)(Mrow / 64), Cx / 64),
                              dim3(256), 0, e->stream, ch.xs.p, t.xt16[d].p, Mtot, Cx, Mrow, W,
                              d - 1, t.chain_exp.p + 2, 0, (float*)nullptr);
         else
@@ -977,7 +979,7 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
       hipLaunchKernelGGL(mv::convlstm_wgrad_f16x3_kernel<false>,
                          dim3(mv::wgrad16_blocks(q, false)), dim3(256), mv::kWg16LdsBytes,
                          e->stream, q);
-    });
+    }, -1.0, 3.0);
     if (Cx > 0) {
       mv::Wgrad16Args qx = q;
       for (int d = 0; d < 3; ++d) qx.at[d] = t.xt16[d].p;
@@ -987,13 +989,13 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
         hipLaunchKernelGGL(mv::convlstm_wgrad_f16x3_kernel<true>,
                            dim3(mv::wgrad16_blocks(qx, true)), dim3(256), mv::kWg16LdsBytes,
                            e->stream, qx);
-      });
+      }, -1.0, 3.0);
     }
   } else {
   launch(e, "convlstm_wgrad", 2.0 * cells * 9 * (ch.Cx + C) * 4.0 * C,
          cells * (ch.Cx + 5.0 * C) * 4.0, [&] {
     mv::launch_convlstm_wgrad(wa, e->stream);
-  });
+  }, -1.0, 1.0);
   }
   launch(e, "wgrad_reduce", 0, 4.0 * ncols * (wa.nsplit + 1), [&] {
     hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv(ncols, 256)), dim3(256), 0,

@@ -187,11 +187,8 @@ class Model(object):
     import os
     self.compute_mode = getattr(config, "compute_mode", None) or \
         os.environ.get("MV_COMPUTE", "f16x3")
-    if _lib.activation_code(getattr(config, "activation_func", "tanh")) != 0:
-      # relu / lrelu embeddings are unbounded: outside the scaled fp16 range of the f16x3
-      # operand planes, so those models run on the fp32 matrix pipe (the engine refuses
-      # the other modes for them)
-      self.compute_mode = "f32"
+    # (relu / lrelu models run in f16x3 too: their unbounded x operands carry a per-tensor
+    # exponent, csrc/convlstm_f16x3.h ConvLstm16Args::x_exp)
     if any(use and h * w < 32 for (h, w), use in zip(config.scene_grids, config.use_grids)):
       # the fp16-pipe kernels' epilogue lets a 32-cell wave tile span at most two images
       # (engine.hip run_conv_group_f16x3 refuses smaller grids); such toy grids run on the

@@ -298,3 +298,114 @@ def test_literal_baseline_grids_36x18_and_18x9(built_lib, mode):
     assert cls[s].shape == ocls[s].shape
     assert (cls[s].reshape(2, 12, -1).argmax(-1) == ocls[s].reshape(2, 12, -1).argmax(-1)).all()
     assert np.abs(cls[s] - ocls[s]).max() < 1e-4 and np.abs(reg[s] - oreg[s]).max() < 1e-4
+
+
+@pytest.mark.parametrize("E", [128, 64])
+def test_emb_size_other_than_32(built_lib, E):
+  """--emb_size (code/train.py:53, flag default 128; the published runs use 32): the
+  decoders' x operand, the decode tail, the sparse-x tables and the training step must not be
+  tied to one embedding width.  Greedy both scales (f16x3 and f32) and diverse beam search
+  against the oracle; every gradient of one training step against the fp64 oracle."""
+  import torch
+  from oracle import multiverse_oracle as oracle
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1), emb_size=E)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + E, recurrent_gain=3.0, bias_scale=0.1)
+  assert params["person_pred/decoder_grid_class_0/decoder_rnn/dec_grid_0/kernel"].shape == \
+      (3, 3, E + 256, 1024)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 11)
+  ocls, oreg, _ = oracle.forward(params, cfg, feed)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  for mode in ("f16x3", "f32"):
+    eng.set_compute_mode(mode)
+    cls, reg = eng.forward_greedy(feed)
+    for s in range(2):
+      dc, dr = np.abs(cls[s] - ocls[s]).max(), np.abs(reg[s] - oreg[s]).max()
+      same = (cls[s].reshape(2, 12, -1).argmax(-1) == ocls[s].reshape(2, 12, -1).argmax(-1)).all()
+      print("emb_size %d %-5s scale %d: max|dcls| %.3g max|dreg| %.3g" % (E, mode, s, dc, dr))
+      assert dc < 1e-4 and dr < 1e-4 and same
+  eng.close()
+  # diverse beam search, scale 1
+  from beam_compare import compare_beams
+  bcfg = synth.default_config(batch_size=2, use_grids=(0, 1), beam_size=5, emb_size=E)
+  bparams = synth.make_params(bcfg, seed=synth.SEED_BASE + E, recurrent_gain=3.0, bias_scale=0.1)
+  bfeed = synth.make_feed(bcfg, seed=synth.SEED_BASE + 12)
+  beng = built_lib.Engine(bcfg, device=0)
+  beng.set_params(bparams)
+  beng.set_compute_mode("f16x3")
+  arrs, s = beng.forward_beam(bfeed)
+  beng.close()
+  trace = {}
+  _, obreg, (ologits, oids, olp) = oracle.forward(bparams, bcfg, bfeed, trace=trace)
+  assert s == 1
+  compare_beams(arrs, obreg[1], ologits, oids, olp,
+                np.stack(trace["beam_step_topvals"], axis=-1), trace["beam_trace"])
+  # one training step: loss parts and every gradient tensor
+  tcfg = synth.default_config(batch_size=2, use_grids=(1, 1), is_train=True, emb_size=E)
+  tparams = synth.make_params(tcfg, seed=synth.SEED_BASE + E, recurrent_gain=2.0, bias_scale=0.1)
+  tfeed = synth.make_feed(tcfg, seed=synth.SEED_BASE + 13)
+  oloss, owd, opgl, _ = oracle.loss_and_grads(tparams, tcfg, tfeed)
+  og64 = oracle.loss_and_grads(tparams, tcfg, tfeed, dtype=torch.float64)[3]
+  for mode in ("f16x3", "f32"):
+    teng = built_lib.Engine(tcfg, device=0)
+    teng.set_params(tparams)
+    teng.set_compute_mode(mode)
+    teng.train_init()
+    loss, wd, pgl = teng.train_forward_backward(tfeed)
+    assert abs(loss - oloss) < 1e-4 * max(1.0, abs(oloss)) and np.allclose(pgl, opgl, rtol=1e-4, atol=1e-5)
+    worst = 0.0
+    for name, _ in teng.param_specs():
+      g = teng.get_grad(name).astype("float64")
+      worst = max(worst, float(np.abs(g - og64[name]).max() / max(np.abs(og64[name]).max(), 1e-30)))
+    print("emb_size %d %-5s training step: worst gradient error %.2e of max|g|" % (E, mode, worst))
+    teng.close()
+    assert worst < 2e-3
+
+
+def test_create_rejects_unsupported_shapes(built_lib):
+  """Shape limits are reported by mv_create (Engine()), not by the first forward."""
+  for kw, msg in ((dict(emb_size=48), "emb_size"), (dict(emb_size=16), "emb_size"),
+                  (dict(enc_hidden_size=128, dec_hidden_size=128), "hidden_size")):
+    cfg = synth.default_config(batch_size=1, use_grids=(0, 1), **kw)
+    with pytest.raises(built_lib.MvError, match=msg):
+      built_lib.Engine(cfg, device=0)
+
+
+@pytest.mark.parametrize("act,gain", [("relu", 1.0), ("lrelu", 1.0), ("relu", 8.0)])
+def test_unbounded_activations_run_on_the_fp16_pipe(built_lib, act, gain):
+  """--activation_func relu / lrelu (code/pred_utils.py:112-121): the embeddings that feed the
+  gate convolutions are unbounded, so in f16x3 mode their operand planes carry a per-tensor
+  exponent taken from max |x| (split_planes_dyn_kernel; the accumulators are rescaled once the
+  x k-steps are done).  Greedy forward, both scales, against the fp64 oracle in f16x3 AND f32.
+  gain 8 scales the regression embedding so that 256 x leaves the fp16 range (a fixed-scale
+  plane would overflow to inf); such inputs drive the recurrence hard, so there the bar is
+  "as close to fp64 as the fp32 matrix pipe is" (x 3), not an absolute one."""
+  import torch
+  from oracle import multiverse_oracle as oracle
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1), activation_func=act)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 21, recurrent_gain=2.0, bias_scale=0.1)
+  for s in (0, 1):
+    k = "person_pred/decoder_grid_reg_%d/decoder_rnn/grid_emb/W" % s
+    params[k] = (params[k] * gain).astype("float32")
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 22)
+  ocls, oreg, _ = oracle.forward(params, cfg, feed, dtype=torch.float64)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  err = {}
+  for mode in ("f16x3", "f32"):
+    eng.set_compute_mode(mode)
+    cls, reg = eng.forward_greedy(feed)
+    for s in range(2):
+      assert np.isfinite(cls[s]).all() and np.isfinite(reg[s]).all()
+      dc = float(np.abs(cls[s] - np.asarray(ocls[s])).max())
+      dr = float(np.abs(reg[s] - np.asarray(oreg[s])).max())
+      err[mode, s] = (dc, dr)
+      print("%s gain %g %-5s scale %d: max|dcls| %.3g max|dreg| %.3g (ranges %.3g, %.3g)"
+            % (act, gain, mode, s, dc, dr, np.abs(ocls[s]).max(), np.abs(oreg[s]).max()))
+  eng.close()
+  for s in range(2):
+    for k in (0, 1):
+      bar = 1e-4 if gain == 1.0 else max(1e-4, 3.0 * err["f32", s][k])
+      assert err["f16x3", s][k] < bar, (s, k, err)
+      if gain == 1.0:
+        assert err["f32", s][k] < 1e-4
