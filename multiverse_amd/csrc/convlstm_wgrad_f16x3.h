@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "convlstm_f16x3.h"
 
@@ -251,10 +252,16 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
   }
   auto advance = [&](int& y, int& xk) { if (++xk == wk) { xk = 0; if (++y == H) y = 0; } };
 
-  f16x8 sa[4], sg[4];
+  // Two register sets of staged operands: the loads of stage st + 2 are issued while stage st
+  // multiplies and stage st + 1 waits in the other set -- two stages (~50 MFMAs per wave) of
+  // lead.  With ONE set (rounds 1-3: loads issued at the top of a stage, written to LDS at its
+  // bottom) the lead was 24 MFMAs = 770-1500 cycles against an HBM round trip of 2-4 k cycles
+  // under this kernel's streaming load (both operands are read once, nothing is reused across
+  // the reduction): MFMA busy 0.425 at 1.7 waves / SIMD, LDS and L2 far from saturated.  The
+  // workgroup count per CU is set by LDS (2 x 80 KB), so the 32 extra VGPRs are free.
+  f16x8 sa[4], sg[4], sb[4], sgb[4];
   bool cv0 = false, cv1 = false;                       // h rows: k-step validity, stage in LDS
-  bool nv0 = false, nv1 = false;                       //          ... stage in registers
-  auto stage_load = [&](int st) {
+  auto stage_load = [&](int st, f16x8 (&ra)[4], f16x8 (&rg)[4], bool& nv0, bool& nv1) {
     const int ksb = ks0 + 2 * st;
     const int y0 = ly; advance(ly, lxk);
     const int y1 = ly; advance(ly, lxk);
@@ -272,8 +279,8 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
       const int sh = ((vec & 2) ? nv1 : nv0) ? dy_u * W : 0;   // skipped k-step: unshifted
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        sa[q] = *reinterpret_cast<const f16x8*>(ap[q] + aofs(m0 + vec * 8 + sh));
-        sg[q] = *reinterpret_cast<const f16x8*>(gp[q] + gofs);
+        ra[q] = *reinterpret_cast<const f16x8*>(ap[q] + aofs(m0 + vec * 8 + sh));
+        rg[q] = *reinterpret_cast<const f16x8*>(gp[q] + gofs);
       }
     } else {
 #pragma unroll
@@ -281,65 +288,77 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
         const bool ok = insel & ((unsigned)(ysel + dyq[q]) < (unsigned)H);
         f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (ok) v = *reinterpret_cast<const f16x8*>(ap[q] + aofs(m0 + vec * 8 + dyq[q] * W));
-        sa[q] = v;
-        sg[q] = *reinterpret_cast<const f16x8*>(gp[q] + gofs);
+        ra[q] = v;
+        rg[q] = *reinterpret_cast<const f16x8*>(gp[q] + gofs);
       }
       nv0 = in0; nv1 = in1;
     }
   };
-  auto stage_store = [&](int buf) {
+  auto stage_store = [&](int buf, const f16x8 (&ra)[4], const f16x8 (&rg)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int plane = q >> 1, row = (q & 1) * 64 + (tid >> 2);
       const int o = (plane * 128 + row) * kWg16Pitch + vec * 8;
-      *reinterpret_cast<f16x8*>(&lds[buf][0][o]) = sa[q];
-      *reinterpret_cast<f16x8*>(&lds[buf][1][o]) = sg[q];
+      *reinterpret_cast<f16x8*>(&lds[buf][0][o]) = ra[q];
+      *reinterpret_cast<f16x8*>(&lds[buf][1][o]) = rg[q];
+    }
+  };
+  const int li = lane & 31, k8 = (lane >> 5) * 8;
+  auto stage_mfma = [&](int buf) {
+    const _Float16* A = &lds[buf][0][0];
+    const _Float16* G = &lds[buf][1][0];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (kk ? cv1 : cv0) {                   // uniform
+        f16x8 fa[2][2], fg[2][2];             // [sub-block][plane]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            fa[s2][pl] = *reinterpret_cast<const f16x8*>(
+                A + (pl * 128 + wi * 64 + s2 * 32 + li) * kWg16Pitch + kk * 16 + k8);
+            fg[s2][pl] = *reinterpret_cast<const f16x8*>(
+                G + (pl * 128 + wj * 64 + s2 * 32 + li) * kWg16Pitch + kk * 16 + k8);
+          }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][1], fg[y][0], acc[x][y], 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][0], fg[y][1], acc[x][y], 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][0], fg[y][0], acc[x][y], 0, 0, 0);
+      }
     }
   };
 
   if (nstages > 0) {
-    stage_load(0);
-    stage_store(0);
-    cv0 = nv0; cv1 = nv1;
+    bool av0 = false, av1 = false, bv0 = false, bv1 = false;   // validity of the staged sets
+    stage_load(0, sa, sg, av0, av1);
+    stage_store(0, sa, sg);
+    cv0 = av0; cv1 = av1;
+    if (nstages > 1) stage_load(1, sa, sg, av0, av1);          // set A: stage 1, in flight
     __syncthreads();
-    const int li = lane & 31, k8 = (lane >> 5) * 8;
-    for (int st = 0; st < nstages; ++st) {
-      const bool more = st + 1 < nstages;
-      if (more) stage_load(st + 1);
-      const _Float16* A = &lds[st & 1][0][0];
-      const _Float16* G = &lds[st & 1][1][0];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        if (kk ? cv1 : cv0) {                   // uniform
-          f16x8 fa[2][2], fg[2][2];             // [sub-block][plane]
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-              fa[s2][pl] = *reinterpret_cast<const f16x8*>(
-                  A + (pl * 128 + wi * 64 + s2 * 32 + li) * kWg16Pitch + kk * 16 + k8);
-              fg[s2][pl] = *reinterpret_cast<const f16x8*>(
-                  G + (pl * 128 + wj * 64 + s2 * 32 + li) * kWg16Pitch + kk * 16 + k8);
-            }
-#pragma unroll
-          for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][1], fg[y][0], acc[x][y], 0, 0, 0);
-#pragma unroll
-          for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][0], fg[y][1], acc[x][y], 0, 0, 0);
-#pragma unroll
-          for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][0], fg[y][0], acc[x][y], 0, 0, 0);
-        }
-      }
-      if (more) stage_store((st + 1) & 1);
-      cv0 = nv0; cv1 = nv1;
+    // iteration st: the set holding stage st + 1 goes to LDS after the MFMAs, the other set
+    // takes the loads of stage st + 2
+    for (int st = 0; st < nstages; st += 2) {
+      // even step: stage st + 1 is in set A, stage st + 2 goes to set B
+      if (st + 2 < nstages) stage_load(st + 2, sb, sgb, bv0, bv1);
+      stage_mfma(st & 1);
+      if (st + 1 < nstages) { stage_store((st + 1) & 1, sa, sg); cv0 = av0; cv1 = av1; }
+      __syncthreads();
+      if (st + 1 >= nstages) break;
+      // odd step: stage st + 2 is in set B, stage st + 3 goes to set A
+      if (st + 3 < nstages) stage_load(st + 3, sa, sg, av0, av1);
+      stage_mfma((st + 1) & 1);
+      if (st + 2 < nstages) { stage_store((st + 2) & 1, sb, sgb); cv0 = bv0; cv1 = bv1; }
       __syncthreads();
     }
   }
