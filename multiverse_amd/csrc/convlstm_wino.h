@@ -210,6 +210,35 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[c][rb][i] = 0.f;
 
+  // ---- the wave's tile of the cell state c (64 cells x 16 channels, the epilogue's operand)
+  // starts its way into LDS NOW, by LDS-DMA: no registers, and the HBM round trip that the
+  // epilogue used to open with is hidden behind the whole main loop.  Tile layout and the
+  // lane -> (cell row, 16-byte piece) map: see the epilogue.  c is not written by this launch
+  // (c' goes to the other buffer of the ping-pong pair).
+  float* const ctile = reinterpret_cast<float*>(lds + 2 * kWnStageVec) + wave * 1024;
+  if (wave_live && !a.zero_state) {
+    const uint32_t rowb0 = (uint32_t)C * 4u;
+    const int src_c0 = (valid && a.src_row_c) ? a.src_row_c[r] : r;
+    uint32_t coff0[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      coff0[e] = (valid & (y0 + e < H))
+                     ? (uint32_t)(src_c0 * HW + (y0 + e) * W + xpos) * rowb0 : 0xffffffffu;
+    const __amdgpu_buffer_rsrc_t c_rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<float*>(a.c)), 0, (uint32_t)(a.rows * HW) * rowb0, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int srcl = ((lane >> 2) + 16 * (k & 1)) * 4;
+      const uint32_t ro = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)coff0[k >> 1]);
+      // rows that own no cell read offset 0 (the value is never used)
+      const uint32_t off = ro != 0xffffffffu
+                               ? ro + (uint32_t)(cb16 * kWnCh) * 4u + (uint32_t)(lane & 3) * 16u : 0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          c_rs0, (__attribute__((address_space(3))) void*)(ctile + k * 256), 16, off, 0, 0,
+          MV_EPI_LD_AUX);
+    }
+  }
+
   // ---- the 2-channel fp32 x chunk (regression encoder), direct form
   if (a.x_small && wave_live) {
     const int Cin = Cx + C, N4 = 4 * C;
@@ -372,9 +401,6 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
   const int ch0 = cb16 * kWnCh + 4 * half_e;                 // + rb * 8
   const uint32_t rowb = (uint32_t)C * 4u;                    // bytes per cell
   const uint32_t out_bytes = (uint32_t)(a.rows * HW) * rowb;
-  const int src_c = (valid && a.src_row_c && !a.zero_state) ? a.src_row_c[r] : r;
-  const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(const_cast<float*>(a.zero_state ? a.c_out : a.c)), 0, out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t co_rs = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(a.c_out), 0, out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ho_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -397,22 +423,19 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
   // moved to / from memory with lane l on cell row (l >> 2) + 16 k, 16-byte piece l & 3:
   // four lanes cover the 64 contiguous bytes the workgroup's 16 channels have in a cell.
   // Row r of the tile belongs to lane (r & 31)'s pair-cell: its offsets come by ds_bpermute.
-  float* const tl0 = reinterpret_cast<float*>(lds) + wave * 2048;     // two tiles per wave
-  float* const tl1 = tl0 + 1024;
+  float* const tl0 = ctile;                   // c in, then c' out
+  float* const tl1 = reinterpret_cast<float*>(lds) + wave * 1024;     // h' out (a dead weight stage)
   constexpr uint32_t kNone = 0xffffffffu;
   const uint32_t colb = (uint32_t)(cb16 * kWnCh) * 4u;       // the workgroup's first channel
-  uint32_t coff[2], ooff[2];                  // byte offsets of the lane's cells: c source, outputs
+  uint32_t ooff[2];                           // byte offsets of the lane's output cells
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    coff[e] = okc[e] ? (uint32_t)(src_c * HW + cell[e]) * rowb : kNone;
+  for (int e = 0; e < 2; ++e)
     ooff[e] = okc[e] ? (uint32_t)(r * HW + cell[e]) * rowb : kNone;
-  }
   const int piece = lane_e & 3;
-  uint32_t rcoff[4], rooff[4];                // the same for the four transposed rows of the lane
+  uint32_t rooff[4];                          // output offsets of the four transposed rows of the lane
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int srcl = ((lane_e >> 2) + 16 * (k & 1)) * 4;
-    rcoff[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)coff[k >> 1]);
     rooff[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)ooff[k >> 1]);
   }
   const int wr_idx = (lane_e & 31) * 16 + half_e * 4;        // + e * 512 + rb * 8 (floats)
@@ -424,17 +447,9 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) cprev[e][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (!a.zero_state && !(p.abl & 4)) {
-    u32x4 cl[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      // rows that own no cell read offset 0 (the value is never used)
-      const uint32_t off = rcoff[k] != kNone ? rcoff[k] + colb + (uint32_t)piece * 16u : 0u;
-      cl[k] = __builtin_amdgcn_raw_buffer_load_b128(c_rs, (int)off, 0, MV_EPI_LD_AUX);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      *reinterpret_cast<u32x4*>(tl0 + rd_idx + k * 256) = cl[k];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS ops of a wave retire in order
+    // the tile was requested before the main loop; its barriers carried the vmcnt(0) -- the
+    // explicit wait covers a launch without f16 chunks
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -586,8 +601,9 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 2)
 void convlstm_step_wino_kernel(const ConvLstmWinoGroup g) {
-  // two weight stage buffers; the epilogue reuses them as two 4 KB state tiles per wave
-  __shared__ f16x8 lds[(2 * kWnStageVec > WAVES * 512) ? 2 * kWnStageVec : WAVES * 512];
+  // two weight stage buffers (the epilogue reuses them as one 4 KB h' tile per wave) | one
+  // 4 KB cell-state tile per wave (c in by LDS-DMA from the kernel's start, c' out)
+  extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
   int block = blockIdx.x;
   int pi = 0;
 #pragma unroll
@@ -621,6 +637,9 @@ static inline int wino_waves() {
   return w == 4 ? 4 : 8;
 }
 
+static inline size_t wino_lds_bytes(int waves) {
+  return (size_t)2 * kWnStageBytes + (size_t)waves * 4096;
+}
 static inline unsigned convlstm_wino_blocks(const ConvLstmArgs& a, int waves) {
   const size_t Q = (size_t)a.rows * ((a.H + 1) / 2) * a.W;
   const size_t pairs = (size_t)waves * 32;
@@ -636,6 +655,19 @@ static inline bool wino_enabled() {
 static inline bool wino_geometry_ok(const ConvLstmArgs& a) {
   return a.W > 0 && 32 % a.W == 0 && a.C % kWnCh == 0 && (a.Cx % 16 == 0 || a.x_small) &&
          a.H >= 2;
+}
+
+// dynamic LDS above the 64 KB default: the attribute is set once per process (the engine calls
+// this when it packs the weights, i.e. never inside a graph capture)
+static inline void wino_init_attributes() {
+  static const bool done = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_step_wino_kernel<8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_lds_bytes(8));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_step_wino_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_lds_bytes(4));
+    return true;
+  }();
+  (void)done;
 }
 
 static inline void launch_convlstm_wino_steps(const ConvLstmWinoArgs* probs, int n,
@@ -656,10 +688,13 @@ static inline void launch_convlstm_wino_steps(const ConvLstmWinoArgs* probs, int
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
+  wino_init_attributes();
   if (waves == 8)
-    hipLaunchKernelGGL(convlstm_step_wino_kernel<8>, dim3(total), dim3(512), 0, stream, g);
+    hipLaunchKernelGGL(convlstm_step_wino_kernel<8>, dim3(total), dim3(512), wino_lds_bytes(8),
+                       stream, g);
   else
-    hipLaunchKernelGGL(convlstm_step_wino_kernel<4>, dim3(total), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(convlstm_step_wino_kernel<4>, dim3(total), dim3(256), wino_lds_bytes(4),
+                       stream, g);
 }
 
 }  // namespace mv

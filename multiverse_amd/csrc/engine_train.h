@@ -277,7 +277,8 @@ void run_small_dgrad(mv_engine* e, const float* dout, size_t dout_rs, const floa
 void run_small_wgrad(mv_engine* e, const float* in, const float* dout, float* dw, int R,
                      int H, int W, int Ci, int Co) {
   TrainState& t = TS(e);
-  MV_REQUIRE(Ci * Co <= 512, "small wgrad: Ci*Co %d > 512", Ci * Co);
+  const bool h2g_form = Ci > Co && Ci <= 512 && (Co == 1 || Co == 2);   // hidden2grid
+  MV_REQUIRE(Ci * Co <= 512 || h2g_form, "small wgrad: Ci*Co %d > 512", Ci * Co);
   const long long cells = (long long)R * H * W;
   const int P = Ci * Co;
   const int G = std::max(1, 256 / P);                 // cell groups per workgroup
@@ -295,7 +296,8 @@ void run_small_wgrad(mv_engine* e, const float* in, const float* dout, float* dw
   launch(e, "conv3x3_small_wgrad", 2.0 * cells * 9 * Ci * Co,
          4.0 * cells * ((double)Ci + Co) + 8.0 * (double)nblk * ncols, [&] {
     const size_t lds2 = ((size_t)(cpb + 2 * W + 2) * Co + cpb) * sizeof(float);
-    if (Ci > Co && Ci <= 256 && (Co == 1 || Co == 2) && G == 1 && lds2 <= 48 * 1024) {
+    MV_REQUIRE(Ci * Co <= 512 || lds2 <= 48 * 1024, "small wgrad: LDS of the hidden2grid form");
+    if (h2g_form && G == 1 && lds2 <= 48 * 1024) {
       if (Co == 1)
         hipLaunchKernelGGL(mv::h2g_wgrad_kernel<1>, dim3((unsigned)nblk), dim3(256), lds2,
                            e->stream, in, dout, t.partial.p, R, H, W, Ci, cpb);
@@ -1085,13 +1087,23 @@ void train_backward(mv_engine* e) {
         const float* hsrc = R.hs[0].p + slot * NKC;
         launch(e, "gnn_bwd", NK * (9.0 * 2 * 3 * (C + D) + 9.0 * 4 * C),
                4.0 * NK * (4.0 * C + 2.0 * D), [&] {
-          hipLaunchKernelGGL(mv::gnn_bwd_a_kernel, dim3(cdiv(NK, 4)), dim3(256), 0,
+          if (C <= 256) {
+          hipLaunchKernelGGL(mv::gnn_bwd_a_kernel<1>, dim3(cdiv(NK, 4)), dim3(256), 0,
                              e->stream, hsrc, S.scene_mean.p, dh_b[s][0], R.gnn_a.p,
                              R.gnn_de.p, R.gnn_n.p, N, S.H, S.W, C, gnn_scene_dim(e));
-          hipLaunchKernelGGL(mv::gnn_bwd_b_kernel, dim3(cdiv(NK, 4)), dim3(256), 0,
+          hipLaunchKernelGGL(mv::gnn_bwd_b_kernel<1>, dim3(cdiv(NK, 4)), dim3(256), 0,
                              e->stream, hsrc, S.scene_mean.p, dh_b[s][0], R.gnn_a.p,
                              R.gnn_de.p, R.gnn_n.p, dh_a[s][0], R.dsmean.p, N, S.H, S.W,
                              C, gnn_scene_dim(e), 1);
+          } else {
+          hipLaunchKernelGGL(mv::gnn_bwd_a_kernel<2>, dim3(cdiv(NK, 4)), dim3(256), 0,
+                             e->stream, hsrc, S.scene_mean.p, dh_b[s][0], R.gnn_a.p,
+                             R.gnn_de.p, R.gnn_n.p, N, S.H, S.W, C, gnn_scene_dim(e));
+          hipLaunchKernelGGL(mv::gnn_bwd_b_kernel<2>, dim3(cdiv(NK, 4)), dim3(256), 0,
+                             e->stream, hsrc, S.scene_mean.p, dh_b[s][0], R.gnn_a.p,
+                             R.gnn_de.p, R.gnn_n.p, dh_a[s][0], R.dsmean.p, N, S.H, S.W,
+                             C, gnn_scene_dim(e), 1);
+          }
         });
       } else {
         std::swap(dh_a[s][0], dh_b[s][0]);

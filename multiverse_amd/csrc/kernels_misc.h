@@ -258,10 +258,37 @@ __global__ void grid_emb_onehot_kernel(const int32_t* __restrict__ ids,
 // (gnn_edge / gnn_mask_edge / gnn_node, code/pred_models.py:808-909,
 // exp_mask :1399-1401); exp(-1e30 - max) is exactly 0 in fp32, so the 9-point
 // stencil is the same function.  One wave per cell: lane l holds channels
-// 4l..4l+3 of h (C == 256) and channel l of the scene mean (D <= 64).
+// 256 g + 4l..4l+3 of h (NG groups: C <= 256 NG) and channel l of the scene mean (D <= 64).
 // scene_mean rows are indexed by m / sm_div (beam tiling, :831-834).
 // src_row: optional state-row indirection (beam parents): input row for
 // output row r is src_row[r].
+// Channel groups of the one-wave-per-cell kernels: lane l owns channels 256 g + 4 l .. + 3 of
+// group g < NG (C <= 256 NG: hidden sizes 128 / 256 / 512; lanes past C idle with zeros).
+template <int NG>
+struct CVec {
+  f32x4_t v[NG];
+};
+template <int NG>
+__device__ __forceinline__ CVec<NG> cvec_load(const float* __restrict__ row, int lane, int C) {
+  CVec<NG> r;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c0 = g * 256 + lane * 4;
+    r.v[g] = c0 < C ? *reinterpret_cast<const f32x4_t*>(row + c0) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  return r;
+}
+template <int NG>
+__device__ __forceinline__ float cvec_dot(const CVec<NG>& a, const CVec<NG>& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+    s += a.v[g][0] * b.v[g][0] + a.v[g][1] * b.v[g][1] + a.v[g][2] * b.v[g][2] +
+         a.v[g][3] * b.v[g][3];
+  return s;
+}
+
+template <int NG>
 __global__ __launch_bounds__(256)
 void gnn_attend_kernel(const float* __restrict__ h,
                        const float* __restrict__ scene_mean,
@@ -279,13 +306,13 @@ void gnn_attend_kernel(const float* __restrict__ h,
   const float* hrow = h + (size_t)ms * K * C;
   const float* srow = scene_mean + (size_t)(m / sm_div) * K * D;
 
-  const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)cell * C + lane * 4);
+  const CVec<NG> hi = cvec_load<NG>(hrow + (size_t)cell * C, lane, C);
   const float si = (lane < D) ? srow[(size_t)cell * D + lane] : 0.f;
-  float ssi = hi[0] * hi[0] + hi[1] * hi[1] + hi[2] * hi[2] + hi[3] * hi[3] + si * si;
+  float ssi = cvec_dot<NG>(hi, hi) + si * si;
   ssi = wave_sum(ssi);
   const float invi = rsqrtf(fmaxf(ssi, 1e-12f));
 
-  f32x4_t hj[9];
+  CVec<NG> hj[9];
   float e[9];
   bool ok[9];
   float emax = -INFINITY;
@@ -294,15 +321,14 @@ void gnn_attend_kernel(const float* __restrict__ h,
     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
     ok[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W);
     e[t] = 0.f;
-    hj[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) hj[t].v[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (ok[t]) {  // wave-uniform
       const int cj = yy * W + xx;
-      hj[t] = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)cj * C + lane * 4);
+      hj[t] = cvec_load<NG>(hrow + (size_t)cj * C, lane, C);
       const float sj = (lane < D) ? srow[(size_t)cj * D + lane] : 0.f;
-      float ssj = hj[t][0] * hj[t][0] + hj[t][1] * hj[t][1] + hj[t][2] * hj[t][2] +
-                  hj[t][3] * hj[t][3] + sj * sj;
-      float dot = hi[0] * hj[t][0] + hi[1] * hj[t][1] + hi[2] * hj[t][2] +
-                  hi[3] * hj[t][3] + si * sj;
+      float ssj = cvec_dot<NG>(hj[t], hj[t]) + sj * sj;
+      float dot = cvec_dot<NG>(hi, hj[t]) + si * sj;
       ssj = wave_sum(ssj);
       dot = wave_sum(dot);
       e[t] = dot * invi * rsqrtf(fmaxf(ssj, 1e-12f));
@@ -316,35 +342,41 @@ void gnn_attend_kernel(const float* __restrict__ h,
     den += e[t];
   }
   const float inv = 1.0f / den;
-  f32x4_t node = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const float a = e[t] * inv;
-    node[0] = fmaf(a, hj[t][0], node[0]);
-    node[1] = fmaf(a, hj[t][1], node[1]);
-    node[2] = fmaf(a, hj[t][2], node[2]);
-    node[3] = fmaf(a, hj[t][3], node[3]);
-  }
-  f32x4_t o = {hi[0] + node[0], hi[1] + node[1], hi[2] + node[2], hi[3] + node[3]};
-  *reinterpret_cast<f32x4_t*>(out + ((size_t)m * K + cell) * C + lane * 4) = o;
-  if (p16) {
-    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-    f16x4_t a, b;
-    const size_t idx = plane_index((long long)m * K + cell, lane * 4, C);   // 4 of one 8-group
-    if (p16_stride == 0) {
+  for (int g = 0; g < NG; ++g) {
+    const int c0 = g * 256 + lane * 4;
+    if (c0 >= C) continue;
+    f32x4_t node = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = bf16_half_bits(o[j]);
-      *reinterpret_cast<f16x4_t*>(p16 + idx) = a;
-    } else {
+    for (int t = 0; t < 9; ++t) {
+      const float a = e[t] * inv;
+      node[0] = fmaf(a, hj[t].v[g][0], node[0]);
+      node[1] = fmaf(a, hj[t].v[g][1], node[1]);
+      node[2] = fmaf(a, hj[t].v[g][2], node[2]);
+      node[3] = fmaf(a, hj[t].v[g][3], node[3]);
+    }
+    f32x4_t o = {hi.v[g][0] + node[0], hi.v[g][1] + node[1], hi.v[g][2] + node[2],
+                 hi.v[g][3] + node[3]};
+    *reinterpret_cast<f32x4_t*>(out + ((size_t)m * K + cell) * C + c0) = o;
+    if (p16) {
+      typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+      f16x4_t a, b;
+      const size_t idx = plane_index((long long)m * K + cell, c0, C);   // 4 of one 8-group
+      if (p16_stride == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float sc = o[j] * 256.0f;
-        const _Float16 h0 = (_Float16)sc;
-        a[j] = h0;
-        b[j] = (_Float16)(sc - (float)h0);
+        for (int j = 0; j < 4; ++j) a[j] = bf16_half_bits(o[j]);
+        *reinterpret_cast<f16x4_t*>(p16 + idx) = a;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sc = o[j] * 256.0f;
+          const _Float16 h0 = (_Float16)sc;
+          a[j] = h0;
+          b[j] = (_Float16)(sc - (float)h0);
+        }
+        *reinterpret_cast<f16x4_t*>(p16 + idx) = a;
+        *reinterpret_cast<f16x4_t*>(p16 + p16_stride + idx) = b;
       }
-      *reinterpret_cast<f16x4_t*>(p16 + idx) = a;
-      *reinterpret_cast<f16x4_t*>(p16 + p16_stride + idx) = b;
     }
   }
 }
@@ -1013,13 +1045,15 @@ void hidden2grid_kernel(const float* __restrict__ h, const float* __restrict__ w
   for (int t = 0; t < 9; ++t) {
     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
     if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      const f32x4_t hv = *reinterpret_cast<const f32x4_t*>(
-          hrow + (size_t)(yy * W + xx) * C + lane * 4);
-      const float* wp = w + ((size_t)t * C + lane * 4) * P;
+      for (int c0 = lane * 4; c0 < C; c0 += 256) {     // channel groups of 256 (any C % 4 == 0)
+        const f32x4_t hv = *reinterpret_cast<const f32x4_t*>(
+            hrow + (size_t)(yy * W + xx) * C + c0);
+        const float* wp = w + ((size_t)t * C + c0) * P;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int p = 0; p < P; ++p) acc[p] = fmaf(hv[j], wp[j * P + p], acc[p]);
+          for (int p = 0; p < P; ++p) acc[p] = fmaf(hv[j], wp[j * P + p], acc[p]);
+      }
     }
   }
 #pragma unroll

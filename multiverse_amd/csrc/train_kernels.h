@@ -123,6 +123,7 @@ void lstm_gate_bwd4_kernel(float* __restrict__ gates, const float* __restrict__ 
 // Pass A (one wave per cell i): recompute n_i = rsqrt(max(|u_i|^2,1e-12)),
 // e_ij, a_ij; da_ij = g_i . h_j; de_ij = a_ij (da_ij - sum_k a_ik da_ik).
 // Stores a, de [M*K, 9] (0 for out-of-grid taps) and n [M*K].
+template <int NG>
 __global__ __launch_bounds__(256)
 void gnn_bwd_a_kernel(const float* __restrict__ h, const float* __restrict__ smean,
                       const float* __restrict__ g, float* __restrict__ a_out,
@@ -137,10 +138,10 @@ void gnn_bwd_a_kernel(const float* __restrict__ h, const float* __restrict__ sme
   const int y = cell / W, x = cell - y * W;
   const float* hrow = h + (size_t)m * K * C;
   const float* srow = smean + (size_t)m * K * D;
-  const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)cell * C + lane * 4);
-  const f32x4_t gi = *reinterpret_cast<const f32x4_t*>(g + cell_id * C + lane * 4);
+  const CVec<NG> hi = cvec_load<NG>(hrow + (size_t)cell * C, lane, C);
+  const CVec<NG> gi = cvec_load<NG>(g + cell_id * C, lane, C);
   const float si = (lane < D) ? srow[(size_t)cell * D + lane] : 0.f;
-  float ssi = hi[0] * hi[0] + hi[1] * hi[1] + hi[2] * hi[2] + hi[3] * hi[3] + si * si;
+  float ssi = cvec_dot<NG>(hi, hi) + si * si;
   ssi = wave_sum(ssi);
   const float invi = rsqrtf(fmaxf(ssi, 1e-12f));
   float e[9], da[9];
@@ -153,11 +154,11 @@ void gnn_bwd_a_kernel(const float* __restrict__ h, const float* __restrict__ sme
     e[t] = 0.f; da[t] = 0.f;
     if (ok[t]) {
       const int cj = yy * W + xx;
-      const f32x4_t hj = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)cj * C + lane * 4);
+      const CVec<NG> hj = cvec_load<NG>(hrow + (size_t)cj * C, lane, C);
       const float sj = (lane < D) ? srow[(size_t)cj * D + lane] : 0.f;
-      float ssj = hj[0] * hj[0] + hj[1] * hj[1] + hj[2] * hj[2] + hj[3] * hj[3] + sj * sj;
-      float dot = hi[0] * hj[0] + hi[1] * hj[1] + hi[2] * hj[2] + hi[3] * hj[3] + si * sj;
-      float dg = gi[0] * hj[0] + gi[1] * hj[1] + gi[2] * hj[2] + gi[3] * hj[3];
+      float ssj = cvec_dot<NG>(hj, hj) + sj * sj;
+      float dot = cvec_dot<NG>(hi, hj) + si * sj;
+      float dg = cvec_dot<NG>(gi, hj);
       ssj = wave_sum(ssj);
       dot = wave_sum(dot);
       da[t] = wave_sum(dg);
@@ -194,6 +195,7 @@ void gnn_bwd_a_kernel(const float* __restrict__ h, const float* __restrict__ sme
 //   df_j = sum_t (de[j][t] + de[j+d_t][8-t]) f_{j+d_t},  f_k = n_k u_k
 //   du_j = n_j (df_j - f_j (f_j . df_j))      (n_j clamped: du_j = n_j df_j)
 //   ds_j = du_j[C:]
+template <int NG>
 __global__ __launch_bounds__(256)
 void gnn_bwd_b_kernel(const float* __restrict__ h, const float* __restrict__ smean,
                       const float* __restrict__ g, const float* __restrict__ a_in,
@@ -211,12 +213,13 @@ void gnn_bwd_b_kernel(const float* __restrict__ h, const float* __restrict__ sme
   const float* hrow = h + rbase * C;
   const float* srow = smean + rbase * D;
   const float* grow = g + rbase * C;
-  const f32x4_t hj = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)cell * C + lane * 4);
+  const CVec<NG> hj = cvec_load<NG>(hrow + (size_t)cell * C, lane, C);
   const float sj = (lane < D) ? srow[(size_t)cell * D + lane] : 0.f;
   const float nj = n_in[cell_id];
-  const f32x4_t gj = *reinterpret_cast<const f32x4_t*>(grow + (size_t)cell * C + lane * 4);
-  f32x4_t acc = gj;                    // residual + attention-weighted neighbours
-  f32x4_t dfh = {0.f, 0.f, 0.f, 0.f};  // df_j, h part
+  CVec<NG> acc = cvec_load<NG>(grow + (size_t)cell * C, lane, C);   // residual + weighted neighbours
+  CVec<NG> dfh;                        // df_j, h part
+#pragma unroll
+  for (int gq = 0; gq < NG; ++gq) dfh.v[gq] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float dfs = 0.f;                     // df_j, scene part (lane < D)
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
@@ -227,30 +230,37 @@ void gnn_bwd_b_kernel(const float* __restrict__ h, const float* __restrict__ sme
       const float a_kj = a_in[kid * 9 + (8 - t)];
       const float w = de_in[cell_id * 9 + t] + de_in[kid * 9 + (8 - t)];
       const float nk = n_in[kid];
-      const f32x4_t gk = *reinterpret_cast<const f32x4_t*>(grow + (size_t)ck * C + lane * 4);
-      const f32x4_t hk = *reinterpret_cast<const f32x4_t*>(hrow + (size_t)ck * C + lane * 4);
+      const CVec<NG> gk = cvec_load<NG>(grow + (size_t)ck * C, lane, C);
+      const CVec<NG> hk = cvec_load<NG>(hrow + (size_t)ck * C, lane, C);
       const float sk = (lane < D) ? srow[(size_t)ck * D + lane] : 0.f;
       const float wn = w * nk;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[q] = fmaf(a_kj, gk[q], acc[q]);
-        dfh[q] = fmaf(wn, hk[q], dfh[q]);
-      }
+      for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc.v[gq][q] = fmaf(a_kj, gk.v[gq][q], acc.v[gq][q]);
+          dfh.v[gq][q] = fmaf(wn, hk.v[gq][q], dfh.v[gq][q]);
+        }
       dfs = fmaf(wn, sk, dfs);
     }
   }
   // projection f_j . df_j
-  float proj = (hj[0] * dfh[0] + hj[1] * dfh[1] + hj[2] * dfh[2] + hj[3] * dfh[3] +
-                sj * dfs) * nj;
+  float proj = (cvec_dot<NG>(hj, dfh) + sj * dfs) * nj;
   proj = wave_sum(proj);
   const bool clamped = nj >= 1.0e6f;   // |u|^2 <= 1e-12: l2_normalize is u * 1e6
-  f32x4_t o;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float du = clamped ? nj * dfh[q] : nj * (dfh[q] - (hj[q] * nj) * proj);
-    o[q] = acc[q] + du;
+  for (int gq = 0; gq < NG; ++gq) {
+    const int c0 = gq * 256 + lane * 4;
+    if (c0 >= C) continue;
+    f32x4_t o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float du = clamped ? nj * dfh.v[gq][q]
+                               : nj * (dfh.v[gq][q] - (hj.v[gq][q] * nj) * proj);
+      o[q] = acc.v[gq][q] + du;
+    }
+    *reinterpret_cast<f32x4_t*>(dh + cell_id * C + c0) = o;
   }
-  *reinterpret_cast<f32x4_t*>(dh + cell_id * C + lane * 4) = o;
   if (lane < D) {
     const float du = clamped ? nj * dfs : nj * (dfs - (sj * nj) * proj);
     float* o2 = ds + cell_id * D + lane;
@@ -468,12 +478,12 @@ void h2g_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ do
     smask[i] = mask;
   }
   __syncthreads();
-  float acc[9][CO];
+  for (int ci = tid; ci < Ci; ci += blockDim.x) {     // one pass per 256 input channels
+    float acc[9][CO];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int co = 0; co < CO; ++co) acc[t][co] = 0.f;
-  for (int ci = tid; ci < Ci; ci += blockDim.x) {     // Ci <= 256: one pass
+      for (int co = 0; co < CO; ++co) acc[t][co] = 0.f;
     const float* ip = in + (size_t)m0 * Ci + ci;
     const int n = (int)(m1 - m0);
     for (int i = 0; i < n; ++i) {

@@ -365,7 +365,8 @@ def test_emb_size_other_than_32(built_lib, E):
 def test_create_rejects_unsupported_shapes(built_lib):
   """Shape limits are reported by mv_create (Engine()), not by the first forward."""
   for kw, msg in ((dict(emb_size=48), "emb_size"), (dict(emb_size=16), "emb_size"),
-                  (dict(enc_hidden_size=128, dec_hidden_size=128), "hidden_size")):
+                  (dict(enc_hidden_size=192, dec_hidden_size=192), "hidden_size"),
+                  (dict(enc_hidden_size=1024, dec_hidden_size=1024), "hidden_size")):
     cfg = synth.default_config(batch_size=1, use_grids=(0, 1), **kw)
     with pytest.raises(built_lib.MvError, match=msg):
       built_lib.Engine(cfg, device=0)
@@ -409,3 +410,70 @@ def test_unbounded_activations_run_on_the_fp16_pipe(built_lib, act, gain):
       assert err["f16x3", s][k] < bar, (s, k, err)
       if gain == 1.0:
         assert err["f32", s][k] < 1e-4
+
+
+@pytest.mark.parametrize("Ch,grids", [(128, (1, 1)), (512, (0, 1))])
+def test_hidden_size_other_than_256(built_lib, Ch, grids):
+  """--enc_hidden_size / --dec_hidden_size (code/train.py:54-57; the published runs use 256):
+  128 and 512 through every kernel of the path -- gate convolutions (fp32 pipe, f16x3 direct
+  and Winograd forms), graph attention, hidden2grid, beam search, and one training step
+  (dgrad, wgrad, graph-attention backward) -- against the oracle.  Scale 1 only at 512 (the
+  CPU oracle's cost grows with the square of the width)."""
+  import torch
+  from oracle import multiverse_oracle as oracle
+  from beam_compare import compare_beams
+  kw = dict(enc_hidden_size=Ch, dec_hidden_size=Ch)
+  cfg = synth.default_config(batch_size=2, use_grids=grids, **kw)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + Ch, recurrent_gain=3.0, bias_scale=0.1)
+  s_on = [s for s in range(2) if grids[s]]
+  kname = "person_pred/encoder_grid_class_%d/enc_grid_%d/kernel" % (s_on[0], s_on[0])
+  assert params[kname].shape == (3, 3, 64 + Ch, 4 * Ch)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 31)
+  ocls, oreg, _ = oracle.forward(params, cfg, feed)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  for mode in ("f16x3", "f32"):
+    eng.set_compute_mode(mode)
+    cls, reg = eng.forward_greedy(feed)
+    for s in s_on:
+      dc, dr = np.abs(cls[s] - ocls[s]).max(), np.abs(reg[s] - oreg[s]).max()
+      same = (cls[s].reshape(2, 12, -1).argmax(-1) == ocls[s].reshape(2, 12, -1).argmax(-1)).all()
+      print("hidden %d %-5s scale %d: max|dcls| %.3g max|dreg| %.3g" % (Ch, mode, s, dc, dr))
+      assert dc < 1e-4 and dr < 1e-4 and same
+  eng.close()
+  # diverse beam search, scale 1
+  bcfg = synth.default_config(batch_size=2, use_grids=(0, 1), beam_size=5, **kw)
+  bparams = synth.make_params(bcfg, seed=synth.SEED_BASE + Ch, recurrent_gain=3.0, bias_scale=0.1)
+  bfeed = synth.make_feed(bcfg, seed=synth.SEED_BASE + 32)
+  beng = built_lib.Engine(bcfg, device=0)
+  beng.set_params(bparams)
+  beng.set_compute_mode("f16x3")
+  arrs, s = beng.forward_beam(bfeed)
+  beng.close()
+  trace = {}
+  _, obreg, (ologits, oids, olp) = oracle.forward(bparams, bcfg, bfeed, trace=trace)
+  compare_beams(arrs, obreg[1], ologits, oids, olp,
+                np.stack(trace["beam_step_topvals"], axis=-1), trace["beam_trace"])
+  # one training step: loss parts and every gradient tensor, scale 1
+  tcfg = synth.default_config(batch_size=2, use_grids=(0, 1), is_train=True, **kw)
+  tparams = synth.make_params(tcfg, seed=synth.SEED_BASE + Ch, recurrent_gain=2.0, bias_scale=0.1)
+  tfeed = synth.make_feed(tcfg, seed=synth.SEED_BASE + 33)
+  oloss, owd, opgl, _ = oracle.loss_and_grads(tparams, tcfg, tfeed)
+  og64 = oracle.loss_and_grads(tparams, tcfg, tfeed, dtype=torch.float64)[3]
+  for mode in ("f16x3", "f32"):
+    teng = built_lib.Engine(tcfg, device=0)
+    teng.set_params(tparams)
+    teng.set_compute_mode(mode)
+    teng.train_init()
+    loss, wd, pgl = teng.train_forward_backward(tfeed)
+    assert abs(loss - oloss) < 1e-4 * max(1.0, abs(oloss)) and np.allclose(pgl, opgl, rtol=1e-4, atol=1e-5)
+    worst = 0.0
+    for name, _ in teng.param_specs():
+      g = teng.get_grad(name).astype("float64")
+      worst = max(worst, float(np.abs(g - og64[name]).max() / max(np.abs(og64[name]).max(), 1e-30)))
+    print("hidden %d %-5s training step: worst gradient error %.2e of max|g|" % (Ch, mode, worst))
+    # two optimizer steps run (device-side repacks of every weight form)
+    teng.train_apply(1.0)
+    teng.train_step(tfeed)
+    teng.close()
+    assert worst < 2e-3
