@@ -100,6 +100,11 @@ VARIANT_CASES = [
     # convolutions and grid_emb; tf.nn.leaky_relu's default alpha 0.2
     ("relu", dict(activation_func="relu"), 1),
     ("lrelu", dict(activation_func="lrelu"), 1),
+    # shapes other than the published run's (code/train.py:53-57): --emb_size 128 is the flag's
+    # own default, --enc/dec_hidden_size 128 / 512 the neighbouring widths
+    ("emb128", dict(emb_size=128), 1),
+    ("hidden128", dict(enc_hidden_size=128, dec_hidden_size=128), 1),
+    ("hidden512", dict(enc_hidden_size=512, dec_hidden_size=512), 1),
 ]
 VARIANT_SEED = synth.SEED_BASE + 40
 

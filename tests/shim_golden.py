@@ -90,6 +90,9 @@ VARIANT_CASES = {
     "sck1": (dict(scene_conv_kernel=1), 1),
     "relu": (dict(activation_func="relu"), 1),
     "lrelu": (dict(activation_func="lrelu"), 1),
+    "emb128": (dict(emb_size=128), 1),
+    "hidden128": (dict(enc_hidden_size=128, dec_hidden_size=128), 1),
+    "hidden512": (dict(enc_hidden_size=512, dec_hidden_size=512), 1),
 }
 VARIANT_SEED = synth.SEED_BASE + 40
 

@@ -11,6 +11,7 @@ C ABI, against (a) the frozen runs of the reference's own Trainer on the TF-1 sh
   --optimizer momentum / adam / rmsprop             :1667-1681
   --use_cosine_lr                                   :1646-1654
   --scene_conv_kernel 1                             code/train.py:65
+  --emb_size 128, --enc/dec_hidden_size 128 / 512   code/train.py:53-57
   --activation_func relu / lrelu                    code/train.py:58-59, code/pred_utils.py:86-94
                                                     (f16x3: per-tensor exponent of the x planes)
 
@@ -29,7 +30,8 @@ import shim_golden as sg
 pytestmark = pytest.mark.gpu
 LOSS_VARIANTS = ["soft1", "soft7_mask", "mask", "teacher", "teacher_soft4", "no_onehot",
                  "dropout07", "sck1",       # sck1: --scene_conv_kernel 1 (1x1 projections on MFMA)
-                 "relu", "lrelu"]           # --activation_func
+                 "relu", "lrelu",           # --activation_func
+                 "emb128", "hidden128", "hidden512"]   # --emb_size / --enc,dec_hidden_size
 OPTIMIZERS = ["momentum", "rmsprop", "adam", "cosine"]     # cosine: --use_cosine_lr + momentum
 SLOTS = {"momentum": 1, "rmsprop": 2, "adam": 2, "cosine": 1}
 
