@@ -1,0 +1,277 @@
+# coding=utf-8
+"""CPU: a numpy twin of what csrc/convlstm_wino.h computes and of the index maps it relies on.
+
+No GPU here: these tests hold (a) the ALGEBRA of the Winograd F(2,3) row-pair form with f16x3
+operands -- the fp64 kernel transform split into two fp16 planes of 256 U, the in-kernel input
+transform as an error-free TwoSum on fp16 plane pairs, three fp16 products per component
+accumulated in fp32, the output transform -- against a direct fp64 3x3 SAME convolution, and
+(b) the LAYOUT bookkeeping the kernel's correctness rests on: pair-cell tiling, the DPP column
+shift condition, the XCD-pair column-block map, the LDS state-tile transposition, the plane
+addresses of the permlane32-swap stores, the weight pack order.  The GPU tests
+(tests/test_gpu_wino.py) hold the kernel itself."""
+import numpy as np
+import pytest
+
+F16 = np.float16
+
+
+def split_planes(v, scale=256.0):
+  """fp32 -> (hi, lo) fp16 planes of scale * v (convlstm_f16x3.h split_planes_item)."""
+  s = (np.asarray(v, dtype=np.float32) * np.float32(scale)).astype(np.float32)
+  hi = s.astype(F16)
+  lo = (s - hi.astype(np.float32)).astype(F16)
+  return hi, lo
+
+
+def two_sum_planes(a_hi, a_lo, b_hi, b_lo, sub):
+  """wn_combine: (a_hi + a_lo) +- (b_hi + b_lo) as a plane pair, every operation rounded to
+  fp16 like v_pk_add_f16 / v_pk_fma_f16(x, -1, y) (a - b is ONE rounding either way)."""
+  bh = -b_hi if sub else b_hi
+  bl = -b_lo if sub else b_lo
+  s = (a_hi + bh).astype(F16)
+  bb = (s - a_hi).astype(F16)
+  t = (s - bb).astype(F16)
+  e1 = (a_hi - t).astype(F16)
+  e2 = (bh - bb).astype(F16)
+  lo = ((e1 + e2).astype(F16) + (a_lo + bl).astype(F16)).astype(F16)
+  return s, lo
+
+
+def test_two_sum_of_plane_pairs_is_exact_to_the_residual_class():
+  rng = np.random.default_rng(0)
+  a = np.tanh(rng.normal(size=20000) * 2).astype(np.float32)
+  b = np.tanh(rng.normal(size=20000) * 2).astype(np.float32)
+  b[::3] = a[::3] * np.float32(1.0 + 2.0 ** -9)          # near-cancellation
+  a[1::7] *= np.float32(1e-3)                             # low plane subnormal
+  ah, al = split_planes(a)
+  bh, bl = split_planes(b)
+  for sub in (False, True):
+    hi, lo = two_sum_planes(ah, al, bh, bl, sub)
+    exact = (ah.astype(np.float64) + al.astype(np.float64)) + \
+        (-1.0 if sub else 1.0) * (bh.astype(np.float64) + bl.astype(np.float64))
+    got = hi.astype(np.float64) + lo.astype(np.float64)
+    # TwoSum of the high planes is error-free: what is lost is one fp16 rounding of the LOW part
+    scale = 256.0 * np.maximum(np.abs(a), np.abs(b)).astype(np.float64)
+    err = np.abs(got - exact)
+    assert (err <= 2.0 ** -20 * np.maximum(scale, 2.0 ** -4)).all(), err.max()
+    # ... and the high plane alone is the correctly rounded sum of the high planes
+    assert (hi == (ah.astype(np.float32) + (-1 if sub else 1) * bh.astype(np.float32)).astype(F16)).all()
+
+
+def _conv3x3_same(d, w):
+  """d [H, W, Ci], w [3, 3, Ci, N] (fp64) -> [H, W, N], out(y, x) = sum d(y+ky-1, x+kx-1) w[ky, kx]."""
+  H, W, Ci = d.shape
+  pad = np.zeros((H + 2, W + 2, Ci))
+  pad[1:-1, 1:-1] = d
+  out = np.zeros((H, W, w.shape[3]))
+  for ky in range(3):
+    for kx in range(3):
+      out += pad[ky:ky + H, kx:kx + W] @ w[ky, kx]
+  return out
+
+
+def _wino_rows_f16x3(d, w):
+  """The kernel's arithmetic for one image: rows paired, dx direct; operands as fp16 plane
+  pairs, products a0 w0 + a0 w1 + a1 w0 with fp32 accumulation (pairwise here), output
+  transform in fp32, result / 2^16."""
+  H, W, Ci = d.shape
+  N = w.shape[3]
+  Hp = (H + 1) // 2
+  # kernel transform in fp64, planes of 256 U (pack_wino_kernel)
+  g0, g1, g2 = w[0], w[1], w[2]                       # [3 dx][Ci][N] each
+  U = [g0, 0.5 * (g0 + g1 + g2), 0.5 * (g0 - g1 + g2), g2]
+  Uh, Ul = [], []
+  for u in U:
+    sv = u * 256.0
+    h = sv.astype(F16)
+    Uh.append(h)
+    Ul.append((sv - h.astype(np.float64)).astype(F16))
+  dh, dl = split_planes(d)
+  zero = np.zeros((W, Ci), F16)
+
+  def row(r):
+    return (dh[r], dl[r]) if 0 <= r < H else (zero, zero)
+
+  out = np.zeros((H, W, N), np.float32)
+  for t in range(Hp):
+    rm1, r0, r1, r2 = row(2 * t - 1), row(2 * t), row(2 * t + 1), row(2 * t + 2)
+    V = [two_sum_planes(rm1[0], rm1[1], r1[0], r1[1], True),      # d(-1) - d(+1)
+         two_sum_planes(r0[0], r0[1], r1[0], r1[1], False),       # d(0) + d(+1)
+         two_sum_planes(r1[0], r1[1], r0[0], r0[1], True),        # d(+1) - d(0)
+         two_sum_planes(r0[0], r0[1], r2[0], r2[1], True)]        # d(0) - d(+2)
+    M = []
+    for c in range(4):
+      acc = np.zeros((W, N), np.float32)
+      for dx in range(3):
+        vh = np.zeros((W, Ci), np.float32)
+        vl = np.zeros((W, Ci), np.float32)
+        lo_x, hi_x = max(0, 1 - dx), min(W, W + 1 - dx)           # x + dx - 1 inside the row
+        vh[lo_x:hi_x] = V[c][0][lo_x + dx - 1:hi_x + dx - 1]
+        vl[lo_x:hi_x] = V[c][1][lo_x + dx - 1:hi_x + dx - 1]
+        uh, ul = Uh[c][dx].astype(np.float32), Ul[c][dx].astype(np.float32)
+        acc += (vl @ uh).astype(np.float32)
+        acc += (vh @ ul).astype(np.float32)
+        acc += (vh @ uh).astype(np.float32)
+      M.append(acc)
+    y0 = (M[0] + M[1]) + M[2]
+    y1 = (M[1] - M[2]) - M[3]
+    out[2 * t] = y0 * np.float32(2.0 ** -16)
+    if 2 * t + 1 < H:
+      out[2 * t + 1] = y1 * np.float32(2.0 ** -16)
+  return out
+
+
+@pytest.mark.parametrize("H,W", [(18, 32), (9, 16), (6, 8), (2, 32)])
+def test_winograd_row_pairs_with_f16x3_operands_equal_the_direct_convolution(H, W):
+  rng = np.random.default_rng(H * 100 + W)
+  Ci, N = 48, 24
+  d = np.tanh(rng.normal(size=(H, W, Ci))).astype(np.float32)
+  w = (rng.normal(size=(3, 3, Ci, N)) * 0.06).astype(np.float32)
+  ref = _conv3x3_same(d.astype(np.float64), w.astype(np.float64))
+  got = _wino_rows_f16x3(d, w.astype(np.float64))
+  err = np.abs(got - ref).max()
+  print("H %d W %d: max |winograd f16x3 - fp64 direct| = %.3g (max |y| %.3g)" % (H, W, err,
+                                                                             np.abs(ref).max()))
+  assert err < 4e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_one_hot_taps_land_on_the_right_output_rows():
+  """Every (ky, kx) tap, even and odd source rows: the row pairing and the sign pattern of the
+  output transform (what a transposed or mis-signed component would break)."""
+  H, W, Ci, N = 6, 8, 16, 4
+  for ky in range(3):
+    for kx in range(3):
+      for (sy, sx) in ((2, 5), (3, 2), (0, 0), (5, 7)):
+        d = np.zeros((H, W, Ci), np.float32)
+        d[sy, sx, 3] = 0.75
+        w = np.zeros((3, 3, Ci, N))
+        w[ky, kx, 3, 1] = 0.5
+        ref = _conv3x3_same(d.astype(np.float64), w)
+        got = _wino_rows_f16x3(d, w)
+        assert np.abs(got - ref).max() < 1e-7, (ky, kx, sy, sx)
+
+
+# ------------------------------------------------------------------ index maps
+
+def _pair_cell(q, H, W):
+  Hp = (H + 1) // 2
+  Kp = Hp * W
+  r, pc = divmod(q, Kp)
+  t, x = divmod(pc, W)
+  return r, 2 * t, x
+
+
+@pytest.mark.parametrize("rows,H,W", [(3, 18, 32), (5, 9, 16), (2, 6, 8), (1, 9, 16)])
+def test_pair_cell_tiling_covers_every_cell_once_and_keeps_the_dpp_shift_legal(rows, H, W):
+  Hp = (H + 1) // 2
+  Q = rows * Hp * W
+  seen = np.zeros((rows, H, W), np.int32)
+  for q in range(Q):
+    r, y0, x = _pair_cell(q, H, W)
+    for e in (0, 1):
+      if y0 + e < H:
+        seen[r, y0 + e, x] += 1
+    # lanes of a wave tile are 32 consecutive q: W | 32 => lane % 32 == 0 is x == 0, so the
+    # lane a wave_shr:1 / wave_shl:1 brings in across a tile or half-wave edge is always masked
+    lane = q % 32
+    assert x == lane % W
+    if lane == 0:
+      assert x == 0
+    if lane == 31:
+      assert x == W - 1
+  assert (seen == 1).all()
+
+
+def test_column_block_map_puts_the_halves_of_a_state_line_on_one_xcd():
+  ncb = 16                                            # C = 256
+  for mtiles in (1, 3, 72):
+    got = {}
+    for block in range(ncb * mtiles):
+      grp, w16 = divmod(block, 16)
+      cb16 = (grp % (ncb // 16)) * 16 + 2 * (w16 & 7) + (w16 >> 3)
+      mt = grp // (ncb // 16)
+      assert (cb16, mt) not in got
+      got[(cb16, mt)] = block % 8                     # XCD of the workgroup
+    assert len(got) == ncb * mtiles
+    for (cb16, mt), xcd in got.items():
+      assert xcd == cb16 // 2                         # blocks 2x, 2x+1 = one 128-byte line
+
+
+def test_lds_state_tile_transposition_is_a_bijection_onto_cell_rows():
+  """Epilogue: lane (col, half) writes 16 B at [e*32 + col][rb*8 + half*4]; transposed, lane l
+  moves row (l >> 2) + 16 k, piece l & 3.  Both cover the 64 x 16-float tile exactly once, and
+  the transposed row belongs to the pair-cell of lane (row & 31), e = row >> 5."""
+  tile = np.zeros((64, 16), np.int32)
+  for lane in range(64):
+    col, half = lane & 31, lane >> 5
+    for e in (0, 1):
+      for rb in (0, 1):
+        idx = col * 16 + half * 4 + e * 512 + rb * 8
+        assert idx % 4 == 0
+        tile.reshape(-1)[idx:idx + 4] += 1
+  assert (tile == 1).all()
+  tile[:] = 0
+  for lane in range(64):
+    for k in range(4):
+      idx = (lane >> 2) * 16 + (lane & 3) * 4 + k * 256
+      tile.reshape(-1)[idx:idx + 4] += 1
+      row = idx // 16
+      assert row == (lane >> 2) + 16 * k
+      assert row & 31 == (lane >> 2) + 16 * (k & 1) and row >> 5 == k >> 1   # bpermute source, e
+  assert (tile == 1).all()
+
+
+def _plane_index(m, c, C):
+  return ((m >> 5) * (C >> 4) + (c >> 4)) * 512 + (((c >> 3) & 1) * 256 + (m & 31) * 8 + (c & 7))
+
+
+def test_plane_store_addresses_of_the_half_wave_swap():
+  """After v_permlane32_swap the lower half-wave holds channels 0-7 of row block rb for the
+  e = 0 cells, the upper half-wave for the e = 1 cells; the 16-byte store lands at
+  plane_index(cell, cb16*16 + rb*8, C)."""
+  C, H, W = 256, 18, 32
+  HW = H * W
+  for cb16 in (0, 5, 15):
+    for (r, y0) in ((0, 0), (2, 16)):
+      for rb in (0, 1):
+        for half in (0, 1):
+          addrs = []
+          for col in range(32):
+            mc = r * HW + (y0 + half) * W + col
+            o0 = ((mc >> 5) * (C >> 4) + cb16) * 512 + (mc & 31) * 8
+            addrs.append(o0 + rb * 256)
+            assert o0 + rb * 256 == _plane_index(mc, cb16 * 16 + rb * 8, C)
+          # 32 lanes = one contiguous 512-byte run (8 halves = 16 bytes per lane)
+          assert addrs == list(range(addrs[0], addrs[0] + 256, 8))
+
+
+def test_weight_pack_order_matches_the_stage_reads():
+  """pack_wino_kernel's element order against the kernel's LDS reads: vector
+  ((((ci*3 + dx)*2 + plane)*2 + rb)*64 + lane of stage s = 2*chunk + (comp >> 1) holds, at
+  element e, U_comp[dx][chunk*16 + 8*(lane >> 5) + e][gate (lane & 31) >> 3][channel
+  cb16*16 + rb*8 + (lane & 7)]."""
+  Cx16, C = 32, 64
+  nxc, nst = Cx16 // 16, 2 * (Cx16 // 16 + C // 16)
+  seen = set()
+  total = (C // 16) * nst * 2 * 3 * 2 * 64 * 8
+  for idx in range(0, total, 97):                     # a stride coprime to the layout
+    e = idx & 7
+    l = (idx >> 3) & 63
+    rb = (idx >> 9) & 1
+    t = idx >> 10
+    dx = t % 3; t //= 3
+    ci = t & 1; t >>= 1
+    s, cb16 = t % nst, t // nst
+    chunk, comp = s >> 1, (s & 1) * 2 + ci
+    assert 0 <= comp < 4 and cb16 < C // 16
+    is_x = chunk < nxc
+    cin = (0 if is_x else Cx16) + (chunk if is_x else chunk - nxc) * 16 + 8 * (l >> 5) + e
+    n = ((l & 31) >> 3) * C + cb16 * 16 + rb * 8 + (l & 7)
+    base = ((((cb16 * nst + s) * 2 + ci) * 3 + dx) * (2 * 2 * 64 * 8))
+    for plane in (0, 1):
+      out = base + ((plane * 2 + rb) * 64 + l) * 8 + e
+      vec_in_stage = (out - (cb16 * nst + s) * (2 * 3 * 2 * 2 * 64 * 8)) // 8
+      assert vec_in_stage == (((ci * 3 + dx) * 2 + plane) * 2 + rb) * 64 + l
+      assert (out, ) not in seen
+      seen.add((out, ))
+    assert 0 <= cin < Cx16 + C and 0 <= n < 4 * C
