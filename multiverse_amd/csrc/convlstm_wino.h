@@ -153,9 +153,15 @@ __device__ __forceinline__ f16x8 wn_lane_shift(const f16x8& v, bool up, bool ok)
   return __builtin_bit_cast(f16x8, r);
 }
 
-template <int WAVES>
+// EPI = kEpiLstm: the forward step (LSTM epilogue).  EPI = kEpiStore: dgrad of the gate
+// convolution -- the operand is the gate gradient G [M][4C] as planes under its own exponent
+// (g_exp), the A rows are 64 OUTPUT COLUMNS (d h channels, then d x channels) instead of 4 gates
+// x 16 channels, the chunk range is one of n_kslice split-K slices, and the epilogue stores
+// y * 2^-(8 + e) to out0 / out1 (or their per-slice partial tiles).
+template <int WAVES, int EPI = kEpiLstm>
 __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, int cb16, int mt,
-                                                   f16x8* lds /* [2][kWnStageVec] */) {
+                                                   f16x8* lds /* [2][kWnStageVec] */,
+                                                   int kslice = 0, int n_kslice = 1) {
   constexpr int kWnPairs = WAVES * 32;             // pair-cells per workgroup
   const ConvLstm16Args& q = p.b;
   const ConvLstmArgs& a = q.f;
@@ -216,7 +222,7 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
   // lane -> (cell row, 16-byte piece) map: see the epilogue.  c is not written by this launch
   // (c' goes to the other buffer of the ping-pong pair).
   float* const ctile = reinterpret_cast<float*>(lds + 2 * kWnStageVec) + wave * 1024;
-  if (wave_live && !a.zero_state) {
+  if (EPI == kEpiLstm && wave_live && !a.zero_state) {
     const uint32_t rowb0 = (uint32_t)C * 4u;
     const int src_c0 = (valid && a.src_row_c) ? a.src_row_c[r] : r;
     uint32_t coff0[2];
@@ -240,7 +246,7 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
   }
 
   // ---- the 2-channel fp32 x chunk (regression encoder), direct form
-  if (a.x_small && wave_live) {
+  if (EPI == kEpiLstm && a.x_small && wave_live) {
     const int Cin = Cx + C, N4 = 4 * C;
     const int nk = 9 * Cx;
     const int n0 = (col >> 3) * C + cb16 * kWnCh + (col & 7);
@@ -272,8 +278,13 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
 
   // ---- f16 chunks of 16 input channels: x chunks first, then h chunks
   const int nxc = p.n_xc;
-  const int ck_lo = a.sx_corr ? nxc : 0;                    // sparse x: table terms instead
-  const int ck_hi = (p.abl & 1) ? ck_lo : (a.zero_state ? nxc : nxc + (C >> 4));
+  int ck_lo = a.sx_corr ? nxc : 0;                          // sparse x: table terms instead
+  int ck_hi = (p.abl & 1) ? ck_lo : (a.zero_state ? nxc : nxc + (C >> 4));
+  if (EPI == kEpiStore && n_kslice > 1) {                   // dgrad split-K: equal chunk ranges
+    const int per = (C >> 4) / n_kslice;
+    ck_lo = kslice * per;
+    ck_hi = ck_lo + per;
+  }
   if (ck_hi > ck_lo) {
     const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wpw) +
                         (size_t)cb16 * 2 * (nxc + (C >> 4)) * kWnStageVec;
@@ -392,6 +403,54 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
     return;
   }
 
+  if constexpr (EPI == kEpiStore) {
+    // registers of acc[c][rb]: output column cb*64 + rb*32 + 8*(reg >> 2) + 4*half + (reg & 3)
+    // of the lane's pair-cell, rows y0 (e = 0) and y0 + 1 (e = 1)
+    const float scale = ldexpf(1.0f, -(8 + (q.g_exp ? q.g_exp[0] : 0)));
+    const int M_total = a.rows * HW;
+    const int half_s = lane >> 5;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const bool okc = valid & (y0 + e < H);
+      const size_t m = (size_t)r * HW + (size_t)(y0 + e) * W + xpos;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int jg = 0; jg < 4; ++jg) {
+          const int col = cb16 * 64 + rb * 32 + 8 * jg + 4 * half_s;
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int reg = jg * 4 + j;
+            const float m0 = acc[0][rb][reg], m1 = acc[1][rb][reg], m2 = acc[2][rb][reg],
+                        m3 = acc[3][rb][reg];
+            v[j] = (e == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3) * scale;
+          }
+          float* dst = nullptr;
+          int stride = 0, cc = col;
+          if (col < a.out0_cols) {
+            stride = a.out0_cols;
+            dst = n_kslice > 1 ? (a.out0 ? q.part0 + (size_t)kslice * M_total * stride : nullptr)
+                               : a.out0;
+          } else if (col - a.out0_cols < a.out1_cols) {
+            stride = a.out1_cols; cc = col - a.out0_cols;
+            dst = n_kslice > 1 ? (a.out1 ? q.part1 + (size_t)kslice * M_total * stride : nullptr)
+                               : a.out1;
+          }
+          if (dst && okc) {
+            float* o = dst + m * stride + cc;
+            if (cc + 4 <= stride && (stride & 3) == 0) {
+              *reinterpret_cast<f32x4*>(o) = v;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (cc + j < stride) o[j] = v[j];
+            }
+          }
+        }
+    }
+    return;
+  }
   // ---------------------------------------------------------------- epilogue
   // registers of acc[c][rb]: gate = reg >> 2, channel = cb16*16 + rb*8 + 4*half + (reg & 3);
   // the lane's pair-cell gives rows y0 (e = 0) and y0 + 1 (e = 1).
@@ -652,6 +711,10 @@ static inline bool wino_enabled() {
   static const bool off = getenv("MV_WINO") && atoi(getenv("MV_WINO")) == 0;
   return !off;
 }
+static inline bool wino_dgrad_enabled() {
+  static const bool off = getenv("MV_WINO_DGRAD") && atoi(getenv("MV_WINO_DGRAD")) == 0;
+  return !off;
+}
 static inline bool wino_geometry_ok(const ConvLstmArgs& a) {
   return a.W > 0 && 32 % a.W == 0 && a.C % kWnCh == 0 && (a.Cx % 16 == 0 || a.x_small) &&
          a.H >= 2;
@@ -694,6 +757,109 @@ static inline void launch_convlstm_wino_steps(const ConvLstmWinoArgs* probs, int
                        stream, g);
   else
     hipLaunchKernelGGL(convlstm_step_wino_kernel<4>, dim3(total), dim3(256), wino_lds_bytes(4),
+                       stream, g);
+}
+
+// ------------------------------------------------------------------ dgrad in Winograd form
+// d[h | x][m][col] = conv3x3(G, W')[m][col], W'[ky'][kx'][n][col] = W[2 - ky'][2 - kx'][ci(col)][n]
+// (the transposed, tap-flipped kernel; col < C -> ci = Cx + col, else ci = col - C).  Pack of
+// its F(2,3) row transform: [cb64][stage][comp in stage][dx][plane][row block][lane][8]; A row
+// l & 31 of row block rb = output column cb64*64 + rb*32 + (l & 31); k = 8 (l >> 5) + e = gate
+// column of the chunk.  Columns past C + Cx are zero.
+__global__ void pack_wino_dgrad_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
+                                       int Cx, int C, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx & 7;
+  const int l = (idx >> 3) & 63;
+  const int rb = (idx >> 9) & 1;
+  size_t t = idx >> 10;                           // ((cb64 * nst + s) * 2 + ci) * 3 + dx
+  const int dx = (int)(t % 3); t /= 3;
+  const int ci2 = (int)(t & 1); t >>= 1;
+  const int N4 = 4 * C, nst = 2 * (N4 / 16);
+  const int s = (int)(t % nst), cb = (int)(t / nst);
+  const int chunk = s >> 1, comp = (s & 1) * 2 + ci2;
+  const int n = chunk * 16 + 8 * (l >> 5) + e;    // gate column = reduction index
+  const int col = cb * 64 + rb * 32 + (l & 31);
+  const int Cin = Cx + C;
+  int ci = -1;
+  if (col < C) ci = Cx + col;
+  else if (col - C < Cx) ci = col - C;
+  double u = 0.0;
+  if (ci >= 0) {
+    const double g0 = w[((size_t)((2 - 0) * 3 + (2 - dx)) * Cin + ci) * N4 + n];
+    const double g1 = w[((size_t)((2 - 1) * 3 + (2 - dx)) * Cin + ci) * N4 + n];
+    const double g2 = w[((size_t)((2 - 2) * 3 + (2 - dx)) * Cin + ci) * N4 + n];
+    u = comp == 0 ? g0 : (comp == 1 ? 0.5 * (g0 + g1 + g2)
+                                    : (comp == 2 ? 0.5 * (g0 - g1 + g2) : g2));
+  }
+  const double sv = u * 256.0;
+  const _Float16 v0 = (_Float16)sv;
+  const _Float16 v1 = (_Float16)(sv - (double)v0);
+  const size_t base = ((((size_t)cb * nst + s) * 2 + ci2) * 3 + dx) * (2 * 2 * 64 * 8);
+  out[base + ((size_t)(0 * 2 + rb) * 64 + l) * 8 + e] = v0;
+  out[base + ((size_t)(1 * 2 + rb) * 64 + l) * 8 + e] = v1;
+}
+static inline int wino_dgrad_colblocks(int Cx, int C) { return (C + Cx + 63) / 64; }
+static inline size_t wino_dgrad_wpack_elems(int Cx, int C) {   // in halves
+  return (size_t)wino_dgrad_colblocks(Cx, C) * 2 * (size_t)(4 * C / 16) * kWnStageVec * 8;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2)
+void convlstm_dgrad_wino_kernel(const ConvLstmWinoGroup g) {
+  extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
+  int block = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxGroup - 1; ++i)
+    if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
+  if (pi > 0) block -= g.block_end[pi - 1];
+  // block -> (column block of 64, k slice, row tile): combo = block % (ncb * nks), so that a
+  // combo's 768 KB of weight planes (C = 256) stay in the L2 of the XCDs block % 8 maps it to
+  auto run = [&](const ConvLstmWinoArgs& p) {
+    const int ncb = p.b.f.n_colblocks;               // host: wino_dgrad_colblocks (or C / 64)
+    const int nks = p.b.n_kslice > 1 ? p.b.n_kslice : 1;
+    const int combo = block % (ncb * nks);
+    convlstm_wino_body<WAVES, kEpiStore>(p, combo % ncb, block / (ncb * nks), lds, combo / ncb, nks);
+  };
+  switch (pi) {
+    case 0: run(g.p[0]); break;
+    case 1: run(g.p[1]); break;
+    case 2: run(g.p[2]); break;
+    default: run(g.p[3]); break;
+  }
+}
+
+static inline void launch_convlstm_wino_dgrads(const ConvLstmWinoArgs* probs, int n,
+                                               hipStream_t stream) {
+  ConvLstmWinoGroup g{};
+  g.n = n;
+  const int waves = wino_waves();
+  unsigned total = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = probs[i];
+    const ConvLstmArgs& a = probs[i].b.f;
+    const size_t Q = (size_t)a.rows * ((a.H + 1) / 2) * a.W;
+    const size_t pairs = (size_t)waves * 32;
+    total += (unsigned)((Q + pairs - 1) / pairs) * (unsigned)a.n_colblocks *
+             (unsigned)(probs[i].b.n_kslice > 1 ? probs[i].b.n_kslice : 1);
+    g.block_end[i] = (int32_t)total;
+  }
+  for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_dgrad_wino_kernel<8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_lds_bytes(8));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_dgrad_wino_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_lds_bytes(4));
+    return true;
+  }();
+  (void)attr;
+  if (waves == 8)
+    hipLaunchKernelGGL(convlstm_dgrad_wino_kernel<8>, dim3(total), dim3(512), wino_lds_bytes(8),
+                       stream, g);
+  else
+    hipLaunchKernelGGL(convlstm_dgrad_wino_kernel<4>, dim3(total), dim3(256), wino_lds_bytes(4),
                        stream, g);
 }
 

@@ -23,6 +23,7 @@ struct TrainChain {               // one ConvLSTM cell over its T steps
   DevBuf<float> gates;            // [T][N][K][4C]   activations -> G in place
   DevBuf<float> wdpack;           // dgrad weight pack
   DevBuf<_Float16> wd16;          // f16x3 compute mode: the same as two fp16 planes
+  DevBuf<_Float16> wdw;           // ... and in Winograd F(2,3) form (convlstm_wino.h, dgrad)
 };
 
 struct TrainScale {
@@ -362,6 +363,14 @@ void run_pack(mv_engine* e, TrainChain& ch) {
       ch.wd16.alloc(dh);
       hipLaunchKernelGGL(mv::pack_f16x3_dgrad_kernel, dim3(cdiv(dh / 2, 256)), dim3(256), 0,
                          e->stream, cc.kernel->dev.p, ch.wd16.p, Cx, C, dh / 2);
+      if (e->compute_mode == 1 && mv::wino_enabled() && mv::wino_dgrad_enabled()) {
+        const size_t dw = mv::wino_dgrad_wpack_elems(Cx, C);
+        ch.wdw.alloc(dw);
+        hipLaunchKernelGGL(mv::pack_wino_dgrad_kernel, dim3(cdiv(dw / 2, 256)), dim3(256), 0,
+                           e->stream, cc.kernel->dev.p, ch.wdw.p, Cx, C, dw / 2);
+      } else {
+        ch.wdw.release();
+      }
     }
     if (small) {
       const size_t n = (size_t)(C / mv::kChBlock) * mv::kBN * mv::kBK;
@@ -784,9 +793,33 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       }
     }
   }
+  // the Winograd F(2,3) form of the same convolution (two thirds of the MFMAs) when every
+  // problem of the group fits its tiling; MV_WINO_DGRAD=0 keeps the direct kernel
+  bool wino = e->compute_mode == 1 && mv::wino_enabled() && mv::wino_dgrad_enabled();
+  std::vector<mv::ConvLstmWinoArgs> pw;
+  if (wino) {
+    pw.resize(p16.size());
+    for (size_t i = 0; i < p16.size() && wino; ++i) {
+      const ConvLstmArgs& a = p16[i].f;
+      const int Creal = a.out0_cols;
+      if (!(a.W > 0 && 32 % a.W == 0 && a.H >= 2 && Creal % 64 == 0) || !chains[i]->wdw.p ||
+          (p16[i].n_kslice > 1 && (a.C / 16) % p16[i].n_kslice != 0)) {
+        wino = false;
+        break;
+      }
+      pw[i].b = p16[i];
+      pw[i].b.f.n_colblocks = (a.out1 && a.out1_cols > 0)
+                                  ? mv::wino_dgrad_colblocks(a.out1_cols, Creal) : Creal / 64;
+      pw[i].wpw = chains[i]->wdw.p;
+      pw[i].n_xc = 0;
+    }
+  }
   launch(e, "convlstm_dgrad", fl, by, [&] {
-    mv::launch_convlstm16_dgrads(p16.data(), (int)p16.size(), e->stream);
-  }, -1.0, 3.0);
+    if (wino)
+      mv::launch_convlstm_wino_dgrads(pw.data(), (int)pw.size(), e->stream);
+    else
+      mv::launch_convlstm16_dgrads(p16.data(), (int)p16.size(), e->stream);
+  }, -1.0, wino ? 2.0 : 3.0);
   mv::SumSlicesArgs sa{};
   unsigned blocks = 0;
   double sbytes = 0;
