@@ -1044,6 +1044,7 @@ struct SumSlicesArgs {
   unsigned long long n[2 * kMaxGroup];     // elements per slice (multiple of 4)
   unsigned block_end[2 * kMaxGroup];
   int nseg, nslice;
+  int nslice_seg[2 * kMaxGroup];           // per segment; 0 = nslice
 };
 __global__ __launch_bounds__(256)
 void sum_slices_kernel(const SumSlicesArgs a) {
@@ -1057,7 +1058,8 @@ void sum_slices_kernel(const SumSlicesArgs a) {
   if (i4 >= n4) return;
   const f32x4* src = reinterpret_cast<const f32x4*>(a.part[seg]);
   f32x4 v = src[i4];
-  for (int s2 = 1; s2 < a.nslice; ++s2) {
+  const int ns = a.nslice_seg[seg] > 0 ? a.nslice_seg[seg] : a.nslice;
+  for (int s2 = 1; s2 < ns; ++s2) {
     const f32x4 w = src[(size_t)s2 * n4 + i4];
     v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
   }

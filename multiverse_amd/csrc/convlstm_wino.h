@@ -62,6 +62,7 @@ struct ConvLstmWinoArgs {
   const _Float16* wpw;     // [cb16][stage][comp in stage 2][dx 3][plane 2][row block 2][lane 64][8]
   const float* w_hwio;     // the fp32 kernel [3,3,Cx+C,4C] (x_small chunk)
   int32_t n_xc;            // 16-channel x chunks present in the pack (0 when x_small)
+  int32_t nks_main, nks_x; // dgrad: split-K slices of the d h column blocks / of the d x blocks
   int32_t abl;             // MV_WINO_ABL (timing ablations, results are garbage): 1 = no main
                            // loop, 2 = no epilogue (accumulators folded into a never-taken
                            // store), 4 = no c loads, 8 = no c' / h' / gate stores, 16 = no h'
@@ -815,13 +816,29 @@ void convlstm_dgrad_wino_kernel(const ConvLstmWinoGroup g) {
   for (int i = 0; i < kMaxGroup - 1; ++i)
     if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
   if (pi > 0) block -= g.block_end[pi - 1];
-  // block -> (column block of 64, k slice, row tile): combo = block % (ncb * nks), so that a
-  // combo's 768 KB of weight planes (C = 256) stay in the L2 of the XCDs block % 8 maps it to
+  // block -> (column block of 64, k slice, row tile).  The d h column blocks first, their
+  // (block, slice) combos numbering EIGHT (C = 256: 4 blocks x 2 slices), combo = block % 8 =
+  // XCD: an L2 then keeps exactly one combo's weight planes (1.5 MB) while G streams through;
+  // the d x blocks follow as a region of their own with eight slices (384 KB per combo).  (One
+  // region of 5 blocks x 4 slices put five combos = 3.8 MB on every XCD's 4 MB L2.)
   auto run = [&](const ConvLstmWinoArgs& p) {
-    const int ncb = p.b.f.n_colblocks;               // host: wino_dgrad_colblocks (or C / 64)
-    const int nks = p.b.n_kslice > 1 ? p.b.n_kslice : 1;
-    const int combo = block % (ncb * nks);
-    convlstm_wino_body<WAVES, kEpiStore>(p, combo % ncb, block / (ncb * nks), lds, combo / ncb, nks);
+    const ConvLstmArgs& a = p.b.f;
+    const int ncb = a.n_colblocks;                   // host: wino_dgrad_colblocks (or C / 64)
+    const int ncm = a.out0_cols / 64;                // d h column blocks
+    const int nkm = p.nks_main > 1 ? p.nks_main : 1, nkx = p.nks_x > 1 ? p.nks_x : 1;
+    const int Q = a.rows * ((a.H + 1) >> 1) * a.W;
+    const int mtiles = (Q + WAVES * 32 - 1) / (WAVES * 32);
+    const int main_blocks = mtiles * ncm * nkm;
+    if (block < main_blocks) {
+      const int combo = block % (ncm * nkm);
+      convlstm_wino_body<WAVES, kEpiStore>(p, combo % ncm, block / (ncm * nkm), lds, combo / ncm,
+                                           nkm);
+    } else {
+      const int b2 = block - main_blocks, nxb = ncb - ncm;
+      const int combo = b2 % (nxb * nkx);
+      convlstm_wino_body<WAVES, kEpiStore>(p, ncm + combo % nxb, b2 / (nxb * nkx), lds,
+                                           combo / nxb, nkx);
+    }
   };
   switch (pi) {
     case 0: run(g.p[0]); break;
@@ -842,8 +859,10 @@ static inline void launch_convlstm_wino_dgrads(const ConvLstmWinoArgs* probs, in
     const ConvLstmArgs& a = probs[i].b.f;
     const size_t Q = (size_t)a.rows * ((a.H + 1) / 2) * a.W;
     const size_t pairs = (size_t)waves * 32;
-    total += (unsigned)((Q + pairs - 1) / pairs) * (unsigned)a.n_colblocks *
-             (unsigned)(probs[i].b.n_kslice > 1 ? probs[i].b.n_kslice : 1);
+    const unsigned mtiles = (unsigned)((Q + pairs - 1) / pairs);
+    const unsigned ncm = (unsigned)(a.out0_cols / 64), nxb = (unsigned)a.n_colblocks - ncm;
+    total += mtiles * (ncm * (unsigned)(probs[i].nks_main > 1 ? probs[i].nks_main : 1) +
+                       nxb * (unsigned)(probs[i].nks_x > 1 ? probs[i].nks_x : 1));
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;

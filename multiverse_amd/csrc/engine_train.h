@@ -759,6 +759,16 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
                            const std::vector<int>& slots, double fl, double by) {
   TrainState& t = TS(e);
   std::vector<mv::ConvLstm16Args> p16(probs.size());
+  // the Winograd F(2,3) form of the same convolution (two thirds of the MFMAs) when every
+  // problem of the group fits its tiling; MV_WINO_DGRAD=0 keeps the direct kernel
+  bool wino = e->compute_mode == 1 && mv::wino_enabled() && mv::wino_dgrad_enabled();
+  for (size_t i = 0; i < probs.size() && wino; ++i) {
+    const ConvLstmArgs& a = probs[i];
+    if (!(a.W > 0 && 32 % a.W == 0 && a.H >= 2 && a.out0_cols % 64 == 0 && (a.C / 16) % 8 == 0) ||
+        !chains[i]->wdw.p)
+      wino = false;
+  }
+  std::vector<mv::ConvLstmWinoArgs> pw(wino ? probs.size() : 0);
   for (size_t i = 0; i < probs.size(); ++i) {
     const ConvLstmArgs& a = probs[i];
     mv::ConvLstm16Args& q = p16[i];
@@ -779,11 +789,32 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     q.wp16 = chains[i]->wd16.p;
     q.n_xk = 0; q.n_hk = 9 * (a.C / 16); q.w_ksteps = q.n_hk;
     q.g_exp = t.gexp.p + slots[i];
+    const size_t M = (size_t)a.rows * a.H * a.W;
+    if (wino) {
+      // split-K of the Winograd form: (d h column block, slice) combos = 8 = the XCDs, the d x
+      // blocks a region of their own with eight slices (convlstm_dgrad_wino_kernel)
+      const int ncm = a.out0_cols / 64;
+      const bool need_dx = a.out1 && a.out1_cols > 0;
+      int nkm = std::max(1, 8 / ncm);
+      while ((a.C / 16) % nkm != 0) nkm /= 2;
+      const int nkx = need_dx ? 8 : 1;
+      mv::ConvLstmWinoArgs& w = pw[i];
+      w.nks_main = nkm; w.nks_x = nkx;
+      if (nkm > 1) { t.dpart0[i].alloc((size_t)nkm * M * a.out0_cols); q.part0 = t.dpart0[i].p; }
+      if (need_dx) {
+        t.dpart1[i].alloc((size_t)nkx * M * ((a.out1_cols + 3) / 4 * 4));
+        q.part1 = t.dpart1[i].p;
+      }
+      w.b = q;
+      w.b.f.n_colblocks = need_dx ? mv::wino_dgrad_colblocks(a.out1_cols, a.out0_cols) : ncm;
+      w.wpw = chains[i]->wdw.p;
+      w.n_xc = 0;
+      continue;
+    }
     // split-K over four channel-group ranges (see convlstm16_dgrad_dispatch)
     const int nstages = q.n_hk / 3;
     static const int ks_env = getenv("MV_DGRAD_KSLICES") ? atoi(getenv("MV_DGRAD_KSLICES")) : 4;
     if (ks_env > 1 && nstages % (2 * ks_env) == 0) {
-      const size_t M = (size_t)a.rows * a.H * a.W;
       q.n_kslice = ks_env;
       t.dpart0[i].alloc((size_t)ks_env * M * a.out0_cols);
       q.part0 = t.dpart0[i].p;
@@ -791,27 +822,6 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
         t.dpart1[i].alloc((size_t)ks_env * M * ((a.out1_cols + 3) / 4 * 4));
         q.part1 = t.dpart1[i].p;
       }
-    }
-  }
-  // the Winograd F(2,3) form of the same convolution (two thirds of the MFMAs) when every
-  // problem of the group fits its tiling; MV_WINO_DGRAD=0 keeps the direct kernel
-  bool wino = e->compute_mode == 1 && mv::wino_enabled() && mv::wino_dgrad_enabled();
-  std::vector<mv::ConvLstmWinoArgs> pw;
-  if (wino) {
-    pw.resize(p16.size());
-    for (size_t i = 0; i < p16.size() && wino; ++i) {
-      const ConvLstmArgs& a = p16[i].f;
-      const int Creal = a.out0_cols;
-      if (!(a.W > 0 && 32 % a.W == 0 && a.H >= 2 && Creal % 64 == 0) || !chains[i]->wdw.p ||
-          (p16[i].n_kslice > 1 && (a.C / 16) % p16[i].n_kslice != 0)) {
-        wino = false;
-        break;
-      }
-      pw[i].b = p16[i];
-      pw[i].b.f.n_colblocks = (a.out1 && a.out1_cols > 0)
-                                  ? mv::wino_dgrad_colblocks(a.out1_cols, Creal) : Creal / 64;
-      pw[i].wpw = chains[i]->wdw.p;
-      pw[i].n_xc = 0;
     }
   }
   launch(e, "convlstm_dgrad", fl, by, [&] {
@@ -825,10 +835,12 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
   double sbytes = 0;
   for (size_t i = 0; i < p16.size(); ++i) {
     const mv::ConvLstm16Args& q = p16[i];
-    if (q.n_kslice <= 1) continue;
+    const int ns0 = wino ? pw[i].nks_main : q.n_kslice, ns1 = wino ? pw[i].nks_x : q.n_kslice;
     const size_t M = (size_t)q.f.rows * q.f.H * q.f.W;
-    sa.nslice = q.n_kslice;
+    sa.nslice = 1;
     for (int o = 0; o < 2; ++o) {
+      const int ns = o ? ns1 : ns0;
+      if (ns <= 1) continue;
       float* out = o ? q.f.out1 : q.f.out0;
       const size_t n = M * (size_t)(o ? q.f.out1_cols : q.f.out0_cols);
       if (!out || n == 0) continue;
@@ -836,9 +848,10 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       sa.part[sa.nseg] = o ? q.part1 : q.part0;
       sa.out[sa.nseg] = out;
       sa.n[sa.nseg] = n;
+      sa.nslice_seg[sa.nseg] = ns;
       blocks += cdiv(n / 4, 256);
       sa.block_end[sa.nseg] = blocks;
-      sbytes += 4.0 * n * (q.n_kslice + 1);
+      sbytes += 4.0 * n * (ns + 1);
       ++sa.nseg;
     }
   }
