@@ -7,6 +7,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -107,3 +108,61 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
   r = np.load(os.path.join(str(tmp_path), "grad.npz"))
   assert float(r["worst"]) < 1e-4, float(r["worst"])
   assert float(r["dloss"]) < 1e-3 and float(r["dpgl"]) < 1e-3
+
+
+# ---- the shared-memory RCCL stand-in of the two-ranks-on-one-GPU test (tests/fake_rccl)
+
+_FAKE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "libfakerccl.so")
+
+
+@pytest.mark.skipif(not os.path.exists(_FAKE), reason="tests/fake_rccl not built (__graft_entry__.build())")
+def test_fake_rccl_exports_what_comm_h_binds():
+  """TEST INFRASTRUCTURE check: the stand-in carries the seven entry points
+  multiverse_amd/csrc/comm.h resolves by dlsym, ids are unique and tagged, group calls nest,
+  a world of one attaches without a peer, and foreign ids / dtypes are refused."""
+  import ctypes as C
+  lib = C.CDLL(_FAKE)
+  for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce",
+               "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+    assert getattr(lib, name)
+  lib.ncclGetErrorString.restype = C.c_char_p
+  ids = []
+  for _ in range(2):
+    buf = (C.c_uint8 * 128)()
+    assert lib.ncclGetUniqueId(buf) == 0
+    assert bytes(buf)[24:30] == b"mvfake"
+    ids.append(bytes(buf))
+  assert ids[0] != ids[1]
+  assert lib.ncclGroupEnd() != 0                       # not inside a group
+  assert lib.ncclGroupStart() == 0 and lib.ncclGroupStart() == 0
+  assert lib.ncclGroupEnd() == 0 and lib.ncclGroupEnd() == 0 and lib.ncclGroupEnd() != 0
+
+  class Id(C.Structure):
+    _fields_ = [("internal", C.c_uint8 * 128)]
+  comm = C.c_void_p()
+  uid = Id.from_buffer_copy(ids[0])
+  assert lib.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0 and comm.value
+  # float + sum only; a NULL buffer is an argument error, not a crash
+  assert lib.ncclAllReduce(None, None, C.c_size_t(4), 7, 0, comm, None) != 0
+  assert b"fake rccl" in lib.ncclGetErrorString(5)
+  assert lib.ncclCommDestroy(comm) == 0
+  foreign = Id()                                       # an id this library did not draw
+  assert lib.ncclCommInitRank(C.byref(comm), 1, foreign, 0) != 0
+  assert lib.ncclCommInitRank(C.byref(comm), 2, uid, 2) != 0      # rank out of range
+
+
+@pytest.mark.skipif(not os.path.exists(_FAKE), reason="tests/fake_rccl not built (__graft_entry__.build())")
+def test_mv_rccl_lib_selects_exactly_that_library():
+  """MV_RCCL_LIB (comm.h): the engine library binds the named RCCL and no other -- here the
+  stand-in, recognisable by the tag in the unique id it hands out; a missing file is reported."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  code = ("import sys; sys.path.insert(0, %r)\n"
+          "from multiverse_amd import _lib\n"
+          "print(_lib.comm_unique_id()[24:30])\n" % root)
+  out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, MV_RCCL_LIB=_FAKE))
+  assert b"mvfake" in out
+  r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MV_RCCL_LIB="/nonexistent/librccl.so"),
+                     capture_output=True)
+  assert r.returncode != 0 and b"MV_RCCL_LIB" in r.stderr
