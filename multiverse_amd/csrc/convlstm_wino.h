@@ -34,10 +34,10 @@
 // are 16-byte vectors, and the h' operand planes leave the registers as 8-byte stores that
 // a wave lays down as contiguous 512-byte runs (no LDS transpose).  A wave owns 32
 // pair-cells (64 cells) x 16 channels x 4 gates x 4 Winograd components = 128
-// accumulator registers; a workgroup = 8 waves = 256 pair-cells of one 16-channel column
-// block, sharing that block's weight stage (24 KB = 2 components x 3 dx x 2 planes x 2
+// accumulator registers; a workgroup = 4 (or 8) waves = 128 (256) pair-cells of one 16-channel
+// column block, sharing that block's weight stage (24 KB = 2 components x 3 dx x 2 planes x 2
 // row blocks) through a double LDS buffer filled by LDS-DMA; 36 MFMAs per wave and stage.
-// One workgroup per CU (2 waves per SIMD, <= 256 registers).
+// Two 4-wave workgroups (or one 8-wave workgroup) per CU: 2 waves per SIMD, <= 256 registers.
 //
 // The regression encoder's 2-channel pixel-offset input keeps its fp32 chunk
 // (v_mfma_f32_32x32x2_f32, weights x 2^16 read straight from the HWIO kernel): direct
@@ -48,8 +48,8 @@
 namespace mv {
 
 // Waves per workgroup (template parameter WAVES): 8 waves = 256 pair-cells share one weight
-// stage, ONE workgroup per CU; 4 waves = 128 pair-cells, TWO workgroups per CU whose
-// barriers and transform phases de-phase each other at twice the stage traffic from L2.
+// stage, ONE workgroup per CU; 4 waves (the default) = 128 pair-cells, TWO workgroups per CU at
+// twice the stage traffic from L2.
 constexpr int kWnCh = 16;                            // output channels per workgroup
 constexpr int kWnStageVec = 2 * 3 * 2 * 2 * 64;      // 16-byte vectors per LDS stage (24 KB)
 constexpr uint32_t kWnStageBytes = kWnStageVec * 16;
@@ -691,10 +691,12 @@ void convlstm_step_wino_kernel(const ConvLstmWinoGroup g) {
   }
 }
 
-// MV_WINO_WAVES = 8 | 4: waves per workgroup (A/B runs)
+// MV_WINO_WAVES = 4 | 8: waves per workgroup.  4 (two workgroups per CU, twice the L2 -> LDS
+// weight traffic) measured +2 ... +4 % on the greedy workload in five same-box sessions, equal
+// on beam-20 and training: the default.
 static inline int wino_waves() {
-  static const int w = getenv("MV_WINO_WAVES") ? atoi(getenv("MV_WINO_WAVES")) : 8;
-  return w == 4 ? 4 : 8;
+  static const int w = getenv("MV_WINO_WAVES") ? atoi(getenv("MV_WINO_WAVES")) : 4;
+  return w == 8 ? 8 : 4;
 }
 
 static inline size_t wino_lds_bytes(int waves) {
