@@ -57,30 +57,44 @@ struct H2gQGroup {
   int32_t n;
 };
 
-__device__ __forceinline__ void h2g_q_body(const H2gQProblem& a, int block, int C) {
+// One wave = 32 cells.  Round 1-3 form: two 16-byte loads of h' in flight per wave, each
+// touching 32 cell rows (1 KB apart) -- ~2 KB per wave, ~22 KB per CU in flight, and the four
+// loads that share a 128-byte line spread over two loop trips: 2.6 TB/s at batch 64 (latency
+// x bytes in flight), 3.5 TB/s at 2 560 beam rows.  Now the wave issues the loads of a whole
+// 256-channel chunk (32 x 16 bytes per lane = the cell's full 1 KB row: 128 registers) before
+// the MFMA chain starts, the four loads of a line back to back, and the packed weights
+// (C x 128 bytes, shared by the workgroup's four waves) wait in LDS instead of competing
+// for the vector memory queue.  Same products in the same order: bit-identical results.
+template <int NK>        // k-steps (8 channels each) per chunk: 32, or 16 when C == 128
+__device__ __forceinline__ void h2g_q_body(const H2gQProblem& a, int block, int C, float* wl) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    const f32x4* wg = reinterpret_cast<const f32x4*>(a.wq);
+    f32x4* wd = reinterpret_cast<f32x4*>(wl);
+    for (int i = threadIdx.x; i < C * 8; i += 256) wd[i] = wg[i];
+  }
+  __syncthreads();
   const int m_wave = block * 128 + wave * 32;
   if (m_wave >= a.cells) return;
   const int m = m_wave + (lane & 31);
   const float* src = a.h + (size_t)(m < a.cells ? m : 0) * C + (lane >> 5) * 4;
-  const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wq) + lane;
+  const f32x4* wsrc = reinterpret_cast<const f32x4*>(wl) + lane;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const int nk = C >> 3;
-  f32x4 a0 = *reinterpret_cast<const f32x4*>(src), b0 = wsrc[0];
-  for (int kk = 0; kk < nk; kk += 2) {               // C/8 is even (C % 32 == 0)
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (kk + 1) * 8);
-    const f32x4 b1 = wsrc[(kk + 1) * 64];
+  for (int c0 = 0; c0 < C; c0 += NK * 8) {
+    f32x4 av[NK];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc, 0, 0, 0);
-    const int kn = min(kk + 2, nk - 1);
-    a0 = *reinterpret_cast<const f32x4*>(src + kn * 8);
-    b0 = wsrc[kn * 64];
+    for (int kk = 0; kk < NK; ++kk) av[kk] = *reinterpret_cast<const f32x4*>(src + c0 + kk * 8);
+    // the machine scheduler would sink every load to its use (2 in flight, 40 registers)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc, 0, 0, 0);
+    for (int kk = 0; kk < NK; ++kk) {
+      const f32x4 bv = wsrc[((c0 >> 3) + kk) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][j], bv[j], acc, 0, 0, 0);
+    }
   }
   const int col = lane & 31, QS = 9 * a.P;
   if (col < QS) {
@@ -93,8 +107,10 @@ __device__ __forceinline__ void h2g_q_body(const H2gQProblem& a, int block, int 
   }
 }
 
+template <int NK>
 __global__ __launch_bounds__(256)
 void h2g_q_kernel(const H2gQGroup g, int C) {
+  extern __shared__ __attribute__((aligned(16))) float h2g_wlds[];
   int block = blockIdx.x;
   int pi = 0;
 #pragma unroll
@@ -102,13 +118,14 @@ void h2g_q_kernel(const H2gQGroup g, int C) {
     if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
   if (pi > 0) block -= g.block_end[pi - 1];
   switch (pi) {
-    case 0: h2g_q_body(g.p[0], block, C); break;
-    case 1: h2g_q_body(g.p[1], block, C); break;
-    case 2: h2g_q_body(g.p[2], block, C); break;
-    default: h2g_q_body(g.p[3], block, C); break;
+    case 0: h2g_q_body<NK>(g.p[0], block, C, h2g_wlds); break;
+    case 1: h2g_q_body<NK>(g.p[1], block, C, h2g_wlds); break;
+    case 2: h2g_q_body<NK>(g.p[2], block, C, h2g_wlds); break;
+    default: h2g_q_body<NK>(g.p[3], block, C, h2g_wlds); break;
   }
 }
 
+// C % 128 == 0 (mv_create: hidden_size 128 / 256 / 512)
 static inline void launch_h2g_q(const H2gQProblem* probs, int n, int C, hipStream_t stream) {
   H2gQGroup g{};
   g.n = n;
@@ -119,7 +136,11 @@ static inline void launch_h2g_q(const H2gQProblem* probs, int n, int C, hipStrea
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kTailMax; ++i) g.block_end[i] = (int32_t)total;
-  hipLaunchKernelGGL(h2g_q_kernel, dim3(total), dim3(256), 0, stream, g, C);
+  const size_t lds = (size_t)C * 128;            // <= 64 KB
+  if (C % 256 == 0)
+    hipLaunchKernelGGL(h2g_q_kernel<32>, dim3(total), dim3(256), lds, stream, g, C);
+  else
+    hipLaunchKernelGGL(h2g_q_kernel<16>, dim3(total), dim3(256), lds, stream, g, C);
 }
 
 // ---- grid_emb with 16-byte plane stores.  item = (cell, group of 8 output channels);
