@@ -28,7 +28,8 @@ sub-object of the ONE JSON line with its own `value`, `ms_per_step`, `steps` and
                   scene maps; the reference's own grids are the 18x32 / 9x16 of the headline)
   bf16            configs[4] (inference half): the headline forward with bf16 operands,
                   scene-feature 1x1 projections on MFMA -- REDUCED precision
-  train_bf16_n64  configs[4]: training step, batch 64 per GPU, bf16 forward, 1x1 projections
+  train_bf16_n64  configs[4]: training step, batch 64 per GPU, bf16 forward and dgrad, wgrad on
+                  one fp16 plane per operand, 1x1 projections
   host_path       the headline batch through the host boundary (Tester.step, dense and
                   compact feeds) next to the resident-input rate      [rank 0, N=1 only]
 (`--no-sub` skips them; `--workload beam|train` makes one of them the headline instead.)
@@ -369,8 +370,10 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
                     else "no all-reduce (1 rank)",
                     "forward, dgrad and wgrad on the fp16 matrix pipe (f16x3 split, "
                     "fp32-class error)" if f16 else
-                    "BASELINE configs[4]: forward in bf16 (one MFMA per product, reduced "
-                    "precision), dgrad and wgrad on the f16x3 split" if bf16
+                    "BASELINE configs[4]: forward and dgrad on bf16 operands, wgrad on the "
+                    "leading fp16 plane of each operand (one MFMA per product everywhere, "
+                    "fp32 accumulate, reduced precision; MV_BF16_BWD=0: backward on the "
+                    "f16x3 split)" if bf16
                     else "fp32 matrix pipe"))
   else:
     metric = ("trajectories/sec (8-obs/12-pred, multi-scale %s grid, greedy forward)"
@@ -403,7 +406,8 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
       "dtype": ("bf16 (gate-convolution operands in bf16, one MFMA per product, fp32 "
                 "accumulate; fp32 state and every other kernel; REDUCED precision: logits within "
                 "3e-2 of their range, tests/test_gpu_bf16.py)" + (
-                    "; backward GEMMs on the f16x3 split" if train else "") if bf16 else
+                    "; dgrad on bf16 planes, wgrad on one fp16 plane per operand: gradient "
+                    "cosine vs the fp32 oracle > 0.98 asserted" if train else "") if bf16 else
                 "f16x3 (fp32 operands as two pre-scaled fp16 planes, 3 fp16 MFMAs per "
                 "product, fp32 accumulate and state; measured error vs fp64 <= the fp32-MFMA "
                 "path's, argmax / beam ids bit-exact)" if (f16 and not train) else

@@ -636,7 +636,8 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   }
 
   if constexpr (EPI == kEpiStore) {
-    const float scale = ldexpf(1.0f, -(8 + (p.g_exp ? p.g_exp[0] : 0)));
+    // NPL == 1: bf16 operands are unscaled (bf16 has fp32's exponent range)
+    const float scale = NPL == 2 ? ldexpf(1.0f, -(8 + (p.g_exp ? p.g_exp[0] : 0))) : 1.0f;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int col = cb * kBN + g * 32 + (lane_e & 31);
@@ -954,7 +955,7 @@ static inline void launch_convlstm_bf16_steps(const ConvLstm16Args* probs, int n
 // dgrad on the fp16 matrix pipe: d[h | x] = conv3x3(G, W^T flipped) with G as two
 // fp16 planes under a per-tensor power-of-two scale (split_planes_dyn_kernel) and
 // the transposed, tap-flipped kernel as planes (pack_f16x3_dgrad_kernel).
-template <bool SHIFT>
+template <bool SHIFT, int NPL = 2>
 __device__ __forceinline__ void convlstm16_dgrad_dispatch(const ConvLstm16Args& p, int block,
                                                           f16x8* lds) {
   // block -> (column block, k slice, row tile).  Full-width column blocks first,
@@ -979,11 +980,11 @@ __device__ __forceinline__ void convlstm16_dgrad_dispatch(const ConvLstm16Args& 
     cb = ncb - 1; ks = b2 % nks; mt = b2 / nks;
   }
   if (cb == ncb - 1 && p.f.ng_last == 1)
-    convlstm16_lds_body<kEpiStore, 1, 2, SHIFT>(p, cb, mt, ks, nks, lds);
+    convlstm16_lds_body<kEpiStore, 1, NPL, SHIFT>(p, cb, mt, ks, nks, lds);
   else if (cb == ncb - 1 && p.f.ng_last == 2)
-    convlstm16_lds_body<kEpiStore, 2, 2, SHIFT>(p, cb, mt, ks, nks, lds);
+    convlstm16_lds_body<kEpiStore, 2, NPL, SHIFT>(p, cb, mt, ks, nks, lds);
   else
-    convlstm16_lds_body<kEpiStore, 4, 2, SHIFT>(p, cb, mt, ks, nks, lds);
+    convlstm16_lds_body<kEpiStore, 4, NPL, SHIFT>(p, cb, mt, ks, nks, lds);
 }
 
 template <bool SHIFT>
@@ -1004,6 +1005,27 @@ void convlstm_dgrad_f16x3_kernel(const ConvLstm16Group g) {
   }
 }
 
+// The same dgrad with ONE bf16 plane per operand (compute mode 2): G and the transposed,
+// tap-flipped kernel as bf16 bit patterns (split_plane_bf16_kernel, pack_bf16_dgrad_kernel),
+// one v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate, nothing scaled.
+template <bool SHIFT>
+__global__ __launch_bounds__(kThreads16, MV_CONV_MINWAVES)
+void convlstm_dgrad_bf16_kernel(const ConvLstm16Group g) {
+  __shared__ f16x8 lds[MV_BF16_UNITS * kStageVec];
+  int block = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxGroup - 1; ++i)
+    if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
+  if (pi > 0) block -= g.block_end[pi - 1];
+  switch (pi) {
+    case 0: convlstm16_dgrad_dispatch<SHIFT, 1>(g.p[0], block, lds); break;
+    case 1: convlstm16_dgrad_dispatch<SHIFT, 1>(g.p[1], block, lds); break;
+    case 2: convlstm16_dgrad_dispatch<SHIFT, 1>(g.p[2], block, lds); break;
+    default: convlstm16_dgrad_dispatch<SHIFT, 1>(g.p[3], block, lds); break;
+  }
+}
+
 static inline unsigned convlstm16_blocks(const ConvLstmArgs& a) {
   const size_t M = (size_t)a.rows * a.H * a.W;
   return (unsigned)((M + kBlockRows16 - 1) / kBlockRows16) * (unsigned)a.n_colblocks;
@@ -1021,7 +1043,7 @@ static inline unsigned convlstm16_step_blocks(const ConvLstmArgs& a, int mode) {
 }
 
 static inline void launch_convlstm16_dgrads(const ConvLstm16Args* probs, int n,
-                                            hipStream_t stream) {
+                                            hipStream_t stream, bool bf16 = false) {
   ConvLstm16Group g{};
   g.n = n;
   unsigned total = 0;
@@ -1031,7 +1053,12 @@ static inline void launch_convlstm16_dgrads(const ConvLstm16Args* probs, int n,
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
-  if (conv_group_shift(probs, n))
+  const bool shift = conv_group_shift(probs, n);
+  if (bf16 && shift)
+    hipLaunchKernelGGL(convlstm_dgrad_bf16_kernel<true>, dim3(total), dim3(kThreads16), 0, stream, g);
+  else if (bf16)
+    hipLaunchKernelGGL(convlstm_dgrad_bf16_kernel<false>, dim3(total), dim3(kThreads16), 0, stream, g);
+  else if (shift)
     hipLaunchKernelGGL(convlstm_dgrad_f16x3_kernel<true>, dim3(total), dim3(kThreads16), 0, stream, g);
   else
     hipLaunchKernelGGL(convlstm_dgrad_f16x3_kernel<false>, dim3(total), dim3(kThreads16), 0, stream, g);
@@ -1096,6 +1123,48 @@ __global__ void pack_f16x3_dgrad_kernel(const float* __restrict__ w, _Float16* _
 }
 static inline size_t f16x3_dgrad_wpack_elems(int Cx, int C) {   // in halves
   return (size_t)convlstm_dgrad_colblocks(Cx, C) * 9 * (size_t)(4 * C / 16) * 2 * 4 * 64 * 8;
+}
+// The same pack as ONE unscaled bf16 plane: [cb][k-step][sub-block][lane][8]
+__global__ void pack_bf16_dgrad_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
+                                       int Cx, int C, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx & 7;
+  const int l = (idx >> 3) & 63;
+  const int g = (idx >> 9) & 3;
+  const size_t t = idx >> 11;                    // cb * nk + s
+  const int nk = 9 * (4 * C / 16);
+  const int s = t % nk, cb = t / nk;
+  const int grp = s / 9, tap = s - grp * 9;
+  const int k = 8 * (l >> 5) + e;
+  const int n = grp * 16 + k;
+  const int col = cb * kBN + g * 32 + (l & 31);
+  const int Cin = Cx + C, N4 = 4 * C;
+  int ci = -1;
+  if (col < C) ci = Cx + col;
+  else if (col - C < Cx) ci = col - C;
+  out[idx] = bf16_as_half((ci < 0) ? 0.f : w[((size_t)(8 - tap) * Cin + ci) * N4 + n]);
+}
+static inline size_t bf16_dgrad_wpack_elems(int Cx, int C) {    // in halves
+  return f16x3_dgrad_wpack_elems(Cx, C) / 2;
+}
+// fp32 [M][C] -> one bf16 plane in the tiled operand layout (plane_index)
+__global__ void split_plane_bf16_kernel(const float* __restrict__ in, _Float16* __restrict__ p0,
+                                        int M, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8n = C >> 3;
+  const size_t per_tile = (size_t)32 * c8n;
+  const size_t tb = i / per_tile;
+  const int r = (int)(i - tb * per_tile);
+  const int c8 = r >> 5, cell = r & 31;
+  const long long m = (long long)tb * 32 + cell;
+  if (m >= M) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(in + (size_t)m * C + c8 * 8);
+  const f32x4 v0 = src[0], v1 = src[1];
+  f16x8 a;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = bf16_as_half(j < 4 ? v0[j] : v1[j - 4]);
+  *reinterpret_cast<f16x8*>(p0 + plane_index(m, c8 * 8, C)) = a;
 }
 
 // fp32 -> two fp16 planes under a per-tensor power-of-two scale 2^e chosen from

@@ -176,17 +176,25 @@ struct Wgrad16Args {
 
 constexpr int kWg16Pitch = 40;                         // halves per LDS row (32 cells + pad)
 constexpr int kWg16Tile = 2 * 128 * kWg16Pitch;        // halves per operand tile (2 planes)
+// NP = MFMAs per product: 3 = the f16x3 split (both planes of both operands); 1 = the leading
+// fp16 plane of each operand only -- 11 significand bits, fp32 accumulate: the backward of
+// the reduced-precision compute mode (BASELINE.json configs[4]; the lower planes are neither
+// loaded nor staged, a tile is half the LDS).
+template <int NP> constexpr int wg16_tile() { return (NP == 1 ? 1 : 2) * 128 * kWg16Pitch; }
 
 // XROWS = false: h rows.  A workgroup's 128 tile rows are 128 channels of ONE tap,
 //   so "tap row outside the image" is uniform per k-step and its MFMAs are skipped.
 // XROWS = true: x rows (Ca = Cx channels, any width).  Tile rows enumerate
 //   (tap, channel) pairs, R = tap * Cx + ci < 9 Cx, so each row has its own operand
 //   copy / row shift and an invalid (row, k-step) is staged as zeros instead.
-template <bool XROWS>
+template <bool XROWS, int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds_raw[];   // [buffer][A | G][tile]
-  _Float16 (*lds)[2][kWg16Tile] = reinterpret_cast<_Float16 (*)[2][kWg16Tile]>(lds_raw);
+  constexpr int kTile = wg16_tile<NP>();
+  constexpr int NQ = NP == 1 ? 2 : 4;                  // copy slots per thread and operand
+  constexpr int NPL = NP == 1 ? 1 : 2;                 // planes staged
+  _Float16 (*lds)[2][kTile] = reinterpret_cast<_Float16 (*)[2][kTile]>(lds_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -224,11 +232,11 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
 
   // per-thread copy slots: q -> plane q>>1, tile row (q&1)*64 + tid>>2, 8-cell vector tid&3
   const int vec = tid & 3;
-  const _Float16* ap[4];
-  const _Float16* gp[4];
-  int dyq[4];                                          // XROWS: row shift of slot q (huge = dead row)
+  const _Float16* ap[NQ];
+  const _Float16* gp[NQ];
+  int dyq[NQ];                                         // XROWS: row shift of slot q (huge = dead row)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int plane = q >> 1, row = (q & 1) * 64 + (tid >> 2);
     gp[q] = a.gt + (size_t)plane * N4 * Mrow + (size_t)(n0 + row) * 32 + vec * 8;
     if (XROWS) {
@@ -259,9 +267,9 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
   // under this kernel's streaming load (both operands are read once, nothing is reused across
   // the reduction): MFMA busy 0.425 at 1.7 waves / SIMD, LDS and L2 far from saturated.  The
   // workgroup count per CU is set by LDS (2 x 80 KB), so the 32 extra VGPRs are free.
-  f16x8 sa[4], sg[4], sb[4], sgb[4];
+  f16x8 sa[NQ], sg[NQ], sb[NQ], sgb[NQ];
   bool cv0 = false, cv1 = false;                       // h rows: k-step validity, stage in LDS
-  auto stage_load = [&](int st, f16x8 (&ra)[4], f16x8 (&rg)[4], bool& nv0, bool& nv1) {
+  auto stage_load = [&](int st, f16x8 (&ra)[NQ], f16x8 (&rg)[NQ], bool& nv0, bool& nv1) {
     const int ksb = ks0 + 2 * st;
     const int y0 = ly; advance(ly, lxk);
     const int y1 = ly; advance(ly, lxk);
@@ -278,13 +286,13 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
       nv1 = in1 & ((unsigned)(y1 + dy_u) < (unsigned)H);
       const int sh = ((vec & 2) ? nv1 : nv0) ? dy_u * W : 0;   // skipped k-step: unshifted
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         ra[q] = *reinterpret_cast<const f16x8*>(ap[q] + aofs(m0 + vec * 8 + sh));
         rg[q] = *reinterpret_cast<const f16x8*>(gp[q] + gofs);
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const bool ok = insel & ((unsigned)(ysel + dyq[q]) < (unsigned)H);
         f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (ok) v = *reinterpret_cast<const f16x8*>(ap[q] + aofs(m0 + vec * 8 + dyq[q] * W));
@@ -294,9 +302,9 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
       nv0 = in0; nv1 = in1;
     }
   };
-  auto stage_store = [&](int buf, const f16x8 (&ra)[4], const f16x8 (&rg)[4]) {
+  auto stage_store = [&](int buf, const f16x8 (&ra)[NQ], const f16x8 (&rg)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int plane = q >> 1, row = (q & 1) * 64 + (tid >> 2);
       const int o = (plane * 128 + row) * kWg16Pitch + vec * 8;
       *reinterpret_cast<f16x8*>(&lds[buf][0][o]) = ra[q];
@@ -310,26 +318,28 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       if (kk ? cv1 : cv0) {                   // uniform
-        f16x8 fa[2][2], fg[2][2];             // [sub-block][plane]
+        f16x8 fa[2][NPL], fg[2][NPL];         // [sub-block][plane]
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
+          for (int pl = 0; pl < NPL; ++pl) {
             fa[s2][pl] = *reinterpret_cast<const f16x8*>(
                 A + (pl * 128 + wi * 64 + s2 * 32 + li) * kWg16Pitch + kk * 16 + k8);
             fg[s2][pl] = *reinterpret_cast<const f16x8*>(
                 G + (pl * 128 + wj * 64 + s2 * 32 + li) * kWg16Pitch + kk * 16 + k8);
           }
+        if constexpr (NP == 3) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
           for (int y = 0; y < 2; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][1], fg[y][0], acc[x][y], 0, 0, 0);
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][NPL - 1], fg[y][0], acc[x][y], 0, 0, 0);
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
           for (int y = 0; y < 2; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][0], fg[y][1], acc[x][y], 0, 0, 0);
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[x][0], fg[y][NPL - 1], acc[x][y], 0, 0, 0);
+        }
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -389,6 +399,7 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
 }
 
 constexpr size_t kWg16LdsBytes = (size_t)2 * 2 * kWg16Tile * sizeof(_Float16);   // 80 KB
+constexpr size_t kWg16LdsBytes1 = (size_t)2 * 2 * wg16_tile<1>() * sizeof(_Float16);   // NP = 1: 40 KB
 
 static inline bool wgrad16_ok(int W, int C) { return (W % 16) == 0 && (C % 128) == 0; }
 

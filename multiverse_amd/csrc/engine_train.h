@@ -24,7 +24,17 @@ struct TrainChain {               // one ConvLSTM cell over its T steps
   DevBuf<float> wdpack;           // dgrad weight pack
   DevBuf<_Float16> wd16;          // f16x3 compute mode: the same as two fp16 planes
   DevBuf<_Float16> wdw;           // ... and in Winograd F(2,3) form (convlstm_wino.h, dgrad)
+  DevBuf<_Float16> wdb;           // bf16 compute mode: one bf16 plane (pack_bf16_dgrad_kernel)
 };
+
+// bf16 compute mode (BASELINE.json configs[4]: reduced-precision operands, fp32 accumulate):
+// the backward runs on one plane per operand as well -- dgrad on bf16 planes of G and of the
+// kernel, wgrad on the leading fp16 plane of each operand -- one MFMA per product instead of
+// the f16x3 split's three.  MV_BF16_BWD=0 keeps the backward on the f16x3 split (rounds 2-3).
+static bool bf16_bwd_enabled() {
+  static const bool on = !(getenv("MV_BF16_BWD") && atoi(getenv("MV_BF16_BWD")) == 0);
+  return on;
+}
 
 struct TrainScale {
   DevBuf<float> hs[2], cs[2];     // branch 0 = class, 1 = regression: [To+Tp+1][N][K][C]
@@ -351,14 +361,21 @@ void run_pack(mv_engine* e, TrainChain& ch) {
                          e->stream, cc.kernel->dev.p, cc.wp16.p, Cx, Cx16, C, threads);
       if (mv::wino_enabled() && C_multiple_ok(e, cc)) pack_wino(e, cc);
       cc.wpb.release(); cc.wx32u.release();
-    } else {                    // bf16 forward; dgrad / wgrad stay on the f16x3 split
+    } else {                    // bf16 forward (the backward's packs: below)
       const size_t halves = mv::bf16_wpack_elems(Cx16, C);
       cc.wpb.alloc(halves);
       hipLaunchKernelGGL(mv::pack_bf16_kernel, dim3(cdiv(halves, 256)), dim3(256), 0,
                          e->stream, cc.kernel->dev.p, cc.wpb.p, Cx, Cx16, C, halves);
       cc.wp16.release(); cc.wx32.release(); cc.wpw.release();
     }
-    {
+    if (e->compute_mode == 2 && bf16_bwd_enabled()) {
+      const size_t db = mv::bf16_dgrad_wpack_elems(Cx, C);
+      ch.wdb.alloc(db);
+      hipLaunchKernelGGL(mv::pack_bf16_dgrad_kernel, dim3(cdiv(db, 256)), dim3(256), 0,
+                         e->stream, cc.kernel->dev.p, ch.wdb.p, Cx, C, db);
+      ch.wd16.release(); ch.wdw.release();
+    } else {
+      ch.wdb.release();
       const size_t dh = mv::f16x3_dgrad_wpack_elems(Cx, C);
       ch.wd16.alloc(dh);
       hipLaunchKernelGGL(mv::pack_f16x3_dgrad_kernel, dim3(cdiv(dh / 2, 256)), dim3(256), 0,
@@ -761,6 +778,7 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
   std::vector<mv::ConvLstm16Args> p16(probs.size());
   // the Winograd F(2,3) form of the same convolution (two thirds of the MFMAs) when every
   // problem of the group fits its tiling; MV_WINO_DGRAD=0 keeps the direct kernel
+  const bool bf = e->compute_mode == 2 && bf16_bwd_enabled();
   bool wino = e->compute_mode == 1 && mv::wino_enabled() && mv::wino_dgrad_enabled();
   for (size_t i = 0; i < probs.size() && wino; ++i) {
     const ConvLstmArgs& a = probs[i];
@@ -779,16 +797,21 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     const size_t gcells = (size_t)a.rows * a.H * a.W;
     MV_REQUIRE(t.g16[i].n >= 2 * pst, "internal: G plane scratch");
     _Float16* p0 = t.g16[i].p + mv::kPlanePad;
-    launch(e, "split_planes", 0, 8.0 * n, [&] {
+    launch(e, "split_planes", 0, (bf ? 6.0 : 8.0) * n, [&] {
+      if (bf)
+        hipLaunchKernelGGL(mv::split_plane_bf16_kernel, dim3(mv::split_planes_blocks(gcells, a.C)),
+                           dim3(256), 0, e->stream, a.h, p0, (int)gcells, a.C);
+      else
       hipLaunchKernelGGL(mv::split_planes_dyn_kernel, dim3(mv::split_planes_blocks(gcells, a.C)),
                          dim3(256), 0, e->stream, a.h, p0, p0 + pst, (int)gcells, a.C,
                          t.gmax.p + (size_t)slots[i] * 64, t.gexp.p + slots[i]);
     });
     q.h16 = p0; q.h_plane_stride = (int64_t)pst;
     q.x16 = nullptr; q.x_plane_stride = 0;
-    q.wp16 = chains[i]->wd16.p;
+    q.wp16 = bf ? chains[i]->wdb.p : chains[i]->wd16.p;
+    MV_REQUIRE(q.wp16, "internal: dgrad weight pack of the compute mode is missing");
     q.n_xk = 0; q.n_hk = 9 * (a.C / 16); q.w_ksteps = q.n_hk;
-    q.g_exp = t.gexp.p + slots[i];
+    q.g_exp = bf ? nullptr : t.gexp.p + slots[i];
     const size_t M = (size_t)a.rows * a.H * a.W;
     if (wino) {
       // split-K of the Winograd form: (d h column block, slice) combos = 8 = the XCDs, the d x
@@ -814,6 +837,8 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     // split-K over four channel-group ranges (see convlstm16_dgrad_dispatch)
     const int nstages = q.n_hk / 3;
     static const int ks_env = getenv("MV_DGRAD_KSLICES") ? atoi(getenv("MV_DGRAD_KSLICES")) : 4;
+    if (bf)
+      MV_REQUIRE(nstages % MV_BF16_UNITS == 0, "internal: bf16 dgrad stage count %d", nstages);
     if (ks_env > 1 && nstages % (2 * ks_env) == 0) {
       q.n_kslice = ks_env;
       t.dpart0[i].alloc((size_t)ks_env * M * a.out0_cols);
@@ -828,8 +853,8 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     if (wino)
       mv::launch_convlstm_wino_dgrads(pw.data(), (int)pw.size(), e->stream);
     else
-      mv::launch_convlstm16_dgrads(p16.data(), (int)p16.size(), e->stream);
-  }, -1.0, wino ? 2.0 : 3.0);
+      mv::launch_convlstm16_dgrads(p16.data(), (int)p16.size(), e->stream, bf);
+  }, -1.0, wino ? 2.0 : (bf ? 1.0 : 3.0));
   mv::SumSlicesArgs sa{};
   unsigned blocks = 0;
   double sbytes = 0;
@@ -982,13 +1007,15 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
     MV_REQUIRE(Cx <= 64 || Cx % 64 == 0, "internal: f16x3 wgrad x operand of %d channels", Cx);
     if (!t.wgrad16_attr) {
       HIP_CHECK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(mv::convlstm_wgrad_f16x3_kernel<false>),
+          reinterpret_cast<const void*>(mv::convlstm_wgrad_f16x3_kernel<false, 3>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)mv::kWg16LdsBytes));
       HIP_CHECK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(mv::convlstm_wgrad_f16x3_kernel<true>),
+          reinterpret_cast<const void*>(mv::convlstm_wgrad_f16x3_kernel<true, 3>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)mv::kWg16LdsBytes));
       t.wgrad16_attr = true;
     }
+    // compute mode 2: one fp16 plane per operand (see bf16_bwd_enabled)
+    const bool one = e->compute_mode == 2 && bf16_bwd_enabled();
     launch(e, "wgrad_transpose", 0, cells * (4.0 * C * 8 + (C + Cx) * 8.0 * 3), [&] {
       hipLaunchKernelGGL(mv::chain_exp_kernel, dim3(1), dim3(64), 0, e->stream,
                          t.gmax.p + (size_t)gslot * 64, Tsteps, 64, t.chain_exp.p);
@@ -1024,20 +1051,30 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
     q.Mrow = Mrow; q.H = H; q.W = W; q.Cx = Cx; q.C = C; q.Ca = C;
     mv::wgrad16_plan(q, Mtot, wa.nsplit);
     launch(e, "convlstm_wgrad", 2.0 * cells * 9 * C * 4.0 * C, cells * 5.0 * C * 4.0, [&] {
-      hipLaunchKernelGGL(mv::convlstm_wgrad_f16x3_kernel<false>,
+      if (one)
+        hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_kernel<false, 1>),
+                           dim3(mv::wgrad16_blocks(q, false)), dim3(256), mv::kWg16LdsBytes1,
+                           e->stream, q);
+      else
+      hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_kernel<false, 3>),
                          dim3(mv::wgrad16_blocks(q, false)), dim3(256), mv::kWg16LdsBytes,
                          e->stream, q);
-    }, -1.0, 3.0);
+    }, -1.0, one ? 1.0 : 3.0);
     if (Cx > 0) {
       mv::Wgrad16Args qx = q;
       for (int d = 0; d < 3; ++d) qx.at[d] = t.xt16[d].p;
       qx.Ca = Cx; qx.a_exp = t.chain_exp.p + 2;
       launch(e, "convlstm_wgrad_x", 2.0 * cells * 9 * Cx * 4.0 * C,
              cells * (Cx + 4.0 * C) * 4.0, [&] {
-        hipLaunchKernelGGL(mv::convlstm_wgrad_f16x3_kernel<true>,
+        if (one)
+          hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_kernel<true, 1>),
+                             dim3(mv::wgrad16_blocks(qx, true)), dim3(256), mv::kWg16LdsBytes1,
+                             e->stream, qx);
+        else
+        hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_kernel<true, 3>),
                            dim3(mv::wgrad16_blocks(qx, true)), dim3(256), mv::kWg16LdsBytes,
                            e->stream, qx);
-      }, -1.0, 3.0);
+      }, -1.0, one ? 1.0 : 3.0);
     }
   } else {
   launch(e, "convlstm_wgrad", 2.0 * cells * 9 * (ch.Cx + C) * 4.0 * C,
