@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256)
 void transpose_split_kernel(const float* __restrict__ in, _Float16* __restrict__ out,
                             long long Mtot, int Cc, long long Mrow, int W, int dx,
                             const int32_t* __restrict__ exp_ptr, int exp_const,
-                            float* __restrict__ colsum_out) {
+                            float* __restrict__ colsum_out, int nplanes = 2) {
   __shared__ float tile[64][65];
   const int e = exp_ptr ? exp_ptr[0] : exp_const;
   const float sc2e = __int_as_float((127 + e) << 23);     // 2^e, |e| <= 100 (one multiply = ldexpf)
@@ -91,7 +91,7 @@ void transpose_split_kernel(const float* __restrict__ in, _Float16* __restrict__
     }
     const size_t o = wg16_plane_index(m0 + grp * 8, c0 + ch, Cc);
     *reinterpret_cast<f16x8*>(out + o) = p0;
-    *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow + o) = p1;
+    if (nplanes == 2) *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow + o) = p1;
   }
 }
 
@@ -99,7 +99,7 @@ void transpose_split_kernel(const float* __restrict__ in, _Float16* __restrict__
 __global__ __launch_bounds__(256)
 void transpose_split_narrow_kernel(const float* __restrict__ in, _Float16* __restrict__ out,
                                    long long Mtot, int Cc, long long Mrow, int W, int dx,
-                                   const int32_t* __restrict__ exp_ptr) {
+                                   const int32_t* __restrict__ exp_ptr, int nplanes = 2) {
   __shared__ float tile[64][65];
   const int exp_const = exp_ptr[0];
   const float sc2e = __int_as_float((127 + exp_const) << 23);
@@ -126,7 +126,7 @@ void transpose_split_narrow_kernel(const float* __restrict__ in, _Float16* __res
     }
     const size_t o = wg16_plane_index(m0 + grp * 8, ch, Cc);
     *reinterpret_cast<f16x8*>(out + o) = p0;
-    *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow + o) = p1;
+    if (nplanes == 2) *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow + o) = p1;
   }
 }
 

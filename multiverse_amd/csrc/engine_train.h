@@ -836,7 +836,10 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     }
     // split-K over four channel-group ranges (see convlstm16_dgrad_dispatch)
     const int nstages = q.n_hk / 3;
-    static const int ks_env = getenv("MV_DGRAD_KSLICES") ? atoi(getenv("MV_DGRAD_KSLICES")) : 4;
+    // (the bf16 dgrad is a third as long: whole-K tiles, no partial sums -- 1 208 vs 1 202 /
+    // 1 178 traj/s with 2 / 4 slices at batch 64, profiles/r4u_*)
+    static const int ks_set = getenv("MV_DGRAD_KSLICES") ? atoi(getenv("MV_DGRAD_KSLICES")) : 0;
+    const int ks_env = ks_set > 0 ? ks_set : (bf ? 1 : 4);
     if (bf)
       MV_REQUIRE(nstages % MV_BF16_UNITS == 0, "internal: bf16 dgrad stage count %d", nstages);
     if (ks_env > 1 && nstages % (2 * ks_env) == 0) {
@@ -996,6 +999,10 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
     const long long Mtot = (long long)wa.R * H * W;
     const long long Mrow = (Mtot + 63) / 64 * 64;
     const int Cx = ch.Cx;
+    // compute mode 2: one fp16 plane per operand (see bf16_bwd_enabled); the lower planes are
+    // neither written by the transposes nor read by the GEMMs
+    const bool one = e->compute_mode == 2 && bf16_bwd_enabled();
+    const int npl = one ? 1 : 2;
     MV_REQUIRE((size_t)Mrow <= t.mrow_max, "internal: wgrad plane scratch");
     t.gt16.alloc((size_t)2 * 4 * C * t.mrow_max);
     t.bias_part.alloc(t.mrow_max / 64 * 4 * C);
@@ -1014,18 +1021,17 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)mv::kWg16LdsBytes));
       t.wgrad16_attr = true;
     }
-    // compute mode 2: one fp16 plane per operand (see bf16_bwd_enabled)
-    const bool one = e->compute_mode == 2 && bf16_bwd_enabled();
-    launch(e, "wgrad_transpose", 0, cells * (4.0 * C * 8 + (C + Cx) * 8.0 * 3), [&] {
+
+    launch(e, "wgrad_transpose", 0, cells * (4.0 * C + (C + Cx) * 3.0) * (4.0 + 2.0 * npl), [&] {
       hipLaunchKernelGGL(mv::chain_exp_kernel, dim3(1), dim3(64), 0, e->stream,
                          t.gmax.p + (size_t)gslot * 64, Tsteps, 64, t.chain_exp.p);
       hipLaunchKernelGGL(mv::transpose_split_kernel, dim3((unsigned)(Mrow / 64), 4 * C / 64),
                          dim3(256), 0, e->stream, ch.gates.p, t.gt16.p, Mtot, 4 * C, Mrow, W,
-                         0, t.chain_exp.p, 0, t.bias_part.p);
+                         0, t.chain_exp.p, 0, t.bias_part.p, npl);
       for (int d = 0; d < 3; ++d)
         hipLaunchKernelGGL(mv::transpose_split_kernel, dim3((unsigned)(Mrow / 64), C / 64),
                            dim3(256), 0, e->stream, hin, t.at16[d].p, Mtot, C, Mrow, W,
-                           d - 1, (const int32_t*)nullptr, 8, (float*)nullptr);
+                           d - 1, (const int32_t*)nullptr, 8, (float*)nullptr, npl);
       if (Cx) {   // x operand: exponent from max |x| of the chain
         HIP_CHECK(hipMemsetAsync(t.chain_exp.p + 64, 0, 64 * sizeof(int32_t), e->stream));
         hipLaunchKernelGGL(mv::absmax_bits_kernel, dim3(256), dim3(256), 0, e->stream,
@@ -1037,11 +1043,11 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
         if (Cx % 64 == 0)
           hipLaunchKernelGGL(mv::transpose_split_kernel, dim3((unsigned)(Mrow / 64), Cx / 64),
                              dim3(256), 0, e->stream, ch.xs.p, t.xt16[d].p, Mtot, Cx, Mrow, W,
-                             d - 1, t.chain_exp.p + 2, 0, (float*)nullptr);
+                             d - 1, t.chain_exp.p + 2, 0, (float*)nullptr, npl);
         else
           hipLaunchKernelGGL(mv::transpose_split_narrow_kernel, dim3((unsigned)(Mrow / 64)),
                              dim3(256), 0, e->stream, ch.xs.p, t.xt16[d].p, Mtot, Cx, Mrow, W,
-                             d - 1, t.chain_exp.p + 2);
+                             d - 1, t.chain_exp.p + 2, npl);
       }
     });
     mv::Wgrad16Args q{};
