@@ -11,7 +11,9 @@ bits.  Its own stated tolerance, asserted here:
     fp32 oracle's only where the oracle's top-1 / top-2 margin is below MARGIN_TOL =
     2 x BF16_TOL x range; the flip rate per margin decade is printed;
   * one training step: losses within 2 % of the fp32 oracle's, every gradient tensor's
-    cosine with the oracle's > 0.98.
+    cosine with the oracle's > 0.999 (measured 0.99997 with the backward on one plane per
+    operand -- bf16 dgrad, wgrad on the leading fp16 planes, DESIGN.md 3d -- and 0.99998
+    with MV_BF16_BWD=0, the backward on the f16x3 split).
 """
 import numpy as np
 import pytest
@@ -131,7 +133,7 @@ def test_bf16_training_step_and_beam_run(built_lib):
     a, b = grads[n].reshape(-1).astype(np.float64), og[n].reshape(-1).astype(np.float64)
     cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
     worst = min(worst, cos)
-    assert np.isfinite(a).all() and cos > 0.98, (n, cos)
+    assert np.isfinite(a).all() and cos > 0.999, (n, cos)
   print("  worst gradient cosine vs the fp32 oracle: %.5f" % worst)
   # beam decode in bf16: runs, finite, ids in range, beams distinct
   bcfg = synth.default_config(batch_size=2, use_grids=(1, 0), beam_size=5)
