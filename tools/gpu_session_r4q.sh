@@ -2,6 +2,7 @@
 # Round 4, session q: the class decoder's graph attention on a side stream beside the
 # hidden2grid / tail launches of the previous step (MV_SIDE_GNN=0: in line): parity tests of the
 # greedy forward in stream and graph mode, then the A/B.
+# (The side-stream code was removed after this session: zero gain, profiles/r4q_side_stream.txt.)
 set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r4q

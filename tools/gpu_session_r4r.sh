@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 4, session r: the graph attention of step t+1 and hidden2grid of step t as ONE launch
 # (post_gate_kernel; MV_POST_GATE=0: separate launches): parity tests, then the A/B.
+# (post_gate_kernel was removed after this session: zero gain, profiles/r4r_post_gate_fusion.txt.)
 set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r4r

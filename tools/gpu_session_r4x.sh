@@ -2,6 +2,7 @@
 # Round 4, session x: the LSTM update over common denominators in the inference epilogues
 # (lstm_update_fused: 5 v_exp + 2 v_rcp per element instead of 5 + 5) against the previous build
 # (build/variants/libmv_head.so, MV_LIB_PATH).
+# (lstm_update_fused was removed after this session: zero gain, profiles/r4x_fused_lstm_update.txt.)
 set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r4x
