@@ -2639,7 +2639,12 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
       }
     }
     for (auto& kv : h->planes) kv.second.valid = false;
-    if (h->compute_mode != mode) h->drop_graphs();
+    if (h->compute_mode != mode) {
+      h->drop_graphs();
+      // the backward's weight packs are per mode (f16x3 planes / Winograd form / one bf16
+      // plane): the next training step re-packs them from the current device weights
+      h->train_packs_valid = false;
+    }
     h->compute_mode = mode;
   });
 }

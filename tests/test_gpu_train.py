@@ -221,6 +221,38 @@ def test_train_is_deterministic_and_split_apply_equals_step(built_lib):
     assert (outs[0][1][n] == outs[1][1][n]).all(), n
 
 
+def test_compute_mode_switched_between_training_steps(built_lib):
+  """The backward's weight packs differ per compute mode (f16x3 planes + Winograd form, one
+  bf16 plane, the fp32 pack): a mode switch between two steps must re-pack them from the
+  current weights.  After f16x3 -> bf16 -> f32 -> f16x3 the gradients of the LAST step have to
+  be those of an engine that ran all four steps' updates and the last step in f16x3 -- checked
+  against an engine handed the same weights afresh."""
+  cfg, params, feed = _train_case((0, 1), 2, 4)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.train_init()
+  losses = []
+  for mode in ("f16x3", "bf16", "f32"):
+    eng.set_compute_mode(mode)
+    losses.append(eng.train_step(feed)[0])
+  eng.set_compute_mode("f16x3")
+  cur = {n: eng.get_param(n) for n, _ in eng.param_specs()}
+  l_last, _, _ = eng.train_forward_backward(feed)
+  g_sw = {n: eng.get_grad(n) for n, _ in eng.param_specs()}
+  eng.close()
+  assert all(np.isfinite(l) for l in losses) and losses[2] < losses[0]
+  ref = built_lib.Engine(cfg, device=0)
+  ref.set_params(cur)
+  ref.set_compute_mode("f16x3")
+  ref.train_init()
+  l_ref, _, _ = ref.train_forward_backward(feed)
+  g_ref = {n: ref.get_grad(n) for n, _ in ref.param_specs()}
+  ref.close()
+  assert l_last == l_ref
+  for n in g_ref:
+    assert (g_sw[n] == g_ref[n]).all(), n
+
+
 def test_train_needs_init(built_lib):
   cfg = synth.default_config(batch_size=2, use_grids=(0, 1), is_train=True)
   eng = built_lib.Engine(cfg, device=0)
