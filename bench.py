@@ -130,6 +130,52 @@ def committed_traffic(kernel_file_suffix):
                                 json.load(open(paths[0])).get("kernel_source_sha16"), cur))
 
 
+# engine kernel-table name -> the kernel-name fragment tools/profile_workload.sh files it under
+PMC_KERNEL_OF = {"convlstm_step": ("convlstm_step_wino", "convlstm_step_f16x3_lds",
+                                   "convlstm_step_bf16"),
+                 "convlstm_dgrad": ("convlstm_dgrad",),
+                 "convlstm_wgrad": ("convlstm_wgrad_f16x3",)}
+
+
+def quote_sub_traffic(roofline, tag, stats, mfma_kernels):
+  """Counter traffic of a sub-workload's gate kernels from profiles/r*_<tag>_pmc_<kernel>.json
+  (same rule as the headline: only summaries taken on this tree's kernel sources).  One
+  kernel (beam): `traffic` itself; several (training): `traffic_per_kernel`, and `traffic`
+  = their launch-weighted mean, next to `alg_MB_per_launch` computed the same way."""
+  per, notes = {}, []
+  for name in mfma_kernels:
+    for frag in PMC_KERNEL_OF.get(name, ()):
+      got, why = committed_traffic("%s_pmc_%s.json" % (tag, frag))
+      if got:
+        hb, src = got
+        # the x-row wgrad launches are profiled under the h-row launches' kernel name
+        same = [name] + (["convlstm_wgrad_x"] if name == "convlstm_wgrad" and
+                         "convlstm_wgrad_x" in stats else [])
+        per[name] = {"MB": round(hb["total_corrected"] / 1e6, 1),
+                     "raw_MB": round(hb["total_raw"] / 1e6, 1), "source": src,
+                     "alg_MB_per_launch": round(sum(stats[k]["bytes"] for k in same) /
+                                                sum(stats[k]["launches"] for k in same) / 1e6, 1)}
+        break
+      notes.append(why)
+  if not per:
+    roofline["traffic_note"] = "; ".join(notes[:2]) or "no PMC summary for this workload"
+    return
+  n_of = {k: stats[k]["launches"] + (stats["convlstm_wgrad_x"]["launches"]
+                                     if k == "convlstm_wgrad" and "convlstm_wgrad_x" in stats
+                                     else 0) for k in per}
+  tot = float(sum(n_of.values()))
+  roofline["traffic"] = round(sum(per[k]["MB"] * n_of[k] for k in per) / tot, 1)
+  roofline["traffic_raw_MB"] = round(sum(per[k]["raw_MB"] * n_of[k] for k in per) / tot, 1)
+  roofline["traffic_unit"] = ("MB HBM per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), "
+                              "launch-weighted over the kernels of traffic_per_kernel")
+  if len(per) == 1:
+    only = next(iter(per.values()))
+    roofline["traffic_source"] = only["source"]
+    roofline["alg_MB_per_launch"] = only["alg_MB_per_launch"]
+  else:
+    roofline["traffic_per_kernel"] = per
+
+
 class Ctx(object):
   """Process-group facts every measurement needs."""
 
@@ -335,7 +381,7 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
   # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command
   # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950); bench.py cannot collect
   # PMCs itself, so it quotes a committed summary -- only one taken on these sources.
-  if not beam and not train and batch == 64 and scene_conv_kernel == 3:
+  if not beam and not train and batch == 64 and scene_conv_kernel == 3 and not literal_grids:
     wino = f16 and stats["convlstm_step"]["flops_mfma"] < 2.5 * stats["convlstm_step"]["flops"]
     suffix = ("greedy_pmc_convlstm_step_wino.json" if wino else
               "greedy_pmc_convlstm_step_f16x3_lds.json" if f16 else
@@ -351,6 +397,18 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
       roofline["alg_MB_per_launch"] = round(conv["bytes"] / conv["launches"] / 1e6, 1)
     else:
       roofline["traffic_note"] = why
+  elif f16 and scene_conv_kernel == 3 and ((beam and batch == 128 and beam_size == 20) or
+                                           (train and batch == 32)):
+    # the sub-workloads tools/profile_workload.sh profiles at exactly these sizes
+    try:
+      quote_sub_traffic(roofline, "beam" if beam else "train", stats, mfma_kernels)
+    except Exception as ex:  # pylint: disable=broad-except
+      roofline["traffic_note"] = "PMC summary not quoted: %s" % ex
+  elif bf16 and train and batch == 64 and scene_conv_kernel == 1:
+    try:
+      quote_sub_traffic(roofline, "train_bf16", stats, mfma_kernels)
+    except Exception as ex:  # pylint: disable=broad-except
+      roofline["traffic_note"] = "PMC summary not quoted: %s" % ex
 
   if beam:
     metric = ("trajectories/sec (8-obs/12-pred, 18x32 grid, diverse beam-%d "
@@ -476,7 +534,12 @@ def compact(sub):
   keep["roofline"] = {k: r[k] for k in (
       "kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms",
       "executed_mfma_frac", "hbm_frac", "whole_forward_mfma_frac", "other_kernels_ms_total",
-      "per_kernel_ms", "per_kernel_TFLOPs", "scene_proj1x1_mfma") if k in r}
+      "per_kernel_ms", "per_kernel_TFLOPs", "scene_proj1x1_mfma", "traffic", "traffic_raw_MB",
+      "alg_MB_per_launch", "traffic_source", "traffic_note") if k in r}
+  if "traffic_per_kernel" in r:       # MB per launch: counter / algorithmic, and where from
+    keep["roofline"]["traffic_per_kernel"] = {
+        k: {"MB": v["MB"], "alg_MB": v["alg_MB_per_launch"], "source": v["source"]}
+        for k, v in r["traffic_per_kernel"].items()}
   keep["roofline"]["hbm_kernels"] = {k: {"ms": v["ms"], "frac": v["frac"]}
                                      for k, v in r.get("hbm_kernels", {}).items()}
   for k in ("rccl_ranks", "allreduce"):
