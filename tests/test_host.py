@@ -389,6 +389,52 @@ def test_bench_traffic_is_quoted_only_from_profiles_of_these_sources(tmp_path, m
   assert got is None and "no PMC summary" in why
 
 
+def test_bench_sub_line_traffic_is_launch_weighted_over_the_gate_kernels(tmp_path, monkeypatch):
+  """The beam / training sub-lines quote their gate kernels' counter traffic the same way
+  (bench.quote_sub_traffic): one kernel -> `traffic`; several -> `traffic_per_kernel` and
+  their launch-weighted mean, the x-row wgrad launches counted with the kernel they are
+  profiled under; summaries of other kernel sources are not quoted."""
+  import json
+  import bench
+  from multiverse_amd import buildinfo
+  cur = buildinfo.kernel_source_hash()
+  prof = tmp_path / "profiles"
+  prof.mkdir()
+  monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+
+  def put(name, mb, sha=cur):
+    (prof / name).write_text(json.dumps({
+        "kernel_source_sha16": sha,
+        "hbm_bytes_per_launch": {"total_corrected": mb * 1e6, "total_raw": mb * 0.5e6}}))
+  put("r9_beam_pmc_convlstm_step_wino.json", 1000.0)
+  put("r9_train_pmc_convlstm_step_wino.json", 100.0)
+  put("r9_train_pmc_convlstm_dgrad.json", 200.0)
+  put("r9_train_pmc_convlstm_wgrad_f16x3.json", 400.0)
+  stats = {"convlstm_step": {"bytes": 20e6, "launches": 20},
+           "convlstm_dgrad": {"bytes": 40e6, "launches": 20},
+           "convlstm_wgrad": {"bytes": 30e6, "launches": 6},
+           "convlstm_wgrad_x": {"bytes": 10e6, "launches": 4}}
+  r = {}
+  bench.quote_sub_traffic(r, "beam", stats, ["convlstm_step"])
+  assert r["traffic"] == 1000.0 and r["traffic_raw_MB"] == 500.0
+  assert r["alg_MB_per_launch"] == 1.0 and r["traffic_source"].endswith("step_wino.json")
+  r = {}
+  bench.quote_sub_traffic(r, "train", stats, ["convlstm_step", "convlstm_dgrad",
+                                              "convlstm_wgrad", "convlstm_wgrad_x"])
+  per = r["traffic_per_kernel"]
+  assert sorted(per) == ["convlstm_dgrad", "convlstm_step", "convlstm_wgrad"]
+  assert per["convlstm_wgrad"]["alg_MB_per_launch"] == 4.0       # (30 + 10) MB over 6 + 4 launches
+  assert r["traffic"] == round((100.0 * 20 + 200.0 * 20 + 400.0 * 10) / 50, 1)
+  # a summary of other sources drops out; with none left there is a note instead of a number
+  put("r9_train_pmc_convlstm_dgrad.json", 200.0, sha="0123456789abcdef")
+  r = {}
+  bench.quote_sub_traffic(r, "train", stats, ["convlstm_step", "convlstm_dgrad"])
+  assert r["traffic"] == 100.0 and "traffic_per_kernel" not in r
+  r = {}
+  bench.quote_sub_traffic(r, "train_bf16", stats, ["convlstm_step"])
+  assert "traffic" not in r and "traffic_note" in r
+
+
 def test_bench_algorithmic_counts_match_the_survey():
   """SURVEY.md section 8d, the ConvLSTM sweep alone (what roofline.achieved counts): per step
   2*K*9*(Cx+C)*4C = 3.397 / 2.739 / 3.058 GFLOP (class encoder / regression encoder / decoders)
