@@ -275,3 +275,38 @@ def test_weight_pack_order_matches_the_stage_reads():
       assert (out, ) not in seen
       seen.add((out, ))
     assert 0 <= cin < Cx16 + C and 0 <= n < 4 * C
+
+
+def test_f43_row_form_is_numerically_affordable_with_f16x3_operands():
+  """The study behind DESIGN.md section 8 item 5a (tools/winograd_f43_numerics.py): F(4,3) over
+  image rows -- 6 products per 4 output rows x 3 taps, half of the direct MFMAs -- with operands
+  held as two fp16 planes costs about four times the F(2,3) form's error and stays far inside the
+  1e-4 bar; its F(2,3) branch reproduces the direct convolution like the kernel's twin above."""
+  import importlib.util
+  import os
+  spec = importlib.util.spec_from_file_location(
+      "winograd_f43_numerics",
+      os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                   "winograd_f43_numerics.py"))
+  m = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(m)
+  # exact algebra first: with fp64 planes-free arithmetic A^T [(G g) . (B^T d)] is the correlation
+  rng = np.random.default_rng(5)
+  g = rng.normal(size=3)
+  d = rng.normal(size=6)
+  y = m.AT @ ((m.G @ g) * (m.BT @ d))
+  assert np.allclose(y, [d[i:i + 3] @ g for i in range(4)], atol=1e-12)
+  y2 = m.AT2 @ ((m.G2 @ g) * (m.BT2 @ d[:4]))
+  assert np.allclose(y2, [d[i:i + 3] @ g for i in range(2)], atol=1e-12)
+  # f16x3 operands, model-like magnitudes; H = 10 exercises a partial last 4-row tile
+  H, W, Ci, N = 10, 8, 320, 64
+  lim = np.sqrt(6.0 / (9 * Ci + 9 * 1024))
+  w = rng.uniform(-lim, lim, size=(3, 3, Ci, N))
+  x = np.tanh(rng.normal(size=(H, W, Ci)) * 1.5)
+  ref = m.conv_direct64(x, w)
+  e0 = np.abs(m.conv_direct_f16x3(x, w) - ref).max()
+  e2 = np.abs(m.conv_wino_rows(x, w, 2) - ref).max()
+  e4 = np.abs(m.conv_wino_rows(x, w, 4) - ref).max()
+  print("direct f16x3 %.2e, F(2,3) rows %.2e, F(4,3) rows %.2e (max |pre-activation| %.2f)"
+        % (e0, e2, e4, np.abs(ref).max()))
+  assert e0 < 3e-6 and e2 < 5e-6 and e4 < 2e-5
