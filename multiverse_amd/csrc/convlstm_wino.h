@@ -45,6 +45,16 @@
 #pragma once
 #include "convlstm_f16x3.h"
 
+// -DMV_WINO_ABLC=<bits>: compile-time ablations of the MAIN LOOP for the energy attribution of
+// the gate kernel (tools/gpu_session_r5a.sh; results of such builds are garbage, only time and
+// package power are read): 1 = no input transform (the raw rows serve as the components),
+// 2 = no DPP lane shifts (the centre fragment serves all three dx), 4 = no weight ds_reads
+// (fragments read once in front of the loop), 8 = one MFMA per product instead of three,
+// 16 = no global activation loads in the loop, 32 = no L2 -> LDS weight staging in the loop.
+#ifndef MV_WINO_ABLC
+#define MV_WINO_ABLC 0
+#endif
+
 namespace mv {
 
 // Waves per workgroup (template parameter WAVES): 8 waves = 256 pair-cells share one weight
@@ -333,17 +343,24 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
 #define MV_WN_COMP(COMP, CI, VHI, VLO, BUF)                                                   \
   do {                                                                                        \
     _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                        \
-      const f16x8 b0 = dx == 1 ? (VHI) : wn_lane_shift((VHI), dx == 0, dx == 0 ? okx0 : okx2); \
-      const f16x8 b1 = dx == 1 ? (VLO) : wn_lane_shift((VLO), dx == 0, dx == 0 ? okx0 : okx2); \
+      const bool sh = dx != 1 && !(MV_WINO_ABLC & 2);                                         \
+      const f16x8 b0 = !sh ? (VHI) : wn_lane_shift((VHI), dx == 0, dx == 0 ? okx0 : okx2);    \
+      const f16x8 b1 = !sh ? (VLO) : wn_lane_shift((VLO), dx == 0, dx == 0 ? okx0 : okx2);    \
       f16x8 w0[2], w1[2];                                                                     \
       _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) {                                      \
-        w0[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 0) * 2 + rb) * 64 + lane];                     \
-        w1[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 1) * 2 + rb) * 64 + lane];                     \
+        if (MV_WINO_ABLC & 4) {                                                               \
+          w0[rb] = wfix[rb]; w1[rb] = wfix[2 + rb];                                           \
+        } else {                                                                              \
+          w0[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 0) * 2 + rb) * 64 + lane];                   \
+          w1[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 1) * 2 + rb) * 64 + lane];                   \
+        }                                                                                     \
       }                                                                                       \
-      _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                        \
-        acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[rb], b0, acc[COMP][rb], 0, 0, 0); \
-      _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                        \
-        acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b1, acc[COMP][rb], 0, 0, 0); \
+      if (!(MV_WINO_ABLC & 8)) {                                                              \
+        _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                      \
+          acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[rb], b0, acc[COMP][rb], 0, 0, 0); \
+        _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                      \
+          acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b1, acc[COMP][rb], 0, 0, 0); \
+      }                                                                                       \
       _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                        \
         acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b0, acc[COMP][rb], 0, 0, 0); \
     }                                                                                         \
@@ -357,23 +374,44 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
     load_raw(ck_lo);
     stage_dma(2 * ck_lo, bufA);
     __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
+    f16x8 wfix[4];                           // MV_WINO_ABLC & 4: the only weight fragments read
+    if (MV_WINO_ABLC & 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wfix[i] = bufA[i * 64 + lane];
+    }
     {
     for (int ck = ck_lo; ck < ck_hi; ++ck) {
       const bool more = ck + 1 < ck_hi;
       f16x8 vh0, vl0, vh1, vl1;
+      if (MV_WINO_ABLC & 16) {               // loop-invariant operands must not be hoisted
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(raw[i][0]), "+v"(raw[i][1]));
+      }
+      if (MV_WINO_ABLC & 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(wfix[i]));
+      }
       // stage A: components 0, 1
-      stage_dma(2 * ck + 1, bufB);           // its buffer was last read before the barrier
+      if (!(MV_WINO_ABLC & 32)) stage_dma(2 * ck + 1, bufB);   // its buffer was last read before the barrier
+      if (MV_WINO_ABLC & 1) {
+        vh0 = raw[0][0]; vl0 = raw[0][1]; vh1 = raw[1][0]; vl1 = raw[1][1];
+      } else {
       wn_combine<true>(raw[0][0], raw[0][1], raw[2][0], raw[2][1], m1, vh0, vl0);   // d(-1) - d(+1)
       wn_combine<false>(raw[1][0], raw[1][1], raw[2][0], raw[2][1], m1, vh1, vl1);  // d(0) + d(+1)
+      }
       MV_WN_COMP(0, 0, vh0, vl0, bufA);
       MV_WN_COMP(1, 1, vh1, vl1, bufA);
       __syncthreads();
       // stage B: components 2, 3
+      if (MV_WINO_ABLC & 1) {
+        vh0 = raw[2][0]; vl0 = raw[2][1]; vh1 = raw[3][0]; vl1 = raw[3][1];
+      } else {
       wn_combine<true>(raw[2][0], raw[2][1], raw[1][0], raw[1][1], m1, vh0, vl0);   // d(+1) - d(0)
       wn_combine<true>(raw[1][0], raw[1][1], raw[3][0], raw[3][1], m1, vh1, vl1);   // d(0) - d(+2)
+      }
       if (more) {
-        stage_dma(2 * ck + 2, bufA);
-        load_raw(ck + 1);                    // a whole stage (36 MFMAs) ahead of its use
+        if (!(MV_WINO_ABLC & 32)) stage_dma(2 * ck + 2, bufA);
+        if (!(MV_WINO_ABLC & 16)) load_raw(ck + 1);   // a whole stage (36 MFMAs) ahead of its use
       }
       MV_WN_COMP(2, 0, vh0, vl0, bufB);
       MV_WN_COMP(3, 1, vh1, vl1, bufB);

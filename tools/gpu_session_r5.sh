@@ -1,0 +1,63 @@
+#!/bin/bash
+# Round 5 GPU sessions, one script: tools/gpu_session_r5.sh <tag> <stage> [<stage> ...]
+# (one gpurun call runs the listed stages in order; outputs under gpurun_out/<tag>/).  Stages:
+#   energy    tools/energy_attribution.sh (rocm-smi power x hipEvent time per ablation row)
+#   margins   the at-size parity tests, the Winograd kernel tests and the reference pins with -s:
+#             max|dlogits|, max|dreg|, flips, min oracle margin, per-row beam report
+#   suite     the whole GPU suite (-x -q)
+#   wino      tests/test_gpu_wino.py -s (kernel-level parity of the gate kernel forms)
+#   bench     the default `python bench.py` line (headline + every sub-workload)
+#   headline  `python bench.py --no-sub` x 2 (same-box repeatability of the headline)
+#   profiles  rocprofv3 traces + PMC of greedy / beam / train (tools/profile_workload.sh)
+#   ab:<ENV=V>  headline + beam with the env setting against the default, same box
+set -u
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+T=$1; shift
+O=gpurun_out/$T
+mkdir -p $O
+BQ="python bench.py --no-sub --no-cpu-baseline --no-fp32-ref"
+line() { python - "$1" <<'PY'
+import json, sys
+try:
+  d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+  r = d.get("roofline", {})
+  print(sys.argv[1], d.get("value"), d.get("ms_per_step"), "launch ms", r.get("avg_launch_ms"), "frac", r.get("frac"))
+except Exception as e:
+  print(sys.argv[1], "unreadable:", e)
+PY
+}
+for stage in "$@"; do
+  echo "=== stage $stage"
+  case $stage in
+    energy)
+      bash tools/energy_attribution.sh $T/energy 400 > $O/energy.log 2>&1; cat $O/energy/table.md ;;
+    margins)
+      (time timeout 1500 python -m pytest tests/test_gpu_at_size.py tests/test_gpu_wino.py tests/test_gpu_reference_pin.py -m gpu -q -s) > $O/margins.log 2>&1
+      echo "margins rc $?"; grep -E "passed|failed|error" $O/margins.log | tail -3 ;;
+    suite)
+      (time timeout 1500 python -m pytest tests -q -x -m gpu) > $O/gpu_tests.log 2>&1
+      echo "suite rc $?"; tail -4 $O/gpu_tests.log ;;
+    wino)
+      (time timeout 900 python -m pytest tests/test_gpu_wino.py -m gpu -q -s) > $O/wino_tests.log 2>&1
+      echo "wino rc $?"; grep -E "passed|failed|error" $O/wino_tests.log | tail -3 ;;
+    bench)
+      (time timeout 900 python bench.py) > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc $?"
+      line $O/bench_default.json ;;
+    headline)
+      for i in 1 2; do timeout 300 $BQ --steps 100 > $O/headline_$i.json 2> $O/headline_$i.err; line $O/headline_$i.json; done ;;
+    profiles)
+      bash tools/profile_workload.sh ${T}_greedy > $O/prof_greedy.log 2>&1
+      bash tools/profile_workload.sh ${T}_beam --workload beam > $O/prof_beam.log 2>&1
+      bash tools/profile_workload.sh ${T}_train --workload train > $O/prof_train.log 2>&1
+      for w in greedy beam train; do echo "== $w"; head -8 gpurun_out/prof_${T}_$w/kernel_trace_stats.md; done ;;
+    ab:*)
+      kv=${stage#ab:}; k=${kv%%=*}
+      for w in greedy beam; do
+        wa=""; [ $w = beam ] && wa="--workload beam --steps 3 --warmup 1"
+        [ $w = greedy ] && wa="--steps 100"
+        timeout 300 $BQ $wa > $O/ab_${w}_default.json 2> $O/ab_${w}_default.err; line $O/ab_${w}_default.json
+        env $kv timeout 300 $BQ $wa > $O/ab_${w}_$k.json 2> $O/ab_${w}_$k.err; line $O/ab_${w}_$k.json
+      done ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done

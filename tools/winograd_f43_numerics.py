@@ -21,6 +21,13 @@ G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
               [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]])
 BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0],
                [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], float)
+# F(3,3), points 0, 1, -1, 2, inf: 5 products per 3 output rows x 3 taps (5/9 of the direct MFMAs);
+# 18 = 6 x 3 and 9 = 3 x 3 rows: no partial tiles on either scale of the published configuration
+AT3 = np.array([[1, 1, 1, 1, 0], [0, 1, -1, 2, 0], [0, 1, 1, 4, 1]], float)
+G3 = np.array([[1 / 2, 0, 0], [-1 / 2, -1 / 2, -1 / 2], [-1 / 6, 1 / 6, -1 / 6], [1 / 6, 1 / 3, 2 / 3],
+               [0, 0, 1]])
+BT3 = np.array([[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0],
+                [0, 2, -1, -2, 1]], float)
 AT2 = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], float)
 G2 = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
 BT2 = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], float)
@@ -66,7 +73,7 @@ def conv_wino_rows(d, w, m):
   """F(m,3) over rows, m = 2 or 4; dx taps direct.  Operand planes as the kernel would hold them:
   V = B^T d exactly from the (hi + lo) values of d's planes, re-split under the same 2^8 scale;
   U = G g in fp64, planes under 2^8; M_c in fp32 from three products; y = A^T M in fp32."""
-  at, g, bt = (AT2, G2, BT2) if m == 2 else (AT, G, BT)
+  at, g, bt = {2: (AT2, G2, BT2), 3: (AT3, G3, BT3), 4: (AT, G, BT)}[m]
   nc = m + 2
   H, W, Ci = d.shape
   N = w.shape[3]
@@ -101,10 +108,10 @@ def conv_wino_rows(d, w, m):
 
 def main():
   rng = np.random.default_rng(20200614)
-  H, W, Ci, N = 16, 8, 320, 128
+  H, W, Ci, N = 18, 8, 320, 128
   lim = np.sqrt(6.0 / (9 * Ci + 9 * 1024))
-  print("| operands | max abs error of the pre-activation vs fp64: direct f16x3 | F(2,3) rows | F(4,3) rows | max abs pre-activation |")
-  print("|---|---|---|---|---|")
+  print("| operands | max abs error of the pre-activation vs fp64: direct f16x3 | F(2,3) rows | F(3,3) rows | F(4,3) rows | max abs pre-activation |")
+  print("|---|---|---|---|---|---|")
   for name, gain, dscale in (("reference initialisers, |h| ~ tanh", 1.0, 1.0),
                              ("recurrent gain 3", 3.0, 1.0),
                              ("rows alternating |h| ~ 1 and ~ 1e-3", 1.0, None)):
@@ -115,8 +122,9 @@ def main():
     ref = conv_direct64(d, w)
     e0 = np.abs(conv_direct_f16x3(d, w) - ref).max()
     e2 = np.abs(conv_wino_rows(d, w, 2) - ref).max()
+    e3 = np.abs(conv_wino_rows(d, w, 3) - ref).max()
     e4 = np.abs(conv_wino_rows(d, w, 4) - ref).max()
-    print("| %s | %.2e | %.2e | %.2e | %.2f |" % (name, e0, e2, e4, np.abs(ref).max()))
+    print("| %s | %.2e | %.2e | %.2e | %.2e | %.2f |" % (name, e0, e2, e3, e4, np.abs(ref).max()))
 
 
 if __name__ == "__main__":
