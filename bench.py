@@ -449,6 +449,14 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
                    "the bf16 matrix pipe (BASELINE configs[4]: bf16 operands, fp32 accumulate; "
                    "REDUCED precision, not the fp32 headline)" if bf16
                    else "the fp32 matrix pipe"))
+  # the form the gate kernels of THESE launches ran in, from what the engine issued to the
+  # matrix pipe (3 fp16 MFMA products per fp32 product = direct 3x3; 2 = Winograd F(2,3) over
+  # rows; 1.67 = F(3,3) over rows; training mixes the forms of forward / dgrad / wgrad)
+  f16_form = ""
+  if f16:
+    f16_form = "%s, %.2f fp16 MFMAs issued per fp32 product over the gate kernels" % (
+        roofline.get("gate_kernel_form", "gate kernel form n/a").split(",")[0],
+        conv["flops_mfma"] / conv["flops"] if conv["flops"] else 3.0)
   out = {
       "metric": metric,
       "value": round(value, 2),
@@ -466,12 +474,12 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
                 "3e-2 of their range, tests/test_gpu_bf16.py)" + (
                     "; dgrad on bf16 planes, wgrad on one fp16 plane per operand: gradient "
                     "cosine vs the fp32 oracle > 0.999 asserted" if train else "") if bf16 else
-                "f16x3 (fp32 operands as two pre-scaled fp16 planes, 3 fp16 MFMAs per "
-                "product, fp32 accumulate and state; measured error vs fp64 <= the fp32-MFMA "
-                "path's, argmax / beam ids bit-exact)" if (f16 and not train) else
+                "f16x3 (fp32 operands as two pre-scaled fp16 planes, fp32 accumulate and state; "
+                "%s; measured error vs fp64 <= the fp32-MFMA path's, argmax / beam ids "
+                "bit-exact)" % f16_form if (f16 and not train) else
                 "f16x3 gate convolutions (forward, dgrad, wgrad: fp32 operands as two "
-                "pre-scaled fp16 planes, 3 fp16 MFMAs per product, fp32 accumulate); fp32 "
-                "state, losses, gradients and optimizer" if f16 else "f32"),
+                "pre-scaled fp16 planes, fp32 accumulate; %s); fp32 "
+                "state, losses, gradients and optimizer" % f16_form if f16 else "f32"),
       "data": "synthetic (seeded AR(1) trajectories, rectangle scene masks, "
               "random-init weights with the reference's initialisers)",
       "config": {"workload": workload,

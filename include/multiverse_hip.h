@@ -83,8 +83,9 @@ typedef struct mv_config {
   /* --activation_func (code/train.py:58-59, code/pred_utils.py:86-94): the activation of
    * the scene convolutions (code/pred_models.py:155-165) and of grid_emb (:444, :664).
    * 0 = tanh (published), 1 = relu, 2 = lrelu (tf.nn.leaky_relu, alpha 0.2).  relu / lrelu
-   * outputs are unbounded, so those models run the gate convolutions on the fp32 matrix
-   * pipe: mv_set_compute_mode(1 / 2) is refused for them. */
+   * outputs are unbounded: in compute mode 1 their x operand planes carry a per-tensor
+   * power-of-two scale taken from max |x| (DESIGN.md section 3c "x exponent"), so every
+   * compute mode accepts them. */
   int32_t activation;
 } mv_config;
 
@@ -334,11 +335,16 @@ int  mv_get_opt_slot(mv_handle h, const char* tf_name, int32_t slot, float* out,
 int  mv_set_opt_slot(mv_handle h, const char* tf_name, int32_t slot,
                      const float* data, int64_t elems);
 
-/* Arithmetic of the gate convolution in the inference forward:
+/* Arithmetic of the gate convolutions (forward, and dgrad / wgrad of a training engine):
  *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32), default;
  *   1  "f16x3": every fp32 operand as two pre-scaled fp16 planes, each product as
  *      three fp16 MFMAs accumulating in fp32 -- fp32-roundoff-class error (DESIGN.md
- *      section 3c) at up to 5.3x the fp32 matrix rate.  Same outputs contract. */
+ *      section 3c).  Where the grid fits its tiling the forward step and dgrad run in
+ *      Winograd form over image rows (csrc/convlstm_wino.h: fewer MFMA products for the
+ *      same pre-activations, kernel transform in fp64 at pack time); otherwise the direct
+ *      3x3 form.  Same outputs contract;
+ *   2  bf16 operands (one MFMA per product), fp32 accumulate: REDUCED precision
+ *      (BASELINE configs[4]). */
 int  mv_set_compute_mode(mv_handle h, int32_t mode);
 
 /* Replay the forward as a captured hipGraph (one graph per (mode, T_pred, U)):

@@ -127,6 +127,22 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, _Float16* __restri
   out[base + ((size_t)(1 * 2 + rb) * 64 + l) * 8 + e] = v1;
 }
 
+// MV_WINO_ABL runs without the epilogue's stores: operand planes of pseudo-random values
+// shaped like h (engine.hip mv_set_compute_mode), so that the matrix pipe draws the power it
+// draws on real data.
+__global__ void abl_fill_planes_kernel(_Float16* __restrict__ p0, _Float16* __restrict__ p1,
+                                       size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t x = (uint32_t)i * 2654435761u + 0x9e3779b9u;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  const float u = (float)(int32_t)x * (1.0f / 2147483648.0f);          // (-1, 1)
+  const float v = 256.0f * u * (0.25f + 0.75f * u * u);                // tanh-ish spread
+  const _Float16 h0 = (_Float16)v;
+  p0[i] = h0;
+  p1[i] = (_Float16)(v - (float)h0);
+}
+
 // a - b on packed halves as ONE v_pk_fma_f16 (b * -1 + a, exactly rounded like the
 // subtraction).  Written as a - b, hipcc scalarises a <8 x half> subtraction into v_sub_f16 /
 // SDWA / v_pack triples (there is no v_pk_sub_f16 and the fsub lowering does not use the neg

@@ -2630,6 +2630,16 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
           DevBuf<_Float16>& pb = *h->plane_store.back();
           pb.alloc(2 * (b->n + mv::kPlaneSlack + mv::kPlanePad));
           HIP_CHECK(hipMemset(pb.p, 0, pb.n * sizeof(_Float16)));
+          // timing ablations that drop the epilogue's stores (MV_WINO_ABL & 2 / 8 / 16) would
+          // run the matrix pipe on these zeros and draw far less power per MFMA than real
+          // operands do: such runs start from pseudo-random planes (|256 h| < 256, low plane
+          // ~2^-11 of it) that nothing overwrites
+          if (getenv("MV_WINO_ABL") && (atoi(getenv("MV_WINO_ABL")) & (2 | 8 | 16))) {
+            const size_t pst = b->n + mv::kPlaneSlack + mv::kPlanePad;
+            hipLaunchKernelGGL(mv::abl_fill_planes_kernel, dim3(cdiv(b->n, 256)), dim3(256), 0,
+                               h->stream, pb.p + mv::kPlanePad, pb.p + mv::kPlanePad + pst, b->n);
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+          }
           // p -> first element of plane 0; plane stride n + slack + pad puts a zero
           // pad in front of plane 1 as well (slack: the last partial 32-cell tile row)
           h->planes[b->p] = mv_engine::PlaneBuf{pb.p + mv::kPlanePad,

@@ -910,6 +910,18 @@ void run_dgrad_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
 // In-library gradient all-reduce (comm.h): the elements [off, off + n) of the flat
 // gradient buffer are final on the main stream -> reduce them (sum over the ranks) on the
 // side stream while the backward pass goes on.
+// MV_COMM_FAULT (test hook, honoured only with MV_ALLOW_RCCL_OVERRIDE=1 like MV_RCCL_LIB): the
+// negative control of tests/test_gpu_parallel.py -- bit 1 drops the side stream's wait for the
+// main stream's `ready` event, bit 2 the main stream's wait for the side stream's `done`: over
+// an asynchronous collective either must give wrong parameters (and the test must see it).
+static inline int comm_fault() {
+  static const int f = [] {
+    const char* a = getenv("MV_ALLOW_RCCL_OVERRIDE");
+    const char* v = getenv("MV_COMM_FAULT");
+    return (a && atoi(a) == 1 && v) ? atoi(v) : 0;
+  }();
+  return f;
+}
 void comm_reduce_range(mv_engine* e, size_t off, size_t n) {
   mv::Comm* c = e->comm;
   if (!c || n == 0) return;
@@ -918,7 +930,7 @@ void comm_reduce_range(mv_engine* e, size_t off, size_t n) {
   // gradients of that pass are never applied, so there is nothing to exchange
   if (t.want_dscene) return;
   HIP_CHECK(hipEventRecord(c->ready, e->stream));
-  HIP_CHECK(hipStreamWaitEvent(c->stream, c->ready, 0));
+  if (!(comm_fault() & 1)) HIP_CHECK(hipStreamWaitEvent(c->stream, c->ready, 0));
   float* p = t.grad.p + off;
   ncclResult_t rc = mv::rccl().AllReduce(p, p, n, ncclFloat, ncclSum, c->comm, c->stream);
   MV_REQUIRE(rc == ncclSuccess, "ncclAllReduce(%zu floats at %zu): %s", n, off,
@@ -957,7 +969,7 @@ void comm_reduce_rest_and_join(mv_engine* e) {
     }
   }
   HIP_CHECK(hipEventRecord(c->ready, e->stream));
-  HIP_CHECK(hipStreamWaitEvent(c->stream, c->ready, 0));
+  if (!(comm_fault() & 1)) HIP_CHECK(hipStreamWaitEvent(c->stream, c->ready, 0));
   mv::RcclApi& r = mv::rccl();
   ncclResult_t rc = r.GroupStart();
   MV_REQUIRE(rc == ncclSuccess, "ncclGroupStart: %s", r.GetErrorString(rc));
@@ -976,7 +988,7 @@ void comm_reduce_rest_and_join(mv_engine* e) {
   rc = r.GroupEnd();
   MV_REQUIRE(rc == ncclSuccess, "ncclGroupEnd: %s", r.GetErrorString(rc));
   HIP_CHECK(hipEventRecord(c->done, c->stream));
-  HIP_CHECK(hipStreamWaitEvent(e->stream, c->done, 0));
+  if (!(comm_fault() & 2)) HIP_CHECK(hipStreamWaitEvent(e->stream, c->done, 0));
 }
 
 // gslot: first gmax slot of the chain's steps (f16x3 mode), see train_backward

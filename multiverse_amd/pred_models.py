@@ -193,6 +193,11 @@ class Model(object):
       # the fp16-pipe kernels' epilogue lets a 32-cell wave tile span at most two images
       # (engine.hip run_conv_group_f16x3 refuses smaller grids); such toy grids run on the
       # fp32 matrix pipe, whose kernel wraps over any number of images
+      if self.compute_mode != "f32":
+        import logging
+        logging.getLogger("multiverse_amd").warning(
+            "compute mode %s overridden to f32: a used grid has fewer than 32 cells",
+            self.compute_mode)
       self.compute_mode = "f32"
     self.engine.set_compute_mode(self.compute_mode)
     self.global_step = 0
@@ -316,9 +321,19 @@ class Tester(object):
     finally:
       # a consumer that stops early (break, an exception in its loop body) must not leave
       # submissions in the engine's pipeline: the next caller would collect THEIR outputs
+      # Best effort: when the loop ended on an ENGINE error the same call may fail again --
+      # that secondary error must not mask the original one, and the drain stops there.
       while pending:
         pending.pop(0)
-        eng.collect_greedy()
+        try:
+          eng.collect_greedy()
+        except Exception as drain_err:  # pylint: disable=broad-except
+          import logging
+          logging.getLogger("multiverse_amd").warning(
+              "Tester.steps: pipeline drain stopped on %r (%d submissions abandoned)",
+              drain_err, len(pending))
+          pending.clear()
+          break
 
 
 class Trainer(object):

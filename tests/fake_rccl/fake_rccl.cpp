@@ -16,6 +16,17 @@
 // given, nothing else).  Every barrier has a timeout, so a protocol bug in the caller shows
 // up as ncclSystemError, not as a hung test.  MV_FAKE_RCCL_LOG=<file>: one line per
 // collective (rank, count, group depth) for the test to read.
+//
+// MV_FAKE_RCCL_ASYNC=1: the ASYNCHRONOUS mode -- ncclAllReduce returns at once, like RCCL's:
+// it only ENQUEUES on the caller's stream (a) a device -> pinned-host copy of the send buffer,
+// (b) a host function (hipLaunchHostFunc) that performs the exchange when the stream reaches
+// it -- rendezvous with the other ranks, sum in rank order, an optional extra delay
+// (MV_FAKE_RCCL_DELAY_MS) -- and (c) the pinned-host -> device copy of the sum.  Nothing is
+// synchronised on the caller's behalf, so a missing event wait on either side of the
+// collective (the main stream's `ready` in front of it, the side stream's `done` behind it)
+// reads or applies unreduced gradients and the test FAILS; the synchronous mode above cannot
+// see such bugs.  Staging buffers come from a ring of pinned allocations; ring slots are
+// reused in stream order (one stream per communicator, as comm.h uses it).
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -23,6 +34,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -56,6 +68,18 @@ struct FakeComm {
   std::vector<float> sum;
   int group_depth = 0;
   long collectives = 0;
+  // asynchronous mode
+  static constexpr int kRing = 4;
+  float* stage[kRing] = {};          // pinned: send copy in, sum out
+  size_t stage_cap[kRing] = {};
+  hipStream_t stream_seen = nullptr;
+  std::atomic<int> async_failed{0};
+};
+
+struct AsyncJob {
+  FakeComm* c;
+  float* buf;
+  size_t count;
 };
 
 thread_local int g_group_depth = 0;
@@ -100,6 +124,66 @@ void log_call(const FakeComm* c, size_t count) {
             g_group_depth);
     fclose(f);
   }
+}
+
+bool async_mode() {
+  static const bool on = getenv("MV_FAKE_RCCL_ASYNC") && atoi(getenv("MV_FAKE_RCCL_ASYNC")) == 1;
+  return on;
+}
+
+// runs on a runtime thread when the caller's stream reaches it; no HIP calls in here
+void exchange_on_host(void* user) {
+  AsyncJob* job = static_cast<AsyncJob*>(user);
+  FakeComm* c = job->c;
+  static const int delay_ms = getenv("MV_FAKE_RCCL_DELAY_MS") ? atoi(getenv("MV_FAKE_RCCL_DELAY_MS")) : 0;
+  for (size_t off = 0; off < job->count && !c->async_failed.load(); off += kSlotFloats) {
+    const size_t n = std::min(kSlotFloats, job->count - off);
+    float* mine = c->slots + (size_t)c->rank * kSlotFloats;
+    memcpy(mine, job->buf + off, n * sizeof(float));
+    if (!barrier(c)) { c->async_failed.store(1); break; }
+    float* out = job->buf + off;
+    for (size_t i = 0; i < n; ++i) out[i] = c->slots[i];
+    for (int r = 1; r < c->world; ++r) {
+      const float* s = c->slots + (size_t)r * kSlotFloats;
+      for (size_t i = 0; i < n; ++i) out[i] += s[i];
+    }
+    if (!barrier(c)) { c->async_failed.store(1); break; }
+  }
+  if (delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
+  delete job;
+}
+
+ncclResult_t allreduce_async(FakeComm* c, const float* src, float* dst, size_t count,
+                             hipStream_t stream) {
+  if (c->async_failed.load()) return ncclSystemError;
+  if (c->stream_seen && c->stream_seen != stream) return ncclInvalidUsage;   // ring = stream order
+  c->stream_seen = stream;
+  const int slot = (int)((c->collectives - 1) % FakeComm::kRing);
+  if (c->stage_cap[slot] < count) {
+    // growing a slot: its previous user (kRing collectives ago, same stream) must be done
+    if (c->stage[slot]) {
+      if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+      (void)hipHostFree(c->stage[slot]);
+    }
+    // at least one 16 MB chunk: no bucket of the engine's model ever grows a slot again, so
+    // the synchronisation above never hides a protocol bug after the first kRing collectives
+    const size_t cap = std::max(count, kSlotFloats);
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->stage[slot]), cap * sizeof(float),
+                      hipHostMallocDefault) != hipSuccess)
+      return ncclUnhandledCudaError;
+    c->stage_cap[slot] = cap;
+  }
+  float* buf = c->stage[slot];
+  if (hipMemcpyAsync(buf, src, count * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess)
+    return ncclUnhandledCudaError;
+  AsyncJob* job = new AsyncJob{c, buf, count};
+  if (hipLaunchHostFunc(stream, exchange_on_host, job) != hipSuccess) {
+    delete job;
+    return ncclUnhandledCudaError;
+  }
+  if (hipMemcpyAsync(dst, buf, count * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess)
+    return ncclUnhandledCudaError;
+  return ncclSuccess;
 }
 
 }  // namespace
@@ -155,6 +239,9 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   FakeComm* c = reinterpret_cast<FakeComm*>(comm);
   if (!c) return ncclSuccess;
+  if (c->stream_seen) (void)hipStreamSynchronize(c->stream_seen);   // pending host functions
+  for (int i = 0; i < FakeComm::kRing; ++i)
+    if (c->stage[i]) (void)hipHostFree(c->stage[i]);
   if (c->base) munmap(c->base, c->bytes);
   shm_unlink(c->name.c_str());          // the first rank to leave removes the name
   delete c;
@@ -176,9 +263,10 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count,
   if (datatype != ncclFloat || op != ncclSum) return ncclInvalidArgument;
   log_call(c, count);
   c->collectives += 1;
-  if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
   const float* src = static_cast<const float*>(sendbuff);
   float* dst = static_cast<float*>(recvbuff);
+  if (async_mode()) return allreduce_async(c, src, dst, count, stream);
+  if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
   for (size_t off = 0; off < count; off += kSlotFloats) {
     const size_t n = std::min(kSlotFloats, count - off);
     float* mine = c->slots + (size_t)c->rank * kSlotFloats;

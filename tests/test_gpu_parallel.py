@@ -170,12 +170,14 @@ def test_in_library_rccl_allreduce_world1_is_the_identity(built_lib):
 FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
 
 
-def _lib_worker(rank, world, outdir):
+def _lib_worker(rank, world, outdir, extra_env=None):
   """One rank of the IN-LIBRARY data-parallel step: mv_allreduce_init + the bucketed
   side-stream all-reduce inside mv_train_forward_backward / mv_train_step, over the
   shared-memory RCCL stand-in (MV_RCCL_LIB), both ranks on GPU 0."""
   sys.path.insert(0, ROOT)
   os.environ["MV_RCCL_LIB"] = FAKE_RCCL
+  os.environ["MV_ALLOW_RCCL_OVERRIDE"] = "1"
+  os.environ.update(extra_env or {})
   os.environ["MV_FAKE_RCCL_LOG"] = os.path.join(outdir, "rccl_rank%d.log" % rank)
   os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
   import time
@@ -227,27 +229,80 @@ def _lib_worker(rank, world, outdir):
   np.savez(os.path.join(outdir, "lib_rank%d.npz" % rank), **out)
 
 
-def test_in_library_allreduce_two_ranks_one_gpu(built_lib, tmp_path):
+def _two_ranks_vs_one_process(built_lib, tmp_path, extra_env):
+  """Runs the two ranks (tests/fake_rccl under `extra_env`) and one process on the global batch;
+  returns the deviations instead of asserting them, so that the negative controls can demand
+  that they are LARGE: {"calls": per-rank collective log, "ranks_equal": both ranks bit-identical,
+  "grad": worst |reduced gradient - global-batch gradient| / max|g|, "loss": worst relative loss
+  difference, "param": worst |2 ranks - 1 process| / max(1, max|p|), "param_upd": the same as a
+  fraction of the parameter's update, "slot": optimizer slot 0}."""
+  from multiverse_amd import synth
+  world = 2
+  mp.spawn(_lib_worker, args=(world, str(tmp_path), extra_env), nprocs=world, join=True)
+  r = [np.load(os.path.join(str(tmp_path), "lib_rank%d.npz" % k)) for k in range(world)]
+  res = {"nelem": int(r[0]["nelem"][0]), "calls": []}
+  for k in range(world):
+    lines = open(os.path.join(str(tmp_path), "rccl_rank%d.log" % k)).read().split("\n")
+    res["calls"].append([(int(l.split()[6]), int(l.split()[8])) for l in lines if l.strip()])
+  gcfg = _cfg(N_GLOBAL, synth, True)
+  params = synth.make_params(gcfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0,
+                             bias_scale=0.1)
+  res["ranks_equal"] = all((r[0][n] == r[1][n]).all() and
+                           (r[0]["grad|" + n] == r[1]["grad|" + n]).all() for n in params)
+  eng = built_lib.Engine(gcfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode("f16x3")
+  eng.train_init()
+  res["grad"] = res["loss"] = res["param"] = res["param_upd"] = res["slot"] = 0.0
+  for step in range(STEPS):
+    feed = synth.make_feed(gcfg, seed=synth.SEED_BASE + 200 + step)
+    if step == 0:
+      loss, wd, pgl = eng.train_forward_backward(feed)
+      for n, _ in eng.param_specs():
+        g = eng.get_grad(n)                  # gradient of the GLOBAL batch mean
+        gs = r[0]["grad|" + n] / world       # sum over ranks of the shard means / world
+        scale = max(float(np.abs(g).max()), 1e-30)
+        res["grad"] = max(res["grad"], float(np.abs(gs - g).max()) / scale)
+      eng.train_apply(1.0)
+    else:
+      loss, wd, pgl = eng.train_step(feed)
+    ref = np.asarray([loss, wd] + list(pgl))
+    mean = 0.5 * (r[0]["losses"][step] + r[1]["losses"][step])
+    print("step %d: single-process %s | 2 ranks (mean) %s" % (step, ref, mean))
+    res["loss"] = max(res["loss"], float(np.abs((mean - ref) / np.maximum(np.abs(ref), 1e-7)).max()))
+  for n, _ in eng.param_specs():
+    ref = eng.get_param(n)
+    upd = max(float(np.abs(ref - params[n]).max()), 1e-12)
+    d = float(np.abs(r[0][n] - ref).max())
+    res["param"] = max(res["param"], d / max(1.0, float(np.abs(ref).max())))
+    res["param_upd"] = max(res["param_upd"], d / upd)
+    s_ref = eng.get_opt_slot(n, 0)
+    res["slot"] = max(res["slot"], float(np.abs(r[0]["slot0|" + n] - s_ref).max()) /
+                      max(float(np.abs(s_ref).max()), 1e-30))
+  eng.close()
+  print("2 ranks vs 1 process under %s: %s" % (extra_env, {k: v for k, v in res.items() if k != "calls"}))
+  return res
+
+
+@pytest.mark.parametrize("mode", ["sync", "async"])
+def test_in_library_allreduce_two_ranks_one_gpu(built_lib, tmp_path, mode):
   """The library's own bucketed all-reduce (comm.h, engine_train.h comm_reduce_*) with TWO
   ranks: bucket order, event hand-offs between the main and the side stream, the 1 / world
   scale and clip-after-reduce -- against one process on the global batch.  RCCL refuses two
   ranks on one GPU, so the ranks load the shared-memory stand-in tests/fake_rccl through
   MV_RCCL_LIB (test infrastructure: same entry points, sum in rank order on the host); what
-  is under test is everything on THIS side of ncclAllReduce."""
-  from multiverse_amd import synth
+  is under test is everything on THIS side of ncclAllReduce.  mode "sync": the stand-in blocks
+  the host inside the call; mode "async": it only enqueues work on the caller's stream and
+  returns, as RCCL does (the exchange runs in a host function with an extra 20 ms delay) -- the
+  mode in which a missing event wait is visible (next test)."""
   if not os.path.exists(FAKE_RCCL):
     pytest.skip("tests/fake_rccl/libfakerccl.so not built (__graft_entry__.build())")
-  world = 2
-  mp.spawn(_lib_worker, args=(world, str(tmp_path)), nprocs=world, join=True)
-  r = [np.load(os.path.join(str(tmp_path), "lib_rank%d.npz" % k)) for k in range(world)]
-  nelem = int(r[0]["nelem"][0])
+  env = {"MV_FAKE_RCCL_ASYNC": "1", "MV_FAKE_RCCL_DELAY_MS": "20"} if mode == "async" else {}
+  res = _two_ranks_vs_one_process(built_lib, tmp_path, env)
+  nelem, calls = res["nelem"], res["calls"]
   # what the stand-in saw: per step 13 collectives per rank, the same sizes in the same order
   # on both ranks, covering the gradient buffer exactly once; the last group inside
   # ncclGroupStart / End
-  calls = []
-  for k in range(world):
-    lines = open(os.path.join(str(tmp_path), "rccl_rank%d.log" % k)).read().split("\n")
-    calls.append([(int(l.split()[6]), int(l.split()[8])) for l in lines if l.strip()])
   assert calls[0] == calls[1] and len(calls[0]) == STEPS * 13
   for st in range(STEPS):
     step_calls = calls[0][st * 13:(st + 1) * 13]
@@ -255,49 +310,33 @@ def test_in_library_allreduce_two_ranks_one_gpu(built_lib, tmp_path):
     assert [g for _, g in step_calls[:8]] == [0] * 8            # ConvLSTM buckets, one by one
     assert all(g == 1 for _, g in step_calls[8:])               # the rest as one group
     assert min(c for c, _ in step_calls[:8]) > 2_000_000        # a kernel + its biases each
-  # both ranks hold the same model afterwards, bit for bit
-  gcfg = _cfg(N_GLOBAL, synth, True)
-  params = synth.make_params(gcfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0,
-                             bias_scale=0.1)
-  for n in params:
-    assert (r[0][n] == r[1][n]).all(), n
-    assert (r[0]["grad|" + n] == r[1]["grad|" + n]).all(), n
+  # both ranks hold the same model afterwards, bit for bit ...
+  assert res["ranks_equal"]
   # ... and it is the model one process makes of the global batch
-  eng = built_lib.Engine(gcfg, device=0)
-  eng.set_params(params)
-  eng.set_compute_mode("f16x3")
-  eng.train_init()
-  for step in range(STEPS):
-    feed = synth.make_feed(gcfg, seed=synth.SEED_BASE + 200 + step)
-    if step == 0:
-      loss, wd, pgl = eng.train_forward_backward(feed)
-      worst_g = 0.0
-      for n, _ in eng.param_specs():
-        g = eng.get_grad(n)                  # gradient of the GLOBAL batch mean
-        gs = r[0]["grad|" + n] / world       # sum over ranks of the shard means / world
-        scale = max(float(np.abs(g).max()), 1e-30)
-        worst_g = max(worst_g, float(np.abs(gs - g).max()) / scale)
-        assert np.abs(gs - g).max() <= 2e-4 * scale, (n, np.abs(gs - g).max(), scale)
-      print("reduced gradients vs the global batch: worst %.2e of max|g|" % worst_g)
-      eng.train_apply(1.0)
-    else:
-      loss, wd, pgl = eng.train_step(feed)
-    ref = np.asarray([loss, wd] + list(pgl))
-    mean = 0.5 * (r[0]["losses"][step] + r[1]["losses"][step])
-    print("step %d: single-process %s | 2 ranks (mean) %s" % (step, ref, mean))
-    assert np.allclose(mean, ref, rtol=2e-6, atol=1e-7)
-  worst = 0.0
-  for n, _ in eng.param_specs():
-    ref = eng.get_param(n)
-    upd = max(float(np.abs(ref - params[n]).max()), 1e-12)
-    d = float(np.abs(r[0][n] - ref).max())
-    worst = max(worst, d / max(1.0, float(np.abs(ref).max())))
-    assert d <= 1e-6 * max(1.0, float(np.abs(ref).max())) and d <= 2e-3 * upd, (n, d, upd)
-    s_ref = eng.get_opt_slot(n, 0)
-    assert np.abs(r[0]["slot0|" + n] - s_ref).max() <= 1e-4 * max(np.abs(s_ref).max(), 1e-30)
-  eng.close()
-  print("parameters after %d in-library data-parallel steps: max |2 ranks - 1 process| = %.2e"
-        % (STEPS, worst))
+  print("reduced gradients vs the global batch: worst %.2e of max|g|" % res["grad"])
+  assert res["grad"] <= 2e-4 and res["loss"] <= 2e-6
+  assert res["param"] <= 1e-6 and res["param_upd"] <= 2e-3 and res["slot"] <= 1e-4
+  print("parameters after %d in-library data-parallel steps (%s stand-in): max |2 ranks - 1 "
+        "process| = %.2e" % (STEPS, mode, res["param"]))
+
+
+@pytest.mark.parametrize("fault,what", [("1", "ready"), ("2", "done")])
+def test_two_rank_test_fails_when_an_event_wait_is_dropped(built_lib, tmp_path, fault, what):
+  """Negative control of the test above: MV_COMM_FAULT makes the engine skip ONE of its two
+  event waits around the collectives (1: the side stream no longer waits for the main stream's
+  `ready` -- the collective reads gradients the wgrad kernels have not finished; 2: the main
+  stream no longer waits for `done` -- clip + optimizer run on unreduced gradients).  Over the
+  asynchronous stand-in either must be VISIBLE in the quantities the test above asserts;
+  otherwise that test could not catch an ordering bug in comm_reduce_*."""
+  if not os.path.exists(FAKE_RCCL):
+    pytest.skip("tests/fake_rccl/libfakerccl.so not built (__graft_entry__.build())")
+  env = {"MV_FAKE_RCCL_ASYNC": "1", "MV_FAKE_RCCL_DELAY_MS": "20", "MV_COMM_FAULT": fault}
+  res = _two_ranks_vs_one_process(built_lib, tmp_path, env)
+  broken = (not res["ranks_equal"]) or res["grad"] > 2e-4 or res["param_upd"] > 2e-3
+  print("dropped `%s` wait: ranks_equal %s grad %.2e param_upd %.2e -> %s" % (
+      what, res["ranks_equal"], res["grad"], res["param_upd"],
+      "DETECTED" if broken else "NOT detected"))
+  assert broken, "the two-rank test cannot see a missing `%s` wait" % what
 
 
 def test_bench_spawns_its_own_ranks(built_lib):

@@ -161,8 +161,16 @@ def test_mv_rccl_lib_selects_exactly_that_library():
   code = ("import sys; sys.path.insert(0, %r)\n"
           "from multiverse_amd import _lib\n"
           "print(_lib.comm_unique_id()[24:30])\n" % root)
-  out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, MV_RCCL_LIB=_FAKE))
-  assert b"mvfake" in out
-  r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MV_RCCL_LIB="/nonexistent/librccl.so"),
+  allow = dict(os.environ, MV_ALLOW_RCCL_OVERRIDE="1")
+  r = subprocess.run([sys.executable, "-c", code], env=dict(allow, MV_RCCL_LIB=_FAKE),
+                     capture_output=True)
+  assert r.returncode == 0 and b"mvfake" in r.stdout
+  assert b"WARNING: collectives bound to" in r.stderr      # announced, never silent
+  r = subprocess.run([sys.executable, "-c", code], env=dict(allow, MV_RCCL_LIB="/nonexistent/librccl.so"),
                      capture_output=True)
   assert r.returncode != 0 and b"MV_RCCL_LIB" in r.stderr
+  # the override is a test hook: without MV_ALLOW_RCCL_OVERRIDE=1 it is REFUSED, not ignored
+  env = dict(os.environ, MV_RCCL_LIB=_FAKE)
+  env.pop("MV_ALLOW_RCCL_OVERRIDE", None)
+  r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True)
+  assert r.returncode != 0 and b"MV_ALLOW_RCCL_OVERRIDE" in r.stderr

@@ -5,6 +5,8 @@
 #   margins   the at-size parity tests, the Winograd kernel tests and the reference pins with -s:
 #             max|dlogits|, max|dreg|, flips, min oracle margin, per-row beam report
 #   suite     the whole GPU suite (-x -q)
+#   parallel  tests/test_gpu_parallel.py -s (two ranks on one GPU: gloo, the in-library all-reduce
+#             over tests/fake_rccl in both modes, the dropped-event-wait negative controls)
 #   wino      tests/test_gpu_wino.py -s (kernel-level parity of the gate kernel forms)
 #   bench     the default `python bench.py` line (headline + every sub-workload)
 #   headline  `python bench.py --no-sub` x 2 (same-box repeatability of the headline)
@@ -37,6 +39,9 @@ for stage in "$@"; do
     suite)
       (time timeout 1500 python -m pytest tests -q -x -m gpu) > $O/gpu_tests.log 2>&1
       echo "suite rc $?"; tail -4 $O/gpu_tests.log ;;
+    parallel)
+      (time timeout 1200 python -m pytest tests/test_gpu_parallel.py -m gpu -q -s) > $O/parallel_tests.log 2>&1
+      echo "parallel rc $?"; grep -E "passed|failed|error|DETECTED|detected|max \|2 ranks" $O/parallel_tests.log | tail -8 ;;
     wino)
       (time timeout 900 python -m pytest tests/test_gpu_wino.py -m gpu -q -s) > $O/wino_tests.log 2>&1
       echo "wino rc $?"; grep -E "passed|failed|error" $O/wino_tests.log | tail -3 ;;
