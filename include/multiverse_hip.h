@@ -382,7 +382,8 @@ int  mv_op_convlstm_step(int device, const float* x, const float* c,
                          const float* biases, int32_t M, int32_t H, int32_t W,
                          int32_t Cx, int32_t C, float* c_out, float* h_out);
 /* The same step on the fp16 matrix pipe at fp32 accuracy (f16x3 operand planes):
- * variant 1 = direct 3x3 form, 2 = Winograd F(2,3) over image rows (W must divide 32).
+ * variant 1 = direct 3x3 form, 2 = Winograd F(2,3) over image rows (W must divide 32),
+ * 3 = Winograd F(3,3) over image rows (W must divide 32, H >= 3; csrc/convlstm_wino3.h).
  * h16_out (optional) [M,H,W,C]: the h' OPERAND PLANES the kernel emitted for the next
  * step, decoded back to fp32 ((hi + lo) / 256), so that a test sees the plane layout. */
 int  mv_op_convlstm_step16(int device, int32_t variant, const float* x, const float* c,

@@ -1,0 +1,680 @@
+// ConvLSTM step, f16x3 arithmetic, with the 3x3 gate convolution in Winograd F(3,3) form
+// along the image's ROW axis: five products per THREE output rows and stencil column -- 5/9 of
+// the matrix-pipe work of the direct form (convlstm_f16x3.h), 5/6 of the F(2,3) row-pair form
+// (convlstm_wino.h) -- for the same pre-activations.
+//
+// Why (profiles/r5b_energy_attribution.md): the F(2,3) kernel
+// runs at the package power cap, and the attribution of its energy per launch puts ~4/5 of
+// the dynamic energy into the MFMAs themselves (dropping two of the three MFMAs of every
+// product saves more than half of the launch's energy).  What is left to cut is MFMAs per
+// product.  18 = 6 x 3 and 9 = 3 x 3: on the grids of the published configuration row
+// triples tile exactly (F(4,3) needs a fifth, half-empty tile at 18 rows and computes 12 rows
+// for 9: 30 and 18 products per column against 30 and 15 here, 36 and 20 for F(2,3)).
+//
+// Algebra (points 0, 1, -1, 2, inf; d0..d4 = input rows 3t-1 .. 3t+3, g0..g2 = the kernel rows
+// of one stencil column dx; numpy twin: tests/test_wino_model.py):
+//     V0 = 2 (d0 - d2) + V3          U0 = g0 / 2                 y(3t)   = M0 + M1 + M2 + M3
+//     V1 = (d3 - d2) - 2 d1          U1 = -(g0 + g1 + g2) / 2    y(3t+1) = M1 - M2 + 2 M3
+//     V2 = 2 (d1 - d2) + (d3 - d2)   U2 = (-g0 + g1 - g2) / 6    y(3t+2) = M1 + M2 + 4 M3 + M4
+//     V3 = d3 - d1                   U3 = (g0 + 2 g1 + 4 g2) / 6
+//     V4 = 2 V3 + (d2 - d4)          U4 = -g2
+// M_c[triple-cell][column] = sum_{dx, ci} V_c[triple-cell + dx][ci] U_c[dx][ci][column].
+// As in the row-pair form the dx taps are ONE operand fragment per (component, 16 channels)
+// moved a lane up / down the wave by DPP (a wave's 32 triple-cells are consecutive x of whole
+// image rows: every W of the launch divides 32).
+//
+// Operands.  U_c in fp64 at pack time, two fp16 planes of 256 U (pack_wino3_kernel).  V_c IN
+// the kernel from the ordinary operand planes (plane_layout.h): nine wn_lin<KA, KB> steps per
+// 16 input channels, each KA a + KB b on (high, low) plane pairs with an error-free TwoSum of
+// the high planes and the factors 2 folded into the fused multiply-adds (8 packed-fp16
+// instructions per register, like wn_combine).  |256 V| <= 6 * 256: far inside fp16.
+//
+// Tile.  Weights = A operand (rows = 4 gates x 8 channels), activations = B operand (columns
+// = 32 triple-cells), so a lane's accumulators hold i, j, f, o of four consecutive channels of
+// ONE triple-cell.  A wave owns 32 triple-cells (96 cells) x NRB * 8 channels x 4 gates x 5
+// components = 80 NRB accumulator registers (160 at NRB = 2) + 16 NRB for the direct fp32 x
+// chunk of the regression encoder's middle row: more than two waves per SIMD can hold, and the
+// attribution says occupancy is not what this kernel lacks -- it is built for ONE workgroup of
+// 4 waves per CU (one wave per SIMD, up to 512 registers: the operand rows of the next chunk
+// and a whole chunk of components live in registers).  The workgroup's 4 x 32 triple-cells share
+// one weight stream: a whole 16-input-channel chunk (5 components x 3 dx x 2 planes x NRB row
+// blocks = 30 NRB KB) per LDS stage, double-buffered by LDS-DMA, ONE barrier per chunk (90
+// MFMAs per wave at NRB = 2).
+#pragma once
+#include "convlstm_wino.h"
+
+namespace mv {
+
+template <int NRB>
+struct Wn3 {
+  static constexpr int kCh = 8 * NRB;                         // output channels per workgroup
+  static constexpr int kChunkVec = 5 * 3 * 2 * NRB * 64;      // 16-byte vectors per chunk
+  static constexpr uint32_t kChunkBytes = kChunkVec * 16;
+  static constexpr int kTileFloats = 96 * kCh;                // state tile of a wave
+};
+
+static inline size_t wino3_wpack_elems(int Cx16, int C, int nrb) {   // in halves
+  return (size_t)(C / (8 * nrb)) * (size_t)(Cx16 / 16 + C / 16) * 5 * 3 * 2 * nrb * 64 * 8;
+}
+
+// The pack, from the CURRENT device weights: one thread per (cb, chunk, comp, dx, rb, lane,
+// element), both planes.  Layout [cb][chunk][comp 5][dx 3][plane 2][rb][lane 64][8]: a chunk
+// IS the LDS image of its stage.  Element e of lane l: A-operand row l & 31 = gate (row >> 3),
+// channel cb * 8 nrb + rb * 8 + (row & 7); k = 8 (l >> 5) + e = input channel of the chunk;
+// chunks = x groups of 16 first, then h groups.
+__global__ void pack_wino3_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
+                                  int Cx_total, int Cx16, int C, int nrb, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx & 7;
+  const int l = (idx >> 3) & 63;
+  size_t t = idx >> 9;
+  const int rb = (int)(t % nrb); t /= nrb;
+  const int dx = (int)(t % 3); t /= 3;
+  const int comp = (int)(t % 5); t /= 5;
+  const int nxc = Cx16 / 16, nch = nxc + C / 16;
+  const int chunk = (int)(t % nch), cb = (int)(t / nch);
+  const bool is_x = chunk < nxc;
+  const int cg = is_x ? chunk : chunk - nxc;
+  const int k = 8 * (l >> 5) + e;
+  const int cin = (is_x ? 0 : Cx_total) + cg * 16 + k;
+  const int row = l & 31;
+  const int n = (row >> 3) * C + cb * 8 * nrb + rb * 8 + (row & 7);
+  const int Cin = Cx_total + C, N4 = 4 * C;
+  const double g0 = w[((size_t)(0 * 3 + dx) * Cin + cin) * N4 + n];
+  const double g1 = w[((size_t)(1 * 3 + dx) * Cin + cin) * N4 + n];
+  const double g2 = w[((size_t)(2 * 3 + dx) * Cin + cin) * N4 + n];
+  double u;
+  switch (comp) {
+    case 0: u = 0.5 * g0; break;
+    case 1: u = -0.5 * (g0 + g1 + g2); break;
+    case 2: u = (-g0 + g1 - g2) / 6.0; break;
+    case 3: u = (g0 + 2.0 * g1 + 4.0 * g2) / 6.0; break;
+    default: u = -g2; break;
+  }
+  const double sv = u * 256.0;
+  const _Float16 v0 = (_Float16)sv;
+  const _Float16 v1 = (_Float16)(sv - (double)v0);
+  const size_t vec = ((((size_t)cb * nch + chunk) * 5 + comp) * 3 + dx) * 2;   // + plane
+  out[(((vec + 0) * nrb + rb) * 64 + l) * 8 + e] = v0;
+  out[(((vec + 1) * nrb + rb) * 64 + l) * 8 + e] = v1;
+}
+
+struct Wn3Consts { f16x8 m1, p2, m2; };   // (-1), (2), (-2) as packed halves (laundered SGPRs)
+
+// KA (a_hi + a_lo) + KB (b_hi + b_lo) as a plane pair, KA in {1, 2}, KB in {1, -1, -2}: TwoSum
+// of KA a_hi and KB b_hi (both exact in fp16), everything else into the low plane.  Every
+// line is one packed instruction per register; the products by 1 / 2 are exact, so each
+// fused multiply-add rounds exactly like the sum it stands for.
+template <int KA, int KB>
+__device__ __forceinline__ void wn_lin(const f16x8 a_hi, const f16x8 a_lo, const f16x8 b_hi,
+                                       const f16x8 b_lo, const Wn3Consts& k, f16x8& hi,
+                                       f16x8& lo) {
+  static_assert((KA == 1 && (KB == 1 || KB == -1 || KB == -2)) || (KA == 2 && KB == 1), "form");
+  const f16x8 nka = KA == 1 ? k.m1 : k.m2;                      // -KA
+  f16x8 s, ne2, l1;
+  if (KA == 2) {
+    s = __builtin_elementwise_fma(a_hi, k.p2, b_hi);
+    l1 = __builtin_elementwise_fma(a_lo, k.p2, b_lo);
+  } else if (KB == 1) {
+    s = a_hi + b_hi;
+    l1 = a_lo + b_lo;
+  } else {
+    s = __builtin_elementwise_fma(b_hi, KB == -1 ? k.m1 : k.m2, a_hi);
+    l1 = __builtin_elementwise_fma(b_lo, KB == -1 ? k.m1 : k.m2, a_lo);
+  }
+  const f16x8 bb = __builtin_elementwise_fma(a_hi, nka, s);    // the part of KB b_hi that arrived
+  const f16x8 t = __builtin_elementwise_fma(bb, k.m1, s);      // the part of KA a_hi that arrived
+  const f16x8 ne1 = __builtin_elementwise_fma(a_hi, nka, t);   // -(KA a_hi - t)
+  if (KB == -1) ne2 = bb + b_hi;                                // -(KB b_hi - bb)
+  else ne2 = __builtin_elementwise_fma(b_hi, KB == 1 ? k.m1 : k.p2, bb);
+  hi = s;
+  lo = __builtin_elementwise_fma(ne1 + ne2, k.m1, l1);
+}
+
+template <int WAVES, int NRB>
+__device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, int cb, int mt,
+                                                    f16x8* lds) {
+  using G = Wn3<NRB>;
+  constexpr int CH = G::kCh;
+  constexpr int kTriples = WAVES * 32;                 // triple-cells per workgroup
+  constexpr int kPieces = CH / 4;                      // 16-byte pieces of a tile row
+  constexpr int kPasses = (96 * kPieces + 63) / 64;    // wave passes over a state tile
+  const ConvLstm16Args& q = p.b;
+  const ConvLstmArgs& a = q.f;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int H = a.H, W = a.W, HW = H * W, C = a.C, Cx = a.Cx;
+  const int Ht = (H + 2) / 3, Kt = Ht * W;
+  const int Q_total = a.rows * Kt;
+  const int q_wave = mt * kTriples + wave * 32;
+  const bool wave_live = q_wave < Q_total;       // dead waves still copy and hit barriers
+  const int col = lane & 31, half = lane >> 5;
+
+  int r = 0, y0 = 0, xpos = 0;
+  bool valid;
+  {
+    const int qq = q_wave + col;
+    valid = qq < Q_total;
+    if (valid) {
+      r = qq / Kt;
+      const int pc = qq - r * Kt;
+      const int t = pc / W;
+      y0 = 3 * t;
+      xpos = pc - t * W;
+    }
+  }
+  const int srh = (valid && a.src_row_h) ? a.src_row_h[r] : r;
+  const bool okx0 = valid & (xpos > 0), okx2 = valid & (xpos + 1 < W);
+
+  // operand rows y0 - 1 .. y0 + 3 of the lane's column: byte offsets of the lane's 16-byte
+  // vector in channel group 0 of the tiled planes (from the zero pad in front of a plane, so
+  // that offset 0 reads zeros); an out-of-image row reads offset 0
+  uint32_t roffx[5], roffh[5];
+  {
+    const int KGx = Cx >> 4, KGh = C >> 4;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int rho = y0 - 1 + i;
+      const bool ok = valid & (rho >= 0) & (rho < H);
+      const int cx = r * HW + rho * W + xpos, chh = srh * HW + rho * W + xpos;
+      roffx[i] = ok ? (uint32_t)((((cx >> 5) * KGx) * 512 + half * 256 + (cx & 31) * 8 + kPlanePad) * 2) : 0u;
+      roffh[i] = ok ? (uint32_t)((((chh >> 5) * KGh) * 512 + half * 256 + (chh & 31) * 8 + kPlanePad) * 2) : 0u;
+    }
+  }
+
+  // acc[0..4]: the Winograd components; acc[5]: the direct fp32 x chunk of row y0 + 1
+  f32x16 acc[6][NRB];
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[c][rb][i] = 0.f;
+
+  // LDS: [chunk buffer 0 | chunk buffer 1 | per wave: c tile 96 x CH floats | per wave: two
+  // tables of 96 cell offsets (state source rows, output rows)]
+  float* const ctile = reinterpret_cast<float*>(lds + 2 * G::kChunkVec) + wave * G::kTileFloats;
+  uint32_t* const otab = reinterpret_cast<uint32_t*>(
+      reinterpret_cast<float*>(lds + 2 * G::kChunkVec) + WAVES * G::kTileFloats) + wave * 192;
+  constexpr uint32_t kNone = 0xffffffffu;
+  const uint32_t rowb = (uint32_t)C * 4u;                    // bytes per cell of a state tensor
+  bool okc[3];
+  int cell[3];                                               // cell index inside its image
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    okc[e] = valid & (y0 + e < H);
+    cell[e] = (y0 + e) * W + xpos;
+  }
+  if (wave_live) {
+    const int src_c0 = (valid && a.src_row_c) ? a.src_row_c[r] : r;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      otab[e * 32 + col] = okc[e] ? (uint32_t)(src_c0 * HW + cell[e]) * rowb : kNone;
+      otab[96 + e * 32 + col] = okc[e] ? (uint32_t)(r * HW + cell[e]) * rowb : kNone;
+    }
+  }
+  // ---- the wave's tile of the cell state c (96 cells x CH channels) starts its way into LDS
+  // NOW, by LDS-DMA: pass k moves the tile's bytes [1024 k, 1024 k + 1024), lane l the 16 bytes
+  // of tile row i / kPieces, piece i % kPieces, i = 64 k + l (a row = one cell's CH channels).
+  const uint32_t colb = (uint32_t)(cb * CH) * 4u;            // the workgroup's first channel
+  if (wave_live && !a.zero_state) {
+    const __amdgpu_buffer_rsrc_t c_rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<float*>(a.c)), 0, (uint32_t)(a.rows * HW) * rowb, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < kPasses; ++k) {
+      const int i = k * 64 + lane;
+      const int trow = i / kPieces, piece = i - trow * kPieces;
+      const uint32_t ro = trow < 96 ? otab[trow] : kNone;
+      // rows that own no cell read offset 0 (the value is never used)
+      const uint32_t off = ro != kNone ? ro + colb + (uint32_t)piece * 16u : 0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          c_rs0, (__attribute__((address_space(3))) void*)(ctile + k * 256), 16, off, 0, 0,
+          MV_EPI_LD_AUX);
+    }
+  }
+
+  // ---- the 2-channel fp32 x chunk (regression encoder), direct form: row y0 into M0 (only
+  // y(3t) holds M0), row y0 + 2 into M4 (only y(3t+2)), row y0 + 1 into its own accumulator
+  if (a.x_small && wave_live) {
+    const int Cin = Cx + C, N4 = 4 * C;
+    const int nk = 9 * Cx;
+    const int n0 = (col >> 3) * C + cb * CH + (col & 7);
+    for (int k2 = 0; 2 * k2 < nk; ++k2) {
+      const int k = 2 * k2 + half;
+      const bool kok = k < nk;
+      const int tap = kok ? k / Cx : 0, chn = kok ? k - tap * Cx : 0;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      float wv[NRB];
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        const float tw = p.w_hwio[((size_t)tap * Cin + chn) * N4 + n0 + rb * 8];
+        wv[rb] = kok ? tw * 65536.0f : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int yy = y0 + e + dy, xx = xpos + dx;
+        const bool ok = kok & valid & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+        const int off = ok ? r * a.x_row_stride + (yy * W + xx) * Cx + chn : 0;
+        const float tv = a.x[off];
+        const float v = ok ? tv : 0.f;
+        constexpr int kSlot[3] = {0, 5, 4};
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+          acc[kSlot[e]][rb] =
+              __builtin_amdgcn_mfma_f32_32x32x2f32(wv[rb], v, acc[kSlot[e]][rb], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- f16 chunks of 16 input channels: x chunks first, then h chunks
+  const int nxc = p.n_xc;
+  const int ck_lo = a.sx_corr ? nxc : 0;                          // sparse x: table terms instead
+  const int ck_hi = (p.abl & 1) ? ck_lo : (a.zero_state ? nxc : nxc + (C >> 4));
+  if (ck_hi > ck_lo) {
+    const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wpw) +
+                        (size_t)cb * (nxc + (C >> 4)) * G::kChunkVec;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<f16x8*>(wblk)), 0, 0x7fffffff, 0x00020000);
+    const _Float16* const x16 = q.x16 ? q.x16 : q.h16;
+    const int64_t xps = q.x16 ? q.x_plane_stride : 0;
+    const _Float16* const h16 = q.h16 ? q.h16 : q.x16;
+    const int64_t hps = q.h16 ? q.h_plane_stride : 0;
+    const __amdgpu_buffer_rsrc_t xrs0 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<_Float16*>(x16 - kPlanePad)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs1 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<_Float16*>(x16 + xps - kPlanePad)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrs0 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<_Float16*>(h16 - kPlanePad)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrs1 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<_Float16*>(h16 + hps - kPlanePad)), 0, 0x7fffffff, 0x00020000);
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // chunk copy: the pack IS the LDS image; 30 NRB pieces of 64 vectors over the waves
+    constexpr int kChunkPieces = 30 * NRB;
+    auto chunk_dma = [&](int ck, f16x8* dstbuf) {
+#pragma unroll
+      for (int i = 0; i < (kChunkPieces + WAVES - 1) / WAVES; ++i) {
+        const int piece = i * WAVES + wave_u;
+        if (kChunkPieces % WAVES == 0 || piece < kChunkPieces) {
+          const int v0 = piece * 64;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              wrs, (__attribute__((address_space(3))) void*)(dstbuf + v0), 16,
+              (uint32_t)(v0 + lane) * 16u, (uint32_t)ck * G::kChunkBytes, 0, MV_DMA_AUX);
+        }
+      }
+    };
+    f16x8 raw[5][2];
+    auto load_raw = [&](int ck) {
+      const bool is_x = ck < nxc;
+      const uint32_t cgo = (uint32_t)(is_x ? ck : ck - nxc) * 1024u;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const uint32_t o = is_x ? roffx[i] : roffh[i];
+        const int off = o ? (int)(o + cgo) : 0;
+        raw[i][0] = __builtin_bit_cast(
+            f16x8, __builtin_amdgcn_raw_buffer_load_b128(is_x ? xrs0 : hrs0, off, 0, 0));
+        raw[i][1] = __builtin_bit_cast(
+            f16x8, __builtin_amdgcn_raw_buffer_load_b128(is_x ? xrs1 : hrs1, off, 0, 0));
+      }
+    };
+    // one component: 3 dx x NRB row blocks x 3 MFMAs from chunk buffer `buf`
+#define MV_W3_COMP(COMP, VHI, VLO, BUF)                                                       \
+  do {                                                                                        \
+    _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                        \
+      const f16x8 b0 = dx == 1 ? (VHI) : wn_lane_shift((VHI), dx == 0, dx == 0 ? okx0 : okx2); \
+      const f16x8 b1 = dx == 1 ? (VLO) : wn_lane_shift((VLO), dx == 0, dx == 0 ? okx0 : okx2); \
+      f16x8 w0[NRB], w1[NRB];                                                                 \
+      _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) {                                    \
+        w0[rb] = (BUF)[((((COMP) * 3 + dx) * 2 + 0) * NRB + rb) * 64 + lane];                 \
+        w1[rb] = (BUF)[((((COMP) * 3 + dx) * 2 + 1) * NRB + rb) * 64 + lane];                 \
+      }                                                                                       \
+      _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                      \
+        acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[rb], b0, acc[COMP][rb], 0, 0, 0); \
+      _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                      \
+        acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b1, acc[COMP][rb], 0, 0, 0); \
+      _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                      \
+        acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b0, acc[COMP][rb], 0, 0, 0); \
+    }                                                                                         \
+  } while (0)
+
+    uint32_t mone = 0xBC00BC00u, ptwo = 0x40004000u, mtwo = 0xC000C000u;   // opaque to hipcc
+    asm volatile("" : "+s"(mone), "+s"(ptwo), "+s"(mtwo));
+    Wn3Consts kc;
+    kc.m1 = __builtin_bit_cast(f16x8, u32x4{mone, mone, mone, mone});
+    kc.p2 = __builtin_bit_cast(f16x8, u32x4{ptwo, ptwo, ptwo, ptwo});
+    kc.m2 = __builtin_bit_cast(f16x8, u32x4{mtwo, mtwo, mtwo, mtwo});
+    load_raw(ck_lo);
+    chunk_dma(ck_lo, lds);
+    __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
+    for (int ck = ck_lo; ck < ck_hi; ++ck) {
+      f16x8* const buf = lds + (((ck - ck_lo) & 1) ? G::kChunkVec : 0);
+      f16x8* const nbuf = lds + (((ck - ck_lo) & 1) ? 0 : G::kChunkVec);
+      const bool more = ck + 1 < ck_hi;
+      if (more) chunk_dma(ck + 1, nbuf);     // its buffer was last read before the barrier
+      // input transform of the chunk: nine plane-pair combinations
+      f16x8 v0h, v0l, v1h, v1l, v2h, v2l, v3h, v3l, v4h, v4l, th, tl, t3h, t3l;
+      wn_lin<1, -1>(raw[3][0], raw[3][1], raw[1][0], raw[1][1], kc, v3h, v3l);   // V3 = d3 - d1
+      wn_lin<1, -1>(raw[0][0], raw[0][1], raw[2][0], raw[2][1], kc, th, tl);     // d0 - d2
+      wn_lin<2, 1>(th, tl, v3h, v3l, kc, v0h, v0l);                              // V0
+      wn_lin<1, -1>(raw[3][0], raw[3][1], raw[2][0], raw[2][1], kc, t3h, t3l);   // d3 - d2
+      wn_lin<1, -2>(t3h, t3l, raw[1][0], raw[1][1], kc, v1h, v1l);               // V1
+      wn_lin<1, -1>(raw[1][0], raw[1][1], raw[2][0], raw[2][1], kc, th, tl);     // d1 - d2
+      wn_lin<2, 1>(th, tl, t3h, t3l, kc, v2h, v2l);                              // V2
+      wn_lin<1, -1>(raw[2][0], raw[2][1], raw[4][0], raw[4][1], kc, th, tl);     // d2 - d4
+      wn_lin<2, 1>(v3h, v3l, th, tl, kc, v4h, v4l);                              // V4
+      if (more) load_raw(ck + 1);            // a whole chunk (90 MFMAs at NRB = 2) ahead of its use
+      MV_W3_COMP(0, v0h, v0l, buf);
+      MV_W3_COMP(1, v1h, v1l, buf);
+      MV_W3_COMP(2, v2h, v2l, buf);
+      MV_W3_COMP(3, v3h, v3l, buf);
+      MV_W3_COMP(4, v4h, v4l, buf);
+      __syncthreads();
+    }
+#undef MV_W3_COMP
+  }
+  if (!wave_live) return;
+  if (p.abl & 2) {                          // keep every accumulator live, store nothing
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += acc[c][rb][i];
+    if (sum == 12345.678f) a.h_out[0] = sum;
+    return;
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // registers of acc[c][rb]: gate = reg >> 2, channel = cb * CH + rb * 8 + 4 * half + (reg & 3);
+  // the lane's triple-cell gives rows y0 + e, e = 0, 1, 2.
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));          // keep the address arithmetic below the loop
+  const int half_e = lane_e >> 5;
+  const int ch0 = cb * CH + 4 * half_e;                      // + rb * 8
+  const uint32_t out_bytes = (uint32_t)(a.rows * HW) * rowb;
+  const __amdgpu_buffer_rsrc_t co_rs = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.c_out), 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ho_rs = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.h_out), 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t go_rs = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(a.gates_out ? a.gates_out : a.h_out), 0, a.gates_out ? 4u * out_bytes : 0u,
+      0x00020000);
+  // ---- state I/O through LDS.  A lane owns 4 channels per row block of the three cells of its
+  // triple-cell: stored from the accumulator layout every lane of a wave instruction would
+  // touch its own cache line.  Instead the wave's tile of a state tensor -- 96 cells x CH
+  // channels fp32, row e * 32 + column -- passes through a wave-private LDS tile and moves to /
+  // from memory LINEARLY: pass k, lane l = 16 bytes at tile byte 1024 k + 16 l, i.e. kPieces
+  // lanes cover the contiguous bytes the workgroup's CH channels have in a cell.
+  float* const tl0 = ctile;                   // c in, then c' out
+  float* const tl1 = reinterpret_cast<float*>(lds) + wave * G::kTileFloats;   // h' out (dead chunk buffer)
+  const int wr_idx = (lane_e & 31) * CH + half_e * 4;        // + e * 32 * CH + rb * 8 (floats)
+  f32x4 cprev[3][NRB];
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) cprev[e][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!a.zero_state && !(p.abl & 4)) {
+    // the tile was requested before the main loop; its barriers carried the vmcnt(0) -- the
+    // explicit wait covers a launch without f16 chunks
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+        cprev[e][rb] = *reinterpret_cast<const f32x4*>(tl0 + wr_idx + e * 32 * CH + rb * 8);
+  }
+  // sparse x: hot cell of the lane's image
+  int hot_y = 0, hot_x = 0;
+  if (a.sx_corr) {
+    const int hr = a.sx_hot_div > 1 ? r / a.sx_hot_div : r;
+    const uint32_t hyx = a.sx_cellyx[a.sx_hot[(size_t)hr * a.sx_hot_stride]];
+    hot_y = (int)(hyx >> 16); hot_x = (int)(hyx & 0xffffu);
+  }
+  const float un = kF16Unscale;
+  const bool planes = q.h16_out != nullptr;
+  u32x2 ph[3][NRB], pl[3][NRB];               // h' as plane halves (hi, lo), [e][rb]
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int y = y0 + e;
+    const uint32_t mcell = (uint32_t)(r * HW + cell[e]);     // output cell, flat
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const int ch = ch0 + rb * 8;
+      // per-gate additive terms (4 channels each)
+      f32x4 add[4];
+      {
+        const float* bsrc = a.bias;
+        if (a.sx_corr && a.sx_bias) {
+          const int cls = 3 * (y == 0 ? 0 : (y == H - 1 ? 2 : 1)) +
+                          (xpos == 0 ? 0 : (xpos == W - 1 ? 2 : 1));
+          bsrc = a.sx_bias + (size_t)(okc[e] ? cls : 4) * 4 * C;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          add[g] = *reinterpret_cast<const f32x4*>(bsrc + g * C + ch);
+        if (a.sx_corr) {
+          const int dy = y - hot_y, dxh = xpos - hot_x, rad = a.sx_rad;
+          if (okc[e] && dy >= -rad && dy <= rad && dxh >= -rad && dxh <= rad) {
+            const int side = 2 * rad + 1;
+            const int idx = a.sx_by_class
+                                ? 3 * (hot_y == 0 ? 0 : (hot_y == H - 1 ? 2 : 1)) +
+                                      (hot_x == 0 ? 0 : (hot_x == W - 1 ? 2 : 1))
+                                : r;
+            const float* ct = a.sx_corr +
+                ((size_t)idx * side * side + (dy + rad) * side + (dxh + rad)) * 4 * C + ch;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 cv = *reinterpret_cast<const f32x4*>(ct + g * C);
+              add[g][0] += cv[0]; add[g][1] += cv[1]; add[g][2] += cv[2]; add[g][3] += cv[3];
+            }
+          }
+        }
+      }
+      f32x4 cn4, hn4, si4, tj4, sf4, so4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int reg = g * 4 + j;
+          const float m0 = acc[0][rb][reg], m1 = acc[1][rb][reg], m2 = acc[2][rb][reg],
+                      m3 = acc[3][rb][reg], m4 = acc[4][rb][reg], mx = acc[5][rb][reg];
+          float yv;
+          if (e == 0) yv = (m0 + m1) + (m2 + m3);
+          else if (e == 1) yv = ((m1 - m2) + 2.0f * m3) + mx;
+          else yv = (m1 + m2) + (4.0f * m3 + m4);
+          pre[g] = __builtin_fmaf(yv, un, add[g][j]);   // un = 2^-16: the product is exact
+        }
+        float si, tj, sf, so;
+        if (p.abl & 32) {
+          si = pre[0] * 0.25f + 0.5f; tj = pre[1] * 0.5f; sf = pre[2] * 0.25f + 0.5f;
+          so = pre[3] * 0.25f + 0.5f;
+        } else {
+          si = sigm_(pre[0]); tj = tanh_(pre[1]); sf = sigm_(pre[2] + a.forget_bias);
+          so = sigm_(pre[3]);
+        }
+        float cn = sf * cprev[e][rb][j];
+        cn = cn + si * tj;
+        const float hn = ((p.abl & 32) ? cn * 0.5f : tanh_(cn)) * so;
+        cn4[j] = cn; hn4[j] = hn; si4[j] = si; tj4[j] = tj; sf4[j] = sf; so4[j] = so;
+      }
+      // c' and h' into the wave's two LDS tiles (the c tile was read into cprev above)
+      *reinterpret_cast<f32x4*>(tl0 + wr_idx + e * 32 * CH + rb * 8) = cn4;
+      if (!a.skip_h32) *reinterpret_cast<f32x4*>(tl1 + wr_idx + e * 32 * CH + rb * 8) = hn4;
+      if (a.gates_out && okc[e] && !(p.abl & 8)) {
+        // training forward: the four gate activations [m][4][C] (stored from the lane)
+        const uint32_t g0 = (mcell * 4u * (uint32_t)C + (uint32_t)ch) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, si4), go_rs, (int)g0,
+                                               0, MV_EPI_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tj4), go_rs,
+                                               (int)(g0 + rowb), 0, MV_EPI_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sf4), go_rs,
+                                               (int)(g0 + 2 * rowb), 0, MV_EPI_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, so4), go_rs,
+                                               (int)(g0 + 3 * rowb), 0, MV_EPI_ST_AUX);
+      }
+      if (planes) {
+        f16x4 p0, p1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sc = hn4[j] * kF16Scale;
+          const _Float16 h0 = (_Float16)sc;
+          p0[j] = h0;
+          p1[j] = (_Float16)(sc - (float)h0);
+        }
+        ph[e][rb] = __builtin_bit_cast(u32x2, p0);
+        pl[e][rb] = __builtin_bit_cast(u32x2, p1);
+      }
+    }
+  }
+  // ---- c' / h' out: the tiles leave LDS linearly, kPieces lanes per cell
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (!(p.abl & 8)) {
+#pragma unroll
+    for (int k = 0; k < kPasses; ++k) {
+      const int i = k * 64 + lane_e;
+      const int trow = i / kPieces, piece = i - trow * kPieces;
+      if (96 * kPieces % 64 == 0 || trow < 96) {
+        const uint32_t ro = otab[96 + trow];
+        const u32x4 cv = *reinterpret_cast<const u32x4*>(tl0 + i * 4);
+        u32x4 hv = cv;
+        if (!a.skip_h32) hv = *reinterpret_cast<const u32x4*>(tl1 + i * 4);
+        if (ro != kNone) {
+          const int off = (int)(ro + colb + (uint32_t)piece * 16u);
+          __builtin_amdgcn_raw_buffer_store_b128(cv, co_rs, off, 0, MV_EPI_ST_AUX);
+          if (!a.skip_h32) __builtin_amdgcn_raw_buffer_store_b128(hv, ho_rs, off, 0, MV_EPI_ST_AUX);
+        }
+      }
+    }
+  }
+  // ---- operand planes of h' for the next gate convolution: tile (m >> 5, channel group of
+  // 16), k half, 8 channels = one 16-byte vector per cell.  A lane holds 4 of the 8 for each
+  // of its three cells; v_permlane32_swap hands the lower half-wave the complete vectors of
+  // the e = 0 cells and the upper half-wave those of the e = 1 cells, a second swap the lower
+  // half-wave those of the e = 2 cells: 16 bytes per lane, 512 contiguous bytes per half-wave.
+  if (planes && !(p.abl & 16)) {
+    const uint32_t mc01 = (uint32_t)(r * HW + (half_e ? cell[1] : cell[0]));
+    const uint32_t mc2 = (uint32_t)(r * HW + cell[2]);
+    const bool ok01 = half_e ? okc[1] : okc[0];
+    const bool ok2 = okc[2] && half_e == 0;
+    const size_t KG = (size_t)(C >> 4);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const int c8 = cb * NRB + rb;                          // the vector's 8-channel group
+      const size_t grp = (size_t)(c8 >> 1) * 512 + (size_t)(c8 & 1) * 256;
+      const size_t o01 = (size_t)(mc01 >> 5) * KG * 512 + grp + (size_t)((int)(mc01 & 31u) * 8);
+      const size_t o2 = (size_t)(mc2 >> 5) * KG * 512 + grp + (size_t)((int)(mc2 & 31u) * 8);
+#pragma unroll
+      for (int pn = 0; pn < 2; ++pn) {
+        const u32x2 A = pn ? pl[0][rb] : ph[0][rb], B = pn ? pl[1][rb] : ph[1][rb];
+        const u32x2 D = pn ? pl[2][rb] : ph[2][rb];
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A[0], B[0], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(A[1], B[1], false, false);
+        // lower lanes: (own A | partner's A) = e 0, channels 0-3 | 4-7; upper lanes:
+        // (partner's B | own B) = e 1, channels 0-3 | 4-7
+        const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+        if (ok01)
+          *reinterpret_cast<u32x4*>(q.h16_out + (size_t)pn * q.h16_out_stride + o01) = v;
+        const u32x2 t0 = __builtin_amdgcn_permlane32_swap(D[0], D[0], false, false);
+        const u32x2 t1 = __builtin_amdgcn_permlane32_swap(D[1], D[1], false, false);
+        const u32x4 v2 = {t0[0], t1[0], t0[1], t1[1]};        // lower lanes: e 2, channels 0-3 | 4-7
+        if (ok2)
+          *reinterpret_cast<u32x4*>(q.h16_out + (size_t)pn * q.h16_out_stride + o2) = v2;
+      }
+    }
+  }
+}
+
+template <int WAVES, int NRB>
+__global__ __launch_bounds__(WAVES * 64, 1)
+void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
+  extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
+  int block = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxGroup - 1; ++i)
+    if (i + 1 < g.n && (int)blockIdx.x >= g.block_end[i]) pi = i + 1;
+  if (pi > 0) block -= g.block_end[pi - 1];
+  // block -> (column block, row tile), as in convlstm_step_wino_kernel: XCD x holds the
+  // ADJACENT column blocks 2x, 2x + 1 of sixteen (the two halves of every 128-byte line of the
+  // state tensors at CH = 16) through one L2
+  auto cbmap = [&](int ncb, int& cb, int& mt) {
+    if (g.map_mode == 1 && (ncb & 15) == 0) {
+      const int grp = block / 16, w16 = block - grp * 16;      // 16 consecutive blocks
+      cb = (grp % (ncb / 16)) * 16 + 2 * (w16 & 7) + (w16 >> 3);
+      mt = grp / (ncb / 16);
+    } else {
+      cb = block % ncb; mt = block / ncb;
+    }
+  };
+  int cb, mt;
+  constexpr int CH = Wn3<NRB>::kCh;
+  switch (pi) {
+    case 0: cbmap(g.p[0].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB>(g.p[0], cb, mt, lds); break;
+    case 1: cbmap(g.p[1].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB>(g.p[1], cb, mt, lds); break;
+    case 2: cbmap(g.p[2].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB>(g.p[2], cb, mt, lds); break;
+    default: cbmap(g.p[3].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB>(g.p[3], cb, mt, lds); break;
+  }
+}
+
+constexpr int kW3Waves = 4, kW3Nrb = 2;
+
+static inline size_t wino3_lds_bytes() {
+  return (size_t)2 * Wn3<kW3Nrb>::kChunkBytes + (size_t)kW3Waves * Wn3<kW3Nrb>::kTileFloats * 4 +
+         (size_t)kW3Waves * 192 * 4;
+}
+static inline unsigned convlstm_wino3_blocks(const ConvLstmArgs& a) {
+  const size_t Q = (size_t)a.rows * ((a.H + 2) / 3) * a.W;
+  const size_t triples = (size_t)kW3Waves * 32;
+  return (unsigned)((Q + triples - 1) / triples) * (unsigned)(a.C / Wn3<kW3Nrb>::kCh);
+}
+
+// MV_WINO3=0 keeps the F(2,3) row-pair kernel (A/B runs).
+static inline bool wino3_enabled() {
+  static const bool off = getenv("MV_WINO3") && atoi(getenv("MV_WINO3")) == 0;
+  return !off;
+}
+// The F(3,3) form serves a problem when W divides 32 (the DPP column shift), C is a multiple
+// of the channel block, the x operand comes as 16-channel planes (or is the 2-channel fp32
+// chunk) under the FIXED 2^8 scale -- the per-tensor exponent of unbounded activations leaves
+// one bit of headroom, the components here need three (|V| <= 6 max |d|) -- and the grid has
+// at least three rows.
+static inline bool wino3_geometry_ok(const ConvLstmArgs& a, const ConvLstm16Args& q) {
+  return a.W > 0 && 32 % a.W == 0 && a.C % Wn3<kW3Nrb>::kCh == 0 &&
+         (a.Cx % 16 == 0 || a.x_small) && a.H >= 3 && q.x_exp == nullptr;
+}
+
+static inline void wino3_init_attributes() {
+  static const bool done = [] {
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(convlstm_step_wino3_kernel<kW3Waves, kW3Nrb>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes());
+    return true;
+  }();
+  (void)done;
+}
+
+static inline void launch_convlstm_wino3_steps(const ConvLstmWinoArgs* probs, int n,
+                                               hipStream_t stream) {
+  ConvLstmWinoGroup g{};
+  g.n = n;
+  static const int abl = getenv("MV_WINO_ABL") ? atoi(getenv("MV_WINO_ABL")) : 0;
+  static const int map_mode = getenv("MV_WINO_MAP") ? atoi(getenv("MV_WINO_MAP")) : 1;
+  g.map_mode = map_mode;
+  unsigned total = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = probs[i];
+    g.p[i].abl = abl;
+    total += convlstm_wino3_blocks(probs[i].b.f);
+    g.block_end[i] = (int32_t)total;
+  }
+  for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
+  wino3_init_attributes();
+  hipLaunchKernelGGL((convlstm_step_wino3_kernel<kW3Waves, kW3Nrb>), dim3(total),
+                     dim3(kW3Waves * 64), wino3_lds_bytes(), stream, g);
+}
+
+}  // namespace mv

@@ -26,6 +26,7 @@
 #include "convlstm_wgrad.h"
 #include "convlstm_f16x3.h"
 #include "convlstm_wino.h"
+#include "convlstm_wino3.h"
 #include "convlstm_wgrad_f16x3.h"
 #include "kernels_misc.h"
 #include "decode_tail.h"
@@ -111,6 +112,7 @@ struct ConvCell {           // one ConvLSTMCell: packed kernel + biases
   DevBuf<_Float16> wpb;     // bf16 compute mode: one unscaled bf16 plane, fragment order
   DevBuf<float> wx32u;      // bf16, Cx <= 3: the fp32 x chunk, unscaled
   DevBuf<_Float16> wpw;     // f16x3, Winograd F(2,3) form of the kernel (convlstm_wino.h)
+  DevBuf<_Float16> wpw3;    // f16x3, Winograd F(3,3) form of the kernel (convlstm_wino3.h)
   bool host_stale = false;  // device copy was updated by the optimizer
   int Cx = 0;
 };
@@ -541,6 +543,10 @@ void ensure_packed(mv_engine* e, ConvCell& cc) {
                       hipMemcpyHostToDevice));
 }
 
+static bool C_multiple_ok(const mv_engine* e, const ConvCell& cc) {
+  return e->cfg.hidden_size % mv::kWnCh == 0 &&
+         (cc.Cx % 16 == 0 || (cc.Cx > 0 && 9 * cc.Cx <= mv::kBK));
+}
 // f16x3 packs (two scaled fp16 planes in fragment order; the fp32 x chunk of the
 // 2-channel regression-encoder input scaled by 2^16), from the CURRENT weights.
 void ensure_packed16(mv_engine* e, ConvCell& cc) {
@@ -555,8 +561,12 @@ void ensure_packed16(mv_engine* e, ConvCell& cc) {
   {   // 256 w must stay inside fp16 (|w| < 255): true of any sane checkpoint, checked anyway
     float mx = 0.f;
     for (float v : cc.kernel->host) mx = std::max(mx, std::fabs(v));
-    MV_REQUIRE(mx * mv::kF16Scale < 60000.f, "f16x3: |%s| reaches %g, outside the scaled "
-               "fp16 range; use compute mode f32", cc.kernel->name.c_str(), mx);
+    // the Winograd packs store 256 (g0 +- g1 + g2) / 2 (F(2,3)) and 256 (g0 + g1 + g2) / 2,
+    // 256 (g0 + 2 g1 + 4 g2) / 6 (F(3,3)): up to 1.5 max |w| -- the bound covers them
+    const float reach = (mv::wino_enabled() && C_multiple_ok(e, cc)) ? 1.5f : 1.0f;
+    MV_REQUIRE(mx * reach * mv::kF16Scale < 60000.f, "f16x3: |%s| reaches %g (x %g in the "
+               "transformed kernel planes), outside the scaled fp16 range; use compute mode f32",
+               cc.kernel->name.c_str(), mx, reach);
   }
   const bool small = cc.Cx > 0 && 9 * cc.Cx <= mv::kBK;
   // the h part (and an x part that is a multiple of 16 channels) as fp16 planes
@@ -588,10 +598,6 @@ void ensure_packed16(mv_engine* e, ConvCell& cc) {
                       hipMemcpyHostToDevice));
 }
 
-static bool C_multiple_ok(const mv_engine* e, const ConvCell& cc) {
-  return e->cfg.hidden_size % mv::kWnCh == 0 &&
-         (cc.Cx % 16 == 0 || (cc.Cx > 0 && 9 * cc.Cx <= mv::kBK));
-}
 // Winograd F(2,3) pack of the f16x3 forward (convlstm_wino.h), from the CURRENT device
 // weights; the transform of the kernel rows runs in fp64 on the device.
 void pack_wino(mv_engine* e, ConvCell& cc) {
@@ -605,9 +611,29 @@ void pack_wino(mv_engine* e, ConvCell& cc) {
   hipLaunchKernelGGL(mv::pack_wino_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, e->stream,
                      cc.kernel->dev.p, cc.wpw.p, cc.Cx, Cx16, C, threads);
 }
+// Winograd F(3,3) pack (convlstm_wino3.h), likewise from the CURRENT device weights.
+void pack_wino3(mv_engine* e, ConvCell& cc) {
+  const int C = e->cfg.hidden_size;
+  const bool small = cc.Cx > 0 && 9 * cc.Cx <= mv::kBK;
+  const int Cx16 = small ? 0 : cc.Cx;
+  const size_t halves = mv::wino3_wpack_elems(Cx16, C, mv::kW3Nrb);
+  mv::wino3_init_attributes();
+  cc.wpw3.alloc(halves);
+  const size_t threads = halves / 2;
+  hipLaunchKernelGGL(mv::pack_wino3_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, e->stream,
+                     cc.kernel->dev.p, cc.wpw3.p, cc.Cx, Cx16, C, mv::kW3Nrb, threads);
+}
+// every weight-mutating path releases BOTH Winograd packs first (or re-packs them): a non-null
+// pack is by construction a pack of the current weights
+void pack_wino_forms(mv_engine* e, ConvCell& cc) {
+  cc.wpw.release(); cc.wpw3.release();
+  if (!(mv::wino_enabled() && C_multiple_ok(e, cc))) return;
+  pack_wino(e, cc);
+  if (mv::wino3_enabled()) pack_wino3(e, cc);
+}
 void ensure_packed_wino(mv_engine* e, ConvCell& cc) {
   if (cc.wpw.p) return;
-  if (C_multiple_ok(e, cc)) pack_wino(e, cc);
+  pack_wino_forms(e, cc);
 }
 
 // bf16 packs (one unscaled plane; the 2-channel regression-encoder input keeps its fp32
@@ -880,14 +906,41 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       pw[i].n_xc = p16[i].f.x_small ? 0 : p16[i].f.Cx / 16;
     }
   }
+  // ... and its F(3,3) form (five ninths, convlstm_wino3.h) when every problem fits THAT tiling
+  bool wino3 = wino && mv::wino3_enabled();
+  if (wino3) {
+    for (size_t i = 0; i < p16.size() && wino3; ++i) {
+      ConvCell* cc = cell_of_pack(e, probs[i].wpack);
+      if (!mv::wino3_geometry_ok(p16[i].f, p16[i]) || !cc->wpw3.p) wino3 = false;
+    }
+    if (wino3)
+      for (size_t i = 0; i < p16.size(); ++i)
+        pw[i].wpw = cell_of_pack(e, probs[i].wpack)->wpw3.p;
+  }
+  // fp16 MFMA products ISSUED per executed fp32 product: 3 in the direct form; in a Winograd
+  // form 3 * (components * row tiles) / (3 * H) -- partial tiles count (9 rows = 5 pairs: 2.22,
+  // not 2), weighted over the group by executed FLOPs
+  double factor = e->compute_mode == 2 ? 1.0 : 3.0;
+  if (wino) {
+    double num = 0, den = 0;
+    for (const auto& a : probs) {
+      const double cx = a.sx_corr ? 0.0 : (double)a.Cx;
+      const double fl = (double)a.rows * a.H * a.W * (cx + (a.zero_state ? 0 : a.C));
+      const double per = wino3 ? 5.0 * ((a.H + 2) / 3) / a.H : 4.0 * ((a.H + 1) / 2) / a.H;
+      num += fl * per; den += fl;
+    }
+    factor = den > 0 ? num / den : (wino3 ? 5.0 / 3.0 : 2.0);
+  }
   launch(e, "convlstm_step", flops, bytes, [&] {
     if (e->compute_mode == 2)
       mv::launch_convlstm_bf16_steps(p16.data(), (int)p16.size(), e->stream);
+    else if (wino3)
+      mv::launch_convlstm_wino3_steps(pw.data(), (int)pw.size(), e->stream);
     else if (wino)
       mv::launch_convlstm_wino_steps(pw.data(), (int)pw.size(), e->stream);
     else
       mv::launch_convlstm16_steps(p16.data(), (int)p16.size(), e->stream);
-  }, dense, e->compute_mode == 2 ? 1.0 : (wino ? 2.0 : 3.0));
+  }, dense, factor);
 }
 
 // One launch for up to four independent ConvLSTM steps (class / regression
@@ -2092,7 +2145,7 @@ int mv_set_param(mv_handle h, const char* tf_name, const float* data,
       for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
         if (cc->kernel == p) {
           cc->wpack.release(); cc->wp16.release(); cc->wx32.release();
-          cc->wpb.release(); cc->wx32u.release(); cc->wpw.release();
+          cc->wpb.release(); cc->wx32u.release(); cc->wpw.release(); cc->wpw3.release();
           cc->host_stale = false;
         }
     }
@@ -2855,6 +2908,15 @@ int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const flo
       ctx.up(wp, p16.data(), p16.size());
       q.wp16 = wp.p;
       mv::launch_convlstm16_steps(&q, 1, ctx.stream);
+    } else if (variant == 3) {
+      MV_REQUIRE(mv::wino3_geometry_ok(a, q), "Winograd F(3,3) form: W %d must divide 32, H >= 3", W);
+      const size_t halves = mv::wino3_wpack_elems(Cx16, C, mv::kW3Nrb);
+      wp.alloc(halves);
+      hipLaunchKernelGGL(mv::pack_wino3_kernel, dim3(cdiv(halves / 2, 256)), dim3(256), 0,
+                         ctx.stream, dk.p, wp.p, Cx, Cx16, C, mv::kW3Nrb, halves / 2);
+      mv::ConvLstmWinoArgs wq{};
+      wq.b = q; wq.wpw = wp.p; wq.w_hwio = dk.p; wq.n_xc = Cx16 / 16;
+      mv::launch_convlstm_wino3_steps(&wq, 1, ctx.stream);
     } else {
       MV_REQUIRE(mv::wino_geometry_ok(a), "Winograd form: W %d must divide 32, H >= 2", W);
       const size_t halves = mv::wino_wpack_elems(Cx16, C);

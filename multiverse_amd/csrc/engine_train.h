@@ -359,14 +359,14 @@ void run_pack(mv_engine* e, TrainChain& ch) {
       const size_t threads = halves / 2;
       hipLaunchKernelGGL(mv::pack_f16x3_kernel, dim3(cdiv(threads, 256)), dim3(256), 0,
                          e->stream, cc.kernel->dev.p, cc.wp16.p, Cx, Cx16, C, threads);
-      if (mv::wino_enabled() && C_multiple_ok(e, cc)) pack_wino(e, cc);
+      pack_wino_forms(e, cc);     // releases both Winograd packs, re-packs what is enabled
       cc.wpb.release(); cc.wx32u.release();
     } else {                    // bf16 forward (the backward's packs: below)
       const size_t halves = mv::bf16_wpack_elems(Cx16, C);
       cc.wpb.alloc(halves);
       hipLaunchKernelGGL(mv::pack_bf16_kernel, dim3(cdiv(halves, 256)), dim3(256), 0,
                          e->stream, cc.kernel->dev.p, cc.wpb.p, Cx, Cx16, C, halves);
-      cc.wp16.release(); cc.wx32.release(); cc.wpw.release();
+      cc.wp16.release(); cc.wx32.release(); cc.wpw.release(); cc.wpw3.release();
     }
     if (e->compute_mode == 2 && bf16_bwd_enabled()) {
       const size_t db = mv::bf16_dgrad_wpack_elems(Cx, C);
@@ -399,7 +399,7 @@ void run_pack(mv_engine* e, TrainChain& ch) {
     }
   } else {
     cc.wp16.release(); cc.wx32.release();   // rebuilt lazily if the mode is switched on
-    cc.wpb.release(); cc.wx32u.release(); cc.wpw.release();
+    cc.wpb.release(); cc.wx32u.release(); cc.wpw.release(); cc.wpw3.release();
   }
 }
 

@@ -1,8 +1,9 @@
 # coding=utf-8
-"""GPU: the Winograd F(2,3) form of the f16x3 ConvLSTM step (csrc/convlstm_wino.h) -- the
-default gate kernel of the f16x3 compute mode whenever the grid widths divide 32 -- against
-the CPU oracle, the direct f16x3 form and its own emitted operand planes, kernel by kernel
-through the C ABI (mv_op_convlstm_step16).  The end-to-end parity tests (forward, beam,
+"""GPU: the Winograd forms of the f16x3 ConvLSTM step -- F(3,3) over row triples
+(csrc/convlstm_wino3.h, variant 3: the default gate kernel of the f16x3 compute mode whenever
+the grid widths divide 32) and F(2,3) over row pairs (csrc/convlstm_wino.h, variant 2: its
+fall-back, and the dgrad form) -- against the CPU oracle, the direct f16x3 form and their own
+emitted operand planes, kernel by kernel through the C ABI (mv_op_convlstm_step16).  The end-to-end parity tests (forward, beam,
 training, at-size) run through the same kernel inside the engine.
 
 Tolerance: 2e-5 absolute on O(1) gate sums -- the bar of the fp32-MFMA kernel test
@@ -62,16 +63,21 @@ SHAPES = [
     (5, 9, 16, 16, False),    # a wave tile straddles three images' worth of pairs
     (1, 6, 8, 32, False),     # W = 8: four row pairs per wave tile, partial workgroup
     (3, 18, 32, 32, False),   # M tiles not a multiple of the workgroup
+    (2, 7, 16, 32, False),    # H = 7: the last row triple holds ONE row (F(3,3) remainder 1)
+    (2, 8, 32, 64, False),    # H = 8: the last row triple holds two rows (remainder 2)
+    (1, 3, 32, 2, False),     # a single row triple per image, fp32 x chunk
 ]
+FORMS = [(2, "F(2,3)"), (3, "F(3,3)")]
 
 
+@pytest.mark.parametrize("variant,form", FORMS)
 @pytest.mark.parametrize("M,H,W,Cx,zero", SHAPES)
-def test_wino_step_vs_oracle(built_lib, M, H, W, Cx, zero):
+def test_wino_step_vs_oracle(built_lib, M, H, W, Cx, zero, variant, form):
   x, c, h, kernel, biases, co, ho = _case(M, H, W, Cx, zero, M * 1000 + H * 10 + Cx)
-  cg, hg, h16 = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=2)
+  cg, hg, h16 = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=variant)
   ec, eh = np.abs(cg - co), np.abs(hg - ho)
-  print("winograd  M=%d %dx%d Cx=%d zero=%s: max|dc| %.3g max|dh| %.3g, planes vs h' %.3g"
-        % (M, H, W, Cx, zero, ec.max(), eh.max(), np.abs(h16 - hg).max()))
+  print("winograd %s M=%d %dx%d Cx=%d zero=%s: max|dc| %.3g max|dh| %.3g, planes vs h' %.3g"
+        % (form, M, H, W, Cx, zero, ec.max(), eh.max(), np.abs(h16 - hg).max()))
   assert ec.max() < 2e-5, _where(ec, "c'")
   assert eh.max() < 2e-5, _where(eh, "h'")
   # the operand planes the epilogue emitted for the next step ARE h' (two fp16 planes of
@@ -87,22 +93,26 @@ def test_wino_agrees_with_direct_form(built_lib, M, H, W, Cx, zero):
   x, c, h, kernel, biases, co, ho = _case(M, H, W, Cx, zero, 77 + M + Cx)
   c1, h1, p1 = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=1)
   c2, h2, p2 = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=2)
-  d1, d2 = np.abs(c1 - co).max(), np.abs(c2 - co).max()
-  print("direct f16x3 max|dc| %.3g, winograd %.3g, between them %.3g"
-        % (d1, d2, np.abs(c1 - c2).max()))
-  assert d1 < 2e-5 and d2 < 2e-5
+  c3, h3, p3 = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=3)
+  d1, d2, d3 = np.abs(c1 - co).max(), np.abs(c2 - co).max(), np.abs(c3 - co).max()
+  print("max|dc| vs the oracle: direct f16x3 %.3g, F(2,3) %.3g, F(3,3) %.3g; F(2,3) - direct %.3g, "
+        "F(3,3) - direct %.3g" % (d1, d2, d3, np.abs(c1 - c2).max(), np.abs(c1 - c3).max()))
+  assert d1 < 2e-5 and d2 < 2e-5 and d3 < 2e-5
   assert np.abs(c1 - c2).max() < 1e-5 and np.abs(h1 - h2).max() < 1e-5
   assert np.abs(p1 - p2).max() < 1e-5
+  assert np.abs(c1 - c3).max() < 1.5e-5 and np.abs(h1 - h3).max() < 1.5e-5
+  assert np.abs(p1 - p3).max() < 1.5e-5
 
 
-def test_wino_transpose_detecting(built_lib):
-  """One hot input cell / one hot weight tap per case: tap orientation, row-pair parity and
-  row <-> column swaps that symmetric data would hide.  Every (ky, kx) tap, an even and an
-  odd source row."""
+@pytest.mark.parametrize("variant,form", FORMS)
+def test_wino_transpose_detecting(built_lib, variant, form):
+  """One hot input cell / one hot weight tap per case: tap orientation, the row class inside
+  the tile (even / odd rows of a pair; rows 3t, 3t+1, 3t+2 of a triple; the image's first and
+  last rows) and row <-> column swaps that symmetric data would hide.  Every (ky, kx) tap."""
   M, H, W, Cx, C = 1, 6, 8, 32, 256
   for ky in range(3):
     for kx in range(3):
-      for (sy, sx) in ((2, 5), (3, 2)):
+      for (sy, sx) in ((2, 5), (3, 2), (4, 6), (0, 0), (5, 7)):
         x = np.zeros((M, H, W, Cx), "f4")
         x[0, sy, sx, 3] = 1.0
         kernel = np.zeros((3, 3, Cx + C, 4 * C), "f4")
@@ -112,9 +122,10 @@ def test_wino_transpose_detecting(built_lib):
         c = np.zeros((M, H, W, C), "f4")
         h = np.zeros((M, H, W, C), "f4")
         co, ho = oracle.convlstm_step_np(x, c, h, kernel, biases)
-        cg, hg, _ = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=2)
+        cg, hg, _ = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=variant)
         oy, ox = sy - (ky - 1), sx - (kx - 1)      # out(y,x) sees in(y+ky-1, x+kx-1)
-        assert abs(co[0, oy, ox, 17]) > 0.5
+        if 0 <= oy < H and 0 <= ox < W:
+          assert abs(co[0, oy, ox, 17]) > 0.5
         err = np.abs(cg - co)
         assert err.max() < 1e-6, "tap (%d,%d) source (%d,%d)\n%s" % (ky, kx, sy, sx,
                                                                     _where(err, "c'"))
@@ -137,6 +148,8 @@ def test_wino_dynamic_range(built_lib):
   co, ho = oracle.convlstm_step_np(x, cst, h, kernel, biases)
   c1, h1, _ = built_lib.op_convlstm_step16(x, cst, h, kernel, biases, variant=1)
   c2, h2, _ = built_lib.op_convlstm_step16(x, cst, h, kernel, biases, variant=2)
-  print("dynamic range: direct %.3g, winograd %.3g" % (np.abs(c1 - co).max(),
-                                                      np.abs(c2 - co).max()))
+  c3, h3, _ = built_lib.op_convlstm_step16(x, cst, h, kernel, biases, variant=3)
+  print("dynamic range: direct %.3g, F(2,3) %.3g, F(3,3) %.3g" % (
+      np.abs(c1 - co).max(), np.abs(c2 - co).max(), np.abs(c3 - co).max()))
   assert np.abs(c2 - co).max() < 2e-5 and np.abs(h2 - ho).max() < 2e-5
+  assert np.abs(c3 - co).max() < 3e-5 and np.abs(h3 - ho).max() < 3e-5

@@ -310,3 +310,149 @@ def test_f43_row_form_is_numerically_affordable_with_f16x3_operands():
   print("direct f16x3 %.2e, F(2,3) rows %.2e, F(4,3) rows %.2e (max |pre-activation| %.2f)"
         % (e0, e2, e4, np.abs(ref).max()))
   assert e0 < 3e-6 and e2 < 5e-6 and e4 < 2e-5
+
+
+# ------------------------------------------------------------------ F(3,3) over rows (round 5)
+# csrc/convlstm_wino3.h: five products per THREE output rows and tap column (5/9 of the direct
+# MFMAs; 18 = 6 x 3 and 9 = 3 x 3 rows: no partial tiles on the published grids).  Points
+# 0, 1, -1, 2, inf; with d0..d4 = input rows 3t-1 .. 3t+3 and g0..g2 the kernel rows of one
+# stencil column:
+#   V0 = 2 (d0 - d2) + V3        U0 = g0 / 2                  y(3t)   = M0 + M1 + M2 + M3
+#   V1 = (d3 - d2) - 2 d1        U1 = -(g0 + g1 + g2) / 2     y(3t+1) = M1 - M2 + 2 M3
+#   V2 = 2 (d1 - d2) + (d3 - d2) U2 = (-g0 + g1 - g2) / 6     y(3t+2) = M1 + M2 + 4 M3 + M4
+#   V3 = d3 - d1                 U3 = (g0 + 2 g1 + 4 g2) / 6
+#   V4 = 2 V3 + (d2 - d4)        U4 = -g2
+# Every V is a chain of wn_lin<KA, KB> steps (KA a + KB b on plane pairs, TwoSum of the high
+# planes with the factors 2 folded into the fused multiply-adds).
+
+
+def lin_planes(a_hi, a_lo, b_hi, b_lo, ka, kb):
+  """wn_lin<KA, KB>: ka (a_hi + a_lo) + kb (b_hi + b_lo) as a plane pair; ka in {1, 2}, kb in
+  {1, -1, -2}.  Every line is ONE v_pk_fma_f16 / v_pk_add_f16: the products by 1, 2 are exact,
+  so each operation rounds once, to fp16."""
+  ka, kb = F16(ka), F16(kb)
+  s = (ka * a_hi + kb * b_hi).astype(F16)
+  bb = (s - ka * a_hi).astype(F16)
+  t = (s - bb).astype(F16)
+  ne1 = (t - ka * a_hi).astype(F16)          # -(ka a_hi - t)
+  ne2 = (bb - kb * b_hi).astype(F16)         # -(kb b_hi - bb)
+  l1 = (ka * a_lo + kb * b_lo).astype(F16)
+  ne = (ne1 + ne2).astype(F16)
+  lo = (l1 - ne).astype(F16)
+  return s, lo
+
+
+def test_lin_planes_is_exact_to_the_residual_class():
+  rng = np.random.default_rng(1)
+  a = np.tanh(rng.normal(size=20000) * 2).astype(np.float32)
+  b = np.tanh(rng.normal(size=20000) * 2).astype(np.float32)
+  b[::3] = a[::3] * np.float32(1.0 + 2.0 ** -9)
+  a[1::7] *= np.float32(1e-3)
+  ah, al = split_planes(a)
+  bh, bl = split_planes(b)
+  for ka, kb in ((1, -1), (2, 1), (1, -2), (1, 1)):
+    hi, lo = lin_planes(ah, al, bh, bl, ka, kb)
+    exact = ka * (ah.astype(np.float64) + al.astype(np.float64)) + \
+        kb * (bh.astype(np.float64) + bl.astype(np.float64))
+    got = hi.astype(np.float64) + lo.astype(np.float64)
+    scale = 256.0 * (abs(ka) * np.abs(a) + abs(kb) * np.abs(b)).astype(np.float64)
+    err = np.abs(got - exact)
+    assert (err <= 2.0 ** -19 * np.maximum(scale, 2.0 ** -4)).all(), (ka, kb, err.max())
+    assert (hi == (ka * ah.astype(np.float32) + kb * bh.astype(np.float32)).astype(F16)).all()
+
+
+def _wino3_transform(rows):
+  """rows: five (hi, lo) plane pairs d0..d4 -> the five components, in the kernel's order of
+  operations (convlstm_wino3.h wn3_transform)."""
+  d0, d1, d2, d3, d4 = rows
+  v3 = lin_planes(d3[0], d3[1], d1[0], d1[1], 1, -1)
+  t = lin_planes(d0[0], d0[1], d2[0], d2[1], 1, -1)
+  v0 = lin_planes(t[0], t[1], v3[0], v3[1], 2, 1)
+  t3 = lin_planes(d3[0], d3[1], d2[0], d2[1], 1, -1)
+  v1 = lin_planes(t3[0], t3[1], d1[0], d1[1], 1, -2)
+  t4 = lin_planes(d1[0], d1[1], d2[0], d2[1], 1, -1)
+  v2 = lin_planes(t4[0], t4[1], t3[0], t3[1], 2, 1)
+  t5 = lin_planes(d2[0], d2[1], d4[0], d4[1], 1, -1)
+  v4 = lin_planes(v3[0], v3[1], t5[0], t5[1], 2, 1)
+  return [v0, v1, v2, v3, v4]
+
+
+def _wino3_kernel_transform(w):
+  g0, g1, g2 = w[0], w[1], w[2]
+  return [0.5 * g0, -0.5 * (g0 + g1 + g2), (-g0 + g1 - g2) / 6.0, (g0 + 2.0 * g1 + 4.0 * g2) / 6.0,
+          -g2]
+
+
+def _wino3_rows_f16x3(d, w):
+  """The F(3,3) kernel's arithmetic for one image (same conventions as _wino_rows_f16x3)."""
+  H, W, Ci = d.shape
+  N = w.shape[3]
+  Ht = (H + 2) // 3
+  Uh, Ul = [], []
+  for u in _wino3_kernel_transform(w):
+    sv = u * 256.0
+    h = sv.astype(F16)
+    Uh.append(h)
+    Ul.append((sv - h.astype(np.float64)).astype(F16))
+  dh, dl = split_planes(d)
+  zero = np.zeros((W, Ci), F16)
+
+  def row(r):
+    return (dh[r], dl[r]) if 0 <= r < H else (zero, zero)
+
+  out = np.zeros((H, W, N), np.float32)
+  for t in range(Ht):
+    V = _wino3_transform([row(3 * t - 1 + i) for i in range(5)])
+    M = []
+    for c in range(5):
+      acc = np.zeros((W, N), np.float32)
+      for dx in range(3):
+        vh = np.zeros((W, Ci), np.float32)
+        vl = np.zeros((W, Ci), np.float32)
+        lo_x, hi_x = max(0, 1 - dx), min(W, W + 1 - dx)
+        vh[lo_x:hi_x] = V[c][0][lo_x + dx - 1:hi_x + dx - 1]
+        vl[lo_x:hi_x] = V[c][1][lo_x + dx - 1:hi_x + dx - 1]
+        uh, ul = Uh[c][dx].astype(np.float32), Ul[c][dx].astype(np.float32)
+        acc += (vl @ uh).astype(np.float32)
+        acc += (vh @ ul).astype(np.float32)
+        acc += (vh @ uh).astype(np.float32)
+      M.append(acc)
+    two, four = np.float32(2.0), np.float32(4.0)
+    ys = [((M[0] + M[1]) + (M[2] + M[3])),
+          ((M[1] - M[2]) + two * M[3]),
+          ((M[1] + M[2]) + (four * M[3] + M[4]))]
+    for e in range(3):
+      if 3 * t + e < H:
+        out[3 * t + e] = ys[e] * np.float32(2.0 ** -16)
+  return out
+
+
+@pytest.mark.parametrize("H,W", [(18, 32), (9, 16), (6, 8), (7, 8), (3, 32), (4, 16)])
+def test_winograd_row_triples_with_f16x3_operands_equal_the_direct_convolution(H, W):
+  rng = np.random.default_rng(H * 100 + W + 7)
+  Ci, N = 48, 24
+  d = np.tanh(rng.normal(size=(H, W, Ci))).astype(np.float32)
+  w = (rng.normal(size=(3, 3, Ci, N)) * 0.06).astype(np.float32)
+  ref = _conv3x3_same(d.astype(np.float64), w.astype(np.float64))
+  got3 = _wino3_rows_f16x3(d, w.astype(np.float64))
+  got2 = _wino_rows_f16x3(d, w.astype(np.float64))
+  e3, e2 = np.abs(got3 - ref).max(), np.abs(got2 - ref).max()
+  print("H %d W %d: max |F(3,3) f16x3 - fp64 direct| = %.3g (F(2,3): %.3g; max |y| %.3g)" % (
+      H, W, e3, e2, np.abs(ref).max()))
+  assert e3 < 1.2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_f33_one_hot_taps_land_on_the_right_output_rows():
+  """Every (ky, kx) tap and every row class of the 3-row tile (source rows 3t, 3t+1, 3t+2, the
+  image's first and last rows): what a transposed or mis-signed component would break."""
+  H, W, Ci, N = 9, 8, 16, 4
+  for ky in range(3):
+    for kx in range(3):
+      for (sy, sx) in ((3, 5), (4, 2), (5, 1), (0, 0), (8, 7), (2, 3)):
+        d = np.zeros((H, W, Ci), np.float32)
+        d[sy, sx, 3] = 0.75
+        w = np.zeros((3, 3, Ci, N))
+        w[ky, kx, 3, 1] = 0.5
+        ref = _conv3x3_same(d.astype(np.float64), w)
+        got = _wino3_rows_f16x3(d, w)
+        assert np.abs(got - ref).max() < 1e-6, (ky, kx, sy, sx, np.abs(got - ref).max())
