@@ -132,6 +132,60 @@ __device__ __forceinline__ void wn_lin(const f16x8 a_hi, const f16x8 a_lo, const
   lo = __builtin_elementwise_fma(ne1 + ne2, k.m1, l1);
 }
 
+// The same on ONE register (two halves) of each plane: the unit the software-pipelined main
+// loop places between MFMAs.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+struct Wn3K2 { f16x2 m1, p2, m2; };
+struct Pl8 { uint32_t h[4], l[4]; };       // 8 halves per lane as a (high, low) plane pair
+
+template <int KA, int KB>
+__device__ __forceinline__ void wn_lin2(uint32_t ahi, uint32_t alo, uint32_t bhi, uint32_t blo,
+                                        const Wn3K2& k, uint32_t& hi, uint32_t& lo) {
+  static_assert((KA == 1 && (KB == 1 || KB == -1 || KB == -2)) || (KA == 2 && KB == 1), "form");
+  const f16x2 a_hi = __builtin_bit_cast(f16x2, ahi), a_lo = __builtin_bit_cast(f16x2, alo);
+  const f16x2 b_hi = __builtin_bit_cast(f16x2, bhi), b_lo = __builtin_bit_cast(f16x2, blo);
+  const f16x2 nka = KA == 1 ? k.m1 : k.m2;                      // -KA
+  f16x2 s, ne2, l1;
+  if (KA == 2) {
+    s = __builtin_elementwise_fma(a_hi, k.p2, b_hi);
+    l1 = __builtin_elementwise_fma(a_lo, k.p2, b_lo);
+  } else if (KB == 1) {
+    s = a_hi + b_hi;
+    l1 = a_lo + b_lo;
+  } else {
+    s = __builtin_elementwise_fma(b_hi, KB == -1 ? k.m1 : k.m2, a_hi);
+    l1 = __builtin_elementwise_fma(b_lo, KB == -1 ? k.m1 : k.m2, a_lo);
+  }
+  const f16x2 bb = __builtin_elementwise_fma(a_hi, nka, s);
+  const f16x2 t = __builtin_elementwise_fma(bb, k.m1, s);
+  const f16x2 ne1 = __builtin_elementwise_fma(a_hi, nka, t);
+  if (KB == -1) ne2 = bb + b_hi;
+  else ne2 = __builtin_elementwise_fma(b_hi, KB == 1 ? k.m1 : k.p2, bb);
+  const f16x2 lo2 = __builtin_elementwise_fma(ne1 + ne2, k.m1, l1);
+  hi = __builtin_bit_cast(uint32_t, s);
+  lo = __builtin_bit_cast(uint32_t, lo2);
+}
+__device__ __forceinline__ f16x8 pl8_vec(const uint32_t (&r)[4]) {
+  const u32x4 v = {r[0], r[1], r[2], r[3]};
+  return __builtin_bit_cast(f16x8, v);
+}
+// one plane's four registers moved one lane up (dx = -1: lane l takes lane l - 1) or down
+__device__ __forceinline__ void pl8_shift(const uint32_t (&src)[4], bool up, bool ok,
+                                          uint32_t (&dst)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t t =
+        up ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src[j], 0x138, 0xf, 0xf, true)
+           : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src[j], 0x130, 0xf, 0xf, true);
+    dst[j] = ok ? t : 0u;
+  }
+}
+
+// MV_WINO3_PIPE=0 at build time: the plain main loop (transform, then 90 MFMAs, per chunk)
+#ifndef MV_WINO3_PIPE
+#define MV_WINO3_PIPE 1
+#endif
+
 template <int WAVES, int NRB>
 __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, int cb, int mt,
                                                     f16x8* lds) {
@@ -345,6 +399,166 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     kc.m1 = __builtin_bit_cast(f16x8, u32x4{mone, mone, mone, mone});
     kc.p2 = __builtin_bit_cast(f16x8, u32x4{ptwo, ptwo, ptwo, ptwo});
     kc.m2 = __builtin_bit_cast(f16x8, u32x4{mtwo, mtwo, mtwo, mtwo});
+    if constexpr (MV_WINO3_PIPE && NRB == 2) {
+    // ---- software-pipelined main loop.  One wave per SIMD: nothing but this wave's own
+    // instruction stream can fill the shadow of its MFMAs (8 passes = 32 cycles each, ~7 VALU
+    // issue slots), so the stream is laid out by hand and PINNED (sched_barrier fences between
+    // the slices): behind every MFMA of a (component, dx) group sits one slice of the work for
+    // what comes next -- the weight fragments of the next group (4 ds_reads), the lane shifts
+    // of the next dx (8 DPP + 8 selects per plane), one register of the input transform of the
+    // NEXT component (8 packed-fp16 instructions), or a few of the chunk-ahead memory requests
+    // (operand rows of chunk k + 1, its weight stage by LDS-DMA).  Components run in the order
+    // 3, 0, 1, 2, 4 (V3 feeds V0 and V4), dx in the order 1, 0, 2 (the unshifted fragment first).
+    Wn3K2 k2;
+    {
+      const f16x2 c1 = __builtin_bit_cast(f16x2, mone), c2 = __builtin_bit_cast(f16x2, ptwo),
+                  c3 = __builtin_bit_cast(f16x2, mtwo);
+      k2.m1 = c1; k2.p2 = c2; k2.m2 = c3;
+    }
+    struct Wf { f16x8 w0[2], w1[2]; };
+    auto ldw = [&](const f16x8* buf, int comp, int dx, Wf& w) __attribute__((always_inline)) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        w.w0[rb] = buf[(((comp * 3 + dx) * 2 + 0) * 2 + rb) * 64 + lane];
+        w.w1[rb] = buf[(((comp * 3 + dx) * 2 + 1) * 2 + rb) * 64 + lane];
+      }
+    };
+    auto load_rows = [&](int ck, Pl8 (&dst)[5], int i0, int i1) __attribute__((always_inline)) {
+      const bool is_x = ck < nxc;
+      const uint32_t cgo = (uint32_t)(is_x ? ck : ck - nxc) * 1024u;
+#pragma unroll
+      for (int i = i0; i < i1; ++i) {
+        const uint32_t o = is_x ? roffx[i] : roffh[i];
+        const int off = o ? (int)(o + cgo) : 0;
+        const u32x4 a0 = __builtin_amdgcn_raw_buffer_load_b128(is_x ? xrs0 : hrs0, off, 0, 0);
+        const u32x4 a1 = __builtin_amdgcn_raw_buffer_load_b128(is_x ? xrs1 : hrs1, off, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dst[i].h[j] = a0[j]; dst[i].l[j] = a1[j]; }
+      }
+    };
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    auto dma_part = [&](int ck, f16x8* dstbuf, int i0, int i1) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = i0; i < i1; ++i) {
+        const int piece = i * WAVES + wave_u;                  // scalar: one VGPR for all pieces
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            wrs, (__attribute__((address_space(3))) void*)(dstbuf + piece * 64), 16, lane16,
+            (uint32_t)ck * G::kChunkBytes + (uint32_t)piece * 1024u, 0, MV_DMA_AUX);
+      }
+    };
+    static_assert(kChunkPieces % WAVES == 0 && kChunkPieces / WAVES == 15, "DMA slices");
+#define W3_FENCE __builtin_amdgcn_sched_barrier(0)
+    // the results of a slice exist HERE: a value-pinning empty asm between two fences keeps
+    // the instruction selector and the sinking passes from moving the slice to its first use
+#define W3_PIN2(A, B) asm volatile("" : "+v"(A), "+v"(B))
+    // MFMA i of a group: (w1, b0) x 2 row blocks, (w0, b1) x 2, (w0, b0) x 2
+#define W3_MF(I, COMP, W, BH, BL)                                                             \
+  acc[COMP][(I) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                \
+      (I) < 2 ? (W).w1[(I) & 1] : (W).w0[(I) & 1], ((I) >= 2 && (I) < 4) ? (BL) : (BH),       \
+      acc[COMP][(I) & 1], 0, 0, 0)
+#define W3_PINSH(P) asm volatile("" : "+v"((P)[0]), "+v"((P)[1]), "+v"((P)[2]), "+v"((P)[3]))
+    // one component: X = its plane pair; PIECE(n), n = 0..7: the transform running beside it;
+    // EXTRA(n), n = 0..2: memory requests; `wf` holds the fragments of (COMP, dx 1) on entry and
+    // receives those of (NEXTCOMP, dx 1) when NEXTCOMP >= 0 (same chunk buffer)
+#define W3_COMP_PIPE(COMP, X, NEXTCOMP, BUF, PIECE, EXTRA)                                    \
+  do {                                                                                        \
+    Pl8 bs, bt;                                                                               \
+    const f16x8 xh = pl8_vec((X).h), xl = pl8_vec((X).l);                                     \
+    /* group dx = 1 */                                                                        \
+    W3_MF(0, COMP, wf, xh, xl); ldw((BUF), (COMP), 0, wn); W3_FENCE;                          \
+    W3_MF(1, COMP, wf, xh, xl); pl8_shift((X).h, true, okx0, bs.h); W3_PINSH(bs.h); W3_FENCE; \
+    W3_MF(2, COMP, wf, xh, xl); pl8_shift((X).l, true, okx0, bs.l); W3_PINSH(bs.l); W3_FENCE; \
+    W3_MF(3, COMP, wf, xh, xl); PIECE(0); W3_FENCE;                                           \
+    W3_MF(4, COMP, wf, xh, xl); PIECE(1); W3_FENCE;                                           \
+    W3_MF(5, COMP, wf, xh, xl); PIECE(2); W3_FENCE;                                           \
+    /* group dx = 0 */                                                                        \
+    const f16x8 sh = pl8_vec(bs.h), sl = pl8_vec(bs.l);                                       \
+    W3_MF(0, COMP, wn, sh, sl); ldw((BUF), (COMP), 2, wm); W3_FENCE;                          \
+    W3_MF(1, COMP, wn, sh, sl); pl8_shift((X).h, false, okx2, bt.h); W3_PINSH(bt.h); W3_FENCE; \
+    W3_MF(2, COMP, wn, sh, sl); pl8_shift((X).l, false, okx2, bt.l); W3_PINSH(bt.l); W3_FENCE; \
+    W3_MF(3, COMP, wn, sh, sl); PIECE(3); W3_FENCE;                                           \
+    W3_MF(4, COMP, wn, sh, sl); PIECE(4); W3_FENCE;                                           \
+    W3_MF(5, COMP, wn, sh, sl); EXTRA(0); W3_FENCE;                                           \
+    /* group dx = 2 */                                                                        \
+    const f16x8 th_ = pl8_vec(bt.h), tl_ = pl8_vec(bt.l);                                     \
+    W3_MF(0, COMP, wm, th_, tl_); if ((NEXTCOMP) >= 0) ldw((BUF), (NEXTCOMP) < 0 ? 0 : (NEXTCOMP), 1, wf); W3_FENCE; \
+    W3_MF(1, COMP, wm, th_, tl_); PIECE(5); W3_FENCE;                                         \
+    W3_MF(2, COMP, wm, th_, tl_); PIECE(6); W3_FENCE;                                         \
+    W3_MF(3, COMP, wm, th_, tl_); PIECE(7); W3_FENCE;                                         \
+    W3_MF(4, COMP, wm, th_, tl_); EXTRA(1); W3_FENCE;                                         \
+    W3_MF(5, COMP, wm, th_, tl_); EXTRA(2); W3_FENCE;                                         \
+  } while (0)
+    // a transform piece: register n & 3 of OUT = KA A + KB B, pinned
+#define W3_LIN(KA, KB, A, B, OUT, n)                                                          \
+  do {                                                                                        \
+    wn_lin2<KA, KB>((A).h[(n) & 3], (A).l[(n) & 3], (B).h[(n) & 3], (B).l[(n) & 3], k2,       \
+                    (OUT).h[(n) & 3], (OUT).l[(n) & 3]);                                      \
+    W3_PIN2((OUT).h[(n) & 3], (OUT).l[(n) & 3]);                                              \
+  } while (0)
+
+    Pl8 rowsA[5], rowsB[5];
+    Pl8 v3, va, vb, tt, t3;
+    Wf wf, wn, wm;
+    // The body is ONE basic block (no branches: a branch would let the sinking passes carry
+    // the slices into its successors): the requests for chunk k + 1 go out unconditionally --
+    // after the last chunk they fetch that chunk again, into registers / the LDS buffer nobody
+    // reads any more.
+    auto chunk_body = [&](int ck, Pl8 (&C)[5], Pl8 (&N)[5], f16x8* buf, f16x8* nbuf)
+        __attribute__((always_inline)) {
+      const int nck = ck + 1 < ck_hi ? ck + 1 : ck;
+      // after the barrier: the first group's fragments cannot be requested any earlier
+      ldw(buf, 3, 1, wf);
+      W3_FENCE;
+#define W3_NOP(n) do { } while (0)
+      // beside component 3 (V3): V0 = 2 (d0 - d2) + V3; the weight stage of chunk k + 1
+#define W3_P3(n) do { if ((n) < 4) W3_LIN(1, -1, C[0], C[2], tt, n); else W3_LIN(2, 1, tt, v3, va, n); } while (0)
+#define W3_E3(n) dma_part(nck, nbuf, 5 * (n), 5 * (n) + 5)
+      W3_COMP_PIPE(3, v3, 0, buf, W3_P3, W3_E3);
+      // beside component 0 (V0): V1 = (d3 - d2) - 2 d1; rows 1, 3 of chunk k + 1 (row 0 of
+      // this chunk is dead: at most six operand rows live)
+#define W3_P0(n) do { if ((n) < 4) W3_LIN(1, -1, C[3], C[2], t3, n); else W3_LIN(1, -2, t3, C[1], vb, n); } while (0)
+#define W3_E0(n) do { if ((n) == 0) load_rows(nck, N, 1, 2); else if ((n) == 1) load_rows(nck, N, 3, 4); } while (0)
+      W3_COMP_PIPE(0, va, 1, buf, W3_P0, W3_E0);
+      // beside component 1 (V1): V2 = 2 (d1 - d2) + (d3 - d2); rows 0, 2 of chunk k + 1
+#define W3_P1(n) do { if ((n) < 4) W3_LIN(1, -1, C[1], C[2], tt, n); else W3_LIN(2, 1, tt, t3, va, n); } while (0)
+#define W3_E1(n) do { if ((n) == 0) load_rows(nck, N, 0, 1); else if ((n) == 1) load_rows(nck, N, 2, 3); } while (0)
+      W3_COMP_PIPE(1, vb, 2, buf, W3_P1, W3_E1);
+      // beside component 2 (V2): V4 = 2 V3 + (d2 - d4); row 4 of chunk k + 1
+#define W3_P2(n) do { if ((n) < 4) W3_LIN(1, -1, C[2], C[4], tt, n); else W3_LIN(2, 1, v3, tt, vb, n); } while (0)
+#define W3_E2(n) do { if ((n) == 0) load_rows(nck, N, 4, 5); } while (0)
+      W3_COMP_PIPE(2, va, 4, buf, W3_P2, W3_E2);
+      // beside component 4 (V4): V3 of chunk k + 1 = d3 - d1 of ITS rows
+#define W3_P4(n) do { if ((n) < 4) W3_LIN(1, -1, N[3], N[1], v3, n); } while (0)
+      W3_COMP_PIPE(4, vb, -1, buf, W3_P4, W3_NOP);
+      __syncthreads();
+    };
+    load_rows(ck_lo, rowsA, 0, 5);
+    chunk_dma(ck_lo, lds);
+    __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      wn_lin2<1, -1>(rowsA[3].h[n], rowsA[3].l[n], rowsA[1].h[n], rowsA[1].l[n], k2, v3.h[n], v3.l[n]);
+    for (int ck = ck_lo; ck < ck_hi; ck += 2) {
+      chunk_body(ck, rowsA, rowsB, lds, lds + G::kChunkVec);
+      if (ck + 1 < ck_hi) chunk_body(ck + 1, rowsB, rowsA, lds + G::kChunkVec, lds);
+    }
+#undef W3_PIN2
+#undef W3_PINSH
+#undef W3_LIN
+#undef W3_E1
+#undef W3_E2
+#undef W3_FENCE
+#undef W3_MF
+#undef W3_COMP_PIPE
+#undef W3_NOP
+#undef W3_P3
+#undef W3_E3
+#undef W3_P0
+#undef W3_E0
+#undef W3_P1
+#undef W3_P2
+#undef W3_P4
+    } else {
     load_raw(ck_lo);
     chunk_dma(ck_lo, lds);
     __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
@@ -371,6 +585,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       MV_W3_COMP(3, v3h, v3l, buf);
       MV_W3_COMP(4, v4h, v4l, buf);
       __syncthreads();
+    }
     }
 #undef MV_W3_COMP
   }

@@ -2836,7 +2836,7 @@ int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const flo
                           int32_t M, int32_t H, int32_t W, int32_t Cx, int32_t C,
                           float* c_out, float* h_out, float* h16_out) {
   return guarded(nullptr, [&] {
-    MV_REQUIRE(variant == 1 || variant == 2, "variant %d: 1 = direct f16x3, 2 = Winograd", variant);
+    MV_REQUIRE(variant >= 1 && variant <= 3, "variant %d: 1 = direct f16x3, 2 = Winograd F(2,3), 3 = Winograd F(3,3)", variant);
     MV_REQUIRE(C % mv::kChBlock == 0 && C % mv::kBK == 0, "C %d must be a multiple of 32", C);
     MV_REQUIRE(mv::f16x3_cx_supported(Cx), "Cx %d unsupported (multiple of 16, or <= 3)", Cx);
     MV_REQUIRE(H * W >= 32, "grids of at least 32 cells");
