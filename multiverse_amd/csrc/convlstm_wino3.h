@@ -165,6 +165,43 @@ __device__ __forceinline__ void wn_lin2(uint32_t ahi, uint32_t alo, uint32_t bhi
   hi = __builtin_bit_cast(uint32_t, s);
   lo = __builtin_bit_cast(uint32_t, lo2);
 }
+// wn_lin2 in two halves of four instructions (a: s, l1, bb, t; b: ne2, ne1, their sum, lo):
+// a slice of the pipelined loop holds half a of one register next to half b of the previous
+// one, two independent chains the scheduler interleaves (a dependent packed-fp16 pair costs a
+// wait state).
+struct Wn3Tmp { f16x2 l1, bb, t; };
+template <int KA, int KB>
+__device__ __forceinline__ void wn_lin2a(uint32_t ahi, uint32_t alo, uint32_t bhi, uint32_t blo,
+                                         const Wn3K2& k, uint32_t& hi, Wn3Tmp& m) {
+  static_assert((KA == 1 && (KB == 1 || KB == -1 || KB == -2)) || (KA == 2 && KB == 1), "form");
+  const f16x2 a_hi = __builtin_bit_cast(f16x2, ahi), a_lo = __builtin_bit_cast(f16x2, alo);
+  const f16x2 b_hi = __builtin_bit_cast(f16x2, bhi), b_lo = __builtin_bit_cast(f16x2, blo);
+  f16x2 s;
+  if (KA == 2) {
+    s = __builtin_elementwise_fma(a_hi, k.p2, b_hi);
+    m.l1 = __builtin_elementwise_fma(a_lo, k.p2, b_lo);
+  } else if (KB == 1) {
+    s = a_hi + b_hi;
+    m.l1 = a_lo + b_lo;
+  } else {
+    s = __builtin_elementwise_fma(b_hi, KB == -1 ? k.m1 : k.m2, a_hi);
+    m.l1 = __builtin_elementwise_fma(b_lo, KB == -1 ? k.m1 : k.m2, a_lo);
+  }
+  m.bb = __builtin_elementwise_fma(a_hi, KA == 1 ? k.m1 : k.m2, s);
+  m.t = __builtin_elementwise_fma(m.bb, k.m1, s);
+  hi = __builtin_bit_cast(uint32_t, s);
+}
+template <int KA, int KB>
+__device__ __forceinline__ void wn_lin2b(uint32_t ahi, uint32_t bhi, const Wn3K2& k,
+                                         const Wn3Tmp& m, uint32_t& lo) {
+  const f16x2 a_hi = __builtin_bit_cast(f16x2, ahi), b_hi = __builtin_bit_cast(f16x2, bhi);
+  const f16x2 ne1 = __builtin_elementwise_fma(a_hi, KA == 1 ? k.m1 : k.m2, m.t);
+  f16x2 ne2;
+  if (KB == -1) ne2 = m.bb + b_hi;
+  else ne2 = __builtin_elementwise_fma(b_hi, KB == 1 ? k.m1 : k.p2, m.bb);
+  const f16x2 lo2 = __builtin_elementwise_fma(ne1 + ne2, k.m1, m.l1);
+  lo = __builtin_bit_cast(uint32_t, lo2);
+}
 __device__ __forceinline__ f16x8 pl8_vec(const uint32_t (&r)[4]) {
   const u32x4 v = {r[0], r[1], r[2], r[3]};
   return __builtin_bit_cast(f16x8, v);
@@ -248,10 +285,12 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       for (int i = 0; i < 16; ++i) acc[c][rb][i] = 0.f;
 
   // LDS: [chunk buffer 0 | chunk buffer 1 | per wave: c tile 96 x CH floats | per wave: two
-  // tables of 96 cell offsets (state source rows, output rows)]
+  // tables of 96 cell offsets (state source rows, output rows) | per wave: the shift slot of
+  // the pipelined main loop (130 vectors)]
   float* const ctile = reinterpret_cast<float*>(lds + 2 * G::kChunkVec) + wave * G::kTileFloats;
-  uint32_t* const otab = reinterpret_cast<uint32_t*>(
-      reinterpret_cast<float*>(lds + 2 * G::kChunkVec) + WAVES * G::kTileFloats) + wave * 192;
+  uint32_t* const otab_base = reinterpret_cast<uint32_t*>(
+      reinterpret_cast<float*>(lds + 2 * G::kChunkVec) + WAVES * G::kTileFloats);
+  uint32_t* const otab = otab_base + wave * 192;
   constexpr uint32_t kNone = 0xffffffffu;
   const uint32_t rowb = (uint32_t)C * 4u;                    // bytes per cell of a state tensor
   bool okc[3];
@@ -404,11 +443,18 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     // instruction stream can fill the shadow of its MFMAs (8 passes = 32 cycles each, ~7 VALU
     // issue slots), so the stream is laid out by hand and PINNED (sched_barrier fences between
     // the slices): behind every MFMA of a (component, dx) group sits one slice of the work for
-    // what comes next -- the weight fragments of the next group (4 ds_reads), the lane shifts
-    // of the next dx (8 DPP + 8 selects per plane), one register of the input transform of the
-    // NEXT component (8 packed-fp16 instructions), or a few of the chunk-ahead memory requests
-    // (operand rows of chunk k + 1, its weight stage by LDS-DMA).  Components run in the order
-    // 3, 0, 1, 2, 4 (V3 feeds V0 and V4), dx in the order 1, 0, 2 (the unshifted fragment first).
+    // what comes next -- the weight fragments of the next group (4 ds_reads), half a register
+    // each of two steps of the input transform of the NEXT component (4 + 4 packed-fp16
+    // instructions, two independent chains), the lane-shifted fragments (below), or a few of
+    // the chunk-ahead memory requests (operand rows of chunk k + 1, its weight stage by
+    // LDS-DMA).  Components run in the order 3, 0, 1, 2, 4 (V3 feeds V0 and V4), dx in the
+    // order 1, 0, 2 (the unshifted fragment first).
+    // The dx = 0 / 2 fragments are the component moved one lane up / down the wave.  By DPP
+    // that is 8 moves + 8 selects per plane and direction, 160 VALU instructions per chunk --
+    // more than the MFMA shadow has room for next to the transform.  Here the finished
+    // component goes through a wave-private LDS slot instead (2 ds_writes) and comes back
+    // shifted (4 ds_reads at lane -+ 1; a lane whose neighbour lies outside its image row reads
+    // a zero vector): no VALU work at all.
     Wn3K2 k2;
     {
       const f16x2 c1 = __builtin_bit_cast(f16x2, mone), c2 = __builtin_bit_cast(f16x2, ptwo),
@@ -457,47 +503,67 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       (I) < 2 ? (W).w1[(I) & 1] : (W).w0[(I) & 1], ((I) >= 2 && (I) < 4) ? (BL) : (BH),       \
       acc[COMP][(I) & 1], 0, 0, 0)
 #define W3_PINSH(P) asm volatile("" : "+v"((P)[0]), "+v"((P)[1]), "+v"((P)[2]), "+v"((P)[3]))
-    // one component: X = its plane pair; PIECE(n), n = 0..7: the transform running beside it;
-    // EXTRA(n), n = 0..2: memory requests; `wf` holds the fragments of (COMP, dx 1) on entry and
-    // receives those of (NEXTCOMP, dx 1) when NEXTCOMP >= 0 (same chunk buffer)
-#define W3_COMP_PIPE(COMP, X, NEXTCOMP, BUF, PIECE, EXTRA)                                    \
+    // the wave's shift slot: [64 vectors high plane | zero | 64 vectors low plane | zero]
+    f16x8* const vsh = reinterpret_cast<f16x8*>(otab_base + WAVES * 192) + wave * 130;
+    vsh[64] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    vsh[129] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    const f16x8* const vup = okx0 ? vsh + (lane - 1) : vsh + 64;     // dx = 0: lane l - 1
+    const f16x8* const vdn = okx2 ? vsh + (lane + 1) : vsh + 64;     // dx = 2: lane l + 1
+    auto vsh_put = [&](const Pl8& v) __attribute__((always_inline)) {
+      vsh[lane] = pl8_vec(v.h);
+      vsh[65 + lane] = pl8_vec(v.l);
+    };
+    // one component: X = its plane pair (already in the shift slot); MIX(n), n = 0..8: the
+    // transform running beside it (half a of register n, half b of register n - 1); XNEXT: the
+    // component MIX builds (goes to the shift slot); EXTRA(n), n = 0..2: memory requests; `wf`
+    // holds the fragments of (COMP, dx 1) on entry and receives those of (NEXTCOMP, dx 1) when
+    // NEXTCOMP >= 0 (same chunk buffer)
+#define W3_COMP_PIPE(COMP, X, NEXTCOMP, BUF, MIX, XNEXT, EXTRA)                               \
   do {                                                                                        \
-    Pl8 bs, bt;                                                                               \
     const f16x8 xh = pl8_vec((X).h), xl = pl8_vec((X).l);                                     \
+    f16x8 sh, sl, th_, tl_;                                                                   \
     /* group dx = 1 */                                                                        \
     W3_MF(0, COMP, wf, xh, xl); ldw((BUF), (COMP), 0, wn); W3_FENCE;                          \
-    W3_MF(1, COMP, wf, xh, xl); pl8_shift((X).h, true, okx0, bs.h); W3_PINSH(bs.h); W3_FENCE; \
-    W3_MF(2, COMP, wf, xh, xl); pl8_shift((X).l, true, okx0, bs.l); W3_PINSH(bs.l); W3_FENCE; \
-    W3_MF(3, COMP, wf, xh, xl); PIECE(0); W3_FENCE;                                           \
-    W3_MF(4, COMP, wf, xh, xl); PIECE(1); W3_FENCE;                                           \
-    W3_MF(5, COMP, wf, xh, xl); PIECE(2); W3_FENCE;                                           \
+    W3_MF(1, COMP, wf, xh, xl); sh = vup[0]; sl = vup[65]; W3_FENCE;                          \
+    W3_MF(2, COMP, wf, xh, xl); th_ = vdn[0]; tl_ = vdn[65]; W3_FENCE;                        \
+    W3_MF(3, COMP, wf, xh, xl); MIX(0); W3_FENCE;                                             \
+    W3_MF(4, COMP, wf, xh, xl); MIX(1); W3_FENCE;                                             \
+    W3_MF(5, COMP, wf, xh, xl); MIX(2); W3_FENCE;                                             \
     /* group dx = 0 */                                                                        \
-    const f16x8 sh = pl8_vec(bs.h), sl = pl8_vec(bs.l);                                       \
     W3_MF(0, COMP, wn, sh, sl); ldw((BUF), (COMP), 2, wm); W3_FENCE;                          \
-    W3_MF(1, COMP, wn, sh, sl); pl8_shift((X).h, false, okx2, bt.h); W3_PINSH(bt.h); W3_FENCE; \
-    W3_MF(2, COMP, wn, sh, sl); pl8_shift((X).l, false, okx2, bt.l); W3_PINSH(bt.l); W3_FENCE; \
-    W3_MF(3, COMP, wn, sh, sl); PIECE(3); W3_FENCE;                                           \
-    W3_MF(4, COMP, wn, sh, sl); PIECE(4); W3_FENCE;                                           \
-    W3_MF(5, COMP, wn, sh, sl); EXTRA(0); W3_FENCE;                                           \
+    W3_MF(1, COMP, wn, sh, sl); MIX(3); W3_FENCE;                                             \
+    W3_MF(2, COMP, wn, sh, sl); MIX(4); W3_FENCE;                                             \
+    W3_MF(3, COMP, wn, sh, sl); MIX(5); W3_FENCE;                                             \
+    W3_MF(4, COMP, wn, sh, sl); MIX(6); W3_FENCE;                                             \
+    W3_MF(5, COMP, wn, sh, sl); MIX(7); W3_FENCE;                                             \
     /* group dx = 2 */                                                                        \
-    const f16x8 th_ = pl8_vec(bt.h), tl_ = pl8_vec(bt.l);                                     \
     W3_MF(0, COMP, wm, th_, tl_); if ((NEXTCOMP) >= 0) ldw((BUF), (NEXTCOMP) < 0 ? 0 : (NEXTCOMP), 1, wf); W3_FENCE; \
-    W3_MF(1, COMP, wm, th_, tl_); PIECE(5); W3_FENCE;                                         \
-    W3_MF(2, COMP, wm, th_, tl_); PIECE(6); W3_FENCE;                                         \
-    W3_MF(3, COMP, wm, th_, tl_); PIECE(7); W3_FENCE;                                         \
+    W3_MF(1, COMP, wm, th_, tl_); MIX(8); W3_FENCE;                                           \
+    W3_MF(2, COMP, wm, th_, tl_); vsh_put(XNEXT); W3_FENCE;                                   \
+    W3_MF(3, COMP, wm, th_, tl_); EXTRA(0); W3_FENCE;                                         \
     W3_MF(4, COMP, wm, th_, tl_); EXTRA(1); W3_FENCE;                                         \
     W3_MF(5, COMP, wm, th_, tl_); EXTRA(2); W3_FENCE;                                         \
   } while (0)
-    // a transform piece: register n & 3 of OUT = KA A + KB B, pinned
-#define W3_LIN(KA, KB, A, B, OUT, n)                                                          \
+    // transform steps by halves: register n & 3 of OUT = KA A + KB B
+#define W3_LA(KA, KB, A, B, OUT, n)                                                           \
+  wn_lin2a<KA, KB>((A).h[(n) & 3], (A).l[(n) & 3], (B).h[(n) & 3], (B).l[(n) & 3], k2,        \
+                   (OUT).h[(n) & 3], tmp[(n) & 1])
+#define W3_LB(KA, KB, A, B, OUT, n)                                                           \
   do {                                                                                        \
-    wn_lin2<KA, KB>((A).h[(n) & 3], (A).l[(n) & 3], (B).h[(n) & 3], (B).l[(n) & 3], k2,       \
-                    (OUT).h[(n) & 3], (OUT).l[(n) & 3]);                                      \
+    wn_lin2b<KA, KB>((A).h[(n) & 3], (B).h[(n) & 3], k2, tmp[(n) & 1], (OUT).l[(n) & 3]);     \
     W3_PIN2((OUT).h[(n) & 3], (OUT).l[(n) & 3]);                                              \
+  } while (0)
+    // a two-step transform OUT = f(MID), MID = g(rows): halves a of register n and b of n - 1
+#define W3_MIX2(n, KA1, KB1, A1, B1, MID, KA2, KB2, A2, B2, OUT)                              \
+  do {                                                                                        \
+    if ((n) < 4) W3_LA(KA1, KB1, A1, B1, MID, n); else if ((n) < 8) W3_LA(KA2, KB2, A2, B2, OUT, n); \
+    if ((n) >= 1 && (n) <= 4) W3_LB(KA1, KB1, A1, B1, MID, (n) - 1);                          \
+    else if ((n) >= 5) W3_LB(KA2, KB2, A2, B2, OUT, (n) - 1);                                 \
   } while (0)
 
     Pl8 rowsA[5], rowsB[5];
     Pl8 v3, va, vb, tt, t3;
+    Wn3Tmp tmp[2];
     Wf wf, wn, wm;
     // The body is ONE basic block (no branches: a branch would let the sinking passes carry
     // the slices into its successors): the requests for chunk k + 1 go out unconditionally --
@@ -511,25 +577,25 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       W3_FENCE;
 #define W3_NOP(n) do { } while (0)
       // beside component 3 (V3): V0 = 2 (d0 - d2) + V3; the weight stage of chunk k + 1
-#define W3_P3(n) do { if ((n) < 4) W3_LIN(1, -1, C[0], C[2], tt, n); else W3_LIN(2, 1, tt, v3, va, n); } while (0)
+#define W3_M3(n) W3_MIX2(n, 1, -1, C[0], C[2], tt, 2, 1, tt, v3, va)
 #define W3_E3(n) dma_part(nck, nbuf, 5 * (n), 5 * (n) + 5)
-      W3_COMP_PIPE(3, v3, 0, buf, W3_P3, W3_E3);
+      W3_COMP_PIPE(3, v3, 0, buf, W3_M3, va, W3_E3);
       // beside component 0 (V0): V1 = (d3 - d2) - 2 d1; rows 1, 3 of chunk k + 1 (row 0 of
       // this chunk is dead: at most six operand rows live)
-#define W3_P0(n) do { if ((n) < 4) W3_LIN(1, -1, C[3], C[2], t3, n); else W3_LIN(1, -2, t3, C[1], vb, n); } while (0)
+#define W3_M0(n) W3_MIX2(n, 1, -1, C[3], C[2], t3, 1, -2, t3, C[1], vb)
 #define W3_E0(n) do { if ((n) == 0) load_rows(nck, N, 1, 2); else if ((n) == 1) load_rows(nck, N, 3, 4); } while (0)
-      W3_COMP_PIPE(0, va, 1, buf, W3_P0, W3_E0);
+      W3_COMP_PIPE(0, va, 1, buf, W3_M0, vb, W3_E0);
       // beside component 1 (V1): V2 = 2 (d1 - d2) + (d3 - d2); rows 0, 2 of chunk k + 1
-#define W3_P1(n) do { if ((n) < 4) W3_LIN(1, -1, C[1], C[2], tt, n); else W3_LIN(2, 1, tt, t3, va, n); } while (0)
+#define W3_M1(n) W3_MIX2(n, 1, -1, C[1], C[2], tt, 2, 1, tt, t3, va)
 #define W3_E1(n) do { if ((n) == 0) load_rows(nck, N, 0, 1); else if ((n) == 1) load_rows(nck, N, 2, 3); } while (0)
-      W3_COMP_PIPE(1, vb, 2, buf, W3_P1, W3_E1);
+      W3_COMP_PIPE(1, vb, 2, buf, W3_M1, va, W3_E1);
       // beside component 2 (V2): V4 = 2 V3 + (d2 - d4); row 4 of chunk k + 1
-#define W3_P2(n) do { if ((n) < 4) W3_LIN(1, -1, C[2], C[4], tt, n); else W3_LIN(2, 1, v3, tt, vb, n); } while (0)
+#define W3_M2(n) W3_MIX2(n, 1, -1, C[2], C[4], tt, 2, 1, v3, tt, vb)
 #define W3_E2(n) do { if ((n) == 0) load_rows(nck, N, 4, 5); } while (0)
-      W3_COMP_PIPE(2, va, 4, buf, W3_P2, W3_E2);
+      W3_COMP_PIPE(2, va, 4, buf, W3_M2, vb, W3_E2);
       // beside component 4 (V4): V3 of chunk k + 1 = d3 - d1 of ITS rows
-#define W3_P4(n) do { if ((n) < 4) W3_LIN(1, -1, N[3], N[1], v3, n); } while (0)
-      W3_COMP_PIPE(4, vb, -1, buf, W3_P4, W3_NOP);
+#define W3_M4(n) do { if ((n) < 4) W3_LA(1, -1, N[3], N[1], v3, n); if ((n) >= 1 && (n) <= 4) W3_LB(1, -1, N[3], N[1], v3, (n) - 1); } while (0)
+      W3_COMP_PIPE(4, vb, -1, buf, W3_M4, v3, W3_NOP);
       __syncthreads();
     };
     load_rows(ck_lo, rowsA, 0, 5);
@@ -538,13 +604,21 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
 #pragma unroll
     for (int n = 0; n < 4; ++n)
       wn_lin2<1, -1>(rowsA[3].h[n], rowsA[3].l[n], rowsA[1].h[n], rowsA[1].l[n], k2, v3.h[n], v3.l[n]);
+    vsh_put(v3);
     for (int ck = ck_lo; ck < ck_hi; ck += 2) {
       chunk_body(ck, rowsA, rowsB, lds, lds + G::kChunkVec);
       if (ck + 1 < ck_hi) chunk_body(ck + 1, rowsB, rowsA, lds + G::kChunkVec, lds);
     }
 #undef W3_PIN2
 #undef W3_PINSH
-#undef W3_LIN
+#undef W3_LA
+#undef W3_LB
+#undef W3_MIX2
+#undef W3_M3
+#undef W3_M0
+#undef W3_M1
+#undef W3_M2
+#undef W3_M4
 #undef W3_E1
 #undef W3_E2
 #undef W3_FENCE
@@ -839,7 +913,7 @@ constexpr int kW3Waves = 4, kW3Nrb = 2;
 
 static inline size_t wino3_lds_bytes() {
   return (size_t)2 * Wn3<kW3Nrb>::kChunkBytes + (size_t)kW3Waves * Wn3<kW3Nrb>::kTileFloats * 4 +
-         (size_t)kW3Waves * 192 * 4;
+         (size_t)kW3Waves * 192 * 4 + (size_t)kW3Waves * 130 * 16;   // + the waves' shift slots
 }
 static inline unsigned convlstm_wino3_blocks(const ConvLstmArgs& a) {
   const size_t Q = (size_t)a.rows * ((a.H + 2) / 3) * a.W;
