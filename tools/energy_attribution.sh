@@ -19,17 +19,20 @@ sample() {   # $1 = log; runs until the file $O/stop appears
   while [ ! -e $O/stop ]; do rocm-smi -c -P 2>/dev/null | grep -E "sclk|Power" >> $1; sleep 0.2; done
 }
 # name : ABLC build bits : run-time MV_WINO_ABL bits
-ROWS="mfma_only:55:2 plus_transform:54:2 plus_dpp:52:2 plus_wreads:48:2 plus_gloads:32:2 plus_dma:0:2 \
-plus_epi_math:0:24 plus_state_stores:0:16 shipped:0:0 one_mfma:8:0 no_transform:1:0 no_transc:0:32 idle:-:-"
+# MV_ENERGY_ROWS overrides the table (same "name:ablc-build:abl" triples; a 4th field "k=v" is
+# exported for the run, e.g. f23:0:0:MV_WINO3=0)
+ROWS=${MV_ENERGY_ROWS:-"mfma_only:55:2 plus_transform:54:2 plus_dpp:52:2 plus_wreads:48:2 plus_gloads:32:2 plus_dma:0:2 \
+plus_epi_math:0:24 plus_state_stores:0:16 shipped:0:0 one_mfma:8:0 no_transform:1:0 no_transc:0:32 idle:-:-"}
 for row in $ROWS; do
-  name=${row%%:*}; rest=${row#*:}; c=${rest%%:*}; a=${rest#*:}
+  IFS=: read -r name c a kv <<< "$row"
   rm -f $O/stop
   sample $O/smi_$name.log &
   SP=$!
   if [ $name = idle ]; then sleep 5
   else
     if [ $c = 0 ]; then unset MV_LIB_PATH; else export MV_LIB_PATH=$ROOT/build/variants/libmv_r5c$c.so; fi
-    MV_WINO_ABL=$a timeout 180 $B > $O/$name.json 2> $O/$name.err
+    if [ -n "${kv:-}" ]; then env $kv MV_WINO_ABL=$a timeout 180 $B > $O/$name.json 2> $O/$name.err
+    else MV_WINO_ABL=$a timeout 180 $B > $O/$name.json 2> $O/$name.err; fi
   fi
   touch $O/stop; wait $SP
 done

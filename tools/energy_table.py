@@ -35,7 +35,7 @@ def main():
   print("|---|---|---|---|---|---|---|---|---|---|---|")
   prev = None
   for row in rows:
-    name, c, a = row.split(":")
+    name, c, a = row.split(":")[:3]
     if name == "idle":
       continue
     try:

@@ -10,6 +10,8 @@
 #   wino      tests/test_gpu_wino.py -s (kernel-level parity of the gate kernel forms)
 #   bench     the default `python bench.py` line (headline + every sub-workload)
 #   headline  `python bench.py --no-sub` x 2 (same-box repeatability of the headline)
+#   w3abl     F(3,3) against F(2,3): shipped / no epilogue / no main loop, time + power
+#   pmcgreedy rocprofv3 trace + PMC of the greedy workload only
 #   profiles  rocprofv3 traces + PMC of greedy / beam / train (tools/profile_workload.sh)
 #   ab:<ENV=V>  headline + beam with the env setting against the default, same box
 set -u
@@ -50,6 +52,20 @@ for stage in "$@"; do
       line $O/bench_default.json ;;
     headline)
       for i in 1 2; do timeout 300 $BQ --steps 100 > $O/headline_$i.json 2> $O/headline_$i.err; line $O/headline_$i.json; done ;;
+    w3abl)
+      MV_ENERGY_ROWS="w3_shipped:0:0 w3_no_epilogue:0:2 w3_no_main_loop:0:1 w3_no_stores:0:24 f23_shipped:0:0:MV_WINO3=0 f23_no_epilogue:0:2:MV_WINO3=0 f23_no_main_loop:0:1:MV_WINO3=0 idle:-:-" \
+        bash tools/energy_attribution.sh $T/w3abl 300 > $O/w3abl.log 2>&1; cat $O/w3abl/table.md ;;
+    pmcgreedy)
+      bash tools/profile_workload.sh ${T}_greedy > $O/prof_greedy.log 2>&1
+      head -6 gpurun_out/prof_${T}_greedy/kernel_trace_stats.md
+      python - <<PY
+import json, glob
+for f in sorted(glob.glob("gpurun_out/prof_${T}_greedy/pmc_convlstm*.json")):
+  d = json.load(open(f))
+  print(d["kernel"], {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items() if k not in ("counters", "kernel", "hbm_bytes_per_launch")},
+        {k: round(v / 1e6, 1) for k, v in (d.get("hbm_bytes_per_launch") or {}).items()})
+PY
+      ;;
     profiles)
       bash tools/profile_workload.sh ${T}_greedy > $O/prof_greedy.log 2>&1
       bash tools/profile_workload.sh ${T}_beam --workload beam > $O/prof_beam.log 2>&1
