@@ -71,6 +71,8 @@ struct ConvLstmWinoArgs {
   ConvLstm16Args b;        // geometry, operand planes, outputs (wp16 / wx32 unused)
   const _Float16* wpw;     // [cb16][stage][comp in stage 2][dx 3][plane 2][row block 2][lane 64][8]
   const float* w_hwio;     // the fp32 kernel [3,3,Cx+C,4C] (x_small chunk)
+  const _Float16* v3x;     // F(3,3), pre-transformed operands (convlstm_wino3.h
+  const _Float16* v3h;     // wino3_transform_kernel): components of the x / h planes, or null
   int32_t n_xc;            // 16-channel x chunks present in the pack (0 when x_small)
   int32_t nks_main, nks_x; // dgrad: split-K slices of the d h column blocks / of the d x blocks
   int32_t abl;             // MV_WINO_ABL (timing ablations, results are garbage): 1 = no main

@@ -132,96 +132,117 @@ __device__ __forceinline__ void wn_lin(const f16x8 a_hi, const f16x8 a_lo, const
   lo = __builtin_elementwise_fma(ne1 + ne2, k.m1, l1);
 }
 
-// The same on ONE register (two halves) of each plane: the unit the software-pipelined main
-// loop places between MFMAs.
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-struct Wn3K2 { f16x2 m1, p2, m2; };
-struct Pl8 { uint32_t h[4], l[4]; };       // 8 halves per lane as a (high, low) plane pair
-
-template <int KA, int KB>
-__device__ __forceinline__ void wn_lin2(uint32_t ahi, uint32_t alo, uint32_t bhi, uint32_t blo,
-                                        const Wn3K2& k, uint32_t& hi, uint32_t& lo) {
-  static_assert((KA == 1 && (KB == 1 || KB == -1 || KB == -2)) || (KA == 2 && KB == 1), "form");
-  const f16x2 a_hi = __builtin_bit_cast(f16x2, ahi), a_lo = __builtin_bit_cast(f16x2, alo);
-  const f16x2 b_hi = __builtin_bit_cast(f16x2, bhi), b_lo = __builtin_bit_cast(f16x2, blo);
-  const f16x2 nka = KA == 1 ? k.m1 : k.m2;                      // -KA
-  f16x2 s, ne2, l1;
-  if (KA == 2) {
-    s = __builtin_elementwise_fma(a_hi, k.p2, b_hi);
-    l1 = __builtin_elementwise_fma(a_lo, k.p2, b_lo);
-  } else if (KB == 1) {
-    s = a_hi + b_hi;
-    l1 = a_lo + b_lo;
-  } else {
-    s = __builtin_elementwise_fma(b_hi, KB == -1 ? k.m1 : k.m2, a_hi);
-    l1 = __builtin_elementwise_fma(b_lo, KB == -1 ? k.m1 : k.m2, a_lo);
-  }
-  const f16x2 bb = __builtin_elementwise_fma(a_hi, nka, s);
-  const f16x2 t = __builtin_elementwise_fma(bb, k.m1, s);
-  const f16x2 ne1 = __builtin_elementwise_fma(a_hi, nka, t);
-  if (KB == -1) ne2 = bb + b_hi;
-  else ne2 = __builtin_elementwise_fma(b_hi, KB == 1 ? k.m1 : k.p2, bb);
-  const f16x2 lo2 = __builtin_elementwise_fma(ne1 + ne2, k.m1, l1);
-  hi = __builtin_bit_cast(uint32_t, s);
-  lo = __builtin_bit_cast(uint32_t, lo2);
+// ---------------------------------------------------------------- the input transform, ONCE
+// In the kernel the transform costs 288 packed-fp16 instructions per wave and 16 input
+// channels -- and every one of the C / 16 column-block workgroups that share a row tile redoes
+// it.  With one wave per SIMD (the accumulator tile leaves no room for a second) those
+// instructions have nowhere to hide: the shadow of an MFMA holds about five single-issue
+// instructions (MI355X guide, "one wave per SIMD"), the transform alone needs 3.2 per MFMA.
+// So the components are formed once per gate step by this pre-pass and the gate kernel loads
+// them like any operand:
+//   out[tile = q >> 5][channel group of 16][component 5][plane 2][k half 2][column q & 31][8]
+// (q = triple-cell index rows x ceil(H / 3) x W; 16 bytes per lane, the 64 lanes of a wave one
+// contiguous KB: lane l IS (k half = l >> 5, column = l & 31), MFMA B-fragment order).  The
+// beam's parent indirection is applied HERE (src_row), the gate kernel reads in output order.
+// Same arithmetic as the in-kernel form (wn_lin chain, error-free TwoSum of the high planes).
+struct Wn3TransformItem {
+  const _Float16* p0;        // plane 0 of the operand (tiled layout, plane_layout.h)
+  int64_t pstride;           // halves to plane 1
+  _Float16* out;
+  const int32_t* src_row;    // optional [rows]
+  int32_t rows, H, W, Cc;    // Cc: channels, a multiple of 16
+};
+constexpr int kW3TrGroup = 8;
+struct Wn3TransformGroup {
+  Wn3TransformItem it[kW3TrGroup];
+  int32_t blk_end[kW3TrGroup];
+  int32_t n;
+};
+static inline size_t wino3_v_elems(int rows, int H, int W, int Cc) {   // in halves
+  const size_t Q = (size_t)rows * ((H + 2) / 3) * W;
+  return ((Q + 31) / 32) * (size_t)(Cc / 16) * 5 * 2 * 64 * 8;
 }
-// wn_lin2 in two halves of four instructions (a: s, l1, bb, t; b: ne2, ne1, their sum, lo):
-// a slice of the pipelined loop holds half a of one register next to half b of the previous
-// one, two independent chains the scheduler interleaves (a dependent packed-fp16 pair costs a
-// wait state).
-struct Wn3Tmp { f16x2 l1, bb, t; };
-template <int KA, int KB>
-__device__ __forceinline__ void wn_lin2a(uint32_t ahi, uint32_t alo, uint32_t bhi, uint32_t blo,
-                                         const Wn3K2& k, uint32_t& hi, Wn3Tmp& m) {
-  static_assert((KA == 1 && (KB == 1 || KB == -1 || KB == -2)) || (KA == 2 && KB == 1), "form");
-  const f16x2 a_hi = __builtin_bit_cast(f16x2, ahi), a_lo = __builtin_bit_cast(f16x2, alo);
-  const f16x2 b_hi = __builtin_bit_cast(f16x2, bhi), b_lo = __builtin_bit_cast(f16x2, blo);
-  f16x2 s;
-  if (KA == 2) {
-    s = __builtin_elementwise_fma(a_hi, k.p2, b_hi);
-    m.l1 = __builtin_elementwise_fma(a_lo, k.p2, b_lo);
-  } else if (KB == 1) {
-    s = a_hi + b_hi;
-    m.l1 = a_lo + b_lo;
-  } else {
-    s = __builtin_elementwise_fma(b_hi, KB == -1 ? k.m1 : k.m2, a_hi);
-    m.l1 = __builtin_elementwise_fma(b_lo, KB == -1 ? k.m1 : k.m2, a_lo);
-  }
-  m.bb = __builtin_elementwise_fma(a_hi, KA == 1 ? k.m1 : k.m2, s);
-  m.t = __builtin_elementwise_fma(m.bb, k.m1, s);
-  hi = __builtin_bit_cast(uint32_t, s);
+static inline unsigned wino3_transform_blocks(int rows, int H, int W, int Cc) {
+  const size_t Q = (size_t)rows * ((H + 2) / 3) * W;
+  return (unsigned)((((Q + 31) / 32) * (size_t)(Cc / 16) + 3) / 4);     // 4 waves per block
 }
-template <int KA, int KB>
-__device__ __forceinline__ void wn_lin2b(uint32_t ahi, uint32_t bhi, const Wn3K2& k,
-                                         const Wn3Tmp& m, uint32_t& lo) {
-  const f16x2 a_hi = __builtin_bit_cast(f16x2, ahi), b_hi = __builtin_bit_cast(f16x2, bhi);
-  const f16x2 ne1 = __builtin_elementwise_fma(a_hi, KA == 1 ? k.m1 : k.m2, m.t);
-  f16x2 ne2;
-  if (KB == -1) ne2 = m.bb + b_hi;
-  else ne2 = __builtin_elementwise_fma(b_hi, KB == 1 ? k.m1 : k.p2, m.bb);
-  const f16x2 lo2 = __builtin_elementwise_fma(ne1 + ne2, k.m1, m.l1);
-  lo = __builtin_bit_cast(uint32_t, lo2);
-}
-__device__ __forceinline__ f16x8 pl8_vec(const uint32_t (&r)[4]) {
-  const u32x4 v = {r[0], r[1], r[2], r[3]};
-  return __builtin_bit_cast(f16x8, v);
-}
-// one plane's four registers moved one lane up (dx = -1: lane l takes lane l - 1) or down
-__device__ __forceinline__ void pl8_shift(const uint32_t (&src)[4], bool up, bool ok,
-                                          uint32_t (&dst)[4]) {
+__global__ __launch_bounds__(256)
+void wino3_transform_kernel(const Wn3TransformGroup g) {
+  int block = blockIdx.x, pi = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint32_t t =
-        up ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src[j], 0x138, 0xf, 0xf, true)
-           : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src[j], 0x130, 0xf, 0xf, true);
-    dst[j] = ok ? t : 0u;
+  for (int i = 0; i < kW3TrGroup - 1; ++i)
+    if (i + 1 < g.n && (int)blockIdx.x >= g.blk_end[i]) pi = i + 1;
+  if (pi > 0) block -= g.blk_end[pi - 1];
+  const Wn3TransformItem& it = g.it[pi];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int KG = it.Cc >> 4;
+  const int H = it.H, W = it.W, HW = H * W;
+  const int Kt = ((H + 2) / 3) * W, Q_total = it.rows * Kt;
+  const int ntile = (Q_total + 31) >> 5;
+  const int wid = block * 4 + wave;
+  if (wid >= ntile * KG) return;
+  const int tile = wid / KG, cg = wid - tile * KG;
+  const int col = lane & 31, half = lane >> 5;
+  const int q = tile * 32 + col;
+  const bool valid = q < Q_total;
+  int r = 0, y0 = 0, xpos = 0;
+  if (valid) {
+    r = q / Kt;
+    const int pc = q - r * Kt;
+    const int t = pc / W;
+    y0 = 3 * t;
+    xpos = pc - t * W;
+  }
+  const int sr = (valid && it.src_row) ? it.src_row[r] : r;
+  f16x8 dh[5], dl[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int rho = y0 - 1 + i;
+    const bool ok = valid & (rho >= 0) & (rho < H);
+    const long long m = (long long)sr * HW + rho * W + xpos;
+    const size_t o = ((size_t)(m >> 5) * KG + cg) * 512 + (size_t)(half * 256 + (int)(m & 31) * 8);
+    const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    dh[i] = ok ? *reinterpret_cast<const f16x8*>(it.p0 + o) : z;
+    dl[i] = ok ? *reinterpret_cast<const f16x8*>(it.p0 + it.pstride + o) : z;
+  }
+  uint32_t mone = 0xBC00BC00u, ptwo = 0x40004000u, mtwo = 0xC000C000u;   // opaque to hipcc
+  asm volatile("" : "+s"(mone), "+s"(ptwo), "+s"(mtwo));
+  Wn3Consts kc;
+  kc.m1 = __builtin_bit_cast(f16x8, u32x4{mone, mone, mone, mone});
+  kc.p2 = __builtin_bit_cast(f16x8, u32x4{ptwo, ptwo, ptwo, ptwo});
+  kc.m2 = __builtin_bit_cast(f16x8, u32x4{mtwo, mtwo, mtwo, mtwo});
+  f16x8 vh[5], vl[5], th, tl, t3h, t3l;
+  wn_lin<1, -1>(dh[3], dl[3], dh[1], dl[1], kc, vh[3], vl[3]);     // V3 = d3 - d1
+  wn_lin<1, -1>(dh[0], dl[0], dh[2], dl[2], kc, th, tl);           // d0 - d2
+  wn_lin<2, 1>(th, tl, vh[3], vl[3], kc, vh[0], vl[0]);            // V0
+  wn_lin<1, -1>(dh[3], dl[3], dh[2], dl[2], kc, t3h, t3l);         // d3 - d2
+  wn_lin<1, -2>(t3h, t3l, dh[1], dl[1], kc, vh[1], vl[1]);         // V1
+  wn_lin<1, -1>(dh[1], dl[1], dh[2], dl[2], kc, th, tl);           // d1 - d2
+  wn_lin<2, 1>(th, tl, t3h, t3l, kc, vh[2], vl[2]);                // V2
+  wn_lin<1, -1>(dh[2], dl[2], dh[4], dl[4], kc, th, tl);           // d2 - d4
+  wn_lin<2, 1>(vh[3], vl[3], th, tl, kc, vh[4], vl[4]);            // V4
+  f16x8* o = reinterpret_cast<f16x8*>(it.out) + ((size_t)tile * KG + cg) * (5 * 2 * 64) + lane;
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    o[(c * 2 + 0) * 64] = vh[c];
+    o[(c * 2 + 1) * 64] = vl[c];
   }
 }
-
-// MV_WINO3_PIPE=0 at build time: the plain main loop (transform, then 90 MFMAs, per chunk)
-#ifndef MV_WINO3_PIPE
-#define MV_WINO3_PIPE 1
-#endif
+static inline void launch_wino3_transforms(const Wn3TransformItem* items, int n,
+                                           hipStream_t stream) {
+  for (int i0 = 0; i0 < n; i0 += kW3TrGroup) {
+    Wn3TransformGroup g{};
+    g.n = n - i0 < kW3TrGroup ? n - i0 : kW3TrGroup;
+    unsigned nb = 0;
+    for (int j = 0; j < g.n; ++j) {
+      g.it[j] = items[i0 + j];
+      nb += wino3_transform_blocks(g.it[j].rows, g.it[j].H, g.it[j].W, g.it[j].Cc);
+      g.blk_end[j] = (int32_t)nb;
+    }
+    for (int j = g.n; j < kW3TrGroup; ++j) g.blk_end[j] = (int32_t)nb;
+    if (nb) hipLaunchKernelGGL(wino3_transform_kernel, dim3(nb), dim3(256), 0, stream, g);
+  }
+}
 
 template <int WAVES, int NRB>
 __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, int cb, int mt,
@@ -438,30 +459,52 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     kc.m1 = __builtin_bit_cast(f16x8, u32x4{mone, mone, mone, mone});
     kc.p2 = __builtin_bit_cast(f16x8, u32x4{ptwo, ptwo, ptwo, ptwo});
     kc.m2 = __builtin_bit_cast(f16x8, u32x4{mtwo, mtwo, mtwo, mtwo});
-    if constexpr (MV_WINO3_PIPE && NRB == 2) {
-    // ---- software-pipelined main loop.  One wave per SIMD: nothing but this wave's own
-    // instruction stream can fill the shadow of its MFMAs (8 passes = 32 cycles each, ~7 VALU
-    // issue slots), so the stream is laid out by hand and PINNED (sched_barrier fences between
-    // the slices): behind every MFMA of a (component, dx) group sits one slice of the work for
-    // what comes next -- the weight fragments of the next group (4 ds_reads), half a register
-    // each of two steps of the input transform of the NEXT component (4 + 4 packed-fp16
-    // instructions, two independent chains), the lane-shifted fragments (below), or a few of
-    // the chunk-ahead memory requests (operand rows of chunk k + 1, its weight stage by
-    // LDS-DMA).  Components run in the order 3, 0, 1, 2, 4 (V3 feeds V0 and V4), dx in the
-    // order 1, 0, 2 (the unshifted fragment first).
-    // The dx = 0 / 2 fragments are the component moved one lane up / down the wave.  By DPP
-    // that is 8 moves + 8 selects per plane and direction, 160 VALU instructions per chunk --
-    // more than the MFMA shadow has room for next to the transform.  Here the finished
-    // component goes through a wave-private LDS slot instead (2 ds_writes) and comes back
-    // shifted (4 ds_reads at lane -+ 1; a lane whose neighbour lies outside its image row reads
-    // a zero vector): no VALU work at all.
-    Wn3K2 k2;
-    {
-      const f16x2 c1 = __builtin_bit_cast(f16x2, mone), c2 = __builtin_bit_cast(f16x2, ptwo),
-                  c3 = __builtin_bit_cast(f16x2, mtwo);
-      k2.m1 = c1; k2.p2 = c2; k2.m2 = c3;
-    }
+    if (p.v3x || p.v3h) {
+    // ---- main loop on PRE-TRANSFORMED operands (wino3_transform_kernel).  One wave per SIMD:
+    // only this wave's own instruction stream can fill the shadow of its MFMAs (32 cycles,
+    // about five single-issue instructions), so the loop carries nothing but requests and is
+    // laid out by hand, PINNED by sched_barrier fences: behind each MFMA of a (component, dx)
+    // group at most a handful of ds_reads / loads / ds_writes.
+    //   * B fragments: the centre fragment of (component, plane) is ONE 16-byte load per lane
+    //     (the wave's 64 lanes = one contiguous KB); the dx = 0 / 2 fragments are the SAME run
+    //     read 16 bytes lower / higher (the neighbour lane's vector: L1 hits); a lane whose
+    //     neighbour lies outside its image row reads past the buffer = zeros.  No DPP, no
+    //     select, no LDS round trip.  Five register sets of six vectors, component c's set is
+    //     refilled FOUR components ahead (set index = component: no unrolling).
+    //   * weights: the next chunk's 15 KB per wave by ordinary loads in three batches of five
+    //     vectors, written to the other LDS buffer a component later (an LDS-DMA piece costs
+    //     60+ cycles of the wave's issue time among MFMAs, a load + ds_write_b128 about 20).
+    static_assert(NRB == 2, "pipelined path: two row blocks");
     struct Wf { f16x8 w0[2], w1[2]; };
+    const int KGx = Cx >> 4, KGh = C >> 4;
+    // (a dead wave -- past the last triple-cell -- reads tile 0: it still hits the barriers)
+    const int tile = __builtin_amdgcn_readfirstlane(wave_live ? (q_wave >> 5) : 0);
+    const size_t vxb = (size_t)tile * (size_t)(KGx > 0 ? KGx : 1) * 10240u;    // bytes per (tile, group): 5 x 2 KB
+    const size_t vhb = (size_t)tile * (size_t)KGh * 10240u;
+    const __amdgpu_buffer_rsrc_t vxrs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<char*>(reinterpret_cast<const char*>(p.v3x ? p.v3x : p.v3h) + (p.v3x ? vxb : 0))),
+        0, (uint32_t)((size_t)(KGx > 0 ? KGx : 1) * 10240u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vhrs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<char*>(reinterpret_cast<const char*>(p.v3h ? p.v3h : p.v3x) + (p.v3h ? vhb : 0))),
+        0, (uint32_t)((size_t)KGh * 10240u), 0x00020000);
+    constexpr uint32_t kOob = 0x80000000u;                // beyond num_records: the load returns 0
+    const uint32_t vo_c = (uint32_t)lane * 16u;
+    const uint32_t vo_up = okx0 ? (uint32_t)(lane - 1) * 16u : kOob;   // dx = 0: lane l - 1
+    const uint32_t vo_dn = okx2 ? (uint32_t)(lane + 1) * 16u : kOob;   // dx = 2: lane l + 1
+    struct Vset { f16x8 ch, cl, uh, ul, dh, dl; };     // centre / up / down x (high, low)
+    // component `comp` of chunk `ck` (clamped to the last chunk: a request past the end
+    // fetches that chunk again, into registers nobody reads)
+    auto vload = [&](int ck, int comp, Vset& v) __attribute__((always_inline)) {
+      const int ckc = ck < ck_hi ? ck : ck_hi - 1;
+      const bool is_x = ckc < nxc;
+      const uint32_t so = (uint32_t)(is_x ? ckc : ckc - nxc) * 10240u + (uint32_t)comp * 2048u;
+#define W3_VL(OFF, PL) __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(     \
+      is_x ? vxrs : vhrs, (int)(OFF), (int)(so + (PL) * 1024u), 0))
+      v.ch = W3_VL(vo_c, 0); v.cl = W3_VL(vo_c, 1);
+      v.uh = W3_VL(vo_up, 0); v.ul = W3_VL(vo_up, 1);
+      v.dh = W3_VL(vo_dn, 0); v.dl = W3_VL(vo_dn, 1);
+#undef W3_VL
+    };
     auto ldw = [&](const f16x8* buf, int comp, int dx, Wf& w) __attribute__((always_inline)) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
@@ -469,169 +512,90 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
         w.w1[rb] = buf[(((comp * 3 + dx) * 2 + 1) * 2 + rb) * 64 + lane];
       }
     };
-    auto load_rows = [&](int ck, Pl8 (&dst)[5], int i0, int i1) __attribute__((always_inline)) {
-      const bool is_x = ck < nxc;
-      const uint32_t cgo = (uint32_t)(is_x ? ck : ck - nxc) * 1024u;
-#pragma unroll
-      for (int i = i0; i < i1; ++i) {
-        const uint32_t o = is_x ? roffx[i] : roffh[i];
-        const int off = o ? (int)(o + cgo) : 0;
-        const u32x4 a0 = __builtin_amdgcn_raw_buffer_load_b128(is_x ? xrs0 : hrs0, off, 0, 0);
-        const u32x4 a1 = __builtin_amdgcn_raw_buffer_load_b128(is_x ? xrs1 : hrs1, off, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { dst[i].h[j] = a0[j]; dst[i].l[j] = a1[j]; }
-      }
-    };
+    static_assert(kChunkPieces % WAVES == 0 && kChunkPieces / WAVES == 15, "weight batches");
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    auto dma_part = [&](int ck, f16x8* dstbuf, int i0, int i1) __attribute__((always_inline)) {
+    u32x4 wst[5];                                          // weight vectors on their way to LDS
+    auto wload = [&](int ck, int batch) __attribute__((always_inline)) {
+      const int ckc = ck < ck_hi ? ck : ck_hi - 1;
 #pragma unroll
-      for (int i = i0; i < i1; ++i) {
-        const int piece = i * WAVES + wave_u;                  // scalar: one VGPR for all pieces
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            wrs, (__attribute__((address_space(3))) void*)(dstbuf + piece * 64), 16, lane16,
-            (uint32_t)ck * G::kChunkBytes + (uint32_t)piece * 1024u, 0, MV_DMA_AUX);
+      for (int i = 0; i < 5; ++i) {
+        const int piece = (batch * 5 + i) * WAVES + wave_u;
+        wst[i] = __builtin_amdgcn_raw_buffer_load_b128(
+            wrs, (int)lane16, (int)((uint32_t)ckc * G::kChunkBytes + (uint32_t)piece * 1024u), 0);
       }
     };
-    static_assert(kChunkPieces % WAVES == 0 && kChunkPieces / WAVES == 15, "DMA slices");
+    auto wstore = [&](f16x8* dstbuf, int batch) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int piece = (batch * 5 + i) * WAVES + wave_u;
+        dstbuf[piece * 64 + lane] = __builtin_bit_cast(f16x8, wst[i]);
+      }
+    };
 #define W3_FENCE __builtin_amdgcn_sched_barrier(0)
-    // the results of a slice exist HERE: a value-pinning empty asm between two fences keeps
-    // the instruction selector and the sinking passes from moving the slice to its first use
-#define W3_PIN2(A, B) asm volatile("" : "+v"(A), "+v"(B))
     // MFMA i of a group: (w1, b0) x 2 row blocks, (w0, b1) x 2, (w0, b0) x 2
 #define W3_MF(I, COMP, W, BH, BL)                                                             \
   acc[COMP][(I) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                \
       (I) < 2 ? (W).w1[(I) & 1] : (W).w0[(I) & 1], ((I) >= 2 && (I) < 4) ? (BL) : (BH),       \
       acc[COMP][(I) & 1], 0, 0, 0)
-#define W3_PINSH(P) asm volatile("" : "+v"((P)[0]), "+v"((P)[1]), "+v"((P)[2]), "+v"((P)[3]))
-    // the wave's shift slot: [64 vectors high plane | zero | 64 vectors low plane | zero]
-    f16x8* const vsh = reinterpret_cast<f16x8*>(otab_base + WAVES * 192) + wave * 130;
-    vsh[64] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    vsh[129] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    const f16x8* const vup = okx0 ? vsh + (lane - 1) : vsh + 64;     // dx = 0: lane l - 1
-    const f16x8* const vdn = okx2 ? vsh + (lane + 1) : vsh + 64;     // dx = 2: lane l + 1
-    auto vsh_put = [&](const Pl8& v) __attribute__((always_inline)) {
-      vsh[lane] = pl8_vec(v.h);
-      vsh[65 + lane] = pl8_vec(v.l);
-    };
-    // one component: X = its plane pair (already in the shift slot); MIX(n), n = 0..8: the
-    // transform running beside it (half a of register n, half b of register n - 1); XNEXT: the
-    // component MIX builds (goes to the shift slot); EXTRA(n), n = 0..2: memory requests; `wf`
-    // holds the fragments of (COMP, dx 1) on entry and receives those of (NEXTCOMP, dx 1) when
-    // NEXTCOMP >= 0 (same chunk buffer)
-#define W3_COMP_PIPE(COMP, X, NEXTCOMP, BUF, MIX, XNEXT, EXTRA)                               \
+    // one component: V = its register set; `wf` holds the fragments of (COMP, dx 1) on entry and
+    // receives those of (NEXTCOMP, dx 1) when NEXTCOMP >= 0 (same chunk buffer); VNEXT / NCK /
+    // NCOMP: the set refilled meanwhile (four components ahead); S0..S2: weight-staging slices
+#define W3_COMP_PRE(COMP, V, NEXTCOMP, BUF, VNEXT, NCK, NCOMP, S0, S1, S2)                    \
   do {                                                                                        \
-    const f16x8 xh = pl8_vec((X).h), xl = pl8_vec((X).l);                                     \
-    f16x8 sh, sl, th_, tl_;                                                                   \
     /* group dx = 1 */                                                                        \
-    W3_MF(0, COMP, wf, xh, xl); ldw((BUF), (COMP), 0, wn); W3_FENCE;                          \
-    W3_MF(1, COMP, wf, xh, xl); sh = vup[0]; sl = vup[65]; W3_FENCE;                          \
-    W3_MF(2, COMP, wf, xh, xl); th_ = vdn[0]; tl_ = vdn[65]; W3_FENCE;                        \
-    W3_MF(3, COMP, wf, xh, xl); MIX(0); W3_FENCE;                                             \
-    W3_MF(4, COMP, wf, xh, xl); MIX(1); W3_FENCE;                                             \
-    W3_MF(5, COMP, wf, xh, xl); MIX(2); W3_FENCE;                                             \
+    W3_MF(0, COMP, wf, (V).ch, (V).cl); ldw((BUF), (COMP), 0, wn); W3_FENCE;                  \
+    W3_MF(1, COMP, wf, (V).ch, (V).cl); W3_FENCE;                                             \
+    W3_MF(2, COMP, wf, (V).ch, (V).cl); S0; W3_FENCE;                                         \
+    W3_MF(3, COMP, wf, (V).ch, (V).cl); W3_FENCE;                                             \
+    W3_MF(4, COMP, wf, (V).ch, (V).cl); W3_FENCE;                                             \
+    W3_MF(5, COMP, wf, (V).ch, (V).cl); W3_FENCE;                                             \
     /* group dx = 0 */                                                                        \
-    W3_MF(0, COMP, wn, sh, sl); ldw((BUF), (COMP), 2, wm); W3_FENCE;                          \
-    W3_MF(1, COMP, wn, sh, sl); MIX(3); W3_FENCE;                                             \
-    W3_MF(2, COMP, wn, sh, sl); MIX(4); W3_FENCE;                                             \
-    W3_MF(3, COMP, wn, sh, sl); MIX(5); W3_FENCE;                                             \
-    W3_MF(4, COMP, wn, sh, sl); MIX(6); W3_FENCE;                                             \
-    W3_MF(5, COMP, wn, sh, sl); MIX(7); W3_FENCE;                                             \
+    W3_MF(0, COMP, wn, (V).uh, (V).ul); ldw((BUF), (COMP), 2, wm); W3_FENCE;                  \
+    W3_MF(1, COMP, wn, (V).uh, (V).ul); W3_FENCE;                                             \
+    W3_MF(2, COMP, wn, (V).uh, (V).ul); S1; W3_FENCE;                                         \
+    W3_MF(3, COMP, wn, (V).uh, (V).ul); W3_FENCE;                                             \
+    W3_MF(4, COMP, wn, (V).uh, (V).ul); W3_FENCE;                                             \
+    W3_MF(5, COMP, wn, (V).uh, (V).ul); W3_FENCE;                                             \
     /* group dx = 2 */                                                                        \
-    W3_MF(0, COMP, wm, th_, tl_); if ((NEXTCOMP) >= 0) ldw((BUF), (NEXTCOMP) < 0 ? 0 : (NEXTCOMP), 1, wf); W3_FENCE; \
-    W3_MF(1, COMP, wm, th_, tl_); MIX(8); W3_FENCE;                                           \
-    W3_MF(2, COMP, wm, th_, tl_); vsh_put(XNEXT); W3_FENCE;                                   \
-    W3_MF(3, COMP, wm, th_, tl_); EXTRA(0); W3_FENCE;                                         \
-    W3_MF(4, COMP, wm, th_, tl_); EXTRA(1); W3_FENCE;                                         \
-    W3_MF(5, COMP, wm, th_, tl_); EXTRA(2); W3_FENCE;                                         \
+    W3_MF(0, COMP, wm, (V).dh, (V).dl); if ((NEXTCOMP) >= 0) ldw((BUF), (NEXTCOMP) < 0 ? 0 : (NEXTCOMP), 1, wf); W3_FENCE; \
+    W3_MF(1, COMP, wm, (V).dh, (V).dl); W3_FENCE;                                             \
+    W3_MF(2, COMP, wm, (V).dh, (V).dl); S2; W3_FENCE;                                         \
+    W3_MF(3, COMP, wm, (V).dh, (V).dl); W3_FENCE;                                             \
+    W3_MF(4, COMP, wm, (V).dh, (V).dl); W3_FENCE;                                             \
+    /* the set this component just finished with is the one refilled now */                   \
+    W3_MF(5, COMP, wm, (V).dh, (V).dl); vload((NCK), (NCOMP), (VNEXT)); W3_FENCE;             \
   } while (0)
-    // transform steps by halves: register n & 3 of OUT = KA A + KB B
-#define W3_LA(KA, KB, A, B, OUT, n)                                                           \
-  wn_lin2a<KA, KB>((A).h[(n) & 3], (A).l[(n) & 3], (B).h[(n) & 3], (B).l[(n) & 3], k2,        \
-                   (OUT).h[(n) & 3], tmp[(n) & 1])
-#define W3_LB(KA, KB, A, B, OUT, n)                                                           \
-  do {                                                                                        \
-    wn_lin2b<KA, KB>((A).h[(n) & 3], (B).h[(n) & 3], k2, tmp[(n) & 1], (OUT).l[(n) & 3]);     \
-    W3_PIN2((OUT).h[(n) & 3], (OUT).l[(n) & 3]);                                              \
-  } while (0)
-    // a two-step transform OUT = f(MID), MID = g(rows): halves a of register n and b of n - 1
-#define W3_MIX2(n, KA1, KB1, A1, B1, MID, KA2, KB2, A2, B2, OUT)                              \
-  do {                                                                                        \
-    if ((n) < 4) W3_LA(KA1, KB1, A1, B1, MID, n); else if ((n) < 8) W3_LA(KA2, KB2, A2, B2, OUT, n); \
-    if ((n) >= 1 && (n) <= 4) W3_LB(KA1, KB1, A1, B1, MID, (n) - 1);                          \
-    else if ((n) >= 5) W3_LB(KA2, KB2, A2, B2, OUT, (n) - 1);                                 \
-  } while (0)
+#define W3_NONE do { } while (0)
 
-    Pl8 rowsA[5], rowsB[5];
-    Pl8 v3, va, vb, tt, t3;
-    Wn3Tmp tmp[2];
+    Vset v0, v1, v2, v3, v4;
     Wf wf, wn, wm;
-    // The body is ONE basic block (no branches: a branch would let the sinking passes carry
-    // the slices into its successors): the requests for chunk k + 1 go out unconditionally --
-    // after the last chunk they fetch that chunk again, into registers / the LDS buffer nobody
-    // reads any more.
-    auto chunk_body = [&](int ck, Pl8 (&C)[5], Pl8 (&N)[5], f16x8* buf, f16x8* nbuf)
-        __attribute__((always_inline)) {
-      const int nck = ck + 1 < ck_hi ? ck + 1 : ck;
-      // after the barrier: the first group's fragments cannot be requested any earlier
-      ldw(buf, 3, 1, wf);
-      W3_FENCE;
-#define W3_NOP(n) do { } while (0)
-      // beside component 3 (V3): V0 = 2 (d0 - d2) + V3; the weight stage of chunk k + 1
-#define W3_M3(n) W3_MIX2(n, 1, -1, C[0], C[2], tt, 2, 1, tt, v3, va)
-#define W3_E3(n) dma_part(nck, nbuf, 5 * (n), 5 * (n) + 5)
-      W3_COMP_PIPE(3, v3, 0, buf, W3_M3, va, W3_E3);
-      // beside component 0 (V0): V1 = (d3 - d2) - 2 d1; rows 1, 3 of chunk k + 1 (row 0 of
-      // this chunk is dead: at most six operand rows live)
-#define W3_M0(n) W3_MIX2(n, 1, -1, C[3], C[2], t3, 1, -2, t3, C[1], vb)
-#define W3_E0(n) do { if ((n) == 0) load_rows(nck, N, 1, 2); else if ((n) == 1) load_rows(nck, N, 3, 4); } while (0)
-      W3_COMP_PIPE(0, va, 1, buf, W3_M0, vb, W3_E0);
-      // beside component 1 (V1): V2 = 2 (d1 - d2) + (d3 - d2); rows 0, 2 of chunk k + 1
-#define W3_M1(n) W3_MIX2(n, 1, -1, C[1], C[2], tt, 2, 1, tt, t3, va)
-#define W3_E1(n) do { if ((n) == 0) load_rows(nck, N, 0, 1); else if ((n) == 1) load_rows(nck, N, 2, 3); } while (0)
-      W3_COMP_PIPE(1, vb, 2, buf, W3_M1, va, W3_E1);
-      // beside component 2 (V2): V4 = 2 V3 + (d2 - d4); row 4 of chunk k + 1
-#define W3_M2(n) W3_MIX2(n, 1, -1, C[2], C[4], tt, 2, 1, v3, tt, vb)
-#define W3_E2(n) do { if ((n) == 0) load_rows(nck, N, 4, 5); } while (0)
-      W3_COMP_PIPE(2, va, 4, buf, W3_M2, vb, W3_E2);
-      // beside component 4 (V4): V3 of chunk k + 1 = d3 - d1 of ITS rows
-#define W3_M4(n) do { if ((n) < 4) W3_LA(1, -1, N[3], N[1], v3, n); if ((n) >= 1 && (n) <= 4) W3_LB(1, -1, N[3], N[1], v3, (n) - 1); } while (0)
-      W3_COMP_PIPE(4, vb, -1, buf, W3_M4, v3, W3_NOP);
-      __syncthreads();
-    };
-    load_rows(ck_lo, rowsA, 0, 5);
+    // prologue: the first chunk's weights by LDS-DMA (nothing to overlap with yet), the first
+    // four components' sets
+    vload(ck_lo, 0, v0); vload(ck_lo, 1, v1); vload(ck_lo, 2, v2); vload(ck_lo, 3, v3);
     chunk_dma(ck_lo, lds);
     __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-      wn_lin2<1, -1>(rowsA[3].h[n], rowsA[3].l[n], rowsA[1].h[n], rowsA[1].l[n], k2, v3.h[n], v3.l[n]);
-    vsh_put(v3);
-    for (int ck = ck_lo; ck < ck_hi; ck += 2) {
-      chunk_body(ck, rowsA, rowsB, lds, lds + G::kChunkVec);
-      if (ck + 1 < ck_hi) chunk_body(ck + 1, rowsB, rowsA, lds + G::kChunkVec, lds);
+    for (int ck = ck_lo; ck < ck_hi; ++ck) {
+      f16x8* const buf = lds + (((ck - ck_lo) & 1) ? G::kChunkVec : 0);
+      f16x8* const nbuf = lds + (((ck - ck_lo) & 1) ? 0 : G::kChunkVec);
+      // after the barrier: the first group's fragments cannot be requested any earlier
+      ldw(buf, 0, 1, wf);
+      W3_FENCE;
+      // the set refilled beside component c belongs to the component four ahead: component 4
+      // of this chunk beside component 0, then components 0..3 of the next chunk -- each into
+      // the set its own predecessor just left
+      W3_COMP_PRE(0, v0, 1, buf, v4, ck, 4, wload(ck + 1, 0), W3_NONE, W3_NONE);
+      W3_COMP_PRE(1, v1, 2, buf, v0, ck + 1, 0, wstore(nbuf, 0), wload(ck + 1, 1), W3_NONE);
+      W3_COMP_PRE(2, v2, 3, buf, v1, ck + 1, 1, wstore(nbuf, 1), wload(ck + 1, 2), W3_NONE);
+      W3_COMP_PRE(3, v3, 4, buf, v2, ck + 1, 2, wstore(nbuf, 2), W3_NONE, W3_NONE);
+      W3_COMP_PRE(4, v4, -1, buf, v3, ck + 1, 3, W3_NONE, W3_NONE, W3_NONE);
+      // the other buffer was filled by ds_writes: lgkmcnt, NOT vmcnt -- the operand sets
+      // requested up to four components ahead stay in flight across the barrier
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-#undef W3_PIN2
-#undef W3_PINSH
-#undef W3_LA
-#undef W3_LB
-#undef W3_MIX2
-#undef W3_M3
-#undef W3_M0
-#undef W3_M1
-#undef W3_M2
-#undef W3_M4
-#undef W3_E1
-#undef W3_E2
 #undef W3_FENCE
 #undef W3_MF
-#undef W3_COMP_PIPE
-#undef W3_NOP
-#undef W3_P3
-#undef W3_E3
-#undef W3_P0
-#undef W3_E0
-#undef W3_P1
-#undef W3_P2
-#undef W3_P4
+#undef W3_COMP_PRE
+#undef W3_NONE
     } else {
     load_raw(ck_lo);
     chunk_dma(ck_lo, lds);

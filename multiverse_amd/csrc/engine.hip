@@ -202,6 +202,9 @@ struct mv_engine {
   // 2 = bf16 operands / fp32 accumulate (one plane, one MFMA per product)
   int compute_mode = 0;
   DevBuf<_Float16> px16[mv::kMaxGroup], ph16[mv::kMaxGroup];   // fallback plane scratch per slot
+  // F(3,3) gate kernel: the pre-transformed operands of a group slot (convlstm_wino3.h
+  // wino3_transform_kernel), x and h
+  DevBuf<_Float16> pv3x[mv::kMaxGroup], pv3h[mv::kMaxGroup];
   // relu / lrelu models in f16x3 mode: the x operands of the gate convolutions are unbounded,
   // so their planes carry a per-tensor exponent (max |x| as float bits [64] | exponent [1])
   // instead of the fixed 2^8; the producers do not emit planes for these buffers
@@ -917,6 +920,41 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
       for (size_t i = 0; i < p16.size(); ++i)
         pw[i].wpw = cell_of_pack(e, probs[i].wpack)->wpw3.p;
   }
+  // F(3,3): the input transform runs ONCE per operand, in a pre-pass, instead of in every one
+  // of the C / 16 column-block workgroups of the gate kernel (convlstm_wino3.h)
+  std::vector<mv::Wn3TransformItem> tr3;
+  double tr3_bytes = 0;
+  if (wino3) {
+    static const bool pre = !(getenv("MV_WINO3_PRE") && atoi(getenv("MV_WINO3_PRE")) == 0);
+    bool fits = pre;
+    for (size_t i = 0; i < p16.size() && fits; ++i) {
+      const ConvLstmArgs& a = p16[i].f;
+      if (!a.zero_state && e->pv3h[i].n < mv::wino3_v_elems(a.rows, a.H, a.W, a.C)) fits = false;
+      if (!a.x_small && a.Cx > 0 && !a.sx_corr &&
+          e->pv3x[i].n < mv::wino3_v_elems(a.rows, a.H, a.W, a.Cx)) fits = false;
+    }
+    for (size_t i = 0; i < p16.size() && fits; ++i) {
+      const mv::ConvLstm16Args& q = p16[i];
+      const ConvLstmArgs& a = q.f;
+      const double cells = (double)a.rows * a.H * a.W;
+      if (!a.zero_state) {
+        tr3.push_back(mv::Wn3TransformItem{q.h16, q.h_plane_stride, e->pv3h[i].p, a.src_row_h,
+                                           a.rows, a.H, a.W, a.C});
+        pw[i].v3h = e->pv3h[i].p;
+        tr3_bytes += cells * a.C * 4.0 * (1.0 + 5.0 / 3.0);
+      }
+      if (!a.x_small && a.Cx > 0 && !a.sx_corr) {
+        tr3.push_back(mv::Wn3TransformItem{q.x16, q.x_plane_stride, e->pv3x[i].p, nullptr,
+                                           a.rows, a.H, a.W, a.Cx});
+        pw[i].v3x = e->pv3x[i].p;
+        tr3_bytes += cells * a.Cx * 4.0 * (1.0 + 5.0 / 3.0);
+      }
+    }
+  }
+  if (!tr3.empty())
+    launch(e, "wino3_transform", 0, tr3_bytes, [&] {
+      mv::launch_wino3_transforms(tr3.data(), (int)tr3.size(), e->stream);
+    });
   // fp16 MFMA products ISSUED per executed fp32 product: 3 in the direct form; in a Winograd
   // form 3 * (components * row tiles) / (3 * H) -- partial tiles count (9 rows = 5 pairs: 2.22,
   // not 2), weighted over the group by executed FLOPs
@@ -2669,6 +2707,16 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
         h->ph16[i].alloc(2 * (rows * K * c.hidden_size + mv::kPlaneSlack + mv::kPlanePad));
         HIP_CHECK(hipMemset(h->px16[i].p, 0, h->px16[i].n * sizeof(_Float16)));
         if (c.activation != 0) h->xexp[i].alloc(65);    // never inside a graph capture
+        if (mode == 1 && mv::wino_enabled() && mv::wino3_enabled() && c.activation == 0) {
+          size_t vx = 0, vh = 0;
+          for (int s = 0; s < c.num_scales; ++s) {
+            if (!h->sc[s].use || h->sc[s].H < 3) continue;
+            vx = std::max(vx, mv::wino3_v_elems((int)rows, h->sc[s].H, h->sc[s].W, (int)((xc + 15) / 16 * 16)));
+            vh = std::max(vh, mv::wino3_v_elems((int)rows, h->sc[s].H, h->sc[s].W, c.hidden_size));
+          }
+          if (vx) h->pv3x[i].alloc(vx);
+          if (vh) h->pv3h[i].alloc(vh);
+        }
         HIP_CHECK(hipMemset(h->ph16[i].p, 0, h->ph16[i].n * sizeof(_Float16)));
       }
     }
@@ -2916,7 +2964,25 @@ int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const flo
                          ctx.stream, dk.p, wp.p, Cx, Cx16, C, mv::kW3Nrb, halves / 2);
       mv::ConvLstmWinoArgs wq{};
       wq.b = q; wq.wpw = wp.p; wq.w_hwio = dk.p; wq.n_xc = Cx16 / 16;
+      // the pre-transformed operands, as the engine hands them over (MV_WINO3_PRE=0: the
+      // in-kernel transform)
+      DevBuf<_Float16> v3x, v3h;
+      if (!(getenv("MV_WINO3_PRE") && atoi(getenv("MV_WINO3_PRE")) == 0)) {
+        std::vector<mv::Wn3TransformItem> tr;
+        if (!zero) {
+          v3h.alloc(mv::wino3_v_elems(M, H, W, C));
+          tr.push_back(mv::Wn3TransformItem{q.h16, q.h_plane_stride, v3h.p, nullptr, M, H, W, C});
+          wq.v3h = v3h.p;
+        }
+        if (Cx16 > 0) {
+          v3x.alloc(mv::wino3_v_elems(M, H, W, Cx16));
+          tr.push_back(mv::Wn3TransformItem{q.x16, q.x_plane_stride, v3x.p, nullptr, M, H, W, Cx16});
+          wq.v3x = v3x.p;
+        }
+        mv::launch_wino3_transforms(tr.data(), (int)tr.size(), ctx.stream);
+      }
       mv::launch_convlstm_wino3_steps(&wq, 1, ctx.stream);
+      HIP_CHECK(hipStreamSynchronize(ctx.stream));    // v3x / v3h die with this scope
     } else {
       MV_REQUIRE(mv::wino_geometry_ok(a), "Winograd form: W %d must divide 32, H >= 2", W);
       const size_t halves = mv::wino_wpack_elems(Cx16, C);
