@@ -244,6 +244,14 @@ static inline void launch_wino3_transforms(const Wn3TransformItem* items, int n,
   }
 }
 
+// -DMV_W3_ABLC=<bits>: compile-time ablations of the pre-transformed main loop (timing only,
+// results are garbage): 1 = no operand loads in the loop, 2 = no weight loads / LDS writes,
+// 4 = no weight-fragment ds_reads (read once in front of the loop), 8 = no barrier,
+// 16 = one MFMA per product instead of three.
+#ifndef MV_W3_ABLC
+#define MV_W3_ABLC 0
+#endif
+
 template <int WAVES, int NRB>
 __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, int cb, int mt,
                                                     f16x8* lds) {
@@ -495,6 +503,10 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     // component `comp` of chunk `ck` (clamped to the last chunk: a request past the end
     // fetches that chunk again, into registers nobody reads)
     auto vload = [&](int ck, int comp, Vset& v) __attribute__((always_inline)) {
+      if ((MV_W3_ABLC & 1) && ck > ck_lo) {       // keep the prologue's registers, opaquely
+        asm volatile("" : "+v"(v.ch), "+v"(v.cl), "+v"(v.uh), "+v"(v.ul), "+v"(v.dh), "+v"(v.dl));
+        return;
+      }
       const int ckc = ck < ck_hi ? ck : ck_hi - 1;
       const bool is_x = ckc < nxc;
       const uint32_t so = (uint32_t)(is_x ? ckc : ckc - nxc) * 10240u + (uint32_t)comp * 2048u;
@@ -505,7 +517,13 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       v.dh = W3_VL(vo_dn, 0); v.dl = W3_VL(vo_dn, 1);
 #undef W3_VL
     };
+    Wf wfix;
     auto ldw = [&](const f16x8* buf, int comp, int dx, Wf& w) __attribute__((always_inline)) {
+      if (MV_W3_ABLC & 4) {
+        asm volatile("" : "+v"(wfix.w0[0]), "+v"(wfix.w0[1]), "+v"(wfix.w1[0]), "+v"(wfix.w1[1]));
+        w = wfix;
+        return;
+      }
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         w.w0[rb] = buf[(((comp * 3 + dx) * 2 + 0) * 2 + rb) * 64 + lane];
@@ -516,6 +534,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     const uint32_t lane16 = (uint32_t)lane * 16u;
     u32x4 wst[5];                                          // weight vectors on their way to LDS
     auto wload = [&](int ck, int batch) __attribute__((always_inline)) {
+      if (MV_W3_ABLC & 2) return;
       const int ckc = ck < ck_hi ? ck : ck_hi - 1;
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
@@ -525,6 +544,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       }
     };
     auto wstore = [&](f16x8* dstbuf, int batch) __attribute__((always_inline)) {
+      if (MV_W3_ABLC & 2) return;
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         const int piece = (batch * 5 + i) * WAVES + wave_u;
@@ -534,6 +554,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
 #define W3_FENCE __builtin_amdgcn_sched_barrier(0)
     // MFMA i of a group: (w1, b0) x 2 row blocks, (w0, b1) x 2, (w0, b0) x 2
 #define W3_MF(I, COMP, W, BH, BL)                                                             \
+  if (!(MV_W3_ABLC & 16) || (I) >= 4)                                                         \
   acc[COMP][(I) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                \
       (I) < 2 ? (W).w1[(I) & 1] : (W).w0[(I) & 1], ((I) >= 2 && (I) < 4) ? (BL) : (BH),       \
       acc[COMP][(I) & 1], 0, 0, 0)
@@ -574,8 +595,12 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     vload(ck_lo, 0, v0); vload(ck_lo, 1, v1); vload(ck_lo, 2, v2); vload(ck_lo, 3, v3);
     chunk_dma(ck_lo, lds);
     __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
+    if (MV_W3_ABLC & 4) {
+      wfix.w0[0] = lds[lane]; wfix.w0[1] = lds[64 + lane];
+      wfix.w1[0] = lds[128 + lane]; wfix.w1[1] = lds[192 + lane];
+    }
     for (int ck = ck_lo; ck < ck_hi; ++ck) {
-      f16x8* const buf = lds + (((ck - ck_lo) & 1) ? G::kChunkVec : 0);
+      f16x8* const buf = lds + ((((ck - ck_lo) & 1) && !(MV_W3_ABLC & 2)) ? G::kChunkVec : 0);
       f16x8* const nbuf = lds + (((ck - ck_lo) & 1) ? 0 : G::kChunkVec);
       // after the barrier: the first group's fragments cannot be requested any earlier
       ldw(buf, 0, 1, wf);
@@ -590,7 +615,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       W3_COMP_PRE(4, v4, -1, buf, v3, ck + 1, 3, W3_NONE, W3_NONE, W3_NONE);
       // the other buffer was filled by ds_writes: lgkmcnt, NOT vmcnt -- the operand sets
       // requested up to four components ahead stay in flight across the barrier
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (!(MV_W3_ABLC & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #undef W3_FENCE
 #undef W3_MF

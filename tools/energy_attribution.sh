@@ -30,7 +30,7 @@ for row in $ROWS; do
   SP=$!
   if [ $name = idle ]; then sleep 5
   else
-    if [ $c = 0 ]; then unset MV_LIB_PATH; else export MV_LIB_PATH=$ROOT/build/variants/libmv_r5c$c.so; fi
+    if [ $c = 0 ]; then unset MV_LIB_PATH; else export MV_LIB_PATH=$ROOT/build/variants/libmv_${MV_ENERGY_LIBPREFIX:-r5c}$c.so; fi
     if [ -n "${kv:-}" ]; then env $kv MV_WINO_ABL=$a timeout 180 $B > $O/$name.json 2> $O/$name.err
     else MV_WINO_ABL=$a timeout 180 $B > $O/$name.json 2> $O/$name.err; fi
   fi

@@ -11,6 +11,7 @@
 #   bench     the default `python bench.py` line (headline + every sub-workload)
 #   headline  `python bench.py --no-sub` x 2 (same-box repeatability of the headline)
 #   w3abl     F(3,3) against F(2,3): shipped / no epilogue / no main loop, time + power
+#   w3loop    main-loop ablation builds of the F(3,3) kernel (-DMV_W3_ABLC), no epilogue
 #   pmcgreedy rocprofv3 trace + PMC of the greedy workload only
 #   profiles  rocprofv3 traces + PMC of greedy / beam / train (tools/profile_workload.sh)
 #   ab:<ENV=V>  headline + beam with the env setting against the default, same box
@@ -55,6 +56,9 @@ for stage in "$@"; do
     w3abl)
       MV_ENERGY_ROWS="w3_shipped:0:0 w3_no_epilogue:0:2 w3_no_main_loop:0:1 w3_no_stores:0:24 f23_shipped:0:0:MV_WINO3=0 f23_no_epilogue:0:2:MV_WINO3=0 f23_no_main_loop:0:1:MV_WINO3=0 idle:-:-" \
         bash tools/energy_attribution.sh $T/w3abl 300 > $O/w3abl.log 2>&1; cat $O/w3abl/table.md ;;
+    w3loop)
+      MV_ENERGY_LIBPREFIX=r5w MV_ENERGY_ROWS="w3_no_epilogue:0:2 w3_no_operand_loads:1:2 w3_no_weight_stream:2:2 w3_no_fragment_reads:4:2 w3_mfma_and_barrier:7:2 w3_mfma_only:15:2 w3_one_mfma_per_product:16:2 w3_one_mfma_only:31:2 w3_shipped:0:0 idle:-:-" \
+        bash tools/energy_attribution.sh $T/w3loop 300 > $O/w3loop.log 2>&1; cat $O/w3loop/table.md ;;
     pmcgreedy)
       bash tools/profile_workload.sh ${T}_greedy > $O/prof_greedy.log 2>&1
       head -6 gpurun_out/prof_${T}_greedy/kernel_trace_stats.md
