@@ -31,15 +31,22 @@
 //
 // Tile.  Weights = A operand (rows = 4 gates x 8 channels), activations = B operand (columns
 // = 32 triple-cells), so a lane's accumulators hold i, j, f, o of four consecutive channels of
-// ONE triple-cell.  A wave owns 32 triple-cells (96 cells) x NRB * 8 channels x 4 gates x 5
-// components = 80 NRB accumulator registers (160 at NRB = 2) + 16 NRB for the direct fp32 x
-// chunk of the regression encoder's middle row: more than two waves per SIMD can hold, and the
-// attribution says occupancy is not what this kernel lacks -- it is built for ONE workgroup of
-// 4 waves per CU (one wave per SIMD, up to 512 registers: the operand rows of the next chunk
-// and a whole chunk of components live in registers).  The workgroup's 4 x 32 triple-cells share
-// one weight stream: a whole 16-input-channel chunk (5 components x 3 dx x 2 planes x NRB row
-// blocks = 30 NRB KB) per LDS stage, double-buffered by LDS-DMA, ONE barrier per chunk (90
-// MFMAs per wave at NRB = 2).
+// ONE triple-cell.  A wave owns 32 triple-cells (96 cells) x 16 channels x 4 gates x 5
+// components = 160 accumulator registers; a workgroup = 4 waves = 128 triple-cells of one
+// 16-channel column block, TWO workgroups per CU (two waves per SIMD, <= 256 registers --
+// possible because the main loop holds no operand rows and no transform temporaries, see
+// below).  The (chunk, component) pairs are ONE sequence; an LDS stage holds two consecutive
+// components (24 KB), double-buffered by LDS-DMA: 36 MFMAs per wave and barrier.
+//
+// What round 5 measured on the way here (profiles/r5*): with the input
+// transform IN the kernel the row-triple form needs the operand rows of a chunk (40
+// registers) next to 160 accumulators -- one wave per SIMD, one workgroup per CU.  In that
+// regime nothing covers a workgroup's prologue, epilogue and dispatch (0.29 of 0.83 ms: the
+// K loop of this problem is only 16-18 chunks long), and the shadow of an MFMA holds five
+// single-issue instructions where transform + shifts + requests need seven: 3-6 % SLOWER
+// than the row-pair kernel, hand-pipelined or not (profiles/r5f_*, r5h_*).  Hence the
+// pre-pass: the transform once per operand instead of once per column block, and a gate
+// kernel that fits twice on a CU again.
 #pragma once
 #include "convlstm_wino.h"
 
@@ -244,14 +251,6 @@ static inline void launch_wino3_transforms(const Wn3TransformItem* items, int n,
   }
 }
 
-// -DMV_W3_ABLC=<bits>: compile-time ablations of the pre-transformed main loop (timing only,
-// results are garbage): 1 = no operand loads in the loop, 2 = no weight loads / LDS writes,
-// 4 = no weight-fragment ds_reads (read once in front of the loop), 8 = no barrier,
-// 16 = one MFMA per product instead of three.
-#ifndef MV_W3_ABLC
-#define MV_W3_ABLC 0
-#endif
-
 template <int WAVES, int NRB>
 __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, int cb, int mt,
                                                     f16x8* lds) {
@@ -304,22 +303,24 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     }
   }
 
-  // acc[0..4]: the Winograd components; acc[5]: the direct fp32 x chunk of row y0 + 1
-  f32x16 acc[6][NRB];
+  // acc[0..4]: the Winograd components
+  f32x16 acc[5][NRB];
 #pragma unroll
-  for (int c = 0; c < 6; ++c)
+  for (int c = 0; c < 5; ++c)
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[c][rb][i] = 0.f;
 
-  // LDS: [chunk buffer 0 | chunk buffer 1 | per wave: c tile 96 x CH floats | per wave: two
-  // tables of 96 cell offsets (state source rows, output rows) | per wave: the shift slot of
-  // the pipelined main loop (130 vectors)]
-  float* const ctile = reinterpret_cast<float*>(lds + 2 * G::kChunkVec) + wave * G::kTileFloats;
-  uint32_t* const otab_base = reinterpret_cast<uint32_t*>(
-      reinterpret_cast<float*>(lds + 2 * G::kChunkVec) + WAVES * G::kTileFloats);
-  uint32_t* const otab = otab_base + wave * 192;
+  // LDS: [stage buffer 0 | stage buffer 1 (two components each; the epilogue reuses them as the
+  // waves' h' tiles) | per wave: c tile 96 x CH floats | per wave: two tables of 96 cell
+  // offsets (state source rows, output rows)]
+  constexpr int kStageVec = 2 * 3 * 2 * NRB * 64;            // 16-byte vectors per stage
+  constexpr uint32_t kStageBytes = kStageVec * 16;
+  static_assert(2 * kStageVec * 16 >= WAVES * G::kTileFloats * 4, "h' tiles fit the stage buffers");
+  float* const ctile = reinterpret_cast<float*>(lds + 2 * kStageVec) + wave * G::kTileFloats;
+  uint32_t* const otab = reinterpret_cast<uint32_t*>(
+      reinterpret_cast<float*>(lds + 2 * kStageVec) + WAVES * G::kTileFloats) + wave * 192;
   constexpr uint32_t kNone = 0xffffffffu;
   const uint32_t rowb = (uint32_t)C * 4u;                    // bytes per cell of a state tensor
   bool okc[3];
@@ -358,7 +359,9 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   }
 
   // ---- the 2-channel fp32 x chunk (regression encoder), direct form: row y0 into M0 (only
-  // y(3t) holds M0), row y0 + 2 into M4 (only y(3t+2)), row y0 + 1 into its own accumulator
+  // y(3t) holds M0), row y0 + 2 into M4 (only y(3t+2)); the middle row has no component of its
+  // own: D / 2 into M1 and -D / 2 into M2 leave y(3t) and y(3t+2) alone (their M1 + M2 terms
+  // cancel) and give y(3t+1) = M1 - M2 its D
   if (a.x_small && wave_live) {
     const int Cin = Cx + C, N4 = 4 * C;
     const int nk = 9 * Cx;
@@ -381,76 +384,88 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
         const int off = ok ? r * a.x_row_stride + (yy * W + xx) * Cx + chn : 0;
         const float tv = a.x[off];
         const float v = ok ? tv : 0.f;
-        constexpr int kSlot[3] = {0, 5, 4};
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
-          acc[kSlot[e]][rb] =
-              __builtin_amdgcn_mfma_f32_32x32x2f32(wv[rb], v, acc[kSlot[e]][rb], 0, 0, 0);
+        for (int rb = 0; rb < NRB; ++rb) {
+          if (e == 1) {
+            acc[1][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[rb], 0.5f * v, acc[1][rb], 0, 0, 0);
+            acc[2][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[rb], -0.5f * v, acc[2][rb], 0, 0, 0);
+          } else {
+            acc[e == 0 ? 0 : 4][rb] =
+                __builtin_amdgcn_mfma_f32_32x32x2f32(wv[rb], v, acc[e == 0 ? 0 : 4][rb], 0, 0, 0);
+          }
+        }
       }
     }
   }
 
-  // ---- f16 chunks of 16 input channels: x chunks first, then h chunks
+  // ---- f16 chunks of 16 input channels (x chunks first, then h chunks), five components each,
+  // on PRE-TRANSFORMED operands.  The (chunk, component) pairs form ONE sequence g = 0 .. G - 1
+  // (the pack is laid out in exactly that order); an LDS stage holds two consecutive
+  // components (24 KB), double-buffered by LDS-DMA: 36 MFMAs per wave and barrier, like the
+  // row-pair kernel.  The accumulator a component adds to must be known at compile time: five
+  // stages walk through the pairs (0,1) (2,3) (4,0) (1,2) (3,4), a switch picks the pair.
   const int nxc = p.n_xc;
   const int ck_lo = a.sx_corr ? nxc : 0;                          // sparse x: table terms instead
   const int ck_hi = (p.abl & 1) ? ck_lo : (a.zero_state ? nxc : nxc + (C >> 4));
   if (ck_hi > ck_lo) {
+    static_assert(NRB == 2, "stage copy: 24 pieces of 64 vectors");
+    const int G_total = (ck_hi - ck_lo) * 5;
+    const int S_total = (G_total + 1) >> 1;
     const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wpw) +
-                        (size_t)cb * (nxc + (C >> 4)) * G::kChunkVec;
+                        ((size_t)cb * (nxc + (C >> 4)) + ck_lo) * G::kChunkVec;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(const_cast<f16x8*>(wblk)), 0, 0x7fffffff, 0x00020000);
-    const _Float16* const x16 = q.x16 ? q.x16 : q.h16;
-    const int64_t xps = q.x16 ? q.x_plane_stride : 0;
-    const _Float16* const h16 = q.h16 ? q.h16 : q.x16;
-    const int64_t hps = q.h16 ? q.h_plane_stride : 0;
-    const __amdgpu_buffer_rsrc_t xrs0 = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(const_cast<_Float16*>(x16 - kPlanePad)), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrs1 = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(const_cast<_Float16*>(x16 + xps - kPlanePad)), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t hrs0 = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(const_cast<_Float16*>(h16 - kPlanePad)), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t hrs1 = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(const_cast<_Float16*>(h16 + hps - kPlanePad)), 0, 0x7fffffff, 0x00020000);
-
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // chunk copy: the pack IS the LDS image; 30 NRB pieces of 64 vectors over the waves
-    constexpr int kChunkPieces = 30 * NRB;
-    auto chunk_dma = [&](int ck, f16x8* dstbuf) {
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    // stage copy: the pack IS the LDS image; 24 pieces of 64 vectors (12 when the last stage
+    // holds one component), 24 / WAVES per wave
+    auto stage_dma = [&](int st, f16x8* dstbuf) {
+      const int npiece = (2 * st + 1 < G_total) ? 24 : 12;
 #pragma unroll
-      for (int i = 0; i < (kChunkPieces + WAVES - 1) / WAVES; ++i) {
+      for (int i = 0; i < 24 / WAVES; ++i) {
         const int piece = i * WAVES + wave_u;
-        if (kChunkPieces % WAVES == 0 || piece < kChunkPieces) {
-          const int v0 = piece * 64;
+        if (piece < npiece)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(
-              wrs, (__attribute__((address_space(3))) void*)(dstbuf + v0), 16,
-              (uint32_t)(v0 + lane) * 16u, (uint32_t)ck * G::kChunkBytes, 0, MV_DMA_AUX);
-        }
+              wrs, (__attribute__((address_space(3))) void*)(dstbuf + piece * 64), 16, lane16,
+              (uint32_t)st * kStageBytes + (uint32_t)piece * 1024u, 0, MV_DMA_AUX);
       }
     };
-    f16x8 raw[5][2];
-    auto load_raw = [&](int ck) {
+    // B fragments: the centre fragment of (component, plane) is one 16-byte load per lane (the
+    // wave's 64 lanes = one contiguous KB of the pre-pass's output: lane l IS k half l >> 5,
+    // column l & 31); a dead wave -- past the last triple-cell -- reads tile 0
+    const int KGx = Cx >> 4, KGh = C >> 4;
+    const int tile = __builtin_amdgcn_readfirstlane(wave_live ? (q_wave >> 5) : 0);
+    const __amdgpu_buffer_rsrc_t vxrs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<char*>(reinterpret_cast<const char*>(p.v3x ? p.v3x : p.v3h) +
+                                      (p.v3x ? (size_t)tile * (size_t)KGx * 10240u : 0))),
+        0, (uint32_t)((size_t)(KGx > 0 ? KGx : 1) * 10240u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vhrs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<char*>(reinterpret_cast<const char*>(p.v3h ? p.v3h : p.v3x) +
+                                      (p.v3h ? (size_t)tile * (size_t)KGh * 10240u : 0))),
+        0, (uint32_t)((size_t)KGh * 10240u), 0x00020000);
+    struct Vc { f16x8 h, l; };
+    // component g of the sequence (clamped to the last one: a request past the end fetches
+    // that component again)
+    auto vload = [&](int g, Vc& v) {
+      const int gc = g < G_total ? g : G_total - 1;
+      const int ck = ck_lo + gc / 5, comp = gc - (gc / 5) * 5;
       const bool is_x = ck < nxc;
-      const uint32_t cgo = (uint32_t)(is_x ? ck : ck - nxc) * 1024u;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const uint32_t o = is_x ? roffx[i] : roffh[i];
-        const int off = o ? (int)(o + cgo) : 0;
-        raw[i][0] = __builtin_bit_cast(
-            f16x8, __builtin_amdgcn_raw_buffer_load_b128(is_x ? xrs0 : hrs0, off, 0, 0));
-        raw[i][1] = __builtin_bit_cast(
-            f16x8, __builtin_amdgcn_raw_buffer_load_b128(is_x ? xrs1 : hrs1, off, 0, 0));
-      }
+      const int so = (is_x ? ck : ck - nxc) * 10240 + comp * 2048;
+      v.h = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                          is_x ? vxrs : vhrs, (int)lane16, so, 0));
+      v.l = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                          is_x ? vxrs : vhrs, (int)lane16, so + 1024, 0));
     };
-    // one component: 3 dx x NRB row blocks x 3 MFMAs from chunk buffer `buf`
-#define MV_W3_COMP(COMP, VHI, VLO, BUF)                                                       \
+    // one component: 3 dx x NRB row blocks x 3 MFMAs from stage buffer `buf`, slot ci
+#define MV_W3_COMP(COMP, CI, VHI, VLO, BUF)                                                   \
   do {                                                                                        \
     _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                        \
       const f16x8 b0 = dx == 1 ? (VHI) : wn_lane_shift((VHI), dx == 0, dx == 0 ? okx0 : okx2); \
       const f16x8 b1 = dx == 1 ? (VLO) : wn_lane_shift((VLO), dx == 0, dx == 0 ? okx0 : okx2); \
       f16x8 w0[NRB], w1[NRB];                                                                 \
       _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) {                                    \
-        w0[rb] = (BUF)[((((COMP) * 3 + dx) * 2 + 0) * NRB + rb) * 64 + lane];                 \
-        w1[rb] = (BUF)[((((COMP) * 3 + dx) * 2 + 1) * NRB + rb) * 64 + lane];                 \
+        w0[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 0) * NRB + rb) * 64 + lane];                   \
+        w1[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 1) * NRB + rb) * 64 + lane];                   \
       }                                                                                       \
       _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                      \
         acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[rb], b0, acc[COMP][rb], 0, 0, 0); \
@@ -460,203 +475,46 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
         acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b0, acc[COMP][rb], 0, 0, 0); \
     }                                                                                         \
   } while (0)
-
-    uint32_t mone = 0xBC00BC00u, ptwo = 0x40004000u, mtwo = 0xC000C000u;   // opaque to hipcc
-    asm volatile("" : "+s"(mone), "+s"(ptwo), "+s"(mtwo));
-    Wn3Consts kc;
-    kc.m1 = __builtin_bit_cast(f16x8, u32x4{mone, mone, mone, mone});
-    kc.p2 = __builtin_bit_cast(f16x8, u32x4{ptwo, ptwo, ptwo, ptwo});
-    kc.m2 = __builtin_bit_cast(f16x8, u32x4{mtwo, mtwo, mtwo, mtwo});
-    if (p.v3x || p.v3h) {
-    // ---- main loop on PRE-TRANSFORMED operands (wino3_transform_kernel).  One wave per SIMD:
-    // only this wave's own instruction stream can fill the shadow of its MFMAs (32 cycles,
-    // about five single-issue instructions), so the loop carries nothing but requests and is
-    // laid out by hand, PINNED by sched_barrier fences: behind each MFMA of a (component, dx)
-    // group at most a handful of ds_reads / loads / ds_writes.
-    //   * B fragments: the centre fragment of (component, plane) is ONE 16-byte load per lane
-    //     (the wave's 64 lanes = one contiguous KB); the dx = 0 / 2 fragments are the SAME run
-    //     read 16 bytes lower / higher (the neighbour lane's vector: L1 hits); a lane whose
-    //     neighbour lies outside its image row reads past the buffer = zeros.  No DPP, no
-    //     select, no LDS round trip.  Five register sets of six vectors, component c's set is
-    //     refilled FOUR components ahead (set index = component: no unrolling).
-    //   * weights: the next chunk's 15 KB per wave by ordinary loads in three batches of five
-    //     vectors, written to the other LDS buffer a component later (an LDS-DMA piece costs
-    //     60+ cycles of the wave's issue time among MFMAs, a load + ds_write_b128 about 20).
-    static_assert(NRB == 2, "pipelined path: two row blocks");
-    struct Wf { f16x8 w0[2], w1[2]; };
-    const int KGx = Cx >> 4, KGh = C >> 4;
-    // (a dead wave -- past the last triple-cell -- reads tile 0: it still hits the barriers)
-    const int tile = __builtin_amdgcn_readfirstlane(wave_live ? (q_wave >> 5) : 0);
-    const size_t vxb = (size_t)tile * (size_t)(KGx > 0 ? KGx : 1) * 10240u;    // bytes per (tile, group): 5 x 2 KB
-    const size_t vhb = (size_t)tile * (size_t)KGh * 10240u;
-    const __amdgpu_buffer_rsrc_t vxrs = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(const_cast<char*>(reinterpret_cast<const char*>(p.v3x ? p.v3x : p.v3h) + (p.v3x ? vxb : 0))),
-        0, (uint32_t)((size_t)(KGx > 0 ? KGx : 1) * 10240u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t vhrs = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(const_cast<char*>(reinterpret_cast<const char*>(p.v3h ? p.v3h : p.v3x) + (p.v3h ? vhb : 0))),
-        0, (uint32_t)((size_t)KGh * 10240u), 0x00020000);
-    constexpr uint32_t kOob = 0x80000000u;                // beyond num_records: the load returns 0
-    const uint32_t vo_c = (uint32_t)lane * 16u;
-    const uint32_t vo_up = okx0 ? (uint32_t)(lane - 1) * 16u : kOob;   // dx = 0: lane l - 1
-    const uint32_t vo_dn = okx2 ? (uint32_t)(lane + 1) * 16u : kOob;   // dx = 2: lane l + 1
-    struct Vset { f16x8 ch, cl, uh, ul, dh, dl; };     // centre / up / down x (high, low)
-    // component `comp` of chunk `ck` (clamped to the last chunk: a request past the end
-    // fetches that chunk again, into registers nobody reads)
-    auto vload = [&](int ck, int comp, Vset& v) __attribute__((always_inline)) {
-      if ((MV_W3_ABLC & 1) && ck > ck_lo) {       // keep the prologue's registers, opaquely
-        asm volatile("" : "+v"(v.ch), "+v"(v.cl), "+v"(v.uh), "+v"(v.ul), "+v"(v.dh), "+v"(v.dl));
-        return;
-      }
-      const int ckc = ck < ck_hi ? ck : ck_hi - 1;
-      const bool is_x = ckc < nxc;
-      const uint32_t so = (uint32_t)(is_x ? ckc : ckc - nxc) * 10240u + (uint32_t)comp * 2048u;
-#define W3_VL(OFF, PL) __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(     \
-      is_x ? vxrs : vhrs, (int)(OFF), (int)(so + (PL) * 1024u), 0))
-      v.ch = W3_VL(vo_c, 0); v.cl = W3_VL(vo_c, 1);
-      v.uh = W3_VL(vo_up, 0); v.ul = W3_VL(vo_up, 1);
-      v.dh = W3_VL(vo_dn, 0); v.dl = W3_VL(vo_dn, 1);
-#undef W3_VL
-    };
-    Wf wfix;
-    auto ldw = [&](const f16x8* buf, int comp, int dx, Wf& w) __attribute__((always_inline)) {
-      if (MV_W3_ABLC & 4) {
-        asm volatile("" : "+v"(wfix.w0[0]), "+v"(wfix.w0[1]), "+v"(wfix.w1[0]), "+v"(wfix.w1[1]));
-        w = wfix;
-        return;
-      }
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        w.w0[rb] = buf[(((comp * 3 + dx) * 2 + 0) * 2 + rb) * 64 + lane];
-        w.w1[rb] = buf[(((comp * 3 + dx) * 2 + 1) * 2 + rb) * 64 + lane];
-      }
-    };
-    static_assert(kChunkPieces % WAVES == 0 && kChunkPieces / WAVES == 15, "weight batches");
-    const uint32_t lane16 = (uint32_t)lane * 16u;
-    u32x4 wst[5];                                          // weight vectors on their way to LDS
-    auto wload = [&](int ck, int batch) __attribute__((always_inline)) {
-      if (MV_W3_ABLC & 2) return;
-      const int ckc = ck < ck_hi ? ck : ck_hi - 1;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int piece = (batch * 5 + i) * WAVES + wave_u;
-        wst[i] = __builtin_amdgcn_raw_buffer_load_b128(
-            wrs, (int)lane16, (int)((uint32_t)ckc * G::kChunkBytes + (uint32_t)piece * 1024u), 0);
-      }
-    };
-    auto wstore = [&](f16x8* dstbuf, int batch) __attribute__((always_inline)) {
-      if (MV_W3_ABLC & 2) return;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int piece = (batch * 5 + i) * WAVES + wave_u;
-        dstbuf[piece * 64 + lane] = __builtin_bit_cast(f16x8, wst[i]);
-      }
-    };
-#define W3_FENCE __builtin_amdgcn_sched_barrier(0)
-    // MFMA i of a group: (w1, b0) x 2 row blocks, (w0, b1) x 2, (w0, b0) x 2
-#define W3_MF(I, COMP, W, BH, BL)                                                             \
-  if (!(MV_W3_ABLC & 16) || (I) >= 4)                                                         \
-  acc[COMP][(I) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                \
-      (I) < 2 ? (W).w1[(I) & 1] : (W).w0[(I) & 1], ((I) >= 2 && (I) < 4) ? (BL) : (BH),       \
-      acc[COMP][(I) & 1], 0, 0, 0)
-    // one component: V = its register set; `wf` holds the fragments of (COMP, dx 1) on entry and
-    // receives those of (NEXTCOMP, dx 1) when NEXTCOMP >= 0 (same chunk buffer); VNEXT / NCK /
-    // NCOMP: the set refilled meanwhile (four components ahead); S0..S2: weight-staging slices
-#define W3_COMP_PRE(COMP, V, NEXTCOMP, BUF, VNEXT, NCK, NCOMP, S0, S1, S2)                    \
+    // one stage: components CA (slot 0) and CB (slot 1; CB < 0: the sequence's last, single
+    // component); the next stage's weights and fragments are requested first
+#define MV_W3_STAGE(CA, CB)                                                                   \
   do {                                                                                        \
-    /* group dx = 1 */                                                                        \
-    W3_MF(0, COMP, wf, (V).ch, (V).cl); ldw((BUF), (COMP), 0, wn); W3_FENCE;                  \
-    W3_MF(1, COMP, wf, (V).ch, (V).cl); W3_FENCE;                                             \
-    W3_MF(2, COMP, wf, (V).ch, (V).cl); S0; W3_FENCE;                                         \
-    W3_MF(3, COMP, wf, (V).ch, (V).cl); W3_FENCE;                                             \
-    W3_MF(4, COMP, wf, (V).ch, (V).cl); W3_FENCE;                                             \
-    W3_MF(5, COMP, wf, (V).ch, (V).cl); W3_FENCE;                                             \
-    /* group dx = 0 */                                                                        \
-    W3_MF(0, COMP, wn, (V).uh, (V).ul); ldw((BUF), (COMP), 2, wm); W3_FENCE;                  \
-    W3_MF(1, COMP, wn, (V).uh, (V).ul); W3_FENCE;                                             \
-    W3_MF(2, COMP, wn, (V).uh, (V).ul); S1; W3_FENCE;                                         \
-    W3_MF(3, COMP, wn, (V).uh, (V).ul); W3_FENCE;                                             \
-    W3_MF(4, COMP, wn, (V).uh, (V).ul); W3_FENCE;                                             \
-    W3_MF(5, COMP, wn, (V).uh, (V).ul); W3_FENCE;                                             \
-    /* group dx = 2 */                                                                        \
-    W3_MF(0, COMP, wm, (V).dh, (V).dl); if ((NEXTCOMP) >= 0) ldw((BUF), (NEXTCOMP) < 0 ? 0 : (NEXTCOMP), 1, wf); W3_FENCE; \
-    W3_MF(1, COMP, wm, (V).dh, (V).dl); W3_FENCE;                                             \
-    W3_MF(2, COMP, wm, (V).dh, (V).dl); S2; W3_FENCE;                                         \
-    W3_MF(3, COMP, wm, (V).dh, (V).dl); W3_FENCE;                                             \
-    W3_MF(4, COMP, wm, (V).dh, (V).dl); W3_FENCE;                                             \
-    /* the set this component just finished with is the one refilled now */                   \
-    W3_MF(5, COMP, wm, (V).dh, (V).dl); vload((NCK), (NCOMP), (VNEXT)); W3_FENCE;             \
+    f16x8* const buf = lds + ((st & 1) ? kStageVec : 0);                                      \
+    f16x8* const nbuf = lds + ((st & 1) ? 0 : kStageVec);                                     \
+    if (st + 1 < S_total) {                                                                   \
+      stage_dma(st + 1, nbuf);               /* its buffer was last read before the barrier */ \
+      vload(2 * st + 2, na); vload(2 * st + 3, nb);   /* a whole stage ahead of their use */  \
+    }                                                                                         \
+    MV_W3_COMP(CA, 0, va.h, va.l, buf);                                                       \
+    if ((CB) >= 0) MV_W3_COMP((CB) < 0 ? 0 : (CB), 1, vb.h, vb.l, buf);                       \
+    va = na; vb = nb;                                                                         \
+    ++st;                                                                                     \
+    __syncthreads();                                                                          \
   } while (0)
-#define W3_NONE do { } while (0)
 
-    Vset v0, v1, v2, v3, v4;
-    Wf wf, wn, wm;
-    // prologue: the first chunk's weights by LDS-DMA (nothing to overlap with yet), the first
-    // four components' sets
-    vload(ck_lo, 0, v0); vload(ck_lo, 1, v1); vload(ck_lo, 2, v2); vload(ck_lo, 3, v3);
-    chunk_dma(ck_lo, lds);
+    Vc va, vb, na, nb;
+    vload(0, va); vload(1, vb);
+    na = va; nb = vb;
+    stage_dma(0, lds);
     __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
-    if (MV_W3_ABLC & 4) {
-      wfix.w0[0] = lds[lane]; wfix.w0[1] = lds[64 + lane];
-      wfix.w1[0] = lds[128 + lane]; wfix.w1[1] = lds[192 + lane];
+    // five stages = ten components = two chunks: (0,1) (2,3) (4,0) (1,2) (3,4); an odd chunk
+    // count ends on (0,1) (2,3) (4)
+    const int nck = ck_hi - ck_lo;
+    int st = 0;
+    for (int pr = 0; pr < (nck >> 1); ++pr) {
+      MV_W3_STAGE(0, 1); MV_W3_STAGE(2, 3); MV_W3_STAGE(4, 0); MV_W3_STAGE(1, 2); MV_W3_STAGE(3, 4);
     }
-    for (int ck = ck_lo; ck < ck_hi; ++ck) {
-      f16x8* const buf = lds + ((((ck - ck_lo) & 1) && !(MV_W3_ABLC & 2)) ? G::kChunkVec : 0);
-      f16x8* const nbuf = lds + (((ck - ck_lo) & 1) ? 0 : G::kChunkVec);
-      // after the barrier: the first group's fragments cannot be requested any earlier
-      ldw(buf, 0, 1, wf);
-      W3_FENCE;
-      // the set refilled beside component c belongs to the component four ahead: component 4
-      // of this chunk beside component 0, then components 0..3 of the next chunk -- each into
-      // the set its own predecessor just left
-      W3_COMP_PRE(0, v0, 1, buf, v4, ck, 4, wload(ck + 1, 0), W3_NONE, W3_NONE);
-      W3_COMP_PRE(1, v1, 2, buf, v0, ck + 1, 0, wstore(nbuf, 0), wload(ck + 1, 1), W3_NONE);
-      W3_COMP_PRE(2, v2, 3, buf, v1, ck + 1, 1, wstore(nbuf, 1), wload(ck + 1, 2), W3_NONE);
-      W3_COMP_PRE(3, v3, 4, buf, v2, ck + 1, 2, wstore(nbuf, 2), W3_NONE, W3_NONE);
-      W3_COMP_PRE(4, v4, -1, buf, v3, ck + 1, 3, W3_NONE, W3_NONE, W3_NONE);
-      // the other buffer was filled by ds_writes: lgkmcnt, NOT vmcnt -- the operand sets
-      // requested up to four components ahead stay in flight across the barrier
-      if (!(MV_W3_ABLC & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-#undef W3_FENCE
-#undef W3_MF
-#undef W3_COMP_PRE
-#undef W3_NONE
-    } else {
-    load_raw(ck_lo);
-    chunk_dma(ck_lo, lds);
-    __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
-    for (int ck = ck_lo; ck < ck_hi; ++ck) {
-      f16x8* const buf = lds + (((ck - ck_lo) & 1) ? G::kChunkVec : 0);
-      f16x8* const nbuf = lds + (((ck - ck_lo) & 1) ? 0 : G::kChunkVec);
-      const bool more = ck + 1 < ck_hi;
-      if (more) chunk_dma(ck + 1, nbuf);     // its buffer was last read before the barrier
-      // input transform of the chunk: nine plane-pair combinations
-      f16x8 v0h, v0l, v1h, v1l, v2h, v2l, v3h, v3l, v4h, v4l, th, tl, t3h, t3l;
-      wn_lin<1, -1>(raw[3][0], raw[3][1], raw[1][0], raw[1][1], kc, v3h, v3l);   // V3 = d3 - d1
-      wn_lin<1, -1>(raw[0][0], raw[0][1], raw[2][0], raw[2][1], kc, th, tl);     // d0 - d2
-      wn_lin<2, 1>(th, tl, v3h, v3l, kc, v0h, v0l);                              // V0
-      wn_lin<1, -1>(raw[3][0], raw[3][1], raw[2][0], raw[2][1], kc, t3h, t3l);   // d3 - d2
-      wn_lin<1, -2>(t3h, t3l, raw[1][0], raw[1][1], kc, v1h, v1l);               // V1
-      wn_lin<1, -1>(raw[1][0], raw[1][1], raw[2][0], raw[2][1], kc, th, tl);     // d1 - d2
-      wn_lin<2, 1>(th, tl, t3h, t3l, kc, v2h, v2l);                              // V2
-      wn_lin<1, -1>(raw[2][0], raw[2][1], raw[4][0], raw[4][1], kc, th, tl);     // d2 - d4
-      wn_lin<2, 1>(v3h, v3l, th, tl, kc, v4h, v4l);                              // V4
-      if (more) load_raw(ck + 1);            // a whole chunk (90 MFMAs at NRB = 2) ahead of its use
-      MV_W3_COMP(0, v0h, v0l, buf);
-      MV_W3_COMP(1, v1h, v1l, buf);
-      MV_W3_COMP(2, v2h, v2l, buf);
-      MV_W3_COMP(3, v3h, v3l, buf);
-      MV_W3_COMP(4, v4h, v4l, buf);
-      __syncthreads();
-    }
+    if (nck & 1) {
+      MV_W3_STAGE(0, 1); MV_W3_STAGE(2, 3); MV_W3_STAGE(4, -1);
     }
 #undef MV_W3_COMP
+#undef MV_W3_STAGE
   }
   if (!wave_live) return;
   if (p.abl & 2) {                          // keep every accumulator live, store nothing
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < 6; ++c)
+    for (int c = 0; c < 5; ++c)
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -759,10 +617,10 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
         for (int g = 0; g < 4; ++g) {
           const int reg = g * 4 + j;
           const float m0 = acc[0][rb][reg], m1 = acc[1][rb][reg], m2 = acc[2][rb][reg],
-                      m3 = acc[3][rb][reg], m4 = acc[4][rb][reg], mx = acc[5][rb][reg];
+                      m3 = acc[3][rb][reg], m4 = acc[4][rb][reg];
           float yv;
           if (e == 0) yv = (m0 + m1) + (m2 + m3);
-          else if (e == 1) yv = ((m1 - m2) + 2.0f * m3) + mx;
+          else if (e == 1) yv = (m1 - m2) + 2.0f * m3;
           else yv = (m1 + m2) + (4.0f * m3 + m4);
           pre[g] = __builtin_fmaf(yv, un, add[g][j]);   // un = 2^-16: the product is exact
         }
@@ -867,7 +725,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
 }
 
 template <int WAVES, int NRB>
-__global__ __launch_bounds__(WAVES * 64, 1)
+__global__ __launch_bounds__(WAVES * 64, 2)
 void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
   extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
   int block = blockIdx.x;
@@ -900,9 +758,9 @@ void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
 
 constexpr int kW3Waves = 4, kW3Nrb = 2;
 
-static inline size_t wino3_lds_bytes() {
-  return (size_t)2 * Wn3<kW3Nrb>::kChunkBytes + (size_t)kW3Waves * Wn3<kW3Nrb>::kTileFloats * 4 +
-         (size_t)kW3Waves * 192 * 4 + (size_t)kW3Waves * 130 * 16;   // + the waves' shift slots
+static inline size_t wino3_lds_bytes() {      // 73.5 KB: two workgroups per CU
+  return (size_t)2 * (2 * 3 * 2 * kW3Nrb * 64 * 16) + (size_t)kW3Waves * Wn3<kW3Nrb>::kTileFloats * 4 +
+         (size_t)kW3Waves * 192 * 4;
 }
 static inline unsigned convlstm_wino3_blocks(const ConvLstmArgs& a) {
   const size_t Q = (size_t)a.rows * ((a.H + 2) / 3) * a.W;

@@ -910,33 +910,26 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     }
   }
   // ... and its F(3,3) form (five ninths, convlstm_wino3.h) when every problem fits THAT tiling
+  // and the slots' buffers hold the pre-transformed operands.  The input transform runs ONCE
+  // per operand, in a pre-pass, instead of in every one of the C / 16 column-block workgroups
+  // of the gate kernel.
   bool wino3 = wino && mv::wino3_enabled();
-  if (wino3) {
-    for (size_t i = 0; i < p16.size() && wino3; ++i) {
-      ConvCell* cc = cell_of_pack(e, probs[i].wpack);
-      if (!mv::wino3_geometry_ok(p16[i].f, p16[i]) || !cc->wpw3.p) wino3 = false;
-    }
-    if (wino3)
-      for (size_t i = 0; i < p16.size(); ++i)
-        pw[i].wpw = cell_of_pack(e, probs[i].wpack)->wpw3.p;
+  for (size_t i = 0; i < p16.size() && wino3; ++i) {
+    const ConvLstmArgs& a = p16[i].f;
+    ConvCell* cc = cell_of_pack(e, probs[i].wpack);
+    if (!mv::wino3_geometry_ok(a, p16[i]) || !cc->wpw3.p) wino3 = false;
+    else if (!a.zero_state && e->pv3h[i].n < mv::wino3_v_elems(a.rows, a.H, a.W, a.C)) wino3 = false;
+    else if (!a.x_small && a.Cx > 0 && !a.sx_corr &&
+             e->pv3x[i].n < mv::wino3_v_elems(a.rows, a.H, a.W, a.Cx)) wino3 = false;
   }
-  // F(3,3): the input transform runs ONCE per operand, in a pre-pass, instead of in every one
-  // of the C / 16 column-block workgroups of the gate kernel (convlstm_wino3.h)
   std::vector<mv::Wn3TransformItem> tr3;
   double tr3_bytes = 0;
   if (wino3) {
-    static const bool pre = !(getenv("MV_WINO3_PRE") && atoi(getenv("MV_WINO3_PRE")) == 0);
-    bool fits = pre;
-    for (size_t i = 0; i < p16.size() && fits; ++i) {
-      const ConvLstmArgs& a = p16[i].f;
-      if (!a.zero_state && e->pv3h[i].n < mv::wino3_v_elems(a.rows, a.H, a.W, a.C)) fits = false;
-      if (!a.x_small && a.Cx > 0 && !a.sx_corr &&
-          e->pv3x[i].n < mv::wino3_v_elems(a.rows, a.H, a.W, a.Cx)) fits = false;
-    }
-    for (size_t i = 0; i < p16.size() && fits; ++i) {
+    for (size_t i = 0; i < p16.size(); ++i) {
       const mv::ConvLstm16Args& q = p16[i];
       const ConvLstmArgs& a = q.f;
       const double cells = (double)a.rows * a.H * a.W;
+      pw[i].wpw = cell_of_pack(e, probs[i].wpack)->wpw3.p;
       if (!a.zero_state) {
         tr3.push_back(mv::Wn3TransformItem{q.h16, q.h_plane_stride, e->pv3h[i].p, a.src_row_h,
                                            a.rows, a.H, a.W, a.C});
@@ -2964,10 +2957,9 @@ int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const flo
                          ctx.stream, dk.p, wp.p, Cx, Cx16, C, mv::kW3Nrb, halves / 2);
       mv::ConvLstmWinoArgs wq{};
       wq.b = q; wq.wpw = wp.p; wq.w_hwio = dk.p; wq.n_xc = Cx16 / 16;
-      // the pre-transformed operands, as the engine hands them over (MV_WINO3_PRE=0: the
-      // in-kernel transform)
+      // the pre-transformed operands, as the engine hands them over
       DevBuf<_Float16> v3x, v3h;
-      if (!(getenv("MV_WINO3_PRE") && atoi(getenv("MV_WINO3_PRE")) == 0)) {
+      {
         std::vector<mv::Wn3TransformItem> tr;
         if (!zero) {
           v3h.alloc(mv::wino3_v_elems(M, H, W, C));
