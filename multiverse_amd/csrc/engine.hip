@@ -564,12 +564,31 @@ void ensure_packed16(mv_engine* e, ConvCell& cc) {
   {   // 256 w must stay inside fp16 (|w| < 255): true of any sane checkpoint, checked anyway
     float mx = 0.f;
     for (float v : cc.kernel->host) mx = std::max(mx, std::fabs(v));
-    // the Winograd packs store 256 (g0 +- g1 + g2) / 2 (F(2,3)) and 256 (g0 + g1 + g2) / 2,
-    // 256 (g0 + 2 g1 + 4 g2) / 6 (F(3,3)): up to 1.5 max |w| -- the bound covers them
-    const float reach = (mv::wino_enabled() && C_multiple_ok(e, cc)) ? 1.5f : 1.0f;
-    MV_REQUIRE(mx * reach * mv::kF16Scale < 60000.f, "f16x3: |%s| reaches %g (x %g in the "
-               "transformed kernel planes), outside the scaled fp16 range; use compute mode f32",
-               cc.kernel->name.c_str(), mx, reach);
+    // the Winograd packs store TRANSFORMED kernel rows -- (g0 +- g1 + g2) / 2 (F(2,3));
+    // (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 6, (g0 + 2 g1 + 4 g2) / 6 (F(3,3)); the dgrad pack the
+    // same of the flipped rows -- which reach up to 1.5 max |w| when three taps of one column
+    // share a sign: the bound is taken on THOSE values, column by column
+    float reach = mx;
+    if (mv::wino_enabled() && C_multiple_ok(e, cc)) {
+      const size_t Cin = (size_t)cc.Cx + C, N4 = 4 * (size_t)C;
+      const float* w = cc.kernel->host.data();
+      for (size_t dxc = 0; dxc < 3 * Cin; ++dxc) {          // (dx, input channel) pairs
+        const size_t dx = dxc / Cin, ci = dxc - dx * Cin;
+        const float* g0 = w + ((0 * 3 + dx) * Cin + ci) * N4;
+        const float* g1 = w + ((1 * 3 + dx) * Cin + ci) * N4;
+        const float* g2 = w + ((2 * 3 + dx) * Cin + ci) * N4;
+        for (size_t n = 0; n < N4; ++n) {
+          const float a = g0[n], b = g1[n], c2 = g2[n];
+          const float t = std::max(std::max(std::fabs(a + b + c2), std::fabs(a - b + c2)) * 0.5f,
+                                   std::max(std::fabs(a + 2.f * b + 4.f * c2),
+                                            std::fabs(4.f * a + 2.f * b + c2)) * (1.f / 6.f));
+          reach = std::max(reach, t);
+        }
+      }
+    }
+    MV_REQUIRE(reach * mv::kF16Scale < 60000.f, "f16x3: |%s| reaches %g (%g in the transformed "
+               "kernel planes of the Winograd forms), outside the scaled fp16 range; use compute "
+               "mode f32", cc.kernel->name.c_str(), mx, reach);
   }
   const bool small = cc.Cx > 0 && 9 * cc.Cx <= mv::kBK;
   // the h part (and an x part that is a multiple of 16 channels) as fp16 planes

@@ -100,3 +100,34 @@ def test_f16x3_runtime_pred_len_no_gnn_and_mode_switch(built_lib):
   assert a[1].shape[1] == 15
   assert (a[1] == c[1]).all() and (ar[1] == cr[1]).all()       # deterministic
   assert np.abs(a[1] - b[1]).max() < TOL and np.abs(ar[1] - br[1]).max() < TOL
+
+
+def test_f16x3_refuses_weights_whose_transformed_planes_leave_the_fp16_range(built_lib):
+  """The f16x3 range guard covers the TRANSFORMED kernel planes of the Winograd packs: three
+  same-sign taps of |w| = 180 in one stencil column are inside the scaled fp16 range one by one
+  (256 * 180 = 46 080) but (g0 + g1 + g2) / 2 = 270 is not (69 120 > 65 504) -- the forward must
+  refuse loudly, not run on infinities; the same weights spread over different columns run, and
+  the fp32 matrix pipe takes either."""
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 0))
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 5)
+  name = "person_pred/decoder_grid_class_0/decoder_rnn/dec_grid_0/kernel"
+  spread = synth.make_params(cfg)
+  spread[name] = spread[name].copy()
+  for ky in range(3):
+    spread[name][ky, ky, 40 + ky, 7] = 180.0            # three different columns: |U| <= 90
+  stacked = synth.make_params(cfg)
+  stacked[name] = stacked[name].copy()
+  stacked[name][:, 1, 40, 7] = 180.0                    # one column: (g0 + g1 + g2) / 2 = 270
+  eng = _engine(built_lib, cfg, spread, "f16x3")
+  eng.forward_greedy(feed)
+  eng.close()
+  eng = _engine(built_lib, cfg, stacked, "f32")
+  eng.forward_greedy(feed)
+  eng.close()
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(stacked)
+  with pytest.raises(Exception) as err:
+    eng.set_compute_mode("f16x3")
+    eng.forward_greedy(feed)
+  assert "transformed kernel planes" in str(err.value)
+  eng.close()
