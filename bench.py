@@ -68,7 +68,7 @@ PEAK_HBM_GBS = 8000.0
 SUB_TIMED_SECONDS = 1.5         # timed region of every sub-workload
 DEFAULT_TIMED_SECONDS = 3.5     # timed region of the headline when --steps is not given
 
-HBM_KERNELS = ("gnn_attend", "hidden2grid", "decode_tail", "split_planes", "lstm_gate_bwd",
+HBM_KERNELS = ("gnn_attend", "hidden2grid", "decode_tail", "split_planes", "wino3_transform", "lstm_gate_bwd",
                "gnn_bwd", "grid_emb_dense", "grid_emb_onehot", "wgrad_transpose",
                "beam_tile_state", "dgrad_slice_sum", "tanh_bwd", "conv3x3_small_dgrad",
                "conv3x3_small_wgrad", "gate_bwd_planes", "beam_step")
@@ -131,7 +131,8 @@ def committed_traffic(kernel_file_suffix):
 
 
 # engine kernel-table name -> the kernel-name fragment tools/profile_workload.sh files it under
-PMC_KERNEL_OF = {"convlstm_step": ("convlstm_step_wino", "convlstm_step_f16x3_lds",
+PMC_KERNEL_OF = {"convlstm_step": ("convlstm_step_wino3", "convlstm_step_wino_kernel",
+                                   "convlstm_step_wino", "convlstm_step_f16x3_lds",
                                    "convlstm_step_bf16"),
                  "convlstm_dgrad": ("convlstm_dgrad",),
                  "convlstm_wgrad": ("convlstm_wgrad_f16x3",)}
@@ -359,13 +360,15 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
     # the engine reports what its launches issued to the matrix pipe (mv_kernel_stat_mfma_flops):
     # 3 fp16 MFMA products per fp32 product in the direct form, 2 in the Winograd F(2,3) form
     # of the forward step (csrc/convlstm_wino.h: four products per two output rows and tap
-    # column instead of six)
+    # column instead of six), 5/3 in the F(3,3) form (csrc/convlstm_wino3.h: five per three)
     per_product = conv["flops_mfma"] / conv["flops"] if conv["flops"] else 3.0
     step_pp = (stats["convlstm_step"]["flops_mfma"] / stats["convlstm_step"]["flops"]
                if stats["convlstm_step"]["flops"] else 3.0)
-    roofline["gate_kernel_form"] = ("winograd F(2,3) over image rows, 2 fp16 MFMA products per "
-                                    "fp32 product" if step_pp < 2.5 else
-                                    "direct 3x3, 3 fp16 MFMA products per fp32 product")
+    roofline["gate_kernel_form"] = (
+        "winograd F(3,3) over image rows on pre-transformed operands, 5/3 fp16 MFMA products per "
+        "fp32 product" if step_pp < 1.9 else
+        "winograd F(2,3) over image rows, 2 fp16 MFMA products per fp32 product" if step_pp < 2.5
+        else "direct 3x3, 3 fp16 MFMA products per fp32 product")
     roofline["note"] = ("f16x3: fp32 operands as two pre-scaled fp16 planes, fp32 accumulate; "
                         "%.2f fp16 MFMA products issued per algorithmic fp32 product over these "
                         "launches; ceiling of the method = peak / that" % per_product)
@@ -382,8 +385,11 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
   # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950); bench.py cannot collect
   # PMCs itself, so it quotes a committed summary -- only one taken on these sources.
   if not beam and not train and batch == 64 and scene_conv_kernel == 3 and not literal_grids:
-    wino = f16 and stats["convlstm_step"]["flops_mfma"] < 2.5 * stats["convlstm_step"]["flops"]
-    suffix = ("greedy_pmc_convlstm_step_wino.json" if wino else
+    pp = (stats["convlstm_step"]["flops_mfma"] / stats["convlstm_step"]["flops"]
+          if stats["convlstm_step"]["flops"] else 3.0)
+    wino = f16 and pp < 2.5
+    suffix = ("greedy_pmc_convlstm_step_wino3.json" if (wino and pp < 1.9) else
+              "greedy_pmc_convlstm_step_wino.json" if wino else
               "greedy_pmc_convlstm_step_f16x3_lds.json" if f16 else
               "greedy_bf16_pmc_convlstm_step_bf16.json" if bf16 else
               "greedy_f32_pmc_convlstm_step_kernel.json")

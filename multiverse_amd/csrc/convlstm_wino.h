@@ -602,20 +602,28 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
         for (int g = 0; g < 4; ++g)
           add[g] = *reinterpret_cast<const f32x4*>(bsrc + g * C + ch);
         if (a.sx_corr) {
+          // UNCONDITIONAL loads (a branch around them would serialise one L2 round trip per
+          // row and row block behind the bias row's): a cell outside the radius reads the
+          // clamped table row and drops it
           const int dy = y - hot_y, dxh = xpos - hot_x, rad = a.sx_rad;
-          if (okc[e] && dy >= -rad && dy <= rad && dxh >= -rad && dxh <= rad) {
-            const int side = 2 * rad + 1;
-            const int idx = a.sx_by_class
-                                ? 3 * (hot_y == 0 ? 0 : (hot_y == H - 1 ? 2 : 1)) +
-                                      (hot_x == 0 ? 0 : (hot_x == W - 1 ? 2 : 1))
-                                : r;
-            const float* ct = a.sx_corr +
-                ((size_t)idx * side * side + (dy + rad) * side + (dxh + rad)) * 4 * C + ch;
+          const bool inr = okc[e] && dy >= -rad && dy <= rad && dxh >= -rad && dxh <= rad;
+          const int dyc = dy < -rad ? -rad : (dy > rad ? rad : dy);
+          const int dxc = dxh < -rad ? -rad : (dxh > rad ? rad : dxh);
+          const int side = 2 * rad + 1;
+          const int idx = a.sx_by_class
+                              ? 3 * (hot_y == 0 ? 0 : (hot_y == H - 1 ? 2 : 1)) +
+                                    (hot_x == 0 ? 0 : (hot_x == W - 1 ? 2 : 1))
+                              : (valid ? r : 0);
+          const float* ct = a.sx_corr +
+              ((size_t)idx * side * side + (dyc + rad) * side + (dxc + rad)) * 4 * C + ch;
+          const float keep = inr ? 1.0f : 0.0f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const f32x4 cv = *reinterpret_cast<const f32x4*>(ct + g * C);
-              add[g][0] += cv[0]; add[g][1] += cv[1]; add[g][2] += cv[2]; add[g][3] += cv[3];
-            }
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 cv = *reinterpret_cast<const f32x4*>(ct + g * C);
+            add[g][0] = __builtin_fmaf(cv[0], keep, add[g][0]);
+            add[g][1] = __builtin_fmaf(cv[1], keep, add[g][1]);
+            add[g][2] = __builtin_fmaf(cv[2], keep, add[g][2]);
+            add[g][3] = __builtin_fmaf(cv[3], keep, add[g][3]);
           }
         }
       }

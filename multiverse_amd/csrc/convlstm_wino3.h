@@ -251,12 +251,20 @@ static inline void launch_wino3_transforms(const Wn3TransformItem* items, int n,
   }
 }
 
-template <int WAVES, int NRB>
+// HALO: grids whose width does not divide 32.  A wave's 32 lanes are still 32 CONSECUTIVE
+// triple-cells, so the DPP lane shift still finds the x neighbour -- except for the tile's first
+// and last lane, whose neighbours sit in other waves.  With HALO a wave's tile starts one
+// triple-cell early and OWNS only its inner 30 lanes: lanes 0 and 31 load and multiply like the
+// rest (their fragments are the neighbours of lanes 1 and 30) but store nothing -- 1 / 16 of the
+// matrix work for any W (the literal 36 x 18 / 18 x 9 grids of BASELINE.json, --scene_h /
+// --scene_w other than 36 x 64).
+template <int WAVES, int NRB, bool HALO>
 __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, int cb, int mt,
                                                     f16x8* lds) {
   using G = Wn3<NRB>;
   constexpr int CH = G::kCh;
-  constexpr int kTriples = WAVES * 32;                 // triple-cells per workgroup
+  constexpr int kOwn = HALO ? 30 : 32;                 // triple-cells a wave stores
+  constexpr int kTriples = WAVES * kOwn;               // triple-cells per workgroup
   constexpr int kPieces = CH / 4;                      // 16-byte pieces of a tile row
   constexpr int kPasses = (96 * kPieces + 63) / 64;    // wave passes over a state tile
   const ConvLstm16Args& q = p.b;
@@ -267,15 +275,16 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   const int H = a.H, W = a.W, HW = H * W, C = a.C, Cx = a.Cx;
   const int Ht = (H + 2) / 3, Kt = Ht * W;
   const int Q_total = a.rows * Kt;
-  const int q_wave = mt * kTriples + wave * 32;
-  const bool wave_live = q_wave < Q_total;       // dead waves still copy and hit barriers
+  const int q_own = mt * kTriples + wave * kOwn;       // first triple-cell the wave owns
+  const int q_wave = HALO ? q_own - 1 : q_own;         // ... and lane 0's
+  const bool wave_live = q_own < Q_total;        // dead waves still copy and hit barriers
   const int col = lane & 31, half = lane >> 5;
 
   int r = 0, y0 = 0, xpos = 0;
   bool valid;
   {
     const int qq = q_wave + col;
-    valid = qq < Q_total;
+    valid = qq >= 0 && qq < Q_total;
     if (valid) {
       r = qq / Kt;
       const int pc = qq - r * Kt;
@@ -325,9 +334,10 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   const uint32_t rowb = (uint32_t)C * 4u;                    // bytes per cell of a state tensor
   bool okc[3];
   int cell[3];                                               // cell index inside its image
+  const bool owned = valid && (!HALO || (col >= 1 && col <= 30));
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
-    okc[e] = valid & (y0 + e < H);
+    okc[e] = owned & (y0 + e < H);
     cell[e] = (y0 + e) * W + xpos;
   }
   if (wave_live) {
@@ -434,15 +444,26 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     // wave's 64 lanes = one contiguous KB of the pre-pass's output: lane l IS k half l >> 5,
     // column l & 31); a dead wave -- past the last triple-cell -- reads tile 0
     const int KGx = Cx >> 4, KGh = C >> 4;
-    const int tile = __builtin_amdgcn_readfirstlane(wave_live ? (q_wave >> 5) : 0);
+    // (HALO: the wave's 32 triple-cells start anywhere: one offset per lane; a lane past either
+    // end of the sequence reads beyond the buffer = zeros)
+    const int tile = __builtin_amdgcn_readfirstlane((wave_live && !HALO) ? (q_wave >> 5) : 0);
+    const size_t ntile_b = (size_t)((Q_total + 31) >> 5) * 10240u;          // bytes per channel group
     const __amdgpu_buffer_rsrc_t vxrs = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(const_cast<char*>(reinterpret_cast<const char*>(p.v3x ? p.v3x : p.v3h) +
                                       (p.v3x ? (size_t)tile * (size_t)KGx * 10240u : 0))),
-        0, (uint32_t)((size_t)(KGx > 0 ? KGx : 1) * 10240u), 0x00020000);
+        0, (uint32_t)(HALO ? ntile_b * (size_t)(KGx > 0 ? KGx : 1) : (size_t)(KGx > 0 ? KGx : 1) * 10240u),
+        0x00020000);
     const __amdgpu_buffer_rsrc_t vhrs = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(const_cast<char*>(reinterpret_cast<const char*>(p.v3h ? p.v3h : p.v3x) +
                                       (p.v3h ? (size_t)tile * (size_t)KGh * 10240u : 0))),
-        0, (uint32_t)((size_t)KGh * 10240u), 0x00020000);
+        0, (uint32_t)(HALO ? ntile_b * (size_t)KGh : (size_t)KGh * 10240u), 0x00020000);
+    uint32_t vo_x = lane16, vo_h = lane16;
+    if (HALO) {
+      const int qq = q_wave + col;
+      const uint32_t in_tile = (uint32_t)((qq & 31) + 32 * half) * 16u;
+      vo_x = valid ? (uint32_t)(qq >> 5) * (uint32_t)KGx * 10240u + in_tile : 0x80000000u;
+      vo_h = valid ? (uint32_t)(qq >> 5) * (uint32_t)KGh * 10240u + in_tile : 0x80000000u;
+    }
     struct Vc { f16x8 h, l; };
     // component g of the sequence (clamped to the last one: a request past the end fetches
     // that component again)
@@ -452,9 +473,9 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       const bool is_x = ck < nxc;
       const int so = (is_x ? ck : ck - nxc) * 10240 + comp * 2048;
       v.h = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                          is_x ? vxrs : vhrs, (int)lane16, so, 0));
+                                          is_x ? vxrs : vhrs, (int)(is_x ? vo_x : vo_h), so, 0));
       v.l = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                          is_x ? vxrs : vhrs, (int)lane16, so + 1024, 0));
+                                          is_x ? vxrs : vhrs, (int)(is_x ? vo_x : vo_h), so + 1024, 0));
     };
     // one component: 3 dx x NRB row blocks x 3 MFMAs from stage buffer `buf`, slot ci
 #define MV_W3_COMP(COMP, CI, VHI, VLO, BUF)                                                   \
@@ -732,7 +753,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   }
 }
 
-template <int WAVES, int NRB>
+template <int WAVES, int NRB, bool HALO>
 __global__ __launch_bounds__(WAVES * 64, 2)
 void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
   extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
@@ -757,10 +778,10 @@ void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
   int cb, mt;
   constexpr int CH = Wn3<NRB>::kCh;
   switch (pi) {
-    case 0: cbmap(g.p[0].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB>(g.p[0], cb, mt, lds); break;
-    case 1: cbmap(g.p[1].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB>(g.p[1], cb, mt, lds); break;
-    case 2: cbmap(g.p[2].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB>(g.p[2], cb, mt, lds); break;
-    default: cbmap(g.p[3].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB>(g.p[3], cb, mt, lds); break;
+    case 0: cbmap(g.p[0].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO>(g.p[0], cb, mt, lds); break;
+    case 1: cbmap(g.p[1].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO>(g.p[1], cb, mt, lds); break;
+    case 2: cbmap(g.p[2].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO>(g.p[2], cb, mt, lds); break;
+    default: cbmap(g.p[3].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO>(g.p[3], cb, mt, lds); break;
   }
 }
 
@@ -770,9 +791,9 @@ static inline size_t wino3_lds_bytes() {      // 73.5 KB: two workgroups per CU
   return (size_t)2 * (2 * 3 * 2 * kW3Nrb * 64 * 16) + (size_t)kW3Waves * Wn3<kW3Nrb>::kTileFloats * 4 +
          (size_t)kW3Waves * 192 * 4;
 }
-static inline unsigned convlstm_wino3_blocks(const ConvLstmArgs& a) {
+static inline unsigned convlstm_wino3_blocks(const ConvLstmArgs& a, bool halo) {
   const size_t Q = (size_t)a.rows * ((a.H + 2) / 3) * a.W;
-  const size_t triples = (size_t)kW3Waves * 32;
+  const size_t triples = (size_t)kW3Waves * (halo ? 30 : 32);
   return (unsigned)((Q + triples - 1) / triples) * (unsigned)(a.C / Wn3<kW3Nrb>::kCh);
 }
 
@@ -781,20 +802,24 @@ static inline bool wino3_enabled() {
   static const bool off = getenv("MV_WINO3") && atoi(getenv("MV_WINO3")) == 0;
   return !off;
 }
-// The F(3,3) form serves a problem when W divides 32 (the DPP column shift), C is a multiple
-// of the channel block, the x operand comes as 16-channel planes (or is the 2-channel fp32
-// chunk) under the FIXED 2^8 scale -- the per-tensor exponent of unbounded activations leaves
-// one bit of headroom, the components here need three (|V| <= 6 max |d|) -- and the grid has
-// at least three rows.
+// The F(3,3) form serves a problem when C is a multiple of the channel block, the x operand
+// comes as 16-channel planes (or is the 2-channel fp32 chunk) under the FIXED 2^8 scale -- the
+// per-tensor exponent of unbounded activations leaves one bit of headroom, the components here
+// need three (|V| <= 6 max |d|) -- and the grid has at least three rows.  Any width: one that
+// does not divide 32 takes the HALO tiling (30 of 32 lanes owned).
 static inline bool wino3_geometry_ok(const ConvLstmArgs& a, const ConvLstm16Args& q) {
-  return a.W > 0 && 32 % a.W == 0 && a.C % Wn3<kW3Nrb>::kCh == 0 &&
-         (a.Cx % 16 == 0 || a.x_small) && a.H >= 3 && q.x_exp == nullptr;
+  return a.W > 0 && a.C % Wn3<kW3Nrb>::kCh == 0 && (a.Cx % 16 == 0 || a.x_small) && a.H >= 3 &&
+         q.x_exp == nullptr;
 }
+static inline bool wino3_needs_halo(const ConvLstmArgs& a) { return 32 % a.W != 0; }
 
 static inline void wino3_init_attributes() {
   static const bool done = [] {
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(convlstm_step_wino3_kernel<kW3Waves, kW3Nrb>),
+        reinterpret_cast<const void*>(convlstm_step_wino3_kernel<kW3Waves, kW3Nrb, false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes());
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(convlstm_step_wino3_kernel<kW3Waves, kW3Nrb, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes());
     return true;
   }();
@@ -808,17 +833,23 @@ static inline void launch_convlstm_wino3_steps(const ConvLstmWinoArgs* probs, in
   static const int abl = getenv("MV_WINO_ABL") ? atoi(getenv("MV_WINO_ABL")) : 0;
   static const int map_mode = getenv("MV_WINO_MAP") ? atoi(getenv("MV_WINO_MAP")) : 1;
   g.map_mode = map_mode;
+  bool halo = false;                       // one tiling per launch: any problem that needs it
+  for (int i = 0; i < n; ++i) halo = halo || wino3_needs_halo(probs[i].b.f);
   unsigned total = 0;
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
     g.p[i].abl = abl;
-    total += convlstm_wino3_blocks(probs[i].b.f);
+    total += convlstm_wino3_blocks(probs[i].b.f, halo);
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
   wino3_init_attributes();
-  hipLaunchKernelGGL((convlstm_step_wino3_kernel<kW3Waves, kW3Nrb>), dim3(total),
-                     dim3(kW3Waves * 64), wino3_lds_bytes(), stream, g);
+  if (halo)
+    hipLaunchKernelGGL((convlstm_step_wino3_kernel<kW3Waves, kW3Nrb, true>), dim3(total),
+                       dim3(kW3Waves * 64), wino3_lds_bytes(), stream, g);
+  else
+    hipLaunchKernelGGL((convlstm_step_wino3_kernel<kW3Waves, kW3Nrb, false>), dim3(total),
+                       dim3(kW3Waves * 64), wino3_lds_bytes(), stream, g);
 }
 
 }  // namespace mv

@@ -915,24 +915,22 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
   }
   // f16x3: the Winograd F(2,3) form of the same step (two thirds of the MFMAs,
   // convlstm_wino.h) whenever every problem of the group fits its tiling
-  bool wino = e->compute_mode == 1 && mv::wino_enabled();
-  std::vector<mv::ConvLstmWinoArgs> pw;
-  if (wino) {
-    pw.resize(p16.size());
-    for (size_t i = 0; i < p16.size() && wino; ++i) {
-      ConvCell* cc = cell_of_pack(e, probs[i].wpack);
-      if (!mv::wino_geometry_ok(p16[i].f) || !cc->wpw.p) { wino = false; break; }
-      pw[i].b = p16[i];
-      pw[i].wpw = cc->wpw.p;
-      pw[i].w_hwio = cc->kernel->dev.p;
-      pw[i].n_xc = p16[i].f.x_small ? 0 : p16[i].f.Cx / 16;
-    }
+  const bool wino_mode = e->compute_mode == 1 && mv::wino_enabled();
+  bool wino = wino_mode;
+  std::vector<mv::ConvLstmWinoArgs> pw(p16.size());
+  for (size_t i = 0; i < p16.size(); ++i) {
+    ConvCell* cc = cell_of_pack(e, probs[i].wpack);
+    if (!mv::wino_geometry_ok(p16[i].f) || !cc->wpw.p) wino = false;
+    pw[i].b = p16[i];
+    pw[i].wpw = cc->wpw.p;
+    pw[i].w_hwio = cc->kernel->dev.p;
+    pw[i].n_xc = p16[i].f.x_small ? 0 : p16[i].f.Cx / 16;
   }
   // ... and its F(3,3) form (five ninths, convlstm_wino3.h) when every problem fits THAT tiling
-  // and the slots' buffers hold the pre-transformed operands.  The input transform runs ONCE
-  // per operand, in a pre-pass, instead of in every one of the C / 16 column-block workgroups
-  // of the gate kernel.
-  bool wino3 = wino && mv::wino3_enabled();
+  // (any grid width: widths that do not divide 32 take its halo tiling) and the slots' buffers
+  // hold the pre-transformed operands.  The input transform runs ONCE per operand, in a
+  // pre-pass, instead of in every one of the C / 16 column-block workgroups of the gate kernel.
+  bool wino3 = wino_mode && mv::wino3_enabled();
   for (size_t i = 0; i < p16.size() && wino3; ++i) {
     const ConvLstmArgs& a = p16[i].f;
     ConvCell* cc = cell_of_pack(e, probs[i].wpack);
@@ -971,12 +969,14 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
   // form 3 * (components * row tiles) / (3 * H) -- partial tiles count (9 rows = 5 pairs: 2.22,
   // not 2), weighted over the group by executed FLOPs
   double factor = e->compute_mode == 2 ? 1.0 : 3.0;
-  if (wino) {
+  if (wino || wino3) {
     double num = 0, den = 0;
     for (const auto& a : probs) {
       const double cx = a.sx_corr ? 0.0 : (double)a.Cx;
       const double fl = (double)a.rows * a.H * a.W * (cx + (a.zero_state ? 0 : a.C));
-      const double per = wino3 ? 5.0 * ((a.H + 2) / 3) / a.H : 4.0 * ((a.H + 1) / 2) / a.H;
+      // (the halo tiling issues 32 lanes for 30 owned triple-cells)
+      const double per = wino3 ? 5.0 * ((a.H + 2) / 3) / a.H * (mv::wino3_needs_halo(a) ? 32.0 / 30.0 : 1.0)
+                               : 4.0 * ((a.H + 1) / 2) / a.H;
       num += fl * per; den += fl;
     }
     factor = den > 0 ? num / den : (wino3 ? 5.0 / 3.0 : 2.0);
@@ -2969,7 +2969,7 @@ int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const flo
       q.wp16 = wp.p;
       mv::launch_convlstm16_steps(&q, 1, ctx.stream);
     } else if (variant == 3) {
-      MV_REQUIRE(mv::wino3_geometry_ok(a, q), "Winograd F(3,3) form: W %d must divide 32, H >= 3", W);
+      MV_REQUIRE(mv::wino3_geometry_ok(a, q), "Winograd F(3,3) form: H %d >= 3", H);
       const size_t halves = mv::wino3_wpack_elems(Cx16, C, mv::kW3Nrb);
       wp.alloc(halves);
       hipLaunchKernelGGL(mv::pack_wino3_kernel, dim3(cdiv(halves / 2, 256)), dim3(256), 0,

@@ -153,3 +153,53 @@ def test_wino_dynamic_range(built_lib):
       np.abs(c1 - co).max(), np.abs(c2 - co).max(), np.abs(c3 - co).max()))
   assert np.abs(c2 - co).max() < 2e-5 and np.abs(h2 - ho).max() < 2e-5
   assert np.abs(c3 - co).max() < 3e-5 and np.abs(h3 - ho).max() < 3e-5
+
+
+HALO_SHAPES = [
+    (2, 36, 18, 32, False),   # BASELINE.json's literal 36 x 18 grid
+    (3, 18, 9, 64, False),    # ... and 18 x 9: three image rows and a bit per wave tile
+    (2, 9, 24, 32, False),    # W = 24
+    (1, 12, 12, 2, False),    # fp32 x chunk on a halo tiling
+    (2, 6, 18, 16, True),     # zero state
+    (2, 7, 33, 32, False),    # W > 32, H not a multiple of 3
+]
+
+
+@pytest.mark.parametrize("M,H,W,Cx,zero", HALO_SHAPES)
+def test_wino3_widths_that_do_not_divide_32(built_lib, M, H, W, Cx, zero):
+  """F(3,3) on grids whose width does not divide 32 (csrc/convlstm_wino3.h HALO tiling: a wave's
+  tile starts one triple-cell early, owns its inner 30 lanes): against the oracle, the direct
+  f16x3 form and its own operand planes."""
+  x, c, h, kernel, biases, co, ho = _case(M, H, W, Cx, zero, M * 1000 + H * 10 + W + Cx)
+  cg, hg, h16 = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=3)
+  c1, h1, _ = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=1)
+  ec, eh = np.abs(cg - co), np.abs(hg - ho)
+  print("winograd F(3,3) halo M=%d %dx%d Cx=%d zero=%s: max|dc| %.3g max|dh| %.3g (direct %.3g), "
+        "planes vs h' %.3g" % (M, H, W, Cx, zero, ec.max(), eh.max(), np.abs(c1 - co).max(),
+                               np.abs(h16 - hg).max()))
+  assert ec.max() < 2e-5, _where(ec, "c'")
+  assert eh.max() < 2e-5, _where(eh, "h'")
+  assert np.abs(h16 - hg).max() < 1e-6, _where(np.abs(h16 - hg), "h' planes")
+
+
+def test_wino3_halo_transpose_detecting(built_lib):
+  """One hot taps on a W = 18 grid: sources on both sides of a wave tile's seams (lanes 0 / 1 and
+  30 / 31 of the halo tiling) and of the image rows' ends."""
+  M, H, W, Cx, C = 1, 6, 18, 32, 256
+  for ky in range(3):
+    for kx in range(3):
+      for (sy, sx) in ((2, 11), (2, 12), (3, 5), (0, 0), (5, 17), (1, 17), (2, 0)):
+        x = np.zeros((M, H, W, Cx), "f4")
+        x[0, sy, sx, 3] = 1.0
+        kernel = np.zeros((3, 3, Cx + C, 4 * C), "f4")
+        kernel[ky, kx, 3, 1 * C + 17] = 2.0
+        biases = np.zeros(4 * C, "f4")
+        biases[0 * C:1 * C] = 5.0
+        c = np.zeros((M, H, W, C), "f4")
+        h = np.zeros((M, H, W, C), "f4")
+        co, ho = oracle.convlstm_step_np(x, c, h, kernel, biases)
+        cg, hg, _ = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=3)
+        err = np.abs(cg - co)
+        assert err.max() < 1e-6, "tap (%d,%d) source (%d,%d)\n%s" % (ky, kx, sy, sx,
+                                                                    _where(err, "c'"))
+        assert np.abs(hg - ho).max() < 1e-6
