@@ -645,13 +645,13 @@ void pack_wino3(mv_engine* e, ConvCell& cc) {
   hipLaunchKernelGGL(mv::pack_wino3_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, e->stream,
                      cc.kernel->dev.p, cc.wpw3.p, cc.Cx, Cx16, C, mv::kW3Nrb, threads);
 }
-// every weight-mutating path releases BOTH Winograd packs first (or re-packs them): a non-null
-// pack is by construction a pack of the current weights
+// every weight-mutating path comes through here (or releases both packs): a non-null pack is by
+// construction a pack of the CURRENT weights -- re-packed in place when its form is enabled (no
+// hipFree / hipMalloc per training step: they synchronise the device), released otherwise
 void pack_wino_forms(mv_engine* e, ConvCell& cc) {
-  cc.wpw.release(); cc.wpw3.release();
-  if (!(mv::wino_enabled() && C_multiple_ok(e, cc))) return;
-  pack_wino(e, cc);
-  if (mv::wino3_enabled()) pack_wino3(e, cc);
+  const bool on = mv::wino_enabled() && C_multiple_ok(e, cc);
+  if (on) pack_wino(e, cc); else cc.wpw.release();
+  if (on && mv::wino3_enabled()) pack_wino3(e, cc); else cc.wpw3.release();
 }
 void ensure_packed_wino(mv_engine* e, ConvCell& cc) {
   if (cc.wpw.p) return;
