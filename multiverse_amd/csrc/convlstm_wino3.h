@@ -754,7 +754,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
 }
 
 template <int WAVES, int NRB, bool HALO>
-__global__ __launch_bounds__(WAVES * 64, 2)
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2)
 void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
   extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
   int block = blockIdx.x;
@@ -785,7 +785,12 @@ void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
   }
 }
 
-constexpr int kW3Waves = 4, kW3Nrb = 2;
+// -DMV_W3_WAVES=8: one 8-wave workgroup per CU (the weight stage shared by 256 triple-cells:
+// half the L2 -> LDS traffic per MFMA) instead of two 4-wave workgroups (A/B builds)
+#ifndef MV_W3_WAVES
+#define MV_W3_WAVES 4
+#endif
+constexpr int kW3Waves = MV_W3_WAVES, kW3Nrb = 2;
 
 static inline size_t wino3_lds_bytes() {      // 73.5 KB: two workgroups per CU
   return (size_t)2 * (2 * 3 * 2 * kW3Nrb * 64 * 16) + (size_t)kW3Waves * Wn3<kW3Nrb>::kTileFloats * 4 +

@@ -14,6 +14,7 @@
 #   w3loop    main-loop ablation builds of the F(3,3) kernel (-DMV_W3_ABLC), no epilogue
 #   pmcgreedy rocprofv3 trace + PMC of the greedy workload only
 #   profiles  rocprofv3 traces + PMC of greedy / beam / train (tools/profile_workload.sh)
+#   libab:<name>  headline + beam with build/variants/libmv_<name>.so against the default library
 #   ab:<ENV=V>  headline + beam with the env setting against the default, same box
 set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
@@ -82,6 +83,13 @@ PY
         [ $w = greedy ] && wa="--steps 100"
         timeout 300 $BQ $wa > $O/ab_${w}_default.json 2> $O/ab_${w}_default.err; line $O/ab_${w}_default.json
         env $kv timeout 300 $BQ $wa > $O/ab_${w}_$k.json 2> $O/ab_${w}_$k.err; line $O/ab_${w}_$k.json
+      done ;;
+    libab:*)
+      name=${stage#libab:}
+      for w in greedy beam; do
+        wa="--steps 100"; [ $w = beam ] && wa="--workload beam --steps 3 --warmup 1"
+        timeout 300 $BQ $wa > $O/libab_${w}_default.json 2> $O/libab_${w}_default.err; line $O/libab_${w}_default.json
+        MV_LIB_PATH=$PWD/build/variants/libmv_$name.so timeout 300 $BQ $wa > $O/libab_${w}_$name.json 2> $O/libab_${w}_$name.err; line $O/libab_${w}_$name.json
       done ;;
     *) echo "unknown stage $stage" ;;
   esac
