@@ -27,6 +27,7 @@
 #include "convlstm_f16x3.h"
 #include "convlstm_wino.h"
 #include "convlstm_wino3.h"
+#include "convlstm_generic.h"
 #include "convlstm_wgrad_f16x3.h"
 #include "kernels_misc.h"
 #include "decode_tail.h"
@@ -448,11 +449,16 @@ void validate_config(const mv_config& c) {
   // f16x3 wgrad tile; the one-wave-per-cell kernels take up to two 256-channel groups
   MV_REQUIRE(c.hidden_size == 128 || c.hidden_size == 256 || c.hidden_size == 512,
              "hidden_size %d unsupported (128, 256 or 512)", c.hidden_size);
-  MV_REQUIRE(c.convlstm_kernel == 3, "convlstm_kernel %d unsupported (3 only)",
-             c.convlstm_kernel);
-  MV_REQUIRE(c.scene_conv_dim > 0 && c.scene_conv_dim <= 64 &&
+  // --convlstm_kernel (code/train.py:70): 3 runs the matrix-pipe kernels; any other size runs
+  // the plain fp32 loops of csrc/convlstm_generic.h (compute mode 0 only: slow, but it runs)
+  MV_REQUIRE(c.convlstm_kernel >= 1 && c.convlstm_kernel <= 9,
+             "convlstm_kernel %d unsupported (1 .. 9)", c.convlstm_kernel);
+  // --scene_conv_dim (code/train.py:69): whole 32-channel chunks of the class encoder's x
+  // operand; above 64 the graph attention takes its one-wave-per-cell form (two scene
+  // channels per lane) and the class encoder its dense x operand
+  MV_REQUIRE(c.scene_conv_dim > 0 && c.scene_conv_dim <= 128 &&
              mv::convlstm_cx_supported(c.scene_conv_dim),
-             "scene_conv_dim %d unsupported", c.scene_conv_dim);
+             "scene_conv_dim %d unsupported (a multiple of 32 up to 128)", c.scene_conv_dim);
   // the decoders' x operand: whole 32-channel chunks of the gate GEMM, 16-byte plane vectors
   // and the decode tail's LDS (decode_tail.h) -- checked here, not at the first decode step
   MV_REQUIRE(c.emb_size >= 32 && c.emb_size % 32 == 0 && c.emb_size <= 512 &&
@@ -538,6 +544,7 @@ void ensure_packed(mv_engine* e, ConvCell& cc) {
   MV_REQUIRE(cc.kernel->set, "parameter %s not set", cc.kernel->name.c_str());
   MV_REQUIRE(cc.biases->set, "parameter %s not set", cc.biases->name.c_str());
   if (cc.wpack.p) return;
+  if (e->cfg.convlstm_kernel != 3) return;      // generic taps: straight from the HWIO kernel
   const int C = e->cfg.hidden_size;
   std::vector<float> packed(mv::convlstm_wpack_elems(cc.Cx, C));
   mv::pack_convlstm_weights(cc.kernel->host.data(), cc.Cx, C, packed.data());
@@ -786,6 +793,15 @@ ConvLstmArgs conv_problem(mv_engine* e, const ConvCell& cc, const float* x,
   return a;
 }
 
+ConvCell* cell_of_bias(mv_engine* e, const float* bias) {
+  for (int s = 0; s < e->cfg.num_scales; ++s) {
+    ScaleState& S = e->sc[s];
+    for (ConvCell* cc : active_cells(e, S))
+      if (cc->biases->dev.p == bias) return cc;
+  }
+  throw HipError{"internal: unknown ConvLSTM cell"};
+}
+
 ConvCell* cell_of_pack(mv_engine* e, const float* wpack) {
   for (int s = 0; s < e->cfg.num_scales; ++s) {
     ScaleState& S = e->sc[s];
@@ -1010,6 +1026,19 @@ void run_conv_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs) {
   }
   if (e->compute_mode != 0) {
     run_conv_group_f16x3(e, probs, flops, bytes, dense);
+    return;
+  }
+  if (e->cfg.convlstm_kernel != 3) {            // --convlstm_kernel 1 / 5 / ...: plain fp32 loops
+    const double kk = (double)e->cfg.convlstm_kernel * e->cfg.convlstm_kernel / 9.0;
+    launch(e, "convlstm_step", flops * kk, bytes, [&] {
+      for (const auto& a : probs) {
+        mv::ConvGenericArgs ga{};
+        ga.f = a;
+        ga.w = cell_of_bias(e, a.bias)->kernel->dev.p;
+        ga.ksize = e->cfg.convlstm_kernel;
+        mv::launch_convlstm_generic_step(ga, e->stream);
+      }
+    }, dense * kk, 0.0);
     return;
   }
   launch(e, "convlstm_step", flops, bytes, [&] {
@@ -2704,6 +2733,10 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
   return guarded(h, [&] {
     MV_REQUIRE(mode >= 0 && mode <= 2, "compute mode %d (0 = fp32 MFMA, 1 = f16x3, 2 = bf16)",
                mode);
+    MV_REQUIRE(mode == 0 || h->cfg.convlstm_kernel == 3,
+               "compute mode %d needs convlstm_kernel 3 (%d given: the matrix-pipe gate kernels "
+               "are 3 x 3 stencils; mode 0 runs the generic fp32 loops)", mode,
+               h->cfg.convlstm_kernel);
     if (mode != 0) {
       // operand-plane scratch per group slot: even slots class-sized (N*B rows),
       // odd slots regression-sized (N rows), largest enabled grid
@@ -3020,8 +3053,8 @@ int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const flo
 int mv_op_gnn(int device, const float* h, const float* scene_mean, int32_t M,
               int32_t H, int32_t W, int32_t C, int32_t D, float* out) {
   return guarded(nullptr, [&] {
-    MV_REQUIRE(C % 64 == 0 && C <= 512 && D >= 0 && D <= 64,
-               "gnn: C a multiple of 64 up to 512, D <= 64");
+    MV_REQUIRE(C % 64 == 0 && C <= 512 && D >= 0 && D <= 128,
+               "gnn: C a multiple of 64 up to 512, D <= 128");
     OpCtx ctx(device);
     const size_t cells = (size_t)M * H * W;
     DevBuf<float> dh, ds, dout;
@@ -3201,8 +3234,8 @@ int mv_op_gnn_bwd(int device, const float* h, const float* scene_mean, const flo
                   int32_t M, int32_t H, int32_t W, int32_t C, int32_t D, float* dh,
                   float* dscene_mean) {
   return guarded(nullptr, [&] {
-    MV_REQUIRE(C % 64 == 0 && C <= 512 && D >= 0 && D <= 64,
-               "gnn_bwd: C a multiple of 64 up to 512, D <= 64");
+    MV_REQUIRE(C % 64 == 0 && C <= 512 && D >= 0 && D <= 128,
+               "gnn_bwd: C a multiple of 64 up to 512, D <= 128");
     OpCtx ctx(device);
     const size_t cells = (size_t)M * H * W;
     DevBuf<float> dh_, ds_, dg_, a, de, n, odh, ods;

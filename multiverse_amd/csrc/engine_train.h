@@ -335,6 +335,10 @@ void run_small_wgrad(mv_engine* e, const float* in, const float* dout, float* dw
 void run_pack(mv_engine* e, TrainChain& ch) {
   const int C = e->cfg.hidden_size, Cx = ch.Cx;
   ConvCell& cc = *ch.cell;
+  if (e->cfg.convlstm_kernel != 3) {       // generic taps read the HWIO kernel itself
+    cc.host_stale = true;
+    return;
+  }
   {
     const size_t total = mv::convlstm_wpack_elems(Cx, C);
     const int nx = mv::convlstm_xchunks(Cx), nch = nx + 9 * (C / mv::kBK);
@@ -902,6 +906,20 @@ void run_dgrad_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     run_dgrad_group_f16x3(e, probs, chains, slots, fl, by);
     return;
   }
+  if (e->cfg.convlstm_kernel != 3) {
+    launch(e, "convlstm_dgrad", fl, by, [&] {
+      for (size_t i = 0; i < probs.size(); ++i) {
+        const ConvLstmArgs& a = probs[i];        // convlstm_dgrad_args: h = G, C = 4C
+        mv::ConvGenericDgradArgs ga{};
+        ga.g = a.h; ga.w = chains[i]->cell->kernel->dev.p;
+        ga.dh = a.out0; ga.dx = a.out1;
+        ga.rows = a.rows; ga.H = a.H; ga.W = a.W; ga.Cx = a.out1_cols; ga.C = a.out0_cols;
+        ga.ksize = e->cfg.convlstm_kernel;
+        mv::launch_convlstm_generic_dgrad(ga, e->stream);
+      }
+    }, -1.0, 0.0);
+    return;
+  }
   launch(e, "convlstm_dgrad", fl, by, [&] {
     mv::launch_convlstm_dgrads(probs.data(), (int)probs.size(), e->stream);
   }, -1.0, 1.0);
@@ -1003,6 +1021,21 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
   mv::wgrad_plan(wa, 3072);
   MV_REQUIRE(mv::wgrad_partial_elems(wa) <= t.partial.n, "internal: wgrad partial buffer");
   const double cells = (double)wa.R * H * W;
+  if (e->cfg.convlstm_kernel != 3) {       // generic taps: one deterministic pass, no split
+    const int k = e->cfg.convlstm_kernel;
+    launch(e, "convlstm_wgrad", 2.0 * cells * k * k * (ch.Cx + C) * 4.0 * C,
+           cells * (ch.Cx + 5.0 * C) * 4.0, [&] {
+      mv::ConvGenericWgradArgs ga{};
+      ga.x = wa.x; ga.h = wa.h; ga.g = wa.g; ga.dw = grad_of(e, ch.cell->kernel);
+      ga.R = wa.R; ga.H = H; ga.W = W; ga.Cx = ch.Cx; ga.C = C; ga.ksize = k;
+      mv::launch_convlstm_generic_wgrad(ga, e->stream);
+    }, -1.0, 0.0);
+    launch(e, "bias_colsum", 0, cells * 4.0 * C * 4.0, [&] {
+      run_colsum(e, ch.gates.p, (size_t)cells, (size_t)4 * C, grad_of(e, ch.cell->biases),
+                 t.partial.p);
+    });
+    return;
+  }
   const size_t ncols = (size_t)9 * (ch.Cx + C) * 4 * C;
   const bool f16 = e->compute_mode != 0 && mv::wgrad16_ok(W, C);
   if (f16) {

@@ -258,7 +258,8 @@ __global__ void grid_emb_onehot_kernel(const int32_t* __restrict__ ids,
 // (gnn_edge / gnn_mask_edge / gnn_node, code/pred_models.py:808-909,
 // exp_mask :1399-1401); exp(-1e30 - max) is exactly 0 in fp32, so the 9-point
 // stencil is the same function.  One wave per cell: lane l holds channels
-// 256 g + 4l..4l+3 of h (NG groups: C <= 256 NG) and channel l of the scene mean (D <= 64).
+// 256 g + 4l..4l+3 of h (NG groups: C <= 256 NG) and channels l, l + 64 of the scene mean
+// (D <= 128).
 // scene_mean rows are indexed by m / sm_div (beam tiling, :831-834).
 // src_row: optional state-row indirection (beam parents): input row for
 // output row r is src_row[r].
@@ -277,6 +278,18 @@ __device__ __forceinline__ CVec<NG> cvec_load(const float* __restrict__ row, int
     r.v[g] = c0 < C ? *reinterpret_cast<const f32x4_t*>(row + c0) : f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
   return r;
+}
+// the scene part of a cell's feature in the one-wave-per-cell kernels: lane l owns scene
+// channels l and l + 64 (--scene_conv_dim up to 128; the published 64 leaves .b zero)
+struct SVec { float a, b; };
+__device__ __forceinline__ SVec svec_load(const float* __restrict__ row, int lane, int D) {
+  SVec r;
+  r.a = lane < D ? row[lane] : 0.f;
+  r.b = lane + 64 < D ? row[lane + 64] : 0.f;
+  return r;
+}
+__device__ __forceinline__ float svec_dot(const SVec& x, const SVec& y) {
+  return x.a * y.a + x.b * y.b;
 }
 template <int NG>
 __device__ __forceinline__ float cvec_dot(const CVec<NG>& a, const CVec<NG>& b) {
@@ -307,8 +320,8 @@ void gnn_attend_kernel(const float* __restrict__ h,
   const float* srow = scene_mean + (size_t)(m / sm_div) * K * D;
 
   const CVec<NG> hi = cvec_load<NG>(hrow + (size_t)cell * C, lane, C);
-  const float si = (lane < D) ? srow[(size_t)cell * D + lane] : 0.f;
-  float ssi = cvec_dot<NG>(hi, hi) + si * si;
+  const SVec si = svec_load(srow + (size_t)cell * D, lane, D);
+  float ssi = cvec_dot<NG>(hi, hi) + svec_dot(si, si);
   ssi = wave_sum(ssi);
   const float invi = rsqrtf(fmaxf(ssi, 1e-12f));
 
@@ -326,9 +339,9 @@ void gnn_attend_kernel(const float* __restrict__ h,
     if (ok[t]) {  // wave-uniform
       const int cj = yy * W + xx;
       hj[t] = cvec_load<NG>(hrow + (size_t)cj * C, lane, C);
-      const float sj = (lane < D) ? srow[(size_t)cj * D + lane] : 0.f;
-      float ssj = cvec_dot<NG>(hj[t], hj[t]) + sj * sj;
-      float dot = cvec_dot<NG>(hi, hj[t]) + si * sj;
+      const SVec sj = svec_load(srow + (size_t)cj * D, lane, D);
+      float ssj = cvec_dot<NG>(hj[t], hj[t]) + svec_dot(sj, sj);
+      float dot = cvec_dot<NG>(hi, hj[t]) + svec_dot(si, sj);
       ssj = wave_sum(ssj);
       dot = wave_sum(dot);
       e[t] = dot * invi * rsqrtf(fmaxf(ssj, 1e-12f));

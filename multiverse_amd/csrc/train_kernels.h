@@ -140,8 +140,8 @@ void gnn_bwd_a_kernel(const float* __restrict__ h, const float* __restrict__ sme
   const float* srow = smean + (size_t)m * K * D;
   const CVec<NG> hi = cvec_load<NG>(hrow + (size_t)cell * C, lane, C);
   const CVec<NG> gi = cvec_load<NG>(g + cell_id * C, lane, C);
-  const float si = (lane < D) ? srow[(size_t)cell * D + lane] : 0.f;
-  float ssi = cvec_dot<NG>(hi, hi) + si * si;
+  const SVec si = svec_load(srow + (size_t)cell * D, lane, D);
+  float ssi = cvec_dot<NG>(hi, hi) + svec_dot(si, si);
   ssi = wave_sum(ssi);
   const float invi = rsqrtf(fmaxf(ssi, 1e-12f));
   float e[9], da[9];
@@ -155,9 +155,9 @@ void gnn_bwd_a_kernel(const float* __restrict__ h, const float* __restrict__ sme
     if (ok[t]) {
       const int cj = yy * W + xx;
       const CVec<NG> hj = cvec_load<NG>(hrow + (size_t)cj * C, lane, C);
-      const float sj = (lane < D) ? srow[(size_t)cj * D + lane] : 0.f;
-      float ssj = cvec_dot<NG>(hj, hj) + sj * sj;
-      float dot = cvec_dot<NG>(hi, hj) + si * sj;
+      const SVec sj = svec_load(srow + (size_t)cj * D, lane, D);
+      float ssj = cvec_dot<NG>(hj, hj) + svec_dot(sj, sj);
+      float dot = cvec_dot<NG>(hi, hj) + svec_dot(si, sj);
       float dg = cvec_dot<NG>(gi, hj);
       ssj = wave_sum(ssj);
       dot = wave_sum(dot);
@@ -214,13 +214,13 @@ void gnn_bwd_b_kernel(const float* __restrict__ h, const float* __restrict__ sme
   const float* srow = smean + rbase * D;
   const float* grow = g + rbase * C;
   const CVec<NG> hj = cvec_load<NG>(hrow + (size_t)cell * C, lane, C);
-  const float sj = (lane < D) ? srow[(size_t)cell * D + lane] : 0.f;
+  const SVec sj = svec_load(srow + (size_t)cell * D, lane, D);
   const float nj = n_in[cell_id];
   CVec<NG> acc = cvec_load<NG>(grow + (size_t)cell * C, lane, C);   // residual + weighted neighbours
   CVec<NG> dfh;                        // df_j, h part
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq) dfh.v[gq] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float dfs = 0.f;                     // df_j, scene part (lane < D)
+  SVec dfs = {0.f, 0.f};               // df_j, scene part (channels lane, lane + 64)
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
@@ -232,7 +232,7 @@ void gnn_bwd_b_kernel(const float* __restrict__ h, const float* __restrict__ sme
       const float nk = n_in[kid];
       const CVec<NG> gk = cvec_load<NG>(grow + (size_t)ck * C, lane, C);
       const CVec<NG> hk = cvec_load<NG>(hrow + (size_t)ck * C, lane, C);
-      const float sk = (lane < D) ? srow[(size_t)ck * D + lane] : 0.f;
+      const SVec sk = svec_load(srow + (size_t)ck * D, lane, D);
       const float wn = w * nk;
 #pragma unroll
       for (int gq = 0; gq < NG; ++gq)
@@ -241,11 +241,12 @@ void gnn_bwd_b_kernel(const float* __restrict__ h, const float* __restrict__ sme
           acc.v[gq][q] = fmaf(a_kj, gk.v[gq][q], acc.v[gq][q]);
           dfh.v[gq][q] = fmaf(wn, hk.v[gq][q], dfh.v[gq][q]);
         }
-      dfs = fmaf(wn, sk, dfs);
+      dfs.a = fmaf(wn, sk.a, dfs.a);
+      dfs.b = fmaf(wn, sk.b, dfs.b);
     }
   }
   // projection f_j . df_j
-  float proj = (cvec_dot<NG>(hj, dfh) + sj * dfs) * nj;
+  float proj = (cvec_dot<NG>(hj, dfh) + svec_dot(sj, dfs)) * nj;
   proj = wave_sum(proj);
   const bool clamped = nj >= 1.0e6f;   // |u|^2 <= 1e-12: l2_normalize is u * 1e6
 #pragma unroll
@@ -262,8 +263,13 @@ void gnn_bwd_b_kernel(const float* __restrict__ h, const float* __restrict__ sme
     *reinterpret_cast<f32x4_t*>(dh + cell_id * C + c0) = o;
   }
   if (lane < D) {
-    const float du = clamped ? nj * dfs : nj * (dfs - (sj * nj) * proj);
+    const float du = clamped ? nj * dfs.a : nj * (dfs.a - (sj.a * nj) * proj);
     float* o2 = ds + cell_id * D + lane;
+    *o2 = ds_accumulate ? *o2 + du : du;
+  }
+  if (lane + 64 < D) {
+    const float du = clamped ? nj * dfs.b : nj * (dfs.b - (sj.b * nj) * proj);
+    float* o2 = ds + cell_id * D + lane + 64;
     *o2 = ds_accumulate ? *o2 + du : du;
   }
 }

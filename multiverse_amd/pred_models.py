@@ -189,6 +189,14 @@ class Model(object):
         os.environ.get("MV_COMPUTE", "f16x3")
     # (relu / lrelu models run in f16x3 too: their unbounded x operands carry a per-tensor
     # exponent, csrc/convlstm_f16x3.h ConvLstm16Args::x_exp)
+    if getattr(config, "convlstm_kernel", 3) != 3 and self.compute_mode != "f32":
+      # --convlstm_kernel other than 3 (code/train.py:70): the matrix-pipe gate kernels are
+      # 3 x 3 stencils; such models run the generic fp32 loops (csrc/convlstm_generic.h)
+      import logging
+      logging.getLogger("multiverse_amd").warning(
+          "compute mode %s overridden to f32: convlstm_kernel %d runs the generic fp32 path",
+          self.compute_mode, config.convlstm_kernel)
+      self.compute_mode = "f32"
     if any(use and h * w < 32 for (h, w), use in zip(config.scene_grids, config.use_grids)):
       # the fp16-pipe kernels' epilogue lets a 32-cell wave tile span at most two images
       # (engine.hip run_conv_group_f16x3 refuses smaller grids); such toy grids run on the

@@ -105,6 +105,12 @@ VARIANT_CASES = [
     ("emb128", dict(emb_size=128), 1),
     ("hidden128", dict(enc_hidden_size=128, dec_hidden_size=128), 1),
     ("hidden512", dict(enc_hidden_size=512, dec_hidden_size=512), 1),
+    # --convlstm_kernel 1 / 5 (code/train.py:70) and --scene_conv_dim 128 (code/train.py:69):
+    # the engine's generic-tap fp32 path (csrc/convlstm_generic.h), the two-channels-per-lane
+    # graph attention
+    ("ck1", dict(convlstm_kernel=1), 1),
+    ("ck5", dict(convlstm_kernel=5), 1),
+    ("scd128", dict(scene_conv_dim=128), 1),
 ]
 VARIANT_SEED = synth.SEED_BASE + 40
 
