@@ -796,8 +796,9 @@ ConvLstmArgs conv_problem(mv_engine* e, const ConvCell& cc, const float* x,
 ConvCell* cell_of_bias(mv_engine* e, const float* bias) {
   for (int s = 0; s < e->cfg.num_scales; ++s) {
     ScaleState& S = e->sc[s];
+    if (!S.use) continue;                  // an unused scale's cells have no parameters
     for (ConvCell* cc : active_cells(e, S))
-      if (cc->biases->dev.p == bias) return cc;
+      if (cc->biases && cc->biases->dev.p == bias) return cc;
   }
   throw HipError{"internal: unknown ConvLSTM cell"};
 }
