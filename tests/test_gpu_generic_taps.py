@@ -78,10 +78,28 @@ def test_convlstm_kernel_sizes_greedy_forward_vs_oracle(built_lib, k):
   cls, reg = eng.forward_greedy(feed)
   for s in range(2):
     K = cfg.scene_grids[s][0] * cfg.scene_grids[s][1]
-    dc, dr = np.abs(cls[s] - ocls[s]).max(), np.abs(reg[s] - oreg[s]).max()
-    print("convlstm_kernel %d scale %d: max|dcls| %.3g max|dreg| %.3g" % (k, s, dc, dr))
-    assert dc < 1e-4 and dr < 1e-4
-    assert (cls[s].reshape(2, -1, K).argmax(-1) == ocls[s].reshape(2, -1, K).argmax(-1)).all()
+    oc, gc = ocls[s].reshape(2, -1, K), cls[s].reshape(2, -1, K)
+    # A 1 x 1 cell mixes nothing spatially: every cell away from the trajectory carries the
+    # same state, hidden2grid gives those cells EXACTLY tied logits in the oracle, and the
+    # argmax fed back to the next step hangs on rounding.  Steps are compared up to the first
+    # one whose oracle top-1 / top-2 margin is below 1e-4 (none for k = 2, 5).
+    top2 = np.sort(oc, axis=-1)[..., -2:]
+    margin = top2[..., 1] - top2[..., 0]
+    steps = oc.shape[1]
+    for n in range(2):
+      tied = np.nonzero(margin[n] < 1e-4)[0]
+      upto = int(tied[0]) + 1 if len(tied) else steps
+      dc = np.abs(gc[n, :upto] - oc[n, :upto]).max()
+      print("convlstm_kernel %d scale %d row %d: %d of %d steps compared (oracle margin), "
+            "max|dcls| %.3g" % (k, s, n, upto, steps, dc))
+      assert dc < 1e-4
+      ok_steps = upto - 1 if len(tied) else steps
+      assert (gc[n, :ok_steps].argmax(-1) == oc[n, :ok_steps].argmax(-1)).all()
+      if k != 1:
+        assert upto == steps
+    dr = np.abs(reg[s] - oreg[s]).max()
+    print("convlstm_kernel %d scale %d: max|dreg| %.3g" % (k, s, dr))
+    assert dr < 1e-4
   # the matrix-pipe modes are 3 x 3 only: refused, not silently wrong
   for mode in ("f16x3", "bf16"):
     with pytest.raises(Exception) as err:
