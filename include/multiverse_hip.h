@@ -48,10 +48,11 @@ typedef struct mv_config {
   int32_t obs_len;           /* T_o */
   int32_t max_pred_len;      /* upper bound of the run-time T_pred */
   int32_t scene_h, scene_w, scene_class;        /* 36, 64, 11 */
-  int32_t scene_conv_dim, scene_conv_kernel;    /* 64, 3 */
+  int32_t scene_conv_dim, scene_conv_kernel;    /* 64 (a multiple of 32 up to 128), 3 */
   int32_t emb_size;          /* 32 */
   int32_t hidden_size;       /* enc_hidden_size == dec_hidden_size, 256 */
-  int32_t convlstm_kernel;   /* 3 */
+  int32_t convlstm_kernel;   /* 3; other sizes 1 .. 9 run the generic fp32 loops (compute
+                              * mode 0 only, csrc/convlstm_generic.h) */
   int32_t num_scales;        /* len(scene_grid_strides), <= MV_MAX_SCALES */
   int32_t grid_h[MV_MAX_SCALES];
   int32_t grid_w[MV_MAX_SCALES];
