@@ -496,6 +496,34 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
         acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b0, acc[COMP][rb], 0, 0, 0); \
     }                                                                                         \
   } while (0)
+    // -DMV_W3_PF=1 (A/B builds): the low-plane weight fragments of a (component, dx) group are
+    // requested ONE GROUP AHEAD (8 more registers), so that a group's first two MFMAs (w1 x b0)
+    // issue at once and its high-plane reads land behind them; groups pinned by sched_barrier
+#ifndef MV_W3_PF
+#define MV_W3_PF 0
+#endif
+#define MV_W3_GROUP(COMP, CI, DX, VHI, VLO, BUF, NEXT, NCI, NDX)                              \
+  do {                                                                                        \
+    const f16x8 b0 = (DX) == 1 ? (VHI) : wn_lane_shift((VHI), (DX) == 0, (DX) == 0 ? okx0 : okx2); \
+    const f16x8 b1 = (DX) == 1 ? (VLO) : wn_lane_shift((VLO), (DX) == 0, (DX) == 0 ? okx0 : okx2); \
+    f16x8 w0[NRB], w1c[NRB];                                                                  \
+    _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) {                                      \
+      w1c[rb] = w1p[rb];                                                                      \
+      w0[rb] = (BUF)[((((CI) * 3 + (DX)) * 2 + 0) * NRB + rb) * 64 + lane];                   \
+    }                                                                                         \
+    if (NEXT) {                                                                               \
+      _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                      \
+        w1p[rb] = (BUF)[((((NCI) * 3 + (NDX)) * 2 + 1) * NRB + rb) * 64 + lane];              \
+    }                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);       /* every request of the group first */          \
+    _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                        \
+      acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1c[rb], b0, acc[COMP][rb], 0, 0, 0); \
+    _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                        \
+      acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b1, acc[COMP][rb], 0, 0, 0); \
+    _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                        \
+      acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b0, acc[COMP][rb], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  } while (0)
     // one stage: components CA (slot 0) and CB (slot 1; CB < 0: the sequence's last, single
     // component); the next stage's weights and fragments are requested first
 #define MV_W3_STAGE(CA, CB)                                                                   \
@@ -506,8 +534,21 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       stage_dma(st + 1, nbuf);               /* its buffer was last read before the barrier */ \
       vload(2 * st + 2, na); vload(2 * st + 3, nb);   /* a whole stage ahead of their use */  \
     }                                                                                         \
-    MV_W3_COMP(CA, 0, va.h, va.l, buf);                                                       \
-    if ((CB) >= 0) MV_W3_COMP((CB) < 0 ? 0 : (CB), 1, vb.h, vb.l, buf);                       \
+    if (MV_W3_PF) {                                                                           \
+      f16x8 w1p[NRB];                                                                         \
+      _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) w1p[rb] = buf[(1 * NRB + rb) * 64 + lane]; \
+      MV_W3_GROUP(CA, 0, 0, va.h, va.l, buf, true, 0, 1);                                     \
+      MV_W3_GROUP(CA, 0, 1, va.h, va.l, buf, true, 0, 2);                                     \
+      MV_W3_GROUP(CA, 0, 2, va.h, va.l, buf, (CB) >= 0, 1, 0);                                \
+      if ((CB) >= 0) {                                                                        \
+        MV_W3_GROUP((CB) < 0 ? 0 : (CB), 1, 0, vb.h, vb.l, buf, true, 1, 1);                  \
+        MV_W3_GROUP((CB) < 0 ? 0 : (CB), 1, 1, vb.h, vb.l, buf, true, 1, 2);                  \
+        MV_W3_GROUP((CB) < 0 ? 0 : (CB), 1, 2, vb.h, vb.l, buf, false, 0, 0);                 \
+      }                                                                                       \
+    } else {                                                                                  \
+      MV_W3_COMP(CA, 0, va.h, va.l, buf);                                                     \
+      if ((CB) >= 0) MV_W3_COMP((CB) < 0 ? 0 : (CB), 1, vb.h, vb.l, buf);                     \
+    }                                                                                         \
     va = na; vb = nb;                                                                         \
     ++st;                                                                                     \
     __syncthreads();                                                                          \
@@ -529,6 +570,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       MV_W3_STAGE(0, 1); MV_W3_STAGE(2, 3); MV_W3_STAGE(4, -1);
     }
 #undef MV_W3_COMP
+#undef MV_W3_GROUP
 #undef MV_W3_STAGE
   }
   if (!wave_live) return;
