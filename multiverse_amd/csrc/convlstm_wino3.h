@@ -481,12 +481,18 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
 #define MV_W3_COMP(COMP, CI, VHI, VLO, BUF)                                                   \
   do {                                                                                        \
     _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                        \
-      const f16x8 b0 = dx == 1 ? (VHI) : wn_lane_shift((VHI), dx == 0, dx == 0 ? okx0 : okx2); \
-      const f16x8 b1 = dx == 1 ? (VLO) : wn_lane_shift((VLO), dx == 0, dx == 0 ? okx0 : okx2); \
+      const bool sh_ = dx != 1 && !(MV_W3_ABLC & 16);                                         \
+      const f16x8 b0 = !sh_ ? (VHI) : wn_lane_shift((VHI), dx == 0, dx == 0 ? okx0 : okx2);   \
+      const f16x8 b1 = !sh_ ? (VLO) : wn_lane_shift((VLO), dx == 0, dx == 0 ? okx0 : okx2);   \
       f16x8 w0[NRB], w1[NRB];                                                                 \
       _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) {                                    \
-        w0[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 0) * NRB + rb) * 64 + lane];                   \
-        w1[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 1) * NRB + rb) * 64 + lane];                   \
+        if (MV_W3_ABLC & 4) {                                                                 \
+          asm volatile("" : "+v"(wfix[rb]), "+v"(wfix[2 + rb]));                              \
+          w0[rb] = wfix[rb]; w1[rb] = wfix[2 + rb];                                           \
+        } else {                                                                              \
+          w0[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 0) * NRB + rb) * 64 + lane];                 \
+          w1[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 1) * NRB + rb) * 64 + lane];                 \
+        }                                                                                     \
       }                                                                                       \
       _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                      \
         acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[rb], b0, acc[COMP][rb], 0, 0, 0); \
@@ -501,6 +507,12 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     // issue at once and its high-plane reads land behind them; groups pinned by sched_barrier
 #ifndef MV_W3_PF
 #define MV_W3_PF 0
+#endif
+    // -DMV_W3_ABLC=<bits> (timing-only builds, garbage results): 1 = no operand loads in the
+    // loop, 2 = no weight staging in the loop, 4 = weight fragments read once, 8 = no barrier,
+    // 16 = no DPP lane shifts
+#ifndef MV_W3_ABLC
+#define MV_W3_ABLC 0
 #endif
 #define MV_W3_GROUP(COMP, CI, DX, VHI, VLO, BUF, NEXT, NCI, NDX)                              \
   do {                                                                                        \
@@ -531,8 +543,9 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     f16x8* const buf = lds + ((st & 1) ? kStageVec : 0);                                      \
     f16x8* const nbuf = lds + ((st & 1) ? 0 : kStageVec);                                     \
     if (st + 1 < S_total) {                                                                   \
-      stage_dma(st + 1, nbuf);               /* its buffer was last read before the barrier */ \
-      vload(2 * st + 2, na); vload(2 * st + 3, nb);   /* a whole stage ahead of their use */  \
+      if (!(MV_W3_ABLC & 2)) stage_dma(st + 1, nbuf);   /* its buffer was last read before the barrier */ \
+      if (!(MV_W3_ABLC & 1)) { vload(2 * st + 2, na); vload(2 * st + 3, nb); }   /* a whole stage ahead */ \
+      else asm volatile("" : "+v"(na.h), "+v"(na.l), "+v"(nb.h), "+v"(nb.l));                 \
     }                                                                                         \
     if (MV_W3_PF) {                                                                           \
       f16x8 w1p[NRB];                                                                         \
@@ -551,14 +564,20 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     }                                                                                         \
     va = na; vb = nb;                                                                         \
     ++st;                                                                                     \
-    __syncthreads();                                                                          \
+    if (!(MV_W3_ABLC & 8)) __syncthreads();                                                   \
   } while (0)
 
     Vc va, vb, na, nb;
     vload(0, va); vload(1, vb);
     na = va; nb = vb;
     stage_dma(0, lds);
+    if (MV_W3_ABLC & 2) stage_dma(0, lds + kStageVec);
     __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
+    f16x8 wfix[4];
+    if (MV_W3_ABLC & 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wfix[i] = lds[i * 64 + lane];
+    }
     // five stages = ten components = two chunks: (0,1) (2,3) (4,0) (1,2) (3,4); an odd chunk
     // count ends on (0,1) (2,3) (4)
     const int nck = ck_hi - ck_lo;

@@ -58,7 +58,8 @@ for stage in "$@"; do
       MV_ENERGY_ROWS="w3_shipped:0:0 w3_no_epilogue:0:2 w3_no_main_loop:0:1 w3_no_stores:0:24 f23_shipped:0:0:MV_WINO3=0 f23_no_epilogue:0:2:MV_WINO3=0 f23_no_main_loop:0:1:MV_WINO3=0 idle:-:-" \
         bash tools/energy_attribution.sh $T/w3abl 300 > $O/w3abl.log 2>&1; cat $O/w3abl/table.md ;;
     w3loop)
-      MV_ENERGY_LIBPREFIX=r5w MV_ENERGY_ROWS="w3_no_epilogue:0:2 w3_no_operand_loads:1:2 w3_no_weight_stream:2:2 w3_no_fragment_reads:4:2 w3_mfma_and_barrier:7:2 w3_mfma_only:15:2 w3_one_mfma_per_product:16:2 w3_one_mfma_only:31:2 w3_shipped:0:0 idle:-:-" \
+      # each row REMOVES one thing from the shipped main loop (no epilogue in any of them)
+      MV_ENERGY_LIBPREFIX=r5w MV_ENERGY_ROWS="w3_no_epilogue:0:2 w3_no_operand_loads:1:2 w3_no_weight_staging:2:2 w3_no_fragment_reads:4:2 w3_no_barrier:8:2 w3_no_dpp:16:2 w3_mfma_only:31:2 w3_shipped:0:0 idle:-:-" \
         bash tools/energy_attribution.sh $T/w3loop 300 > $O/w3loop.log 2>&1; cat $O/w3loop/table.md ;;
     pmcgreedy)
       bash tools/profile_workload.sh ${T}_greedy > $O/prof_greedy.log 2>&1
