@@ -827,8 +827,18 @@ void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
   // block -> (column block, row tile), as in convlstm_step_wino_kernel: XCD x holds the
   // ADJACENT column blocks 2x, 2x + 1 of sixteen (the two halves of every 128-byte line of the
   // state tensors at CH = 16) through one L2
+  // map_mode 2 / 3 (MV_WINO_MAP, ncb = 16): an XCD holds FOUR / EIGHT column blocks and every
+  // second / fourth row tile -- the pre-transformed operands of a row tile are then fetched by 4 /
+  // 2 of the 8 L2s instead of all of them, at 2 / 4 times the weight working set per L2
   auto cbmap = [&](int ncb, int& cb, int& mt) {
-    if (g.map_mode == 1 && (ncb & 15) == 0) {
+    if ((g.map_mode == 2 || g.map_mode == 3) && ncb == 16) {
+      const int per = g.map_mode == 2 ? 4 : 8;                 // column blocks per XCD
+      const int nt = per / 2;                                  // row tiles per block group
+      const int grp = block / (16 * nt), w = block - grp * (16 * nt);
+      const int xcd = w & 7, j = w >> 3;                       // j: 0 .. per - 1
+      cb = per * (xcd % (16 / per)) + j;
+      mt = grp * nt + xcd / (16 / per);
+    } else if (g.map_mode >= 1 && (ncb & 15) == 0) {
       const int grp = block / 16, w16 = block - grp * 16;      // 16 consecutive blocks
       cb = (grp % (ncb / 16)) * 16 + 2 * (w16 & 7) + (w16 >> 3);
       mt = grp / (ncb / 16);
@@ -857,10 +867,16 @@ static inline size_t wino3_lds_bytes() {      // 73.5 KB: two workgroups per CU
   return (size_t)2 * (2 * 3 * 2 * kW3Nrb * 64 * 16) + (size_t)kW3Waves * Wn3<kW3Nrb>::kTileFloats * 4 +
          (size_t)kW3Waves * 192 * 4;
 }
-static inline unsigned convlstm_wino3_blocks(const ConvLstmArgs& a, bool halo) {
+static inline unsigned convlstm_wino3_blocks(const ConvLstmArgs& a, bool halo, int map_mode = 1) {
   const size_t Q = (size_t)a.rows * ((a.H + 2) / 3) * a.W;
   const size_t triples = (size_t)kW3Waves * (halo ? 30 : 32);
-  return (unsigned)((Q + triples - 1) / triples) * (unsigned)(a.C / Wn3<kW3Nrb>::kCh);
+  size_t mtiles = (Q + triples - 1) / triples;
+  const unsigned ncb = (unsigned)(a.C / Wn3<kW3Nrb>::kCh);
+  if ((map_mode == 2 || map_mode == 3) && ncb == 16) {       // whole block groups (dead tiles idle)
+    const size_t nt = map_mode == 2 ? 2 : 4;
+    mtiles = (mtiles + nt - 1) / nt * nt;
+  }
+  return (unsigned)mtiles * ncb;
 }
 
 // MV_WINO3=0 keeps the F(2,3) row-pair kernel (A/B runs).
@@ -905,7 +921,7 @@ static inline void launch_convlstm_wino3_steps(const ConvLstmWinoArgs* probs, in
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
     g.p[i].abl = abl;
-    total += convlstm_wino3_blocks(probs[i].b.f, halo);
+    total += convlstm_wino3_blocks(probs[i].b.f, halo, map_mode);
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
