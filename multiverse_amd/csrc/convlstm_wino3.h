@@ -477,6 +477,29 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       v.l = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
                                           is_x ? vxrs : vhrs, (int)(is_x ? vo_x : vo_h), so + 1024, 0));
     };
+    // L2 prefetch of the fragments TWO stages ahead: one dword per lane of each of the four
+    // 1 KB runs (every 128-byte line of them) -- their first real request, a stage later, then
+    // hits the XCD's L2 instead of waiting for HBM / Infinity Cache in front of the next barrier
+    // (the operand loads were the largest single item of the main loop: removing them took
+    // 0.567 -> 0.450 ms per launch, profiles/r5s_*).  Four registers, consumed a stage later.
+#ifndef MV_W3_TOUCH
+#define MV_W3_TOUCH 1
+#endif
+    uint32_t pft[4] = {0u, 0u, 0u, 0u};
+    auto vtouch = [&](int g) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int gg = g + u;
+        const int gc = gg < G_total ? gg : G_total - 1;
+        const int ck = ck_lo + gc / 5, comp = gc - (gc / 5) * 5;
+        const bool is_x = ck < nxc;
+        const int so = (is_x ? ck : ck - nxc) * 10240 + comp * 2048;
+        pft[2 * u + 0] = __builtin_amdgcn_raw_buffer_load_b32(is_x ? vxrs : vhrs,
+                                                               (int)(is_x ? vo_x : vo_h), so, 0);
+        pft[2 * u + 1] = __builtin_amdgcn_raw_buffer_load_b32(is_x ? vxrs : vhrs,
+                                                               (int)(is_x ? vo_x : vo_h), so + 1024, 0);
+      }
+    };
     // one component: 3 dx x NRB row blocks x 3 MFMAs from stage buffer `buf`, slot ci
 #define MV_W3_COMP(COMP, CI, VHI, VLO, BUF)                                                   \
   do {                                                                                        \
@@ -542,6 +565,10 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   do {                                                                                        \
     f16x8* const buf = lds + ((st & 1) ? kStageVec : 0);                                      \
     f16x8* const nbuf = lds + ((st & 1) ? 0 : kStageVec);                                     \
+    if (MV_W3_TOUCH) {                                                                        \
+      asm volatile("" :: "v"(pft[0]), "v"(pft[1]), "v"(pft[2]), "v"(pft[3]));                 \
+      if (st + 2 < S_total) vtouch(2 * st + 4);                                               \
+    }                                                                                         \
     if (st + 1 < S_total) {                                                                   \
       if (!(MV_W3_ABLC & 2)) stage_dma(st + 1, nbuf);   /* its buffer was last read before the barrier */ \
       if (!(MV_W3_ABLC & 1)) { vload(2 * st + 2, na); vload(2 * st + 3, nb); }   /* a whole stage ahead */ \
@@ -913,7 +940,10 @@ static inline void launch_convlstm_wino3_steps(const ConvLstmWinoArgs* probs, in
   ConvLstmWinoGroup g{};
   g.n = n;
   static const int abl = getenv("MV_WINO_ABL") ? atoi(getenv("MV_WINO_ABL")) : 0;
-  static const int map_mode = getenv("MV_WINO_MAP") ? atoi(getenv("MV_WINO_MAP")) : 1;
+  // MV_WINO_MAP: 2 (default here): an XCD holds four column blocks and every second row tile --
+  // a row tile's pre-transformed operands then come through 4 of the 8 L2s (+0.7 % greedy and
+  // beam-20 against 1 = two column blocks per XCD, same box; 3 = eight: no better)
+  static const int map_mode = getenv("MV_WINO_MAP") ? atoi(getenv("MV_WINO_MAP")) : 2;
   g.map_mode = map_mode;
   bool halo = false;                       // one tiling per launch: any problem that needs it
   for (int i = 0; i < n; ++i) halo = halo || wino3_needs_halo(probs[i].b.f);
