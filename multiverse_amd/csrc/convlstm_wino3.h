@@ -565,14 +565,17 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   do {                                                                                        \
     f16x8* const buf = lds + ((st & 1) ? kStageVec : 0);                                      \
     f16x8* const nbuf = lds + ((st & 1) ? 0 : kStageVec);                                     \
-    if (MV_W3_TOUCH) {                                                                        \
-      asm volatile("" :: "v"(pft[0]), "v"(pft[1]), "v"(pft[2]), "v"(pft[3]));                 \
-      if (st + 2 < S_total) vtouch(2 * st + 4);                                               \
-    }                                                                                         \
+    const bool touch_ = MV_W3_TOUCH && st + 2 < S_total;                                      \
+    if (MV_W3_TOUCH) asm volatile("" :: "v"(pft[0]), "v"(pft[1]), "v"(pft[2]), "v"(pft[3]));  \
     if (st + 1 < S_total) {                                                                   \
       if (!(MV_W3_ABLC & 2)) stage_dma(st + 1, nbuf);   /* its buffer was last read before the barrier */ \
       if (!(MV_W3_ABLC & 1)) { vload(2 * st + 2, na); vload(2 * st + 3, nb); }   /* a whole stage ahead */ \
       else asm volatile("" : "+v"(na.h), "+v"(na.l), "+v"(nb.h), "+v"(nb.l));                 \
+    }                                                                                         \
+    if (touch_) {        /* the YOUNGEST four requests of the stage: the barrier leaves them */ \
+      __builtin_amdgcn_sched_barrier(0);                                                      \
+      vtouch(2 * st + 4);                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                      \
     }                                                                                         \
     if (MV_W3_PF) {                                                                           \
       f16x8 w1p[NRB];                                                                         \
@@ -591,7 +594,11 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     }                                                                                         \
     va = na; vb = nb;                                                                         \
     ++st;                                                                                     \
-    if (!(MV_W3_ABLC & 8)) __syncthreads();                                                   \
+    if (!(MV_W3_ABLC & 8)) {                                                                  \
+      /* DMA + fragments of the next stage must have landed; the four touches may fly on */   \
+      if (touch_) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
+      else __syncthreads();                                                                   \
+    }                                                                                         \
   } while (0)
 
     Vc va, vb, na, nb;
