@@ -468,6 +468,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     // component g of the sequence (clamped to the last one: a request past the end fetches
     // that component again)
     auto vload = [&](int g, Vc& v) {
+      if (MV_W3_ABLC & 32) g = 0;            // timing: every request hits the same (cached) KB
       const int gc = g < G_total ? g : G_total - 1;
       const int ck = ck_lo + gc / 5, comp = gc - (gc / 5) * 5;
       const bool is_x = ck < nxc;
@@ -483,7 +484,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     // (the operand loads were the largest single item of the main loop: removing them took
     // 0.567 -> 0.450 ms per launch, profiles/r5s_*).  Four registers, consumed a stage later.
 #ifndef MV_W3_TOUCH
-#define MV_W3_TOUCH 1
+#define MV_W3_TOUCH 0      // measured: 4 % SLOWER (0.682 vs 0.641 ms per launch, profiles/r5v_*)
 #endif
     uint32_t pft[4] = {0u, 0u, 0u, 0u};
     auto vtouch = [&](int g) {
@@ -533,7 +534,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
 #endif
     // -DMV_W3_ABLC=<bits> (timing-only builds, garbage results): 1 = no operand loads in the
     // loop, 2 = no weight staging in the loop, 4 = weight fragments read once, 8 = no barrier,
-    // 16 = no DPP lane shifts
+    // 16 = no DPP lane shifts, 32 = operand loads always of the first fragments (cache hits)
 #ifndef MV_W3_ABLC
 #define MV_W3_ABLC 0
 #endif
