@@ -50,6 +50,13 @@
 #pragma once
 #include "convlstm_wino.h"
 
+// -DMV_W3_ABLC=<bits> (timing-only builds of the main loop, garbage results): 1 = no operand
+// loads in the loop, 2 = no weight staging in the loop, 4 = weight fragments read once, 8 = no
+// barrier, 16 = no DPP lane shifts, 32 = operand loads always of the first fragments (cache hits)
+#ifndef MV_W3_ABLC
+#define MV_W3_ABLC 0
+#endif
+
 namespace mv {
 
 template <int NRB>
@@ -532,12 +539,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
 #ifndef MV_W3_PF
 #define MV_W3_PF 0
 #endif
-    // -DMV_W3_ABLC=<bits> (timing-only builds, garbage results): 1 = no operand loads in the
-    // loop, 2 = no weight staging in the loop, 4 = weight fragments read once, 8 = no barrier,
-    // 16 = no DPP lane shifts, 32 = operand loads always of the first fragments (cache hits)
-#ifndef MV_W3_ABLC
-#define MV_W3_ABLC 0
-#endif
+
 #define MV_W3_GROUP(COMP, CI, DX, VHI, VLO, BUF, NEXT, NCI, NDX)                              \
   do {                                                                                        \
     const f16x8 b0 = (DX) == 1 ? (VHI) : wn_lane_shift((VHI), (DX) == 0, (DX) == 0 ? okx0 : okx2); \
