@@ -461,7 +461,7 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
   f16_form = ""
   if f16:
     f16_form = "%s, %.2f fp16 MFMAs issued per fp32 product over the gate kernels" % (
-        roofline.get("gate_kernel_form", "gate kernel form n/a").split(",")[0],
+        roofline.get("gate_kernel_form", "gate kernel form n/a").split(" fp16 MFMA")[0].rsplit(",", 1)[0],
         conv["flops_mfma"] / conv["flops"] if conv["flops"] else 3.0)
   out = {
       "metric": metric,
