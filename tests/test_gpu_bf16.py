@@ -144,3 +144,52 @@ def test_bf16_training_step_and_beam_run(built_lib):
   assert np.isfinite(arrs["logits"]).all() and np.isfinite(arrs["logprobs"]).all()
   assert arrs["ids"].min() >= 0 and arrs["ids"].max() < 18 * 32
   assert (np.diff(arrs["logprobs"], axis=1) <= 1e-6).all()      # sorted best first
+
+
+@pytest.mark.parametrize("act", ["relu", "lrelu"])
+def test_bf16_with_unbounded_activations(built_lib, act):
+  """--activation_func relu / lrelu in bf16 mode (advisor, round 4): the embeddings feeding the
+  gate convolutions are unbounded; bf16 keeps fp32's exponent range, so its single operand plane
+  needs no per-tensor scale (the f16x3 mode's x exponent, tests/test_gpu_edge.py) -- held here:
+  greedy forward within the mode's stated tolerance of the oracle, a training step with finite
+  loss close to the oracle's and gradients of cosine > 0.999, and a second step that improves."""
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1), activation_func=act)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 21, recurrent_gain=2.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 22)
+  eng = _engine(built_lib, cfg, params)
+  cls, reg = eng.forward_greedy(feed)
+  eng.close()
+  ocls, oreg, _ = oracle.forward(params, cfg, feed)
+  for s in range(2):
+    N, Tp = 2, cfg.pred_len
+    assert np.isfinite(cls[s]).all() and np.isfinite(reg[s]).all()
+    gi = cls[s].reshape(N, Tp, -1).argmax(-1)
+    oi = ocls[s].reshape(N, Tp, -1).argmax(-1)
+    rng_c, rng_r = np.abs(ocls[s]).max(), np.abs(oreg[s]).max()
+    ec = 0.0
+    for n in range(N):
+      bad = np.nonzero(gi[n] != oi[n])[0]
+      upto = int(bad[0]) + 1 if bad.size else Tp
+      ec = max(ec, float(np.abs(cls[s][n, :upto] - ocls[s][n, :upto]).max()))
+    er = float(np.abs(reg[s] - oreg[s]).max())
+    print("bf16 %s scale %d: logits err %.2e of range, reg err %.2e of range, %d / %d ids equal"
+          % (act, s, ec / rng_c, er / rng_r, int((gi == oi).sum()), gi.size))
+    assert ec <= BF16_TOL * rng_c
+    assert er <= BF16_TOL * rng_r or not (gi == oi).all()
+  tcfg = synth.default_config(batch_size=2, use_grids=(1, 1), is_train=True, activation_func=act)
+  tparams = synth.make_params(tcfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0, bias_scale=0.1)
+  tfeed = synth.make_feed(tcfg, seed=synth.SEED_BASE + 73)
+  eng = _engine(built_lib, tcfg, tparams)
+  eng.train_init()
+  loss, wd, pgl = eng.train_forward_backward(tfeed)
+  grads = {n: eng.get_grad(n) for n, _ in eng.param_specs()}
+  eng.train_apply(1.0)
+  loss2, _, _ = eng.train_forward_backward(tfeed)
+  eng.close()
+  oloss, owd, opgl, og = oracle.loss_and_grads(tparams, tcfg, tfeed)
+  print("bf16 %s train: loss %.5f oracle %.5f; after one step %.5f" % (act, loss, oloss, loss2))
+  assert abs(loss - oloss) < 2e-2 * abs(oloss) and np.isfinite(loss2) and loss2 < loss
+  for n in sorted(grads):
+    a, b = grads[n].reshape(-1).astype(np.float64), og[n].reshape(-1).astype(np.float64)
+    cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+    assert np.isfinite(a).all() and cos > 0.999, (n, cos)

@@ -456,3 +456,119 @@ def test_f33_one_hot_taps_land_on_the_right_output_rows():
         ref = _conv3x3_same(d.astype(np.float64), w)
         got = _wino3_rows_f16x3(d, w)
         assert np.abs(got - ref).max() < 1e-6, (ky, kx, sy, sx, np.abs(got - ref).max())
+
+
+# ---- layout / schedule bookkeeping of csrc/convlstm_wino3.h (numpy restatements of the index
+# arithmetic the kernel's correctness rests on; the GPU tests hold the kernel itself)
+
+def test_f33_stage_sequence_walks_every_component_of_every_chunk_once():
+  """The (chunk, component) pairs are ONE sequence g = 0 .. 5 n - 1; an LDS stage holds g = 2 s,
+  2 s + 1; the kernel unrolls five stages with the COMPILE-TIME accumulator pairs (0,1) (2,3)
+  (4,0) (1,2) (3,4) per two chunks and ends an odd chunk count on (0,1) (2,3) (4)."""
+  pairs = [(0, 1), (2, 3), (4, 0), (1, 2), (3, 4)]
+  for nck in range(1, 20):
+    seq = []
+    for _ in range(nck // 2):
+      seq += pairs
+    if nck & 1:
+      seq += [(0, 1), (2, 3), (4, -1)]
+    flat = [c for p in seq for c in p if c >= 0]
+    assert flat == [g % 5 for g in range(5 * nck)]                 # accumulator of component g
+    assert len(seq) == (5 * nck + 1) // 2                          # stages
+    # slot ci of component g inside its stage = g & 1; stage bytes 24 KB = 2 x 768 vectors
+    for g, c in enumerate(flat):
+      assert (g >> 1, g & 1) == divmod(g, 2)
+
+
+def test_f33_pack_layout_is_the_stage_image_the_kernel_reads():
+  """pack_wino3_kernel writes [cb][chunk][comp][dx][plane][rb][lane][8]; the kernel's stage st of
+  a column block starts at vector (ck_lo * 5 + 2 st) * 768 and reads fragment (slot ci, dx, plane,
+  rb) at ((ci * 3 + dx) * 2 + plane) * 2 + rb) * 64 + lane."""
+  nrb, nch = 2, 3
+  comp_vec = 3 * 2 * nrb * 64
+
+  def pack_vec(cb, chunk, comp, dx, plane, rb, lane):
+    return ((((((cb * nch + chunk) * 5 + comp) * 3 + dx) * 2 + plane) * nrb + rb) * 64) + lane
+
+  assert comp_vec == 768
+  for ck_lo in (0, 1):
+    for g in range(5 * (nch - ck_lo)):
+      st, ci = g >> 1, g & 1
+      chunk, comp = ck_lo + g // 5, g % 5
+      for dx in range(3):
+        for plane in range(2):
+          for rb in range(nrb):
+            kernel_vec = (1 * nch + ck_lo) * 5 * comp_vec + st * 2 * comp_vec + \
+                (((ci * 3 + dx) * 2 + plane) * nrb + rb) * 64 + 17
+            assert kernel_vec == pack_vec(1, chunk, comp, dx, plane, rb, 17)
+
+
+@pytest.mark.parametrize("H,W,rows", [(18, 32, 3), (9, 16, 5), (36, 18, 2), (7, 33, 2)])
+def test_f33_operand_addresses_of_pre_pass_and_gate_kernel_agree(H, W, rows):
+  """wino3_transform_kernel writes triple-cell q, channel group cg, component c, plane p, k half
+  hf at vector ((q >> 5) * KG + cg) * 640 + (c * 2 + p) * 64 + hf * 32 + (q & 31); the gate
+  kernel reads, for lane l = hf * 32 + column, tile base (q_wave >> 5) * KG * 10240 bytes +
+  cg * 10240 + c * 2048 + p * 1024 + l * 16 (plain tiling) or, per lane, (q >> 5) * KG * 10240 +
+  ((q & 31) + 32 hf) * 16 (halo tiling: q = 30 t - 1 + column)."""
+  KG = 3
+  Kt = ((H + 2) // 3) * W
+  Q = rows * Kt
+  halo = 32 % W != 0
+  own = 30 if halo else 32
+
+  def written(q, cg, c, p, hf):
+    return (((q >> 5) * KG + cg) * 640 + (c * 2 + p) * 64 + hf * 32 + (q & 31)) * 16
+
+  seen = set()
+  ntile = (Q + own - 1) // own
+  for t in range(ntile):
+    q_own = t * own
+    q_wave = q_own - 1 if halo else q_own
+    for lane in range(64):
+      col, hf = lane & 31, lane >> 5
+      q = q_wave + col
+      if not (0 <= q < Q):
+        continue
+      for cg in range(KG):
+        for c in range(5):
+          for p in range(2):
+            so = cg * 10240 + c * 2048 + p * 1024
+            if halo:
+              addr = (q >> 5) * KG * 10240 + ((q & 31) + 32 * hf) * 16 + so
+            else:
+              addr = (q_wave >> 5) * KG * 10240 + lane * 16 + so
+            assert addr == written(q, cg, c, p, hf)
+      if (not halo) or 1 <= col <= 30:
+        seen.add(q)
+  assert seen == set(range(Q))                      # every triple-cell is owned by exactly one lane
+
+
+def test_f33_xcd_map_modes_cover_every_block_once():
+  """Block -> (column block, row tile) of convlstm_step_wino3_kernel: mode 1 (two adjacent column
+  blocks per XCD), modes 2 / 3 (four / eight column blocks per XCD, every second / fourth row
+  tile; the launch rounds the row tiles up to whole groups)."""
+  ncb = 16
+  for mode, per in ((1, 2), (2, 4), (3, 8)):
+    for mtiles in (1, 2, 5, 8):
+      nt = 1 if mode == 1 else per // 2
+      mt_padded = (mtiles + nt - 1) // nt * nt
+      nblocks = mt_padded * ncb
+      seen = {}
+      for block in range(nblocks):
+        if mode == 1:
+          grp, w16 = divmod(block, 16)
+          cb = (grp % (ncb // 16)) * 16 + 2 * (w16 & 7) + (w16 >> 3)
+          mt = grp // (ncb // 16)
+        else:
+          grp, w = divmod(block, 16 * nt)
+          xcd, j = w & 7, w >> 3
+          cb = per * (xcd % (16 // per)) + j
+          mt = grp * nt + xcd // (16 // per)
+        assert 0 <= cb < ncb and 0 <= mt < mt_padded
+        assert (cb, mt) not in seen
+        seen[(cb, mt)] = block % 8                   # the XCD (round-robin dispatch)
+      assert len(seen) == nblocks
+      # the XCDs that touch a row tile (= fetch its operands): 8, 4, 2
+      for mt in range(mt_padded):
+        xcds = {x for (cb, m), x in seen.items() if m == mt}
+        assert len(xcds) == 16 // per, (mode, mt, xcds)
