@@ -50,6 +50,10 @@
 #pragma once
 #include "convlstm_wino.h"
 
+// -DMV_W3_FUSED_LSTM=0: the inference epilogue's LSTM update with separate sigmoids / tanhs (A/B)
+#ifndef MV_W3_FUSED_LSTM
+#define MV_W3_FUSED_LSTM 1
+#endif
 // -DMV_W3_ABLC=<bits> (timing-only builds of the main loop, garbage results): 1 = no operand
 // loads in the loop, 2 = no weight staging in the loop, 4 = weight fragments read once, 8 = no
 // barrier, 16 = no DPP lane shifts, 32 = operand loads always of the first fragments (cache hits)
@@ -751,17 +755,43 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
           else yv = (m1 + m2) + (4.0f * m3 + m4);
           pre[g] = __builtin_fmaf(yv, un, add[g][j]);   // un = 2^-16: the product is exact
         }
-        float si, tj, sf, so;
+        float si = 0.f, tj = 0.f, sf = 0.f, so = 0.f, cn, hn;
         if (p.abl & 32) {
           si = pre[0] * 0.25f + 0.5f; tj = pre[1] * 0.5f; sf = pre[2] * 0.25f + 0.5f;
           so = pre[3] * 0.25f + 0.5f;
+          cn = sf * cprev[e][rb][j] + si * tj;
+          hn = cn * 0.5f * so;
+        } else if (MV_W3_FUSED_LSTM && !a.gates_out) {
+          // Inference (no gate activations to save): the update over COMMON DENOMINATORS --
+          //   D_x = 1 + e^-x (x = i, f + forget bias, o),  D_j = 1 + e^-2|j|,  t = sign(j)(1 - e^-2|j|)
+          //   c' = (c D_i D_j + t D_f) / (D_i D_j D_f)
+          //   h' = sign(c')(1 - e^-2|c'|) / ((1 + e^-2|c'|) D_o)
+          // five v_exp + TWO v_rcp per element instead of five + five.  With two workgroups per
+          // CU the epilogue is bound by the quarter-rate transcendental unit (240 of them per
+          // lane and tile), not by its dependent chains.  The arguments are clamped to +-28
+          // (sigma(-28) = 7e-13: nothing at the 1e-4 bar) so that D_i D_j D_f stays finite.
+          const float kL2E = 1.4426950408889634f;
+          const float xi = fminf(fmaxf(pre[0], -28.f), 28.f);
+          const float xf = fminf(fmaxf(pre[2] + a.forget_bias, -28.f), 28.f);
+          const float xo = fminf(fmaxf(pre[3], -28.f), 28.f);
+          const float Di = 1.0f + __builtin_amdgcn_exp2f(-kL2E * xi);
+          const float Df = 1.0f + __builtin_amdgcn_exp2f(-kL2E * xf);
+          const float Do = 1.0f + __builtin_amdgcn_exp2f(-kL2E * xo);
+          const float Ej = __builtin_amdgcn_exp2f(-2.0f * kL2E * __builtin_fabsf(pre[1]));
+          const float Dj = 1.0f + Ej;
+          const float tn = __builtin_copysignf(1.0f - Ej, pre[1]);
+          const float DiDj = Di * Dj;
+          const float R = __builtin_amdgcn_rcpf(DiDj * Df);
+          cn = __builtin_fmaf(cprev[e][rb][j], DiDj, tn * Df) * R;
+          const float Ec = __builtin_amdgcn_exp2f(-2.0f * kL2E * __builtin_fabsf(cn));
+          hn = __builtin_copysignf(1.0f - Ec, cn) * __builtin_amdgcn_rcpf((1.0f + Ec) * Do);
         } else {
           si = sigm_(pre[0]); tj = tanh_(pre[1]); sf = sigm_(pre[2] + a.forget_bias);
           so = sigm_(pre[3]);
+          cn = sf * cprev[e][rb][j];
+          cn = cn + si * tj;
+          hn = tanh_(cn) * so;
         }
-        float cn = sf * cprev[e][rb][j];
-        cn = cn + si * tj;
-        const float hn = ((p.abl & 32) ? cn * 0.5f : tanh_(cn)) * so;
         cn4[j] = cn; hn4[j] = hn; si4[j] = si; tj4[j] = tj; sf4[j] = sf; so4[j] = so;
       }
       // c' and h' into the wave's two LDS tiles (the c tile was read into cprev above)

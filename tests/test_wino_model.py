@@ -572,3 +572,38 @@ def test_f33_xcd_map_modes_cover_every_block_once():
       for mt in range(mt_padded):
         xcds = {x for (cb, m), x in seen.items() if m == mt}
         assert len(xcds) == 16 // per, (mode, mt, xcds)
+
+
+def test_fused_lstm_update_of_the_f33_inference_epilogue():
+  """csrc/convlstm_wino3.h (inference, no gates to save): c' and h' over common denominators --
+  five exponentials and TWO reciprocals per element instead of five and five.  fp32 twin against
+  the fp64 definition, incl. saturated gates (the +-28 clamp keeps D_i D_j D_f finite)."""
+  rng = np.random.default_rng(0)
+  n = 200000
+  pre = (rng.normal(size=(4, n)) * 4).astype(np.float32)
+  pre[0, :50] = -80.0; pre[2, 50:100] = 90.0; pre[3, 100:150] = -100.0; pre[1, 150:200] = 50.0
+  pre[:, 200:250] = -70.0; pre[:, 250:300] = 70.0
+  c = (rng.normal(size=n) * 3).astype(np.float32)
+  f32 = np.float32
+  L = f32(1.4426950408889634)
+  xi = np.clip(pre[0], -28, 28).astype(f32)
+  xf = np.clip(pre[2] + f32(1.0), -28, 28).astype(f32)
+  xo = np.clip(pre[3], -28, 28).astype(f32)
+  Di = (f32(1) + np.exp2(-L * xi).astype(f32)).astype(f32)
+  Df = (f32(1) + np.exp2(-L * xf).astype(f32)).astype(f32)
+  Do = (f32(1) + np.exp2(-L * xo).astype(f32)).astype(f32)
+  Ej = np.exp2(f32(-2) * L * np.abs(pre[1])).astype(f32)
+  Dj = (f32(1) + Ej).astype(f32)
+  tn = np.copysign((f32(1) - Ej).astype(f32), pre[1]).astype(f32)
+  DiDj = (Di * Dj).astype(f32)
+  R = (f32(1) / (DiDj * Df).astype(f32)).astype(f32)
+  cn = ((c * DiDj + (tn * Df).astype(f32)).astype(f32) * R).astype(f32)
+  Ec = np.exp2(f32(-2) * L * np.abs(cn)).astype(f32)
+  hn = (np.copysign((f32(1) - Ec).astype(f32), cn) *
+        (f32(1) / ((f32(1) + Ec) * Do).astype(f32)).astype(f32)).astype(f32)
+  p64, c64 = pre.astype(np.float64), c.astype(np.float64)
+  sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+  rc = sig(p64[2] + 1.0) * c64 + sig(p64[0]) * np.tanh(p64[1])
+  rh = np.tanh(rc) * sig(p64[3])
+  assert np.isfinite(cn).all() and np.isfinite(hn).all()
+  assert np.abs(cn - rc).max() < 4e-6 and np.abs(hn - rh).max() < 1e-6
