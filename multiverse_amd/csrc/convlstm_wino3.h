@@ -52,7 +52,7 @@
 
 // -DMV_W3_FUSED_LSTM=0: the inference epilogue's LSTM update with separate sigmoids / tanhs (A/B)
 #ifndef MV_W3_FUSED_LSTM
-#define MV_W3_FUSED_LSTM 1
+#define MV_W3_FUSED_LSTM 0      // measured: no gain (0.640 vs 0.640 ms per launch, profiles/r5z_*)
 #endif
 // -DMV_W3_ABLC=<bits> (timing-only builds of the main loop, garbage results): 1 = no operand
 // loads in the loop, 2 = no weight staging in the loop, 4 = weight fragments read once, 8 = no
