@@ -152,7 +152,7 @@ def test_bf16_with_unbounded_activations(built_lib, act):
   gate convolutions are unbounded; bf16 keeps fp32's exponent range, so its single operand plane
   needs no per-tensor scale (the f16x3 mode's x exponent, tests/test_gpu_edge.py) -- held here:
   greedy forward (logits within the mode's 3e-2 of range, regression maps within 8e-2), a training step with finite
-  loss close to the oracle's and gradients of cosine > 0.999, and a second step that improves."""
+  that is REFUSED in bf16 and, after switching the same engine to f16x3, meets the fp32 bars."""
   cfg = synth.default_config(batch_size=2, use_grids=(1, 1), activation_func=act)
   params = synth.make_params(cfg, seed=synth.SEED_BASE + 21, recurrent_gain=2.0, bias_scale=0.1)
   feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 22)
@@ -180,20 +180,24 @@ def test_bf16_with_unbounded_activations(built_lib, act):
     # measured 4 - 5e-2 of the range (tanh: <= 3e-2); the reduced-precision mode's bar for these
     # models is 8e-2, stated here and in DESIGN.md section 3d
     assert er <= 8e-2 * rng_r or not (gi == oi).all()
+  # training such a model in bf16 is refused (engine_train.h train_fwd_bwd: the bf16 forward
+  # of an unbounded pixel-offset embedding left the regression decoder's kernel gradient at
+  # cosine 0.96, whichever backward ran); the same engine trains in f16x3 at the fp32 bars
   tcfg = synth.default_config(batch_size=2, use_grids=(1, 1), is_train=True, activation_func=act)
   tparams = synth.make_params(tcfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0, bias_scale=0.1)
   tfeed = synth.make_feed(tcfg, seed=synth.SEED_BASE + 73)
   eng = _engine(built_lib, tcfg, tparams)
   eng.train_init()
+  with pytest.raises(built_lib.MvError, match="activation_func tanh"):
+    eng.train_forward_backward(tfeed)
+  eng.set_compute_mode("f16x3")
   loss, wd, pgl = eng.train_forward_backward(tfeed)
   grads = {n: eng.get_grad(n) for n, _ in eng.param_specs()}
-  eng.train_apply(1.0)
-  loss2, _, _ = eng.train_forward_backward(tfeed)
   eng.close()
   oloss, owd, opgl, og = oracle.loss_and_grads(tparams, tcfg, tfeed)
-  print("bf16 %s train: loss %.5f oracle %.5f; after one step %.5f" % (act, loss, oloss, loss2))
-  assert abs(loss - oloss) < 2e-2 * abs(oloss) and np.isfinite(loss2) and loss2 < loss
+  print("%s model refused in bf16; f16x3 train: loss %.6f oracle %.6f" % (act, loss, oloss))
+  assert abs(loss - oloss) < 1e-4 * max(1.0, abs(oloss))
   for n in sorted(grads):
     a, b = grads[n].reshape(-1).astype(np.float64), og[n].reshape(-1).astype(np.float64)
     cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
-    assert np.isfinite(a).all() and cos > 0.999, (n, cos)
+    assert np.isfinite(a).all() and cos > 0.9999, (n, cos)
