@@ -41,7 +41,7 @@ for stage in "$@"; do
       (time timeout 1500 python -m pytest tests/test_gpu_at_size.py tests/test_gpu_wino.py tests/test_gpu_reference_pin.py -m gpu -q -s) > $O/margins.log 2>&1
       echo "margins rc $?"; grep -E "passed|failed|error" $O/margins.log | tail -3 ;;
     suite)
-      (time timeout 1500 python -m pytest tests -q -x -m gpu) > $O/gpu_tests.log 2>&1
+      (time timeout 1500 python -m pytest tests -q -m gpu) > $O/gpu_tests.log 2>&1
       echo "suite rc $?"; tail -4 $O/gpu_tests.log ;;
     parallel)
       (time timeout 1200 python -m pytest tests/test_gpu_parallel.py -m gpu -q -s) > $O/parallel_tests.log 2>&1
