@@ -1105,9 +1105,19 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
     q.gt = t.gt16.p; q.partial = t.partial.p; q.g_exp = t.chain_exp.p;
     q.a_exp = t.chain_exp.p + 1;
     q.Mrow = Mrow; q.H = H; q.W = W; q.Cx = Cx; q.C = C; q.Ca = C;
+    // the wide tile (convlstm_wgrad_f16x3.h) balances on 7 / 14 splits; the x rows and the
+    // reduction follow its count
+    const bool wide = mv::wgrad16_wide_ok(W, C);
+    if (wide) wa.nsplit = mv::wgrad16_wide_splits(Mtot, wa.nsplit);
     mv::wgrad16_plan(q, Mtot, wa.nsplit);
     launch(e, "convlstm_wgrad", 2.0 * cells * 9 * C * 4.0 * C, cells * 5.0 * C * 4.0, [&] {
-      if (one)
+      if (wide && one)
+        hipLaunchKernelGGL(mv::convlstm_wgrad_f16x3_wide_kernel<1>,
+                           dim3(mv::wgrad16_wide_blocks(q)), dim3(256), 0, e->stream, q);
+      else if (wide)
+        hipLaunchKernelGGL(mv::convlstm_wgrad_f16x3_wide_kernel<3>,
+                           dim3(mv::wgrad16_wide_blocks(q)), dim3(256), 0, e->stream, q);
+      else if (one)
         hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_kernel<false, 1>),
                            dim3(mv::wgrad16_blocks(q, false)), dim3(256), mv::kWg16LdsBytes1,
                            e->stream, q);

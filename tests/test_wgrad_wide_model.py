@@ -1,0 +1,207 @@
+"""CPU twin of the wide f16x3 wgrad tile (csrc/convlstm_wgrad_f16x3.h,
+`convlstm_wgrad_f16x3_wide_kernel`): the kernel's index arithmetic restated thread by thread in
+numpy -- block decode, the per-thread copy slots and their global addresses in the
+cell-contiguous plane layout, the swizzled LDS image, the fragment reads of each lane, the
+accumulator -> (channel, column) map of the 32x32x16 MFMA, the split ranges -- and held against
+the plain definition  dW[tap][ci][n] = sum_m h[m + d_tap][ci] G[m][n]  (reference
+code/pred_models.py:1694-1717: tf.gradients of the ConvLSTM kernel).  No GPU: this is the
+bookkeeping the GPU parity tests (tests/test_gpu_train.py, test_gpu_at_size.py) then run for
+real."""
+import numpy as np
+import pytest
+
+A_ROWS, G_ROWS = 128, 256
+
+
+def swz(row):
+  return ((row >> 1) & 3) ^ ((row >> 3) & 1)
+
+
+# lane groups of ds_read_b128 / ds_write_b128 (MI355X guide, LDS table)
+READ_GROUPS = [
+    list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+    list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+]
+READ_GROUPS += [[l + 32 for l in g] for g in READ_GROUPS]
+
+
+def test_wgrad_wide_lds_swizzle_is_conflict_free():
+  """Fragment read: lane (li, hf) reads 16 B at row base + li, chunk kk*2 + hf.  Every 16-lane
+  group must touch 16 different 16-byte slots of the 256-byte bank row; a store group of 8
+  consecutive threads (two rows x four chunks) 8 different slots of a 128-byte bank row."""
+  for base in (0, 32, 64, 96, 224):
+    for kk in range(2):
+      for grp in READ_GROUPS:
+        slots = set()
+        for lane in grp:
+          li, hf = lane & 31, lane >> 5
+          row = base + li
+          byte = (row * 4 + ((kk * 2 + hf) ^ swz(li))) * 16
+          slots.add((byte % 256) // 16)
+        assert len(slots) == 16
+  for t0 in range(0, 256, 8):
+    slots = set()
+    for tid in range(t0, t0 + 8):
+      trow, vec = tid >> 2, tid & 3
+      byte = (trow * 4 + (vec ^ swz(trow))) * 16
+      slots.add((byte % 128) // 16)
+    assert len(slots) == 8
+  # rows r and r + 64 k share the swizzle (the copy slots of a thread differ by 64 rows)
+  assert all(swz(r) == swz(r + 64) == swz(r + 128) for r in range(64))
+
+
+@pytest.mark.parametrize("C,nsplit", [(256, 7), (256, 14), (512, 7), (256, 3)])
+def test_wgrad_wide_block_decode_covers_every_tile_of_every_split_once(C, nsplit):
+  ncib, nnb = C // A_ROWS, 4 * C // G_ROWS
+  gpx = (ncib * nnb) >> 3
+  assert gpx >= 1
+  nblocks = nsplit * 9 * ncib * nnb
+  seen = set()
+  per_xcd = [0] * 8
+  for b in range(nblocks):
+    xcd, j = b & 7, b >> 3
+    group = xcd + 8 * (j % gpx)
+    j //= gpx
+    tap, split = j % 9, j // 9
+    ci0, n0 = (group % ncib) * A_ROWS, (group // ncib) * G_ROWS
+    assert split < nsplit and ci0 < C and n0 < 4 * C
+    seen.add((split, tap, ci0, n0))
+    per_xcd[xcd] += 1
+  assert len(seen) == nblocks
+  assert len(set(per_xcd)) == 1          # every XCD the same number of workgroups
+  # an XCD streams gpx (channel block, column block) pairs only
+  for xcd in range(8):
+    pairs = set()
+    for b in range(xcd, nblocks, 8):
+      j = b >> 3
+      pairs.add(xcd + 8 * (j % gpx))
+    assert len(pairs) == gpx
+
+
+def _planes(v):
+  """fp32 -> (hi, lo) fp16 planes as float64 (the kernels' split: hi = f16(v), lo = f16(v - hi))."""
+  hi = v.astype(np.float16)
+  lo = (v - hi.astype(np.float32)).astype(np.float16)
+  return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def _transpose_split(src, Mtot, Cc, Mrow, W, dx, e):
+  """transpose_split_kernel: out[plane][m >> 5][c][m & 31] = src[m + dx][c] * 2^e, zero where
+  x(m) + dx leaves the image row."""
+  out = np.zeros((2, Mrow // 32, Cc, 32))
+  m = np.arange(Mtot)
+  x = m % W
+  ok = (x + dx >= 0) & (x + dx < W) & (m + dx >= 0) & (m + dx < Mtot)
+  v = np.zeros((Mtot, Cc), np.float32)
+  v[ok] = src[(m + dx)[ok]] * np.float32(2.0 ** e)
+  hi, lo = _planes(v)
+  out[0, m >> 5, :, m & 31] = hi
+  out[1, m >> 5, :, m & 31] = lo
+  return out.reshape(2, -1)            # [plane][(m >> 5) * Cc * 32 + c * 32 + (m & 31)]
+
+
+def _wide_kernel_model(at, gt, Mrow, ksteps_total, H, W, C, ksteps_per_split, nsplit, blocks):
+  """The kernel, block by block: returns {(split, tap): [C][4C] partial} for the given blocks."""
+  N4 = 4 * C
+  wk = W // 16
+  ncib = C // A_ROWS
+  gpx = (ncib * (N4 // G_ROWS)) >> 3
+  tid = np.arange(256)
+  vec, trow = tid & 3, tid >> 2
+  wslot = trow * 4 + (vec ^ swz(trow))            # in 16-byte slots; + 64 rows: + 256 slots
+  out = {}
+  for b in blocks:
+    xcd, j = b & 7, b >> 3
+    group = xcd + 8 * (j % gpx)
+    j //= gpx
+    tap, split = j % 9, j // 9
+    ci0, n0 = (group % ncib) * A_ROWS, (group // ncib) * G_ROWS
+    dy, dxi = tap // 3 - 1, tap % 3
+    ks0 = split * ksteps_per_split
+    ks1 = min(ks0 + ksteps_per_split, ksteps_total)
+    nstages = (ks1 - ks0 + 1) // 2 if ks1 > ks0 else 0
+    acc = np.zeros((A_ROWS, G_ROWS))
+    kin = ks0 % (H * wk)
+    ly, lxk = kin // wk, kin % wk
+    for st in range(nstages):
+      ksb = ks0 + 2 * st
+      ys = []
+      for _ in range(2):
+        ys.append(ly)
+        lxk += 1
+        if lxk == wk:
+          lxk = 0
+          ly = (ly + 1) % H
+      nv = [(ksb < ks1) and 0 <= ys[0] + dy < H, (ksb + 1 < ks1) and 0 <= ys[1] + dy < H]
+      m0 = ksb * 16
+      sh = np.where(np.where(vec & 2, nv[1], nv[0]), dy * W, 0)
+      cell = m0 + vec * 8 + sh
+      ao = (cell >> 5) * (C * 32) + (cell & 31)
+      go = m0 * N4
+      ldsA = np.zeros((2, A_ROWS * 4, 8))
+      ldsG = np.zeros((2, G_ROWS * 4, 8))
+      for pl in range(2):
+        for k in range(2):
+          src = (ci0 + trow) * 32 + ao + k * 2048
+          ldsA[pl, k * 256 + wslot] = at[dxi][pl][src[:, None] + np.arange(8)]
+        for k in range(4):
+          src = (n0 + trow) * 32 + vec * 8 + go + k * 2048
+          ldsG[pl, k * 256 + wslot] = gt[pl][src[:, None] + np.arange(8)]
+      # fragments: lane (li, hf) of k-step kk reads slot (row * 4 + ((kk*2+hf) ^ swz(li)))
+      for kk in range(2):
+        if not nv[kk]:
+          continue
+        fa = np.zeros((2, A_ROWS, 16))
+        fg = np.zeros((2, G_ROWS, 16))
+        for hf in range(2):
+          for li in range(32):
+            c = (kk * 2 + hf) ^ swz(li)
+            for base in range(0, A_ROWS, 32):
+              fa[:, base + li, hf * 8:hf * 8 + 8] = ldsA[:, (base + li) * 4 + c]
+            for base in range(0, G_ROWS, 32):
+              fg[:, base + li, hf * 8:hf * 8 + 8] = ldsG[:, (base + li) * 4 + c]
+        # the three MFMAs of a product: a_lo g_hi + a_hi g_lo + a_hi g_hi
+        acc += fa[1] @ fg[0].T + fa[0] @ fg[1].T + fa[0] @ fg[0].T
+    out[(split, tap, ci0, n0)] = acc
+  return out
+
+
+@pytest.mark.parametrize("H,W,R,nsplit", [(3, 16, 3, 1), (2, 32, 4, 3), (5, 16, 2, 2)])
+def test_wgrad_wide_index_arithmetic_gives_the_weight_gradient(H, W, R, nsplit):
+  C = 256
+  N4 = 4 * C
+  rng = np.random.default_rng(17 + H * W + R)
+  Mtot = R * H * W
+  Mrow = (Mtot + 63) // 64 * 64
+  h = rng.uniform(-1, 1, (Mtot, C)).astype(np.float32)
+  g = (rng.standard_normal((Mtot, N4)) * 1e-3).astype(np.float32)
+  a_exp = 8
+  g_exp = 13 - int(np.floor(np.log2(np.abs(g).max())))
+  at = [_transpose_split(h, Mtot, C, Mrow, W, d - 1, a_exp) for d in range(3)]
+  gt = _transpose_split(g, Mtot, N4, Mrow, W, 0, g_exp)
+  ksteps_total = Mtot // 16
+  per = (ksteps_total + nsplit - 1) // nsplit
+  per = (per + 1) & ~1
+  nblocks = nsplit * 9 * (C // A_ROWS) * (N4 // G_ROWS)
+  # every tap on one (channel block, column block) per test, all splits: blocks of XCD `xcd`
+  xcd = (H + W + R) % 8
+  blocks = [b for b in range(nblocks) if (b & 7) == xcd]
+  parts = _wide_kernel_model(at, gt, Mrow, ksteps_total, H, W, C, per, nsplit, blocks)
+  scale = 2.0 ** -(a_exp + g_exp)
+  hd, gd = h.astype(np.float64), g.astype(np.float64)
+  m = np.arange(Mtot)
+  y, x = (m // W) % H, m % W
+  taps_seen = set()
+  sums = {}
+  for (split, tap, ci0, n0), acc in parts.items():
+    sums.setdefault((tap, ci0, n0), np.zeros((A_ROWS, G_ROWS)))
+    sums[(tap, ci0, n0)] += acc * scale
+    taps_seen.add(tap)
+  assert taps_seen == set(range(9))
+  for (tap, ci0, n0), got in sums.items():
+    dy, dx = tap // 3 - 1, tap % 3 - 1
+    ok = (y + dy >= 0) & (y + dy < H) & (x + dx >= 0) & (x + dx < W)
+    src = (m + dy * W + dx)[ok]
+    want = hd[src][:, ci0:ci0 + A_ROWS].T @ gd[m[ok]][:, n0:n0 + G_ROWS]
+    err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+    assert err < 2e-6, (tap, ci0, n0, err)

@@ -16,6 +16,8 @@
 #   profiles  rocprofv3 traces + PMC of greedy / beam / train (tools/profile_workload.sh)
 #   libab:<name>  headline + beam with build/variants/libmv_<name>.so against the default library
 #   ab:<ENV=V>  headline + beam with the env setting against the default, same box
+#   trainab:<ENV=V>  training parity tests, then the training step (configs[2]) with the env
+#             setting against the default, same box: ms per step and per gate kernel
 set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 T=$1; shift
@@ -77,6 +79,23 @@ PY
       bash tools/profile_workload.sh ${T}_beam --workload beam > $O/prof_beam.log 2>&1
       bash tools/profile_workload.sh ${T}_train --workload train > $O/prof_train.log 2>&1
       for w in greedy beam train; do echo "== $w"; head -8 gpurun_out/prof_${T}_$w/kernel_trace_stats.md; done ;;
+    trainab:*)
+      kv=${stage#trainab:}; k=${kv%%=*}
+      (time timeout 900 python -m pytest tests/test_gpu_train.py "tests/test_gpu_at_size.py::test_configs2_batch32_train_step_vs_oracle" -m gpu -q -x) > $O/train_tests.log 2>&1
+      echo "train tests rc $?"; grep -E "passed|failed|error" $O/train_tests.log | tail -3
+      for v in default $k default $k; do
+        f=$O/train_$v.json
+        if [ $v = default ]; then timeout 300 $BQ --workload train > $f 2> $O/train_$v.err
+        else env $kv timeout 300 $BQ --workload train > $f 2> $O/train_$v.err; fi
+        python - $f <<'PY'
+import json, sys
+try:
+  d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1]); r = d["roofline"]
+  print(sys.argv[1], d["value"], "traj/s", d["ms_per_step"], "ms/step", r.get("per_kernel_ms"), "frac", r.get("frac"))
+except Exception as e:
+  print(sys.argv[1], "unreadable:", e)
+PY
+      done ;;
     ab:*)
       kv=${stage#ab:}; k=${kv%%=*}
       for w in greedy beam; do
