@@ -171,7 +171,8 @@ struct Wgrad16Args {
   int32_t H, W, Cx, C;
   int32_t Ca;                // channels of the A operand: C (h rows) or Cx (x rows)
   int32_t ksteps_per_split;  // even
-  int32_t nsplit;            // multiple of 8 (split -> XCD), or the wide kernel's 7 / 14
+  int32_t nsplit;            // multiple of 8 (split -> XCD), or the wide kernel's own count
+  int32_t map_mode;          // wide kernel: tiles -> XCDs (0 by group, 1 by split, 2 mixed)
 };
 
 constexpr int kWg16Pitch = 40;                         // halves per LDS row (32 cells + pad)
@@ -444,16 +445,32 @@ void convlstm_wgrad_f16x3_wide_kernel(const Wgrad16Args a) {
   const int wi = wave >> 1, wj = wave & 1;
   const int H = a.H, W = a.W, C = a.C, N4 = 4 * C;
   const int wk = W / 16;
-  const int ncib = C / kWgwA;
-  const int gpx = (ncib * (N4 / kWgwG)) >> 3;          // (channel, column) groups per XCD
+  const int ncib = C / kWgwA, nnb = N4 / kWgwG;
   const int xcd = blockIdx.x & 7;
   int j = blockIdx.x >> 3;
-  const int group = xcd + 8 * (j % gpx);
-  j /= gpx;
-  const int tap = j % 9;
-  const int split = j / 9;
-  const int ci0 = (group % ncib) * kWgwA;
-  const int n0 = (group / ncib) * kWgwG;
+  int tap, split, cib, nb;
+  if (a.map_mode == 1) {             // split -> XCD: every operand byte through ONE L2
+    const int tps = 9 * ncib * nnb;
+    split = xcd + 8 * (j / tps);
+    j %= tps;
+    tap = j % 9; j /= 9;
+    cib = j % ncib; nb = j / ncib;
+  } else if (a.map_mode == 2) {      // (channel block, split mod 4) -> XCD; ncib == 2
+    const int tps = 9 * nnb;
+    cib = xcd & 1;
+    split = (xcd >> 1) + 4 * (j / tps);
+    j %= tps;
+    tap = j % 9; nb = j / 9;
+  } else {                           // (channel block, column block) -> XCD
+    const int gpx = (ncib * nnb) >> 3;
+    const int group = xcd + 8 * (j % gpx);
+    j /= gpx;
+    tap = j % 9;
+    split = j / 9;
+    cib = group % ncib; nb = group / ncib;
+  }
+  const int ci0 = cib * kWgwA;
+  const int n0 = nb * kWgwG;
   const int dy = tap / 3 - 1;
   const long long Mrow = a.Mrow;
 
@@ -594,11 +611,18 @@ static inline bool wgrad16_wide_ok(int W, int C) {
 // Split count of the wide kernel: 9 taps x nsplit workgroups per XCD and (channel, column) group
 // on 64 slots -- 7 splits = one full round, 14 = two, 21 = three -- never more than the planned count
 // (the partial buffer), and at least ~64 k-steps per split.
-static inline int wgrad16_wide_splits(long long Mtot, int planned) {
-  if (const char* ev = getenv("MV_WGRAD_WIDE_SPLITS")) {
-    const int v = atoi(ev);
-    if (v >= 1 && v <= planned) return v;
-  }
+static inline int wgrad16_wide_map_mode(int C) {
+  static const int m = getenv("MV_WGRAD_WIDE_MAP") ? atoi(getenv("MV_WGRAD_WIDE_MAP")) : 0;
+  if (m == 2 && C != 2 * kWgwA) return 0;
+  return m >= 0 && m <= 2 ? m : 0;
+}
+static inline int wgrad16_wide_splits(long long Mtot, int planned, int map_mode) {
+  int v = 0;
+  if (const char* ev = getenv("MV_WGRAD_WIDE_SPLITS")) v = atoi(ev);
+  const int mult = map_mode == 1 ? 8 : (map_mode == 2 ? 4 : 1);
+  if (v >= 1 && v <= planned && v % mult == 0) return v;
+  if (map_mode == 1) return planned;                 // a multiple of 8 by construction
+  if (map_mode == 2) return planned >= 20 ? 20 : (planned / 4) * 4;
   // measured (training step configs[2], profiles/r5wg_*): the wide kernel takes the same time
   // at 7, 14 and 21 splits; the x rows kernel, which follows the count, is fastest at 21
   const long long ks = Mtot / 16;

@@ -1108,7 +1108,10 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
     // the wide tile (convlstm_wgrad_f16x3.h) balances on 7 / 14 splits; the x rows and the
     // reduction follow its count
     const bool wide = mv::wgrad16_wide_ok(W, C);
-    if (wide) wa.nsplit = mv::wgrad16_wide_splits(Mtot, wa.nsplit);
+    if (wide) {
+      q.map_mode = mv::wgrad16_wide_map_mode(C);
+      wa.nsplit = mv::wgrad16_wide_splits(Mtot, wa.nsplit, q.map_mode);
+    }
     mv::wgrad16_plan(q, Mtot, wa.nsplit);
     launch(e, "convlstm_wgrad", 2.0 * cells * 9 * C * 4.0 * C, cells * 5.0 * C * 4.0, [&] {
       if (wide && one)

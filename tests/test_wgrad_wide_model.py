@@ -50,32 +50,56 @@ def test_wgrad_wide_lds_swizzle_is_conflict_free():
   assert all(swz(r) == swz(r + 64) == swz(r + 128) for r in range(64))
 
 
-@pytest.mark.parametrize("C,nsplit", [(256, 7), (256, 14), (512, 7), (256, 3)])
-def test_wgrad_wide_block_decode_covers_every_tile_of_every_split_once(C, nsplit):
+def decode(b, C, map_mode):
+  """blockIdx -> (split, tap, channel block, column block), the kernel's three XCD maps."""
   ncib, nnb = C // A_ROWS, 4 * C // G_ROWS
+  xcd, j = b & 7, b >> 3
+  if map_mode == 1:
+    tps = 9 * ncib * nnb
+    split = xcd + 8 * (j // tps)
+    j %= tps
+    tap, j = j % 9, j // 9
+    return split, tap, j % ncib, j // ncib
+  if map_mode == 2:
+    tps = 9 * nnb
+    split = (xcd >> 1) + 4 * (j // tps)
+    j %= tps
+    return split, j % 9, xcd & 1, j // 9
   gpx = (ncib * nnb) >> 3
-  assert gpx >= 1
+  group = xcd + 8 * (j % gpx)
+  j //= gpx
+  return j // 9, j % 9, group % ncib, group // ncib
+
+
+@pytest.mark.parametrize("C,nsplit,map_mode", [(256, 7, 0), (256, 21, 0), (512, 7, 0), (256, 3, 0),
+                                               (256, 24, 1), (512, 8, 1), (256, 20, 2),
+                                               (256, 4, 2)])
+def test_wgrad_wide_block_decode_covers_every_tile_of_every_split_once(C, nsplit, map_mode):
+  ncib, nnb = C // A_ROWS, 4 * C // G_ROWS
   nblocks = nsplit * 9 * ncib * nnb
   seen = set()
   per_xcd = [0] * 8
+  streams = [set() for _ in range(8)]      # (operand, block, split) an XCD's L2 sees
   for b in range(nblocks):
-    xcd, j = b & 7, b >> 3
-    group = xcd + 8 * (j % gpx)
-    j //= gpx
-    tap, split = j % 9, j // 9
-    ci0, n0 = (group % ncib) * A_ROWS, (group // ncib) * G_ROWS
-    assert split < nsplit and ci0 < C and n0 < 4 * C
-    seen.add((split, tap, ci0, n0))
-    per_xcd[xcd] += 1
+    split, tap, cib, nb = decode(b, C, map_mode)
+    assert 0 <= split < nsplit and 0 <= tap < 9 and cib < ncib and nb < nnb
+    seen.add((split, tap, cib, nb))
+    per_xcd[b & 7] += 1
+    streams[b & 7].add(("G", nb, split))
+    streams[b & 7].add(("A", cib, split))
   assert len(seen) == nblocks
   assert len(set(per_xcd)) == 1          # every XCD the same number of workgroups
-  # an XCD streams gpx (channel block, column block) pairs only
-  for xcd in range(8):
-    pairs = set()
-    for b in range(xcd, nblocks, 8):
-      j = b >> 3
-      pairs.add(xcd + 8 * (j % gpx))
-    assert len(pairs) == gpx
+  # operand bytes through the eight L2s, in units of (one column block | channel block) x split:
+  # G blocks weigh 256 columns, A blocks 3 x 128 rows
+  traffic = sum(256 if o == "G" else 384 for st in streams for (o, _, _) in st)
+  unique = nsplit * (nnb * 256 + ncib * 384)
+  ratio = traffic / unique
+  if map_mode == 1:
+    assert ratio == 1.0
+  elif map_mode == 2:
+    assert ratio < 1.6
+  elif C == 256:
+    assert 2.8 < ratio < 2.9             # every XCD streams a quarter of G and half of A: 20 / 7
 
 
 def _planes(v):
@@ -100,22 +124,18 @@ def _transpose_split(src, Mtot, Cc, Mrow, W, dx, e):
   return out.reshape(2, -1)            # [plane][(m >> 5) * Cc * 32 + c * 32 + (m & 31)]
 
 
-def _wide_kernel_model(at, gt, Mrow, ksteps_total, H, W, C, ksteps_per_split, nsplit, blocks):
+def _wide_kernel_model(at, gt, Mrow, ksteps_total, H, W, C, ksteps_per_split, nsplit, blocks,
+                       map_mode=0):
   """The kernel, block by block: returns {(split, tap): [C][4C] partial} for the given blocks."""
   N4 = 4 * C
   wk = W // 16
-  ncib = C // A_ROWS
-  gpx = (ncib * (N4 // G_ROWS)) >> 3
   tid = np.arange(256)
   vec, trow = tid & 3, tid >> 2
   wslot = trow * 4 + (vec ^ swz(trow))            # in 16-byte slots; + 64 rows: + 256 slots
   out = {}
   for b in blocks:
-    xcd, j = b & 7, b >> 3
-    group = xcd + 8 * (j % gpx)
-    j //= gpx
-    tap, split = j % 9, j // 9
-    ci0, n0 = (group % ncib) * A_ROWS, (group // ncib) * G_ROWS
+    split, tap, cib, nb = decode(b, C, map_mode)
+    ci0, n0 = cib * A_ROWS, nb * G_ROWS
     dy, dxi = tap // 3 - 1, tap % 3
     ks0 = split * ksteps_per_split
     ks1 = min(ks0 + ksteps_per_split, ksteps_total)
@@ -184,8 +204,10 @@ def test_wgrad_wide_index_arithmetic_gives_the_weight_gradient(H, W, R, nsplit):
   per = (per + 1) & ~1
   nblocks = nsplit * 9 * (C // A_ROWS) * (N4 // G_ROWS)
   # every tap on one (channel block, column block) per test, all splits: blocks of XCD `xcd`
-  xcd = (H + W + R) % 8
-  blocks = [b for b in range(nblocks) if (b & 7) == xcd]
+  # every tap and split of ONE (channel block, column block)
+  pick = ((H + R) % 2, (W // 16 + R) % 4)
+  blocks = [b for b in range(nblocks) if decode(b, C, 0)[2:] == pick]
+  assert len(blocks) == 9 * nsplit
   parts = _wide_kernel_model(at, gt, Mrow, ksteps_total, H, W, C, per, nsplit, blocks)
   scale = 2.0 ** -(a_exp + g_exp)
   hd, gd = h.astype(np.float64), g.astype(np.float64)
