@@ -95,6 +95,59 @@ void transpose_split_kernel(const float* __restrict__ in, _Float16* __restrict__
   }
 }
 
+// The three column-shifted copies (dx = -1, 0, +1) of one operand from ONE read: the block
+// stages its 64 cells plus one neighbour each side.  Same arithmetic per element as
+// transpose_split_kernel (bit-identical planes); grid (Mrow/64, Cc/64).
+__global__ __launch_bounds__(256)
+void transpose_split3_kernel(const float* __restrict__ in, _Float16* __restrict__ out0,
+                             _Float16* __restrict__ out1, _Float16* __restrict__ out2,
+                             long long Mtot, int Cc, long long Mrow, int W,
+                             const int32_t* __restrict__ exp_ptr, int exp_const, int nplanes) {
+  __shared__ float tile[66][65];                   // tile[j] = cell m0 - 1 + j
+  const int e = exp_ptr ? exp_ptr[0] : exp_const;
+  const float sc2e = __int_as_float((127 + e) << 23);
+  const long long m0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  const int lc = (tid & 15) * 4, lj = tid >> 4;
+#pragma unroll
+  for (int pass = 0; pass < 5; ++pass) {
+    const int j = pass * 16 + lj;
+    if (j < 66) {
+      const long long src = m0 - 1 + j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (src >= 0 && src < Mtot) v = *reinterpret_cast<const f32x4*>(in + (size_t)src * Cc + c0 + lc);
+      tile[j][lc + 0] = v[0]; tile[j][lc + 1] = v[1];
+      tile[j][lc + 2] = v[2]; tile[j][lc + 3] = v[3];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    _Float16* const out = d == 0 ? out0 : (d == 1 ? out1 : out2);
+    const int dx = d - 1;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = it * 256 + tid;
+      const int ch = item >> 3, grp = item & 7;
+      f16x8 p0, p1;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const long long m = m0 + grp * 8 + q;
+        const int x = (int)(m % W);
+        const bool ok = (m < Mtot) & (x + dx >= 0) & (x + dx < W);
+        const float sv = ok ? tile[grp * 8 + q + 1 + dx][ch] * sc2e : 0.f;
+        const _Float16 h0 = (_Float16)sv;
+        p0[q] = h0;
+        p1[q] = (_Float16)(sv - (float)h0);
+      }
+      const size_t o = wg16_plane_index(m0 + grp * 8, c0 + ch, Cc);
+      *reinterpret_cast<f16x8*>(out + o) = p0;
+      if (nplanes == 2) *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow + o) = p1;
+    }
+  }
+}
+
 // the same for a narrow tensor (Cc < 64, any Cc): one block = 64 cells x all channels
 __global__ __launch_bounds__(256)
 void transpose_split_narrow_kernel(const float* __restrict__ in, _Float16* __restrict__ out,
@@ -432,7 +485,11 @@ __host__ __device__ __forceinline__ constexpr int wgw_swz(int row) {
   return ((row >> 1) & 3) ^ ((row >> 3) & 1);
 }
 
-template <int NP>         // 3: both planes (f16x3); 1: the leading plane only (compute mode 2)
+// NP = 3: both planes (f16x3); 1: the leading plane only (compute mode 2).
+// XROWS: the x rows -- tile rows enumerate (tap, channel) pairs R = tap * Cx + ci < 9 Cx, so each
+// copy slot has its own operand copy / row shift and an invalid (row, k-step) is staged as zeros
+// (the kernel above, same rule); tiles in plain order (5 x 4 per split at Cx = 64).
+template <int NP, bool XROWS = false>
 __global__ __launch_bounds__(256, 2)
 void convlstm_wgrad_f16x3_wide_kernel(const Wgrad16Args a) {
   constexpr int NPL = NP == 1 ? 1 : 2;
@@ -443,13 +500,19 @@ void convlstm_wgrad_f16x3_wide_kernel(const Wgrad16Args a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 1, wj = wave & 1;
-  const int H = a.H, W = a.W, C = a.C, N4 = 4 * C;
+  const int H = a.H, W = a.W, C = a.C, N4 = 4 * C, Ca = a.Ca;
   const int wk = W / 16;
   const int ncib = C / kWgwA, nnb = N4 / kWgwG;
   const int xcd = blockIdx.x & 7;
   int j = blockIdx.x >> 3;
-  int tap, split, cib, nb;
-  if (a.map_mode == 1) {             // split -> XCD: every operand byte through ONE L2
+  int tap = 4, split, cib = 0, nb, rb = 0;
+  if (XROWS) {
+    const int nrb = (9 * Ca + kWgwA - 1) / kWgwA;
+    j = blockIdx.x;
+    nb = j % nnb; j /= nnb;
+    rb = j % nrb;
+    split = j / nrb;
+  } else if (a.map_mode == 1) {             // split -> XCD: every operand byte through ONE L2
     const int tps = 9 * ncib * nnb;
     split = xcd + 8 * (j / tps);
     j %= tps;
@@ -489,9 +552,24 @@ void convlstm_wgrad_f16x3_wide_kernel(const Wgrad16Args a) {
 
   // copy slots of a thread: row (tid >> 2) + 64 k of an operand plane, 8-cell chunk tid & 3
   const int vec = tid & 3, trow = tid >> 2;
-  const _Float16* const abase = a.at[tap - (tap / 3) * 3] + (size_t)(ci0 + trow) * 32;
+  const _Float16* abase[2];                            // slot k: tile row trow + 64 k
+  int dyq[2];                                          // XROWS: its row shift (huge = dead row)
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (XROWS) {
+      const int R = rb * kWgwA + k * 64 + trow;
+      const bool live = R < 9 * Ca;
+      const int tp = live ? R / Ca : 4;
+      const int ci = live ? R - tp * Ca : 0;
+      dyq[k] = live ? tp / 3 - 1 : (1 << 20);
+      abase[k] = a.at[tp - (tp / 3) * 3] + (size_t)ci * 32;
+    } else {
+      dyq[k] = dy;
+      abase[k] = a.at[tap - (tap / 3) * 3] + (size_t)(ci0 + k * 64 + trow) * 32;
+    }
+  }
   const _Float16* const gbase = a.gt + (size_t)(n0 + trow) * 32 + vec * 8;
-  const size_t apl = (size_t)C * Mrow, gpl = (size_t)N4 * Mrow;     // plane strides
+  const size_t apl = (size_t)Ca * Mrow, gpl = (size_t)N4 * Mrow;    // plane strides
   const int wslot = (trow * 4 + (vec ^ wgw_swz(trow))) * 8;         // halves; + 64 rows: + 2048
   static_assert(wgw_swz(64) == 0 && wgw_swz(5 + 64) == wgw_swz(5), "row + 64 keeps its swizzle");
 
@@ -508,22 +586,32 @@ void convlstm_wgrad_f16x3_wide_kernel(const Wgrad16Args a) {
     const int ksb = ks0 + 2 * st;
     const int y0 = ly; advance(ly, lxk);
     const int y1 = ly; advance(ly, lxk);
-    nv0 = (ksb < ks1) & ((unsigned)(y0 + dy) < (unsigned)H);
-    nv1 = (ksb + 1 < ks1) & ((unsigned)(y1 + dy) < (unsigned)H);
+    const bool in0 = ksb < ks1, in1 = ksb + 1 < ks1;
+    nv0 = in0 & (XROWS || (unsigned)(y0 + dy) < (unsigned)H);
+    nv1 = in1 & (XROWS || (unsigned)(y1 + dy) < (unsigned)H);
     const int m0 = ksb * 16;                           // one 32-cell block
-    const int sh = ((vec & 2) ? nv1 : nv0) ? dy * W : 0;   // a skipped k-step: unshifted
-    const int cell = m0 + vec * 8 + sh;
-    const size_t ao = (size_t)(cell >> 5) * ((size_t)C * 32) + (size_t)(cell & 31);
     const size_t go = (size_t)m0 * N4;
+    const int ysel = (vec & 2) ? y1 : y0;
+    const bool insel = (vec & 2) ? in1 : in0;
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) {
+    for (int k = 0; k < 2; ++k) {
+      // h rows: a skipped k-step loads unshifted (never multiplied); x rows: zeros
+      const bool ok = XROWS ? (insel & ((unsigned)(ysel + dyq[k]) < (unsigned)H))
+                            : ((vec & 2) ? nv1 : nv0);
+      const int cell = m0 + vec * 8 + (ok ? dyq[k] * W : 0);
+      const size_t ao = (size_t)(cell >> 5) * ((size_t)Ca * 32) + (size_t)(cell & 31);
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
-        sa[pl * 2 + k] = *reinterpret_cast<const f16x8*>(abase + pl * apl + ao + k * 2048);
+      for (int pl = 0; pl < NPL; ++pl) {
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (!XROWS || ok) v = *reinterpret_cast<const f16x8*>(abase[k] + pl * apl + ao);
+        sa[pl * 2 + k] = v;
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         sg[pl * 4 + k] = *reinterpret_cast<const f16x8*>(gbase + pl * gpl + go + k * 2048);
-    }
   };
   auto stage_store = [&]() {
 #pragma unroll
@@ -600,7 +688,15 @@ void convlstm_wgrad_f16x3_wide_kernel(const Wgrad16Args a) {
         const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         const int r = wi * 64 + x * 32 + i;
         const int n = n0 + wj * 128 + y * 32 + (lane & 31);
-        ps[((size_t)tap * Cin + a.Cx + ci0 + r) * N4 + n] = acc[x][y][reg] * scale;
+        if (XROWS) {
+          const int R = rb * kWgwA + r;
+          if (R < 9 * Ca) {
+            const int tp = R / Ca, ci = R - tp * Ca;
+            ps[((size_t)tp * Cin + ci) * N4 + n] = acc[x][y][reg] * scale;
+          }
+        } else {
+          ps[((size_t)tap * Cin + a.Cx + ci0 + r) * N4 + n] = acc[x][y][reg] * scale;
+        }
       }
 }
 
@@ -630,8 +726,18 @@ static inline int wgrad16_wide_splits(long long Mtot, int planned, int map_mode)
   if (planned >= 14 && ks >= 14 * 64) return 14;
   return planned >= 7 ? 7 : planned;
 }
-static inline unsigned wgrad16_wide_blocks(const Wgrad16Args& a) {
+static inline unsigned wgrad16_wide_blocks(const Wgrad16Args& a, bool xrows = false) {
+  if (xrows)
+    return (unsigned)a.nsplit * (unsigned)((9 * a.Ca + kWgwA - 1) / kWgwA) *
+           (unsigned)(4 * a.C / kWgwG);
   return (unsigned)a.nsplit * 9u * (unsigned)(a.C / kWgwA) * (unsigned)(4 * a.C / kWgwG);
+}
+// The x rows on the wide tile measured the same as on the 128 x 128 tile (2.59 vs 2.56 ms per
+// training step, profiles/r5wg_wgrad_wide_tile_ab.md: 20 fat workgroups per split fill the chip
+// worse than 40 small ones, which eats the tile's gain): off unless MV_WGRAD_WIDE_X=1.
+static inline bool wgrad16_wide_x_enabled() {
+  static const bool on = getenv("MV_WGRAD_WIDE_X") && atoi(getenv("MV_WGRAD_WIDE_X")) == 1;
+  return on;
 }
 
 constexpr size_t kWg16LdsBytes = (size_t)2 * 2 * kWg16Tile * sizeof(_Float16);   // 80 KB

@@ -1078,6 +1078,12 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
       hipLaunchKernelGGL(mv::transpose_split_kernel, dim3((unsigned)(Mrow / 64), 4 * C / 64),
                          dim3(256), 0, e->stream, ch.gates.p, t.gt16.p, Mtot, 4 * C, Mrow, W,
                          0, t.chain_exp.p, 0, t.bias_part.p, npl);
+      static const bool fused3 = !(getenv("MV_TRANSPOSE3") && atoi(getenv("MV_TRANSPOSE3")) == 0);
+      if (fused3)     // the three column-shifted copies of h from one read
+        hipLaunchKernelGGL(mv::transpose_split3_kernel, dim3((unsigned)(Mrow / 64), C / 64),
+                           dim3(256), 0, e->stream, hin, t.at16[0].p, t.at16[1].p, t.at16[2].p,
+                           Mtot, C, Mrow, W, (const int32_t*)nullptr, 8, npl);
+      else
       for (int d = 0; d < 3; ++d)
         hipLaunchKernelGGL(mv::transpose_split_kernel, dim3((unsigned)(Mrow / 64), C / 64),
                            dim3(256), 0, e->stream, hin, t.at16[d].p, Mtot, C, Mrow, W,
@@ -1089,6 +1095,11 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
         hipLaunchKernelGGL(mv::chain_exp_kernel, dim3(1), dim3(64), 0, e->stream,
                            t.chain_exp.p + 64, 1, 64, t.chain_exp.p + 2);
       }
+      if (Cx && Cx % 64 == 0 && fused3)
+        hipLaunchKernelGGL(mv::transpose_split3_kernel, dim3((unsigned)(Mrow / 64), Cx / 64),
+                           dim3(256), 0, e->stream, ch.xs.p, t.xt16[0].p, t.xt16[1].p,
+                           t.xt16[2].p, Mtot, Cx, Mrow, W, t.chain_exp.p + 2, 0, npl);
+      else
       for (int d = 0; d < 3 && Cx; ++d) {
         if (Cx % 64 == 0)
           hipLaunchKernelGGL(mv::transpose_split_kernel, dim3((unsigned)(Mrow / 64), Cx / 64),
@@ -1135,7 +1146,13 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
       qx.Ca = Cx; qx.a_exp = t.chain_exp.p + 2;
       launch(e, "convlstm_wgrad_x", 2.0 * cells * 9 * Cx * 4.0 * C,
              cells * (Cx + 4.0 * C) * 4.0, [&] {
-        if (one)
+        if (wide && mv::wgrad16_wide_x_enabled() && one)
+          hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_wide_kernel<1, true>),
+                             dim3(mv::wgrad16_wide_blocks(qx, true)), dim3(256), 0, e->stream, qx);
+        else if (wide && mv::wgrad16_wide_x_enabled())
+          hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_wide_kernel<3, true>),
+                             dim3(mv::wgrad16_wide_blocks(qx, true)), dim3(256), 0, e->stream, qx);
+        else if (one)
           hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_kernel<true, 1>),
                              dim3(mv::wgrad16_blocks(qx, true)), dim3(256), mv::kWg16LdsBytes1,
                              e->stream, qx);

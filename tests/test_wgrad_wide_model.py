@@ -125,18 +125,41 @@ def _transpose_split(src, Mtot, Cc, Mrow, W, dx, e):
 
 
 def _wide_kernel_model(at, gt, Mrow, ksteps_total, H, W, C, ksteps_per_split, nsplit, blocks,
-                       map_mode=0):
-  """The kernel, block by block: returns {(split, tap): [C][4C] partial} for the given blocks."""
+                       map_mode=0, xrows=False, Ca=None):
+  """The kernel, block by block.  h rows: {(split, tap, ci0, n0): [128][256] partial}; x rows
+  (tile rows enumerate (tap, channel) pairs): {(split, rb, n0): [128][256]}."""
   N4 = 4 * C
+  Ca = C if Ca is None else Ca
   wk = W // 16
+  nnb = N4 // G_ROWS
+  nrb = (9 * Ca + A_ROWS - 1) // A_ROWS
   tid = np.arange(256)
   vec, trow = tid & 3, tid >> 2
   wslot = trow * 4 + (vec ^ swz(trow))            # in 16-byte slots; + 64 rows: + 256 slots
   out = {}
   for b in blocks:
-    split, tap, cib, nb = decode(b, C, map_mode)
-    ci0, n0 = cib * A_ROWS, nb * G_ROWS
-    dy, dxi = tap // 3 - 1, tap % 3
+    if xrows:
+      j = b
+      nb, j = j % nnb, j // nnb
+      rb, split = j % nrb, j // nrb
+      n0 = nb * G_ROWS
+    else:
+      split, tap, cib, nb = decode(b, C, map_mode)
+      ci0, n0 = cib * A_ROWS, nb * G_ROWS
+    # copy slot k of a thread: tile row trow + 64 k -> (operand copy, channel row, row shift)
+    slot_dx, slot_ci, slot_dy = [], [], []
+    for k in range(2):
+      if xrows:
+        R = rb * A_ROWS + k * 64 + trow
+        live = R < 9 * Ca
+        tp = np.where(live, R // Ca, 4)
+        slot_ci.append(np.where(live, R - tp * Ca, 0))
+        slot_dy.append(np.where(live, tp // 3 - 1, 1 << 20))
+        slot_dx.append(tp % 3)
+      else:
+        slot_ci.append(ci0 + k * 64 + trow)
+        slot_dy.append(np.full(256, tap // 3 - 1))
+        slot_dx.append(np.full(256, tap % 3))
     ks0 = split * ksteps_per_split
     ks1 = min(ks0 + ksteps_per_split, ksteps_total)
     nstages = (ks1 - ks0 + 1) // 2 if ks1 > ks0 else 0
@@ -152,18 +175,33 @@ def _wide_kernel_model(at, gt, Mrow, ksteps_total, H, W, C, ksteps_per_split, ns
         if lxk == wk:
           lxk = 0
           ly = (ly + 1) % H
-      nv = [(ksb < ks1) and 0 <= ys[0] + dy < H, (ksb + 1 < ks1) and 0 <= ys[1] + dy < H]
+      inr = [ksb < ks1, ksb + 1 < ks1]
+      if xrows:
+        nv = inr
+      else:
+        dy = tap // 3 - 1
+        nv = [inr[0] and 0 <= ys[0] + dy < H, inr[1] and 0 <= ys[1] + dy < H]
       m0 = ksb * 16
-      sh = np.where(np.where(vec & 2, nv[1], nv[0]), dy * W, 0)
-      cell = m0 + vec * 8 + sh
-      ao = (cell >> 5) * (C * 32) + (cell & 31)
       go = m0 * N4
+      ysel = np.where(vec & 2, ys[1], ys[0])
+      insel = np.where(vec & 2, inr[1], inr[0])
       ldsA = np.zeros((2, A_ROWS * 4, 8))
       ldsG = np.zeros((2, G_ROWS * 4, 8))
+      for k in range(2):
+        if xrows:
+          ok = insel & (ysel + slot_dy[k] >= 0) & (ysel + slot_dy[k] < H)
+        else:
+          ok = np.where(vec & 2, nv[1], nv[0])
+        cell = m0 + vec * 8 + np.where(ok, slot_dy[k] * W, 0)
+        ao = (cell >> 5) * (Ca * 32) + (cell & 31)
+        src = slot_ci[k] * 32 + ao
+        for pl in range(2):
+          vals = np.stack([at[d][pl][src[:, None] + np.arange(8)] for d in range(3)])
+          v = vals[slot_dx[k], np.arange(256)]
+          if xrows:
+            v = np.where(ok[:, None], v, 0.0)
+          ldsA[pl, k * 256 + wslot] = v
       for pl in range(2):
-        for k in range(2):
-          src = (ci0 + trow) * 32 + ao + k * 2048
-          ldsA[pl, k * 256 + wslot] = at[dxi][pl][src[:, None] + np.arange(8)]
         for k in range(4):
           src = (n0 + trow) * 32 + vec * 8 + go + k * 2048
           ldsG[pl, k * 256 + wslot] = gt[pl][src[:, None] + np.arange(8)]
@@ -182,7 +220,7 @@ def _wide_kernel_model(at, gt, Mrow, ksteps_total, H, W, C, ksteps_per_split, ns
               fg[:, base + li, hf * 8:hf * 8 + 8] = ldsG[:, (base + li) * 4 + c]
         # the three MFMAs of a product: a_lo g_hi + a_hi g_lo + a_hi g_hi
         acc += fa[1] @ fg[0].T + fa[0] @ fg[1].T + fa[0] @ fg[0].T
-    out[(split, tap, ci0, n0)] = acc
+    out[(split, rb, n0) if xrows else (split, tap, ci0, n0)] = acc
   return out
 
 
@@ -227,3 +265,44 @@ def test_wgrad_wide_index_arithmetic_gives_the_weight_gradient(H, W, R, nsplit):
     want = hd[src][:, ci0:ci0 + A_ROWS].T @ gd[m[ok]][:, n0:n0 + G_ROWS]
     err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
     assert err < 2e-6, (tap, ci0, n0, err)
+
+
+@pytest.mark.parametrize("H,W,R,nsplit,Cx", [(3, 16, 3, 2, 64), (2, 32, 3, 1, 2), (4, 16, 2, 3, 32)])
+def test_wgrad_wide_x_rows_tile_rows_enumerate_tap_channel_pairs(H, W, R, nsplit, Cx):
+  """The x rows on the wide tile (XROWS): rows R = tap * Cx + ci, every copy slot with its own
+  operand copy and row shift, invalid (row, k-step) pairs staged as zeros."""
+  C = 256
+  N4 = 4 * C
+  rng = np.random.default_rng(5 + H * W + R + Cx)
+  Mtot = R * H * W
+  Mrow = (Mtot + 63) // 64 * 64
+  x = (rng.standard_normal((Mtot, Cx)) * 3).astype(np.float32)
+  g = (rng.standard_normal((Mtot, N4)) * 1e-3).astype(np.float32)
+  a_exp = 13 - int(np.floor(np.log2(np.abs(x).max())))
+  g_exp = 13 - int(np.floor(np.log2(np.abs(g).max())))
+  at = [_transpose_split(x, Mtot, Cx, Mrow, W, d - 1, a_exp) for d in range(3)]
+  gt = _transpose_split(g, Mtot, N4, Mrow, W, 0, g_exp)
+  ksteps_total = Mtot // 16
+  per = (ksteps_total + nsplit - 1) // nsplit
+  per = (per + 1) & ~1
+  nrb, nnb = (9 * Cx + A_ROWS - 1) // A_ROWS, N4 // G_ROWS
+  nb_pick = (H + R) % nnb
+  blocks = [b for b in range(nsplit * nrb * nnb) if b % nnb == nb_pick]
+  parts = _wide_kernel_model(at, gt, Mrow, ksteps_total, H, W, C, per, nsplit, blocks,
+                             xrows=True, Ca=Cx)
+  scale = 2.0 ** -(a_exp + g_exp)
+  got = np.zeros((nrb * A_ROWS, G_ROWS))
+  for (split, rb, n0), acc in parts.items():
+    assert n0 == nb_pick * G_ROWS
+    got[rb * A_ROWS:(rb + 1) * A_ROWS] += acc * scale
+  assert np.all(got[9 * Cx:] == 0)              # dead rows of the last tile
+  xd, gd = x.astype(np.float64), g.astype(np.float64)
+  m = np.arange(Mtot)
+  y, xx = (m // W) % H, m % W
+  for tap in range(9):
+    dy, dx = tap // 3 - 1, tap % 3 - 1
+    ok = (y + dy >= 0) & (y + dy < H) & (xx + dx >= 0) & (xx + dx < W)
+    src = (m + dy * W + dx)[ok]
+    want = xd[src].T @ gd[m[ok]][:, nb_pick * G_ROWS:(nb_pick + 1) * G_ROWS]
+    err = np.abs(got[tap * Cx:(tap + 1) * Cx] - want).max() / max(np.abs(want).max(), 1e-30)
+    assert err < 2e-6, (tap, err)
