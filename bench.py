@@ -665,7 +665,7 @@ def spawn_ranks(n, argv):
   env.setdefault("OMP_NUM_THREADS", "4")
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
          "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-         "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+         "--master-port", str(free_port()), os.path.abspath(sys.argv[0])] + argv
   return subprocess.call(cmd, env=env)
 
 

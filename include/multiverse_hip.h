@@ -86,7 +86,11 @@ typedef struct mv_config {
    * 0 = tanh (published), 1 = relu, 2 = lrelu (tf.nn.leaky_relu, alpha 0.2).  relu / lrelu
    * outputs are unbounded: in compute mode 1 their x operand planes carry a per-tensor
    * power-of-two scale taken from max |x| (DESIGN.md section 3c "x exponent"), so every
-   * compute mode accepts them. */
+   * compute mode DECODES them.  TRAINING such a model in compute mode 2 (bf16) is refused
+   * -- by mv_train_init on an engine already in mode 2, by mv_set_compute_mode(h, 2) on a
+   * training engine -- because one 8-bit-mantissa plane of an unbounded embedding costs the
+   * regression decoder's kernel gradient too much (cosine 0.96 vs the fp32 oracle): train
+   * them in mode 1. */
   int32_t activation;
 } mv_config;
 
@@ -384,7 +388,8 @@ int  mv_op_convlstm_step(int device, const float* x, const float* c,
                          int32_t Cx, int32_t C, float* c_out, float* h_out);
 /* The same step on the fp16 matrix pipe at fp32 accuracy (f16x3 operand planes):
  * variant 1 = direct 3x3 form, 2 = Winograd F(2,3) over image rows (W must divide 32),
- * 3 = Winograd F(3,3) over image rows (W must divide 32, H >= 3; csrc/convlstm_wino3.h).
+ * 3 = Winograd F(3,3) over image rows (any W -- widths that do not divide 32 take the halo
+ * tiling, operands below 2 GiB --, H >= 3; csrc/convlstm_wino3.h).
  * h16_out (optional) [M,H,W,C]: the h' OPERAND PLANES the kernel emitted for the next
  * step, decoded back to fp32 ((hi + lo) / 256), so that a test sees the plane layout. */
 int  mv_op_convlstm_step16(int device, int32_t variant, const float* x, const float* c,

@@ -42,25 +42,21 @@ inline RcclApi& rccl() {
     // an RCCL already in the process first (NOLOAD matches by SONAME), then ROCm's
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
                            "/opt/rocm/lib/librccl.so"};
-    // MV_RCCL_LIB=<path>: exactly that library and no other (the single-GPU tests put a
-    // shared-memory stand-in there, tests/fake_rccl, so that the bucketed all-reduce can run
-    // with two ranks on one device -- real RCCL refuses duplicate devices)
-    // A test hook: honoured only together with MV_ALLOW_RCCL_OVERRIDE=1, and announced on
-    // stderr, so that a stray environment variable cannot silently redirect the gradient
-    // all-reduce of a production job to another shared object.
+#ifdef MV_TEST_HOOKS
+    // MV_RCCL_LIB=<path> -- ONLY in -DMV_TEST_HOOKS builds (tests/fake_rccl/
+    // libmultiverse_hip_testhooks.so): exactly that library and no other.  The single-GPU
+    // tests put a shared-memory stand-in there (tests/fake_rccl) so that the bucketed
+    // all-reduce can run with two ranks on one device -- real RCCL refuses duplicate devices.
+    // The shipped library does not read the variable: no environment setting can redirect the
+    // gradient all-reduce of a production job to another shared object.
     if (const char* forced = getenv("MV_RCCL_LIB")) {
-      const char* allow = getenv("MV_ALLOW_RCCL_OVERRIDE");
-      if (!allow || atoi(allow) != 1) {
-        a.error = "MV_RCCL_LIB is set but MV_ALLOW_RCCL_OVERRIDE=1 is not: refusing to bind a "
-                  "replacement for librccl (test hook, INTEGRATION.md)";
-        return a;
-      }
       h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
       if (!h) { a.error = std::string("MV_RCCL_LIB: ") + dlerror(); return a; }
       a.where = std::string(forced) + " (MV_RCCL_LIB)";
-      fprintf(stderr, "[multiverse_hip] WARNING: collectives bound to %s instead of librccl "
-              "(MV_RCCL_LIB + MV_ALLOW_RCCL_OVERRIDE: test hook)\n", forced);
+      fprintf(stderr, "[multiverse_hip] TEST-HOOKS BUILD: collectives bound to %s instead of "
+              "librccl\n", forced);
     }
+#endif
     if (!h)
     for (const char* n : names)
       if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) { a.where = std::string(n) + " (already loaded)"; break; }

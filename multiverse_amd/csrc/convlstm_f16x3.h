@@ -259,19 +259,6 @@ __global__ void split_planes_group_kernel(const SplitGroup g) {
 #ifndef MV_BF16_ADIST
 #define MV_BF16_ADIST 1          // bf16 kernel: A operands requested this many k-steps ahead (2: measured -1.5 %)
 #endif
-// Ablation builds of the gate kernel (tools/ablate_gate_kernel.sh):
-// -DMV_ABL=<bits> removes one ingredient of the main loop at a time so that what each
-// costs the matrix pipe can be read off PMC counters on the real launch geometry.  Results
-// of such a build are garbage by construction; the shipped library is MV_ABL=0.
-//   1  no A operand loads   (the fragments of the first k-step stay in their registers)
-//   2  no B LDS reads       (the fragments of the first k-step stay in their registers)
-//   4  no stage DMA, no per-stage barrier (every stage reads LDS buffer 0, filled once)
-//   8  no epilogue          (accumulators folded into one never-taken store)
-//  16  epilogue without the c state loads          32  without the c' / h' fp32 stores
-//  64  epilogue without the h' operand planes     128  without sigmoid / tanh (mul-adds)
-#ifndef MV_ABL
-#define MV_ABL 0
-#endif
 // Cache policy of the three streams (gfx940+ aux bits of the buffer builtins: 1 = sc0,
 // 2 = nt, 16 = sc1): the weight stage DMA, the epilogue's read-once c state and its
 // write-once c' / h' / gate stores.  Tuned per DESIGN.md section 5.
@@ -284,10 +271,6 @@ __global__ void split_planes_group_kernel(const SplitGroup g) {
 #ifndef MV_EPI_ST_AUX
 #define MV_EPI_ST_AUX 0
 #endif
-constexpr bool kAblNoA = (MV_ABL & 1) != 0, kAblNoB = (MV_ABL & 2) != 0,
-               kAblNoDma = (MV_ABL & 4) != 0, kAblNoEpi = (MV_ABL & 8) != 0,
-               kAblNoCLoad = (MV_ABL & 16) != 0, kAblNoStore = (MV_ABL & 32) != 0,
-               kAblNoPlanes = (MV_ABL & 64) != 0, kAblNoMath = (MV_ABL & 128) != 0;
 constexpr int kWaves16 = MV_CONV_WAVES;           // waves per workgroup of the f16x3 kernels
 constexpr int kThreads16 = kWaves16 * 64;
 constexpr int kBlockRows16 = kWaves16 * kWaveRows; // cells per workgroup
@@ -528,17 +511,9 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, SHIFT ? 1 : 0, cc0, cc1);
     if constexpr (NPL == 1) cc1 = cc0;
     __syncthreads();                       // carries the vmcnt(0) of the pending LDS-DMA
-    f16x8 ab0[NG], ab1[NG];                // MV_ABL & 2 only
-    if constexpr (kAblNoB) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        ab0[g] = lds[(0 * NG + g) * 64 + lane];
-        ab1[g] = lds[((NPL - 1) * NG + g) * 64 + lane];
-      }
-    }
     for (int sg = 0; sg < nsg; ++sg) {
       const bool more = sg + 1 < nsg;
-      const f16x8* buf = lds + (kAblNoDma ? 0 : (sg & 1)) * kBufVec;
+      const f16x8* buf = lds + (sg & 1) * kBufVec;
 #pragma unroll
       for (int u = 0; u < R; ++u) {
       const int st = st_lo + sg * R + u;
@@ -548,8 +523,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       const bool n_rowok = stage_rowok(stn);
       f16x8 cn0, cn1;                      // SHIFT: centre fragments of the next stage
       if constexpr (SHIFT) {
-        if constexpr (kAblNoA) { cn0 = cc0; cn1 = cc1; }
-        else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 1, cn0, cn1);   // (re-read at the very end)
+        MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 1, cn0, cn1);   // (re-read at the very end)
         if constexpr (NPL == 1) cn1 = cn0;
       }
 #pragma unroll
@@ -565,20 +539,17 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
           }
         } else {
           fa0 = cc0; fa1 = cc1;            // loaded one k-step ago
-          if constexpr (!kAblNoA) {
-            if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, cc0, cc1);
-            else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 0, cc0, cc1);
-          }
+          if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, cc0, cc1);
+          else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 0, cc0, cc1);
         }
         // the DMA of the next stage goes out behind the first k-step's operands (vmcnt
         // retires in order); its target buffer was last read before the previous barrier
-        if (kq == 1 && more && !kAblNoDma)
+        if (kq == 1 && more)
           stage_dma(st_lo + (sg + 1) * R, lds + ((sg + 1) & 1) * kBufVec);
         if constexpr (NPL == 2) {
           f16x8 b0[NG], b1[NG];
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
-            if constexpr (kAblNoB) { b0[g] = ab0[g]; b1[g] = ab1[g]; continue; }
             b0[g] = buf[((kq * 2 + 0) * NG + g) * 64 + lane];
             b1[g] = buf[((kq * 2 + 1) * NG + g) * 64 + lane];
           }
@@ -614,7 +585,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         }
       }
       }
-      if constexpr (!kAblNoDma) __syncthreads();
+      __syncthreads();
     }
     }
   }
@@ -625,15 +596,6 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   // stage loop runs at the 128-VGPR edge of two 8-wave workgroups per CU).
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
-  if constexpr (kAblNoEpi) {               // keep every accumulator live, store nothing
-    float sum = 0.f;
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sum += acc[g][i];
-    if (sum == 12345.678f) a.h_out[0] = sum;
-    return;
-  }
 
   if constexpr (EPI == kEpiStore) {
     // NPL == 1: bf16 operands are unscaled (bf16 has fp32's exponent range)
@@ -713,7 +675,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       const int rc = (reg & 3) + 8 * (reg >> 2);
       const bool wrapped = rc + 4 * half >= wrap_at;
       cprev[reg] = 0.f;
-      if (!a.zero_state && !kAblNoCLoad)
+      if (!a.zero_state)
         cprev[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
             c_rs, (int)(c_off0 + (wrapped ? c_wrap : 0u) + (uint32_t)rc * rowb), 0,
             MV_EPI_LD_AUX));
@@ -768,21 +730,14 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         } else {
           gi += bi; gj += bj; gf += bf; go += bo;
         }
-        float si, tj, sf, so;
-        if constexpr (kAblNoMath) {
-          si = gi * 0.25f + 0.5f; tj = gj * 0.5f; sf = gf * 0.25f + 0.5f; so = go * 0.25f + 0.5f;
-        } else {
-          si = sigm_(gi); tj = tanh_(gj); sf = sigm_(gf + a.forget_bias); so = sigm_(go);
-        }
+        const float si = sigm_(gi), tj = tanh_(gj), sf = sigm_(gf + a.forget_bias), so = sigm_(go);
         float cn = sf * cprev[reg];
         cn = cn + si * tj;
-        const float hn = (kAblNoMath ? cn * 0.5f : tanh_(cn)) * so;
+        const float hn = tanh_(cn) * so;
         const int o_off = (int)(o_off0 + (uint32_t)rc * rowb);
-        if (!kAblNoStore || cn == 12345.678f) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, cn), co_rs, o_off, 0, MV_EPI_ST_AUX);
         if (!a.skip_h32)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hn), ho_rs, o_off, 0, MV_EPI_ST_AUX);
-        }
         hn_keep = m < M_total ? hn : 0.f;
         if (a.gates_out) {
           const uint32_t g0 = ((uint32_t)(m_wave + row) * 4u * (uint32_t)C + ch) * 4u;
@@ -796,7 +751,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
                                                 (int)(g0 + 3 * rowb), 0, MV_EPI_ST_AUX);
         }
       }
-      if (p.h16_out && !kAblNoPlanes) {
+      if (p.h16_out) {
         // operand planes of h' for the next step: the wave's 32 cells x 32 channels are
         // two plane tiles (32 cells x 16 channels, [k half][cell][8 ch]); a lane holds
         // ONE channel of 16 cells, so the tile is assembled in LDS (the weight stage
@@ -816,7 +771,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
         }
       }
     }
-    if (p.h16_out && !kAblNoPlanes) {
+    if (p.h16_out) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS ops of a wave retire in order
       const size_t tile0 = ((size_t)(m_wave >> 5) * (size_t)(C >> 4) + (size_t)cb * 2) * 512;
 #pragma unroll

@@ -45,16 +45,6 @@
 #pragma once
 #include "convlstm_f16x3.h"
 
-// -DMV_WINO_ABLC=<bits>: compile-time ablations of the MAIN LOOP for the energy attribution of
-// the gate kernel (tools/gpu_session_r5a.sh; results of such builds are garbage, only time and
-// package power are read): 1 = no input transform (the raw rows serve as the components),
-// 2 = no DPP lane shifts (the centre fragment serves all three dx), 4 = no weight ds_reads
-// (fragments read once in front of the loop), 8 = one MFMA per product instead of three,
-// 16 = no global activation loads in the loop, 32 = no L2 -> LDS weight staging in the loop.
-#ifndef MV_WINO_ABLC
-#define MV_WINO_ABLC 0
-#endif
-
 namespace mv {
 
 // Waves per workgroup (template parameter WAVES): 8 waves = 256 pair-cells share one weight
@@ -75,10 +65,6 @@ struct ConvLstmWinoArgs {
   const _Float16* v3h;     // wino3_transform_kernel): components of the x / h planes, or null
   int32_t n_xc;            // 16-channel x chunks present in the pack (0 when x_small)
   int32_t nks_main, nks_x; // dgrad: split-K slices of the d h column blocks / of the d x blocks
-  int32_t abl;             // MV_WINO_ABL (timing ablations, results are garbage): 1 = no main
-                           // loop, 2 = no epilogue (accumulators folded into a never-taken
-                           // store), 4 = no c loads, 8 = no c' / h' / gate stores, 16 = no h'
-                           // plane stores, 32 = sigmoid / tanh replaced by mul-adds
 };
 
 struct ConvLstmWinoGroup {
@@ -127,22 +113,6 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, _Float16* __restri
   const size_t base = ((((size_t)cb16 * nst + s) * 2 + ci) * 3 + dx) * (2 * 2 * 64 * 8);
   out[base + ((size_t)(0 * 2 + rb) * 64 + l) * 8 + e] = v0;
   out[base + ((size_t)(1 * 2 + rb) * 64 + l) * 8 + e] = v1;
-}
-
-// MV_WINO_ABL runs without the epilogue's stores: operand planes of pseudo-random values
-// shaped like h (engine.hip mv_set_compute_mode), so that the matrix pipe draws the power it
-// draws on real data.
-__global__ void abl_fill_planes_kernel(_Float16* __restrict__ p0, _Float16* __restrict__ p1,
-                                       size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t x = (uint32_t)i * 2654435761u + 0x9e3779b9u;
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  const float u = (float)(int32_t)x * (1.0f / 2147483648.0f);          // (-1, 1)
-  const float v = 256.0f * u * (0.25f + 0.75f * u * u);                // tanh-ish spread
-  const _Float16 h0 = (_Float16)v;
-  p0[i] = h0;
-  p1[i] = (_Float16)(v - (float)h0);
 }
 
 // a - b on packed halves as ONE v_pk_fma_f16 (b * -1 + a, exactly rounded like the
@@ -308,7 +278,7 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
   // ---- f16 chunks of 16 input channels: x chunks first, then h chunks
   const int nxc = p.n_xc;
   int ck_lo = a.sx_corr ? nxc : 0;                          // sparse x: table terms instead
-  int ck_hi = (p.abl & 1) ? ck_lo : (a.zero_state ? nxc : nxc + (C >> 4));
+  int ck_hi = a.zero_state ? nxc : nxc + (C >> 4);
   if (EPI == kEpiStore && n_kslice > 1) {                   // dgrad split-K: equal chunk ranges
     const int per = (C >> 4) / n_kslice;
     ck_lo = kslice * per;
@@ -361,24 +331,18 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
 #define MV_WN_COMP(COMP, CI, VHI, VLO, BUF)                                                   \
   do {                                                                                        \
     _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                        \
-      const bool sh = dx != 1 && !(MV_WINO_ABLC & 2);                                         \
+      const bool sh = dx != 1;                                                                \
       const f16x8 b0 = !sh ? (VHI) : wn_lane_shift((VHI), dx == 0, dx == 0 ? okx0 : okx2);    \
       const f16x8 b1 = !sh ? (VLO) : wn_lane_shift((VLO), dx == 0, dx == 0 ? okx0 : okx2);    \
       f16x8 w0[2], w1[2];                                                                     \
       _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) {                                      \
-        if (MV_WINO_ABLC & 4) {                                                               \
-          w0[rb] = wfix[rb]; w1[rb] = wfix[2 + rb];                                           \
-        } else {                                                                              \
-          w0[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 0) * 2 + rb) * 64 + lane];                   \
-          w1[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 1) * 2 + rb) * 64 + lane];                   \
-        }                                                                                     \
+        w0[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 0) * 2 + rb) * 64 + lane];                     \
+        w1[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 1) * 2 + rb) * 64 + lane];                     \
       }                                                                                       \
-      if (!(MV_WINO_ABLC & 8)) {                                                              \
-        _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                      \
-          acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[rb], b0, acc[COMP][rb], 0, 0, 0); \
-        _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                      \
-          acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b1, acc[COMP][rb], 0, 0, 0); \
-      }                                                                                       \
+      _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                        \
+        acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[rb], b0, acc[COMP][rb], 0, 0, 0); \
+      _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                        \
+        acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b1, acc[COMP][rb], 0, 0, 0); \
       _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                        \
         acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b0, acc[COMP][rb], 0, 0, 0); \
     }                                                                                         \
@@ -392,44 +356,23 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
     load_raw(ck_lo);
     stage_dma(2 * ck_lo, bufA);
     __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
-    f16x8 wfix[4];                           // MV_WINO_ABLC & 4: the only weight fragments read
-    if (MV_WINO_ABLC & 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wfix[i] = bufA[i * 64 + lane];
-    }
     {
     for (int ck = ck_lo; ck < ck_hi; ++ck) {
       const bool more = ck + 1 < ck_hi;
       f16x8 vh0, vl0, vh1, vl1;
-      if (MV_WINO_ABLC & 16) {               // loop-invariant operands must not be hoisted
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(raw[i][0]), "+v"(raw[i][1]));
-      }
-      if (MV_WINO_ABLC & 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(wfix[i]));
-      }
       // stage A: components 0, 1
-      if (!(MV_WINO_ABLC & 32)) stage_dma(2 * ck + 1, bufB);   // its buffer was last read before the barrier
-      if (MV_WINO_ABLC & 1) {
-        vh0 = raw[0][0]; vl0 = raw[0][1]; vh1 = raw[1][0]; vl1 = raw[1][1];
-      } else {
+      stage_dma(2 * ck + 1, bufB);           // its buffer was last read before the barrier
       wn_combine<true>(raw[0][0], raw[0][1], raw[2][0], raw[2][1], m1, vh0, vl0);   // d(-1) - d(+1)
       wn_combine<false>(raw[1][0], raw[1][1], raw[2][0], raw[2][1], m1, vh1, vl1);  // d(0) + d(+1)
-      }
       MV_WN_COMP(0, 0, vh0, vl0, bufA);
       MV_WN_COMP(1, 1, vh1, vl1, bufA);
       __syncthreads();
       // stage B: components 2, 3
-      if (MV_WINO_ABLC & 1) {
-        vh0 = raw[2][0]; vl0 = raw[2][1]; vh1 = raw[3][0]; vl1 = raw[3][1];
-      } else {
       wn_combine<true>(raw[2][0], raw[2][1], raw[1][0], raw[1][1], m1, vh0, vl0);   // d(+1) - d(0)
       wn_combine<true>(raw[1][0], raw[1][1], raw[3][0], raw[3][1], m1, vh1, vl1);   // d(0) - d(+2)
-      }
       if (more) {
-        if (!(MV_WINO_ABLC & 32)) stage_dma(2 * ck + 2, bufA);
-        if (!(MV_WINO_ABLC & 16)) load_raw(ck + 1);   // a whole stage (36 MFMAs) ahead of its use
+        stage_dma(2 * ck + 2, bufA);
+        load_raw(ck + 1);                    // a whole stage (36 MFMAs) ahead of its use
       }
       MV_WN_COMP(2, 0, vh0, vl0, bufB);
       MV_WN_COMP(3, 1, vh1, vl1, bufB);
@@ -448,17 +391,6 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
 #undef MV_WN_COMP
   }
   if (!wave_live) return;
-  if (p.abl & 2) {                          // keep every accumulator live, store nothing
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sum += acc[c][rb][i];
-    if (sum == 12345.678f) a.h_out[0] = sum;
-    return;
-  }
 
   if constexpr (EPI == kEpiStore) {
     // registers of acc[c][rb]: output column cb*64 + rb*32 + 8*(reg >> 2) + 4*half + (reg & 3)
@@ -562,7 +494,7 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
   for (int e = 0; e < 2; ++e)
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) cprev[e][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (!a.zero_state && !(p.abl & 4)) {
+  if (!a.zero_state) {
     // the tile was requested before the main loop; its barriers carried the vmcnt(0) -- the
     // explicit wait covers a launch without f16 chunks
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -639,23 +571,17 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
           const float yv = e == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
           pre[g] = __builtin_fmaf(yv, un, add[g][j]);   // un = 2^-16: the product is exact
         }
-        float si, tj, sf, so;
-        if (p.abl & 32) {
-          si = pre[0] * 0.25f + 0.5f; tj = pre[1] * 0.5f; sf = pre[2] * 0.25f + 0.5f;
-          so = pre[3] * 0.25f + 0.5f;
-        } else {
-          si = sigm_(pre[0]); tj = tanh_(pre[1]); sf = sigm_(pre[2] + a.forget_bias);
-          so = sigm_(pre[3]);
-        }
+        const float si = sigm_(pre[0]), tj = tanh_(pre[1]), sf = sigm_(pre[2] + a.forget_bias),
+                    so = sigm_(pre[3]);
         float cn = sf * cprev[e][rb][j];
         cn = cn + si * tj;
-        const float hn = ((p.abl & 32) ? cn * 0.5f : tanh_(cn)) * so;
+        const float hn = tanh_(cn) * so;
         cn4[j] = cn; hn4[j] = hn; si4[j] = si; tj4[j] = tj; sf4[j] = sf; so4[j] = so;
       }
       // c' and h' into the wave's two LDS tiles (the c tile was read into cprev above)
       *reinterpret_cast<f32x4*>(tl0 + wr_idx + e * 512 + rb * 8) = cn4;
       if (!a.skip_h32) *reinterpret_cast<f32x4*>(tl1 + wr_idx + e * 512 + rb * 8) = hn4;
-      if (a.gates_out && okc[e] && !(p.abl & 8)) {
+      if (a.gates_out && okc[e]) {
         // training forward: the four gate activations [m][4][C] (stored from the lane)
         const uint32_t g0 = (mcell * 4u * (uint32_t)C + (uint32_t)ch) * 4u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, si4), go_rs, (int)g0,
@@ -683,7 +609,7 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
   }
   // ---- c' / h' out: four lanes per cell, 64 contiguous bytes each
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (!(p.abl & 8)) {
+  {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const u32x4 cv = *reinterpret_cast<const u32x4*>(tl0 + rd_idx + k * 256);
@@ -701,7 +627,7 @@ __device__ __forceinline__ void convlstm_wino_body(const ConvLstmWinoArgs& p, in
   // cells; v_permlane32_swap hands the lower half-wave the complete vectors of the e = 0 cells
   // and the upper half-wave those of the e = 1 cells: every store is 16 bytes per lane, the 32
   // lanes of a half-wave one contiguous 512-byte run per plane.
-  if (planes && !(p.abl & 16)) {
+  if (planes) {
     const uint32_t mc = (uint32_t)(r * HW + (half_e ? cell[1] : cell[0]));
     const bool okp = half_e ? okc[1] : okc[0];
     const size_t o0 = ((size_t)(mc >> 5) * (size_t)(C >> 4) + (size_t)cb16) * 512 +
@@ -755,13 +681,10 @@ void convlstm_step_wino_kernel(const ConvLstmWinoGroup g) {
   }
 }
 
-// MV_WINO_WAVES = 4 | 8: waves per workgroup.  4 (two workgroups per CU, twice the L2 -> LDS
-// weight traffic) measured +2 ... +4 % on the greedy workload in five same-box sessions, equal
-// on beam-20 and training: the default.
-static inline int wino_waves() {
-  static const int w = getenv("MV_WINO_WAVES") ? atoi(getenv("MV_WINO_WAVES")) : 4;
-  return w == 8 ? 8 : 4;
-}
+// Waves per workgroup: 4 (two workgroups per CU, twice the L2 -> LDS weight traffic of one
+// 8-wave workgroup) measured +2 ... +4 % on the greedy workload in five same-box sessions of
+// round 4, equal on beam-20 and training; the 8-wave build is gone.
+static inline int wino_waves() { return 4; }
 
 static inline size_t wino_lds_bytes(int waves) {
   return (size_t)2 * kWnStageBytes + (size_t)waves * 4096;
@@ -791,8 +714,6 @@ static inline bool wino_geometry_ok(const ConvLstmArgs& a) {
 // this when it packs the weights, i.e. never inside a graph capture)
 static inline void wino_init_attributes() {
   static const bool done = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_step_wino_kernel<8>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_lds_bytes(8));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_step_wino_kernel<4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_lds_bytes(4));
     return true;
@@ -805,7 +726,6 @@ static inline void launch_convlstm_wino_steps(const ConvLstmWinoArgs* probs, int
   ConvLstmWinoGroup g{};
   g.n = n;
   const int waves = wino_waves();
-  static const int abl = getenv("MV_WINO_ABL") ? atoi(getenv("MV_WINO_ABL")) : 0;
   // MV_WINO_MAP: block -> column block map (1, default: the two halves of a 128-byte state
   // line on one XCD)
   static const int map_mode = getenv("MV_WINO_MAP") ? atoi(getenv("MV_WINO_MAP")) : 1;
@@ -813,18 +733,13 @@ static inline void launch_convlstm_wino_steps(const ConvLstmWinoArgs* probs, int
   unsigned total = 0;
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
-    g.p[i].abl = abl;
     total += convlstm_wino_blocks(probs[i].b.f, waves);
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
   wino_init_attributes();
-  if (waves == 8)
-    hipLaunchKernelGGL(convlstm_step_wino_kernel<8>, dim3(total), dim3(512), wino_lds_bytes(8),
-                       stream, g);
-  else
-    hipLaunchKernelGGL(convlstm_step_wino_kernel<4>, dim3(total), dim3(256), wino_lds_bytes(4),
-                       stream, g);
+  hipLaunchKernelGGL(convlstm_step_wino_kernel<4>, dim3(total), dim3(256), wino_lds_bytes(4),
+                     stream, g);
 }
 
 // ------------------------------------------------------------------ dgrad in Winograd form
@@ -933,19 +848,13 @@ static inline void launch_convlstm_wino_dgrads(const ConvLstmWinoArgs* probs, in
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
   static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_dgrad_wino_kernel<8>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_lds_bytes(8));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_dgrad_wino_kernel<4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_lds_bytes(4));
     return true;
   }();
   (void)attr;
-  if (waves == 8)
-    hipLaunchKernelGGL(convlstm_dgrad_wino_kernel<8>, dim3(total), dim3(512), wino_lds_bytes(8),
-                       stream, g);
-  else
-    hipLaunchKernelGGL(convlstm_dgrad_wino_kernel<4>, dim3(total), dim3(256), wino_lds_bytes(4),
-                       stream, g);
+  hipLaunchKernelGGL(convlstm_dgrad_wino_kernel<4>, dim3(total), dim3(256), wino_lds_bytes(4),
+                     stream, g);
 }
 
 }  // namespace mv

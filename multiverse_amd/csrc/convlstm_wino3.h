@@ -50,17 +50,6 @@
 #pragma once
 #include "convlstm_wino.h"
 
-// -DMV_W3_FUSED_LSTM=0: the inference epilogue's LSTM update with separate sigmoids / tanhs (A/B)
-#ifndef MV_W3_FUSED_LSTM
-#define MV_W3_FUSED_LSTM 0      // measured: no gain (0.640 vs 0.640 ms per launch, profiles/r5z_*)
-#endif
-// -DMV_W3_ABLC=<bits> (timing-only builds of the main loop, garbage results): 1 = no operand
-// loads in the loop, 2 = no weight staging in the loop, 4 = weight fragments read once, 8 = no
-// barrier, 16 = no DPP lane shifts, 32 = operand loads always of the first fragments (cache hits)
-#ifndef MV_W3_ABLC
-#define MV_W3_ABLC 0
-#endif
-
 namespace mv {
 
 template <int NRB>
@@ -427,7 +416,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   // stages walk through the pairs (0,1) (2,3) (4,0) (1,2) (3,4), a switch picks the pair.
   const int nxc = p.n_xc;
   const int ck_lo = a.sx_corr ? nxc : 0;                          // sparse x: table terms instead
-  const int ck_hi = (p.abl & 1) ? ck_lo : (a.zero_state ? nxc : nxc + (C >> 4));
+  const int ck_hi = a.zero_state ? nxc : nxc + (C >> 4);
   if (ck_hi > ck_lo) {
     static_assert(NRB == 2, "stage copy: 24 pieces of 64 vectors");
     const int G_total = (ck_hi - ck_lo) * 5;
@@ -479,7 +468,6 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     // component g of the sequence (clamped to the last one: a request past the end fetches
     // that component again)
     auto vload = [&](int g, Vc& v) {
-      if (MV_W3_ABLC & 32) g = 0;            // timing: every request hits the same (cached) KB
       const int gc = g < G_total ? g : G_total - 1;
       const int ck = ck_lo + gc / 5, comp = gc - (gc / 5) * 5;
       const bool is_x = ck < nxc;
@@ -489,45 +477,17 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       v.l = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
                                           is_x ? vxrs : vhrs, (int)(is_x ? vo_x : vo_h), so + 1024, 0));
     };
-    // L2 prefetch of the fragments TWO stages ahead: one dword per lane of each of the four
-    // 1 KB runs (every 128-byte line of them) -- their first real request, a stage later, then
-    // hits the XCD's L2 instead of waiting for HBM / Infinity Cache in front of the next barrier
-    // (the operand loads were the largest single item of the main loop: removing them took
-    // 0.567 -> 0.450 ms per launch, profiles/r5s_*).  Four registers, consumed a stage later.
-#ifndef MV_W3_TOUCH
-#define MV_W3_TOUCH 0      // measured: 4 % SLOWER (0.682 vs 0.641 ms per launch, profiles/r5v_*)
-#endif
-    uint32_t pft[4] = {0u, 0u, 0u, 0u};
-    auto vtouch = [&](int g) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int gg = g + u;
-        const int gc = gg < G_total ? gg : G_total - 1;
-        const int ck = ck_lo + gc / 5, comp = gc - (gc / 5) * 5;
-        const bool is_x = ck < nxc;
-        const int so = (is_x ? ck : ck - nxc) * 10240 + comp * 2048;
-        pft[2 * u + 0] = __builtin_amdgcn_raw_buffer_load_b32(is_x ? vxrs : vhrs,
-                                                               (int)(is_x ? vo_x : vo_h), so, 0);
-        pft[2 * u + 1] = __builtin_amdgcn_raw_buffer_load_b32(is_x ? vxrs : vhrs,
-                                                               (int)(is_x ? vo_x : vo_h), so + 1024, 0);
-      }
-    };
     // one component: 3 dx x NRB row blocks x 3 MFMAs from stage buffer `buf`, slot ci
 #define MV_W3_COMP(COMP, CI, VHI, VLO, BUF)                                                   \
   do {                                                                                        \
     _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                        \
-      const bool sh_ = dx != 1 && !(MV_W3_ABLC & 16);                                         \
+      const bool sh_ = dx != 1;                                                               \
       const f16x8 b0 = !sh_ ? (VHI) : wn_lane_shift((VHI), dx == 0, dx == 0 ? okx0 : okx2);   \
       const f16x8 b1 = !sh_ ? (VLO) : wn_lane_shift((VLO), dx == 0, dx == 0 ? okx0 : okx2);   \
       f16x8 w0[NRB], w1[NRB];                                                                 \
       _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) {                                    \
-        if (MV_W3_ABLC & 4) {                                                                 \
-          asm volatile("" : "+v"(wfix[rb]), "+v"(wfix[2 + rb]));                              \
-          w0[rb] = wfix[rb]; w1[rb] = wfix[2 + rb];                                           \
-        } else {                                                                              \
-          w0[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 0) * NRB + rb) * 64 + lane];                 \
-          w1[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 1) * NRB + rb) * 64 + lane];                 \
-        }                                                                                     \
+        w0[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 0) * NRB + rb) * 64 + lane];                   \
+        w1[rb] = (BUF)[((((CI) * 3 + dx) * 2 + 1) * NRB + rb) * 64 + lane];                   \
       }                                                                                       \
       _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                      \
         acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[rb], b0, acc[COMP][rb], 0, 0, 0); \
@@ -537,88 +497,28 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
         acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b0, acc[COMP][rb], 0, 0, 0); \
     }                                                                                         \
   } while (0)
-    // -DMV_W3_PF=1 (A/B builds): the low-plane weight fragments of a (component, dx) group are
-    // requested ONE GROUP AHEAD (8 more registers), so that a group's first two MFMAs (w1 x b0)
-    // issue at once and its high-plane reads land behind them; groups pinned by sched_barrier
-#ifndef MV_W3_PF
-#define MV_W3_PF 0
-#endif
-
-#define MV_W3_GROUP(COMP, CI, DX, VHI, VLO, BUF, NEXT, NCI, NDX)                              \
-  do {                                                                                        \
-    const f16x8 b0 = (DX) == 1 ? (VHI) : wn_lane_shift((VHI), (DX) == 0, (DX) == 0 ? okx0 : okx2); \
-    const f16x8 b1 = (DX) == 1 ? (VLO) : wn_lane_shift((VLO), (DX) == 0, (DX) == 0 ? okx0 : okx2); \
-    f16x8 w0[NRB], w1c[NRB];                                                                  \
-    _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) {                                      \
-      w1c[rb] = w1p[rb];                                                                      \
-      w0[rb] = (BUF)[((((CI) * 3 + (DX)) * 2 + 0) * NRB + rb) * 64 + lane];                   \
-    }                                                                                         \
-    if (NEXT) {                                                                               \
-      _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                      \
-        w1p[rb] = (BUF)[((((NCI) * 3 + (NDX)) * 2 + 1) * NRB + rb) * 64 + lane];              \
-    }                                                                                         \
-    __builtin_amdgcn_sched_barrier(0);       /* every request of the group first */          \
-    _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                        \
-      acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1c[rb], b0, acc[COMP][rb], 0, 0, 0); \
-    _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                        \
-      acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b1, acc[COMP][rb], 0, 0, 0); \
-    _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                        \
-      acc[COMP][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[rb], b0, acc[COMP][rb], 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);                                                        \
-  } while (0)
     // one stage: components CA (slot 0) and CB (slot 1; CB < 0: the sequence's last, single
     // component); the next stage's weights and fragments are requested first
 #define MV_W3_STAGE(CA, CB)                                                                   \
   do {                                                                                        \
     f16x8* const buf = lds + ((st & 1) ? kStageVec : 0);                                      \
     f16x8* const nbuf = lds + ((st & 1) ? 0 : kStageVec);                                     \
-    const bool touch_ = MV_W3_TOUCH && st + 2 < S_total;                                      \
-    if (MV_W3_TOUCH) asm volatile("" :: "v"(pft[0]), "v"(pft[1]), "v"(pft[2]), "v"(pft[3]));  \
     if (st + 1 < S_total) {                                                                   \
-      if (!(MV_W3_ABLC & 2)) stage_dma(st + 1, nbuf);   /* its buffer was last read before the barrier */ \
-      if (!(MV_W3_ABLC & 1)) { vload(2 * st + 2, na); vload(2 * st + 3, nb); }   /* a whole stage ahead */ \
-      else asm volatile("" : "+v"(na.h), "+v"(na.l), "+v"(nb.h), "+v"(nb.l));                 \
+      stage_dma(st + 1, nbuf);          /* its buffer was last read before the barrier */     \
+      vload(2 * st + 2, na); vload(2 * st + 3, nb);      /* a whole stage ahead */            \
     }                                                                                         \
-    if (touch_) {        /* the YOUNGEST four requests of the stage: the barrier leaves them */ \
-      __builtin_amdgcn_sched_barrier(0);                                                      \
-      vtouch(2 * st + 4);                                                                     \
-      __builtin_amdgcn_sched_barrier(0);                                                      \
-    }                                                                                         \
-    if (MV_W3_PF) {                                                                           \
-      f16x8 w1p[NRB];                                                                         \
-      _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) w1p[rb] = buf[(1 * NRB + rb) * 64 + lane]; \
-      MV_W3_GROUP(CA, 0, 0, va.h, va.l, buf, true, 0, 1);                                     \
-      MV_W3_GROUP(CA, 0, 1, va.h, va.l, buf, true, 0, 2);                                     \
-      MV_W3_GROUP(CA, 0, 2, va.h, va.l, buf, (CB) >= 0, 1, 0);                                \
-      if ((CB) >= 0) {                                                                        \
-        MV_W3_GROUP((CB) < 0 ? 0 : (CB), 1, 0, vb.h, vb.l, buf, true, 1, 1);                  \
-        MV_W3_GROUP((CB) < 0 ? 0 : (CB), 1, 1, vb.h, vb.l, buf, true, 1, 2);                  \
-        MV_W3_GROUP((CB) < 0 ? 0 : (CB), 1, 2, vb.h, vb.l, buf, false, 0, 0);                 \
-      }                                                                                       \
-    } else {                                                                                  \
-      MV_W3_COMP(CA, 0, va.h, va.l, buf);                                                     \
-      if ((CB) >= 0) MV_W3_COMP((CB) < 0 ? 0 : (CB), 1, vb.h, vb.l, buf);                     \
-    }                                                                                         \
+    MV_W3_COMP(CA, 0, va.h, va.l, buf);                                                       \
+    if ((CB) >= 0) MV_W3_COMP((CB) < 0 ? 0 : (CB), 1, vb.h, vb.l, buf);                       \
     va = na; vb = nb;                                                                         \
     ++st;                                                                                     \
-    if (!(MV_W3_ABLC & 8)) {                                                                  \
-      /* DMA + fragments of the next stage must have landed; the four touches may fly on */   \
-      if (touch_) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
-      else __syncthreads();                                                                   \
-    }                                                                                         \
+    __syncthreads();     /* DMA + fragments of the next stage have landed */                  \
   } while (0)
 
     Vc va, vb, na, nb;
     vload(0, va); vload(1, vb);
     na = va; nb = vb;
     stage_dma(0, lds);
-    if (MV_W3_ABLC & 2) stage_dma(0, lds + kStageVec);
     __syncthreads();                         // carries the vmcnt(0) of the pending LDS-DMA
-    f16x8 wfix[4];
-    if (MV_W3_ABLC & 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wfix[i] = lds[i * 64 + lane];
-    }
     // five stages = ten components = two chunks: (0,1) (2,3) (4,0) (1,2) (3,4); an odd chunk
     // count ends on (0,1) (2,3) (4)
     const int nck = ck_hi - ck_lo;
@@ -630,21 +530,9 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       MV_W3_STAGE(0, 1); MV_W3_STAGE(2, 3); MV_W3_STAGE(4, -1);
     }
 #undef MV_W3_COMP
-#undef MV_W3_GROUP
 #undef MV_W3_STAGE
   }
   if (!wave_live) return;
-  if (p.abl & 2) {                          // keep every accumulator live, store nothing
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < 5; ++c)
-#pragma unroll
-      for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sum += acc[c][rb][i];
-    if (sum == 12345.678f) a.h_out[0] = sum;
-    return;
-  }
 
   // ---------------------------------------------------------------- epilogue
   // registers of acc[c][rb]: gate = reg >> 2, channel = cb * CH + rb * 8 + 4 * half + (reg & 3);
@@ -675,7 +563,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   for (int e = 0; e < 3; ++e)
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) cprev[e][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (!a.zero_state && !(p.abl & 4)) {
+  if (!a.zero_state) {
     // the tile was requested before the main loop; its barriers carried the vmcnt(0) -- the
     // explicit wait covers a launch without f16 chunks
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -755,49 +643,17 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
           else yv = (m1 + m2) + (4.0f * m3 + m4);
           pre[g] = __builtin_fmaf(yv, un, add[g][j]);   // un = 2^-16: the product is exact
         }
-        float si = 0.f, tj = 0.f, sf = 0.f, so = 0.f, cn, hn;
-        if (p.abl & 32) {
-          si = pre[0] * 0.25f + 0.5f; tj = pre[1] * 0.5f; sf = pre[2] * 0.25f + 0.5f;
-          so = pre[3] * 0.25f + 0.5f;
-          cn = sf * cprev[e][rb][j] + si * tj;
-          hn = cn * 0.5f * so;
-        } else if (MV_W3_FUSED_LSTM && !a.gates_out) {
-          // Inference (no gate activations to save): the update over COMMON DENOMINATORS --
-          //   D_x = 1 + e^-x (x = i, f + forget bias, o),  D_j = 1 + e^-2|j|,  t = sign(j)(1 - e^-2|j|)
-          //   c' = (c D_i D_j + t D_f) / (D_i D_j D_f)
-          //   h' = sign(c')(1 - e^-2|c'|) / ((1 + e^-2|c'|) D_o)
-          // five v_exp + TWO v_rcp per element instead of five + five.  With two workgroups per
-          // CU the epilogue is bound by the quarter-rate transcendental unit (240 of them per
-          // lane and tile), not by its dependent chains.  The arguments are clamped to +-28
-          // (sigma(-28) = 7e-13: nothing at the 1e-4 bar) so that D_i D_j D_f stays finite.
-          const float kL2E = 1.4426950408889634f;
-          const float xi = fminf(fmaxf(pre[0], -28.f), 28.f);
-          const float xf = fminf(fmaxf(pre[2] + a.forget_bias, -28.f), 28.f);
-          const float xo = fminf(fmaxf(pre[3], -28.f), 28.f);
-          const float Di = 1.0f + __builtin_amdgcn_exp2f(-kL2E * xi);
-          const float Df = 1.0f + __builtin_amdgcn_exp2f(-kL2E * xf);
-          const float Do = 1.0f + __builtin_amdgcn_exp2f(-kL2E * xo);
-          const float Ej = __builtin_amdgcn_exp2f(-2.0f * kL2E * __builtin_fabsf(pre[1]));
-          const float Dj = 1.0f + Ej;
-          const float tn = __builtin_copysignf(1.0f - Ej, pre[1]);
-          const float DiDj = Di * Dj;
-          const float R = __builtin_amdgcn_rcpf(DiDj * Df);
-          cn = __builtin_fmaf(cprev[e][rb][j], DiDj, tn * Df) * R;
-          const float Ec = __builtin_amdgcn_exp2f(-2.0f * kL2E * __builtin_fabsf(cn));
-          hn = __builtin_copysignf(1.0f - Ec, cn) * __builtin_amdgcn_rcpf((1.0f + Ec) * Do);
-        } else {
-          si = sigm_(pre[0]); tj = tanh_(pre[1]); sf = sigm_(pre[2] + a.forget_bias);
-          so = sigm_(pre[3]);
-          cn = sf * cprev[e][rb][j];
-          cn = cn + si * tj;
-          hn = tanh_(cn) * so;
-        }
+        const float si = sigm_(pre[0]), tj = tanh_(pre[1]), sf = sigm_(pre[2] + a.forget_bias),
+                    so = sigm_(pre[3]);
+        float cn = sf * cprev[e][rb][j];
+        cn = cn + si * tj;
+        const float hn = tanh_(cn) * so;
         cn4[j] = cn; hn4[j] = hn; si4[j] = si; tj4[j] = tj; sf4[j] = sf; so4[j] = so;
       }
       // c' and h' into the wave's two LDS tiles (the c tile was read into cprev above)
       *reinterpret_cast<f32x4*>(tl0 + wr_idx + e * 32 * CH + rb * 8) = cn4;
       if (!a.skip_h32) *reinterpret_cast<f32x4*>(tl1 + wr_idx + e * 32 * CH + rb * 8) = hn4;
-      if (a.gates_out && okc[e] && !(p.abl & 8)) {
+      if (a.gates_out && okc[e]) {
         // training forward: the four gate activations [m][4][C] (stored from the lane)
         const uint32_t g0 = (mcell * 4u * (uint32_t)C + (uint32_t)ch) * 4u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, si4), go_rs, (int)g0,
@@ -825,7 +681,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   }
   // ---- c' / h' out: the tiles leave LDS linearly, kPieces lanes per cell
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (!(p.abl & 8)) {
+  {
 #pragma unroll
     for (int k = 0; k < kPasses; ++k) {
       const int i = k * 64 + lane_e;
@@ -848,7 +704,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   // of its three cells; v_permlane32_swap hands the lower half-wave the complete vectors of
   // the e = 0 cells and the upper half-wave those of the e = 1 cells, a second swap the lower
   // half-wave those of the e = 2 cells: 16 bytes per lane, 512 contiguous bytes per half-wave.
-  if (planes && !(p.abl & 16)) {
+  if (planes) {
     const uint32_t mc01 = (uint32_t)(r * HW + (half_e ? cell[1] : cell[0]));
     const uint32_t mc2 = (uint32_t)(r * HW + cell[2]);
     const bool ok01 = half_e ? okc[1] : okc[0];
@@ -882,7 +738,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
 }
 
 template <int WAVES, int NRB, bool HALO>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2)
+__global__ __launch_bounds__(WAVES * 64, 2)
 void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
   extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
   int block = blockIdx.x;
@@ -923,12 +779,7 @@ void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
   }
 }
 
-// -DMV_W3_WAVES=8: one 8-wave workgroup per CU (the weight stage shared by 256 triple-cells:
-// half the L2 -> LDS traffic per MFMA) instead of two 4-wave workgroups (A/B builds)
-#ifndef MV_W3_WAVES
-#define MV_W3_WAVES 4
-#endif
-constexpr int kW3Waves = MV_W3_WAVES, kW3Nrb = 2;
+constexpr int kW3Waves = 4, kW3Nrb = 2;     // two 4-wave workgroups per CU
 
 static inline size_t wino3_lds_bytes() {      // 73.5 KB: two workgroups per CU
   return (size_t)2 * (2 * 3 * 2 * kW3Nrb * 64 * 16) + (size_t)kW3Waves * Wn3<kW3Nrb>::kTileFloats * 4 +
@@ -961,6 +812,18 @@ static inline bool wino3_geometry_ok(const ConvLstmArgs& a, const ConvLstm16Args
          q.x_exp == nullptr;
 }
 static inline bool wino3_needs_halo(const ConvLstmArgs& a) { return 32 % a.W != 0; }
+// The HALO tiling addresses the pre-transformed operands with ONE 32-bit byte offset per lane
+// from the buffer's start (a wave's 32 triple-cells start anywhere) and sends the lanes outside
+// the sequence to offset 2^31, which must lie BEYOND the buffer: a problem whose x or h operand
+// holds 2 GiB or more (36 x 18 grid, 128 rows x 20 beams, 256 channels: 2.8 GB) takes the
+// F(2,3) form instead.  The exact tiling rebases its descriptor per wave tile: no such limit.
+static inline bool wino3_halo_addressable(const ConvLstmArgs& a) {
+  if (!wino3_needs_halo(a)) return true;
+  const size_t lim = (size_t)1 << 31;
+  const int cx16 = a.x_small ? 0 : (a.Cx + 15) / 16 * 16;
+  return wino3_v_elems(a.rows, a.H, a.W, a.C) * 2 < lim &&
+         (cx16 == 0 || wino3_v_elems(a.rows, a.H, a.W, cx16) * 2 < lim);
+}
 
 static inline void wino3_init_attributes() {
   static const bool done = [] {
@@ -979,7 +842,6 @@ static inline void launch_convlstm_wino3_steps(const ConvLstmWinoArgs* probs, in
                                                hipStream_t stream) {
   ConvLstmWinoGroup g{};
   g.n = n;
-  static const int abl = getenv("MV_WINO_ABL") ? atoi(getenv("MV_WINO_ABL")) : 0;
   // MV_WINO_MAP: 2 (default here): an XCD holds four column blocks and every second row tile --
   // a row tile's pre-transformed operands then come through 4 of the 8 L2s (+0.7 % greedy and
   // beam-20 against 1 = two column blocks per XCD, same box; 3 = eight: no better)
@@ -990,7 +852,6 @@ static inline void launch_convlstm_wino3_steps(const ConvLstmWinoArgs* probs, in
   unsigned total = 0;
   for (int i = 0; i < n; ++i) {
     g.p[i] = probs[i];
-    g.p[i].abl = abl;
     total += convlstm_wino3_blocks(probs[i].b.f, halo, map_mode);
     g.block_end[i] = (int32_t)total;
   }

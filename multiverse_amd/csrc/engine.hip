@@ -952,6 +952,7 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     const ConvLstmArgs& a = p16[i].f;
     ConvCell* cc = cell_of_pack(e, probs[i].wpack);
     if (!mv::wino3_geometry_ok(a, p16[i]) || !cc->wpw3.p) wino3 = false;
+    else if (!mv::wino3_halo_addressable(a)) wino3 = false;   // 32-bit lane offsets (HALO)
     else if (!a.zero_state && e->pv3h[i].n < mv::wino3_v_elems(a.rows, a.H, a.W, a.C)) wino3 = false;
     else if (!a.x_small && a.Cx > 0 && !a.sx_corr &&
              e->pv3x[i].n < mv::wino3_v_elems(a.rows, a.H, a.W, a.Cx)) wino3 = false;
@@ -2380,6 +2381,9 @@ int mv_train_init(mv_handle h, const mv_train_config* tc) {
                  "soft_kernel_size %d (3 or 5)", tc->soft_kernel_size);
     MV_REQUIRE(h->cfg.beam_size == 1, "training needs a greedy (beam_size 1) engine "
                "(reference pred_models.py:261)");
+    MV_REQUIRE(!(h->compute_mode == 2 && h->cfg.activation != 0),
+               "training in compute mode 2 (bf16) needs activation_func tanh: relu / lrelu "
+               "models train in mode 1 (f16x3); see mv_config.activation");
     if (!h->train) {
       h->train = new mv_train_holder();
       train_alloc(h);
@@ -2734,6 +2738,9 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
   return guarded(h, [&] {
     MV_REQUIRE(mode >= 0 && mode <= 2, "compute mode %d (0 = fp32 MFMA, 1 = f16x3, 2 = bf16)",
                mode);
+    MV_REQUIRE(!(mode == 2 && h->train && h->cfg.activation != 0),
+               "compute mode 2 (bf16) on a TRAINING engine needs activation_func tanh: relu / "
+               "lrelu models train in mode 1 (f16x3); see mv_config.activation");
     MV_REQUIRE(mode == 0 || h->cfg.convlstm_kernel == 3,
                "compute mode %d needs convlstm_kernel 3 (%d given: the matrix-pipe gate kernels "
                "are 3 x 3 stencils; mode 0 runs the generic fp32 loops)", mode,
@@ -2777,16 +2784,6 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
           DevBuf<_Float16>& pb = *h->plane_store.back();
           pb.alloc(2 * (b->n + mv::kPlaneSlack + mv::kPlanePad));
           HIP_CHECK(hipMemset(pb.p, 0, pb.n * sizeof(_Float16)));
-          // timing ablations that drop the epilogue's stores (MV_WINO_ABL & 2 / 8 / 16) would
-          // run the matrix pipe on these zeros and draw far less power per MFMA than real
-          // operands do: such runs start from pseudo-random planes (|256 h| < 256, low plane
-          // ~2^-11 of it) that nothing overwrites
-          if (getenv("MV_WINO_ABL") && (atoi(getenv("MV_WINO_ABL")) & (2 | 8 | 16))) {
-            const size_t pst = b->n + mv::kPlaneSlack + mv::kPlanePad;
-            hipLaunchKernelGGL(mv::abl_fill_planes_kernel, dim3(cdiv(b->n, 256)), dim3(256), 0,
-                               h->stream, pb.p + mv::kPlanePad, pb.p + mv::kPlanePad + pst, b->n);
-            HIP_CHECK(hipStreamSynchronize(h->stream));
-          }
           // p -> first element of plane 0; plane stride n + slack + pad puts a zero
           // pad in front of plane 1 as well (slack: the last partial 32-cell tile row)
           h->planes[b->p] = mv_engine::PlaneBuf{pb.p + mv::kPlanePad,
@@ -3004,6 +3001,8 @@ int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const flo
       mv::launch_convlstm16_steps(&q, 1, ctx.stream);
     } else if (variant == 3) {
       MV_REQUIRE(mv::wino3_geometry_ok(a, q), "Winograd F(3,3) form: H %d >= 3", H);
+      MV_REQUIRE(mv::wino3_halo_addressable(a), "Winograd F(3,3) form, halo tiling (W %d does "
+                 "not divide 32): an operand of 2 GiB or more is not addressable", W);
       const size_t halves = mv::wino3_wpack_elems(Cx16, C, mv::kW3Nrb);
       wp.alloc(halves);
       hipLaunchKernelGGL(mv::pack_wino3_kernel, dim3(cdiv(halves / 2, 256)), dim3(256), 0,

@@ -933,18 +933,20 @@ void run_dgrad_group(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
 // In-library gradient all-reduce (comm.h): the elements [off, off + n) of the flat
 // gradient buffer are final on the main stream -> reduce them (sum over the ranks) on the
 // side stream while the backward pass goes on.
-// MV_COMM_FAULT (test hook, honoured only with MV_ALLOW_RCCL_OVERRIDE=1 like MV_RCCL_LIB): the
-// negative control of tests/test_gpu_parallel.py -- bit 1 drops the side stream's wait for the
-// main stream's `ready` event, bit 2 the main stream's wait for the side stream's `done`: over
-// an asynchronous collective either must give wrong parameters (and the test must see it).
+// MV_COMM_FAULT -- ONLY in -DMV_TEST_HOOKS builds (the test-hooks copy of the library that
+// __graft_entry__.build() puts under tests/fake_rccl/; the shipped library compiles the waits
+// unconditionally): the negative control of tests/test_gpu_parallel.py -- bit 1 drops the side
+// stream's wait for the main stream's `ready` event, bit 2 the main stream's wait for the side
+// stream's `done`: over an asynchronous collective either must give wrong parameters (and the
+// test must see it).
+#ifdef MV_TEST_HOOKS
 static inline int comm_fault() {
-  static const int f = [] {
-    const char* a = getenv("MV_ALLOW_RCCL_OVERRIDE");
-    const char* v = getenv("MV_COMM_FAULT");
-    return (a && atoi(a) == 1 && v) ? atoi(v) : 0;
-  }();
+  static const int f = getenv("MV_COMM_FAULT") ? atoi(getenv("MV_COMM_FAULT")) : 0;
   return f;
 }
+#else
+static constexpr int comm_fault() { return 0; }
+#endif
 void comm_reduce_range(mv_engine* e, size_t off, size_t n) {
   mv::Comm* c = e->comm;
   if (!c || n == 0) return;

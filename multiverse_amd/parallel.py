@@ -21,6 +21,8 @@ one-GPU tests) and MV_ALLREDUCE=torch.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -140,8 +142,45 @@ def init_engine_comm(engine):
     return False
   box = [_lib.comm_unique_id() if dist.get_rank() == 0 else None]
   dist.broadcast_object_list(box, src=0)
-  engine.comm_init(dist.get_rank(), dist.get_world_size(), box[0])
+  # ncclCommInitRank blocks until EVERY rank has called it: a rank that died, a wrong world
+  # size or a fabric that does not come up would hang the job silently.  It runs under a
+  # deadline (MV_COMM_INIT_TIMEOUT_S, default 180 s) and the process ends LOUDLY when it expires.
+  deadline = float(os.environ.get("MV_COMM_INIT_TIMEOUT_S", "180"))
+  call_with_deadline(
+      lambda: engine.comm_init(dist.get_rank(), dist.get_world_size(), box[0]), deadline,
+      "mv_allreduce_init (ncclCommInitRank) on rank %d of %d" % (dist.get_rank(),
+                                                                 dist.get_world_size()))
   return True
+
+
+def call_with_deadline(fn, seconds, what):
+  """Run a blocking native call (ctypes releases the GIL) under a deadline.  A call that
+  does not come back cannot be cancelled, so on expiry this writes what hung, and why that
+  usually happens, to stderr and ends the PROCESS with status 3 -- a launcher then tears the
+  other ranks down instead of the job hanging until its wall-clock limit."""
+  import sys
+  import threading
+  box = {}
+
+  def run():
+    try:
+      box["r"] = fn()
+    except BaseException as ex:   # pylint: disable=broad-except
+      box["e"] = ex
+  t = threading.Thread(target=run, daemon=True)
+  t.start()
+  t.join(seconds)
+  if t.is_alive():
+    sys.stderr.write(
+        "[multiverse_amd] FATAL: %s did not return within %.0f s.  Every rank must reach it "
+        "(same world size, one visible GPU per rank, HSA_ENABLE_IPC_MODE_LEGACY=0 for dmabuf "
+        "IPC); NCCL_DEBUG=INFO shows where RCCL's bootstrap stands.  Ending this rank "
+        "(MV_COMM_INIT_TIMEOUT_S changes the deadline).\n" % (what, seconds))
+    sys.stderr.flush()
+    os._exit(3)
+  if "e" in box:
+    raise box["e"]
+  return box.get("r")
 
 
 def allreduce_mean_arrays(arrays):

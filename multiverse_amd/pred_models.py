@@ -170,6 +170,26 @@ def build_feed_dict(cfg, batch, is_train=False):
   return feed
 
 
+def f16x3_out_of_range(params, limit=60000.0 / 256.0):
+  """The bound engine.hip ensure_packed16 enforces, on the host copy: max |w| of every
+  3 x 3 gate kernel and of its Winograd-transformed rows ((g0 +- g1 + g2) / 2, (g0 + 2 g1 +
+  4 g2) / 6 and its mirror, column by column) must stay below 60 000 / 256.  Returns None, or
+  (name, max |w|, reach) of the first kernel that does not."""
+  for name in sorted(params):
+    w = np.asarray(params[name])
+    if not name.endswith("/kernel") or w.ndim != 4 or w.shape[0] != 3 or w.shape[1] != 3:
+      continue
+    g0, g1, g2 = (w[i].astype(np.float32) for i in range(3))
+    mx = float(np.abs(w).max())
+    reach = max(mx,
+                float(np.abs(g0 + g1 + g2).max()) * 0.5, float(np.abs(g0 - g1 + g2).max()) * 0.5,
+                float(np.abs(g0 + 2.0 * g1 + 4.0 * g2).max()) / 6.0,
+                float(np.abs(4.0 * g0 + 2.0 * g1 + g2).max()) / 6.0)
+    if not reach < limit:
+      return name, mx, reach
+  return None
+
+
 class Model(object):
   """One engine instance with the reference Model's host-side protocol."""
 
@@ -235,6 +255,19 @@ class Model(object):
 
   def load_params(self, params):
     self.engine.set_params(params)
+    if self.compute_mode == "f16x3":
+      bad = f16x3_out_of_range(params)
+      if bad is not None:
+        # the f16x3 planes hold 256 w (and, in the Winograd packs, 256 x the transformed
+        # kernel rows) in fp16: engine.hip ensure_packed16 refuses a model that leaves that
+        # range.  Such a model decodes on the fp32 matrix pipe instead (same results
+        # contract, 1/5 of the rate) -- the toy-grid pattern above.
+        import logging
+        logging.getLogger("multiverse_amd").warning(
+            "compute mode f16x3 overridden to f32: |%s| reaches %.4g (%.4g in the Winograd "
+            "kernel planes), outside the scaled fp16 range", bad[0], bad[1], bad[2])
+        self.compute_mode = "f32"
+        self.engine.set_compute_mode("f32")
 
   def get_params(self):
     return {n: self.engine.get_param(n) for n, _ in self.engine.param_specs()}

@@ -176,6 +176,13 @@ ncclResult_t allreduce_async(FakeComm* c, const float* src, float* dst, size_t c
   float* buf = c->stage[slot];
   if (hipMemcpyAsync(buf, src, count * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess)
     return ncclUnhandledCudaError;
+  // MV_FAKE_RCCL_POISON=1: between the copy-out and the copy-back the receive buffer holds
+  // NaNs (0xFF bytes), so that a caller whose main stream does not wait for the collective's
+  // completion reads poison WHATEVER the timing -- the deterministic form of the dropped-
+  // `done`-wait negative control (the 20 ms delay alone made it a race)
+  static const bool poison = getenv("MV_FAKE_RCCL_POISON") && atoi(getenv("MV_FAKE_RCCL_POISON")) == 1;
+  if (poison && hipMemsetAsync(dst, 0xFF, count * sizeof(float), stream) != hipSuccess)
+    return ncclUnhandledCudaError;
   AsyncJob* job = new AsyncJob{c, buf, count};
   if (hipLaunchHostFunc(stream, exchange_on_host, job) != hipSuccess) {
     delete job;

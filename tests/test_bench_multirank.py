@@ -1,0 +1,69 @@
+# coding=utf-8
+"""CPU: bench.py's multi-rank control flow at N = 8 (the run the driver makes on an 8-GPU node,
+which no 1-GPU lease can rehearse): `--gpus 8` with no launcher spawns eight ranks on
+127.0.0.1, every rank builds its OWN feed (seed offset 1000 x rank), the timed region is
+bracketed by barriers and its length is the MAXIMUM over the ranks, rank 0 prints ONE JSON line
+with n_gpus 8 and the whole-job value.  The engine is a stand-in (tests/bench_cpu_harness.py):
+what is under test is bench.py and multiverse_amd/parallel.py, over gloo."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "tests", "bench_cpu_harness.py")
+
+
+def _run(tmp_path, workload, n=8, steps=3, batch=2):
+  env = dict(os.environ, MV_BENCH_BACKEND="gloo", MV_HARNESS_DIR=str(tmp_path),
+             OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1")
+  for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, HARNESS, "--gpus", str(n), "--steps", str(steps),
+                      "--warmup", "1", "--batch", str(batch), "--workload", workload,
+                      "--no-cpu-baseline", "--no-fp32-ref"],
+                     env=env, capture_output=True, timeout=600)
+  assert r.returncode == 0, r.stderr.decode()[-3000:]
+  lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+  assert len(lines) == 1, lines                      # ONE line, from rank 0 only
+  recs = [json.load(open(f)) for f in sorted(glob.glob(os.path.join(str(tmp_path), "rank*.json")))]
+  return json.loads(lines[0]), recs
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_8_greedy_control_flow(tmp_path):
+  from multiverse_amd import synth
+  n, steps, batch = 8, 3, 2
+  line, recs = _run(tmp_path, "greedy", n, steps, batch)
+  assert line["n_gpus"] == n and line["steps"] == steps and line["warmup"] == 1
+  assert line["scaling"] == "weak" and line["higher_is_better"] is True
+  assert line["config"]["batch_per_gpu"] == batch and line["config"]["global_batch"] == n * batch
+  assert "batch-sharded x8, no data-path collective" in line["config"]["parallelism"]
+  # every rank ran, each on its own feed
+  assert sorted(r["rank"] for r in recs) == list(range(n))
+  for r in recs:
+    assert r["feed_seeds"] == [synth.SEED_BASE + 2 + 1000 * r["rank"]]
+  # max over ranks: the stand-in's rank r takes 2 (r + 1) ms per step, the line must carry
+  # the slowest rank's 16 ms (not rank 0's 2 ms), and value = ALL ranks' trajectories / that
+  assert line["ms_per_step"] >= 0.9 * 2.0 * n
+  want = n * batch * steps / (line["ms_per_step"] * 1e-3 * steps)
+  assert abs(line["value"] - want) <= 0.02 * want
+  assert "cpu_baseline" not in line                  # rank 0 at N = 1 only
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_8_training_step_control_flow(tmp_path):
+  n, steps = 8, 2
+  line, recs = _run(tmp_path, "train", n, steps, batch=2)
+  assert line["n_gpus"] == n
+  # gloo: the library's RCCL path is off (rccl_ranks 0) and the step all-reduces through
+  # torch.distributed once per step -- warm-up, timed steps, the sizing probe is skipped
+  # (--steps given), one profiled step
+  assert line["rccl_ranks"] == 0 and "allreduce" not in line
+  assert "data-parallel x8, gradient all-reduce" in line["config"]["parallelism"]
+  for r in recs:
+    assert r["allreduce_calls"] == 1 + steps + 1
+  assert line["ms_per_step"] >= 0.9 * 2.0 * n

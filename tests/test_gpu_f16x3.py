@@ -131,3 +131,33 @@ def test_f16x3_refuses_weights_whose_transformed_planes_leave_the_fp16_range(bui
     eng.forward_greedy(feed)
   assert "transformed kernel planes" in str(err.value)
   eng.close()
+
+
+def test_model_falls_back_to_f32_when_the_f16x3_range_guard_would_trip(built_lib, caplog):
+  """The host mirror (pred_models.Model.load_params) applies the engine's range bound to the
+  checkpoint it is handed and, instead of letting the DEFAULT compute mode raise at the first
+  forward, switches that model to the fp32 matrix pipe with a warning -- the pattern it already
+  follows for toy grids.  The engine itself stays loud (test above)."""
+  import logging
+  from multiverse_amd import pred_models
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 0))
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 5)
+  name = "person_pred/decoder_grid_class_0/decoder_rnn/dec_grid_0/kernel"
+  stacked = synth.make_params(cfg)
+  stacked[name] = stacked[name].copy()
+  stacked[name][:, 1, 40, 7] = 180.0                    # (g0 + g1 + g2) / 2 = 270 in one column
+  assert pred_models.f16x3_out_of_range(synth.make_params(cfg)) is None
+  bad = pred_models.f16x3_out_of_range(stacked)
+  assert bad is not None and bad[0] == name and abs(bad[2] - 270.0) < 1.0
+  model = pred_models.get_model(cfg, 0)
+  assert model.compute_mode == "f16x3"
+  with caplog.at_level(logging.WARNING, logger="multiverse_amd"):
+    model.load_params(stacked)
+  assert model.compute_mode == "f32"
+  assert any("overridden to f32" in r.getMessage() for r in caplog.records)
+  cls, reg, _ = model.run_forward(feed)
+  ref = _engine(built_lib, cfg, stacked, "f32")
+  rc, rr = ref.forward_greedy(feed)
+  ref.close()
+  model.close()
+  assert (np.asarray(cls[0]) == rc[0]).all() and (np.asarray(reg[0]) == rr[0]).all()

@@ -64,7 +64,35 @@ def test_convlstm_kernel_sizes_train_step_vs_reference_run(built_lib, name):
   _train_pin(built_lib, name, "f32")
 
 
-@pytest.mark.parametrize("k", [1, 2, 5])
+@pytest.mark.parametrize("k", [2, 4])
+def test_even_convlstm_kernel_train_step_vs_oracle(built_lib, k):
+  """Even kernel sizes: TF's SAME padding puts the extra row / column at the bottom / right
+  (pad_before = (k - 1) // 2); forward, dgrad and wgrad of csrc/convlstm_generic.h each carry
+  that convention in their own index arithmetic.  Loss and EVERY gradient element against the
+  fp64 oracle (whose conv2d SAME the TF-1 shim's reference runs pin for odd and even sizes)."""
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1), is_train=True, convlstm_kernel=k)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 40 + k, recurrent_gain=2.0)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 41 + k)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode("f32")
+  eng.train_init()
+  loss, wd, pgl = eng.train_forward_backward(feed)
+  grads = {n: eng.get_grad(n) for n, _ in eng.param_specs()}
+  eng.close()
+  oloss, owd, opgl, og64 = oracle.loss_and_grads(params, cfg, feed, dtype=torch.float64)
+  print("convlstm_kernel %d: loss %.6f oracle %.6f" % (k, loss, oloss))
+  assert abs(loss - oloss) < 1e-4 * max(1.0, abs(oloss))
+  assert np.allclose(pgl, opgl, rtol=1e-4, atol=1e-5)
+  worst = 0.0
+  for n in sorted(grads):
+    e = _rel(grads[n], og64[n])
+    worst = max(worst, e)
+    assert e < 2e-3, (n, e)
+  print("  worst gradient error (of max|g|): %.2e" % worst)
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 5])
 def test_convlstm_kernel_sizes_greedy_forward_vs_oracle(built_lib, k):
   """Both scales, greedy decode: argmax ids bit-exact, logits / offsets within 1e-4 (k = 2: an
   even kernel -- SAME pads bottom / right)."""

@@ -151,26 +151,57 @@ def test_fake_rccl_exports_what_comm_h_binds():
   assert lib.ncclCommInitRank(C.byref(comm), 2, uid, 2) != 0      # rank out of range
 
 
-@pytest.mark.skipif(not os.path.exists(_FAKE), reason="tests/fake_rccl not built (__graft_entry__.build())")
-def test_mv_rccl_lib_selects_exactly_that_library():
-  """MV_RCCL_LIB (comm.h): the engine library binds the named RCCL and no other -- here the
-  stand-in, recognisable by the tag in the unique id it hands out; a missing file is reported."""
+_HOOKS = os.path.join(os.path.dirname(_FAKE), "libmultiverse_hip_testhooks.so")
+
+
+@pytest.mark.skipif(not (os.path.exists(_FAKE) and os.path.exists(_HOOKS)),
+                    reason="tests/fake_rccl not built (__graft_entry__.build())")
+def test_mv_rccl_lib_is_a_hook_of_the_test_build_only():
+  """MV_RCCL_LIB (comm.h) exists ONLY in the -DMV_TEST_HOOKS copy of the library (selected
+  with MV_LIB_PATH): there it binds exactly the named RCCL -- here the stand-in, recognisable
+  by the tag in the unique id it hands out -- and reports a missing file.  The SHIPPED library
+  does not read the variable at all: its unique id never carries the stand-in's tag."""
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   code = ("import sys; sys.path.insert(0, %r)\n"
           "from multiverse_amd import _lib\n"
           "print(_lib.comm_unique_id()[24:30])\n" % root)
-  allow = dict(os.environ, MV_ALLOW_RCCL_OVERRIDE="1")
-  r = subprocess.run([sys.executable, "-c", code], env=dict(allow, MV_RCCL_LIB=_FAKE),
+  hooks = dict(os.environ, MV_LIB_PATH=_HOOKS)
+  r = subprocess.run([sys.executable, "-c", code], env=dict(hooks, MV_RCCL_LIB=_FAKE),
                      capture_output=True)
   assert r.returncode == 0 and b"mvfake" in r.stdout
-  assert b"WARNING: collectives bound to" in r.stderr      # announced, never silent
-  r = subprocess.run([sys.executable, "-c", code], env=dict(allow, MV_RCCL_LIB="/nonexistent/librccl.so"),
-                     capture_output=True)
+  assert b"TEST-HOOKS BUILD: collectives bound to" in r.stderr      # announced, never silent
+  r = subprocess.run([sys.executable, "-c", code],
+                     env=dict(hooks, MV_RCCL_LIB="/nonexistent/librccl.so"), capture_output=True)
   assert r.returncode != 0 and b"MV_RCCL_LIB" in r.stderr
-  # the override is a test hook: without MV_ALLOW_RCCL_OVERRIDE=1 it is REFUSED, not ignored
+  # the shipped library: the variable is not a knob -- whatever it binds (the real RCCL, or
+  # nothing on a box without one), it is not the stand-in
   env = dict(os.environ, MV_RCCL_LIB=_FAKE)
-  env.pop("MV_ALLOW_RCCL_OVERRIDE", None)
+  env.pop("MV_LIB_PATH", None)
   r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True)
-  assert r.returncode != 0 and b"MV_ALLOW_RCCL_OVERRIDE" in r.stderr
+  assert b"mvfake" not in r.stdout and b"TEST-HOOKS" not in r.stderr
+
+
+def test_comm_init_deadline_ends_the_process_loudly():
+  """parallel.call_with_deadline (wrapped around mv_allreduce_init / ncclCommInitRank): a
+  native call that never returns must end the rank with status 3 and say what hung -- the first
+  real 8-GPU run must FAIL, not hang, if RCCL's bootstrap stalls; a call that returns in time
+  hands its value (or its exception) through."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  code = ("import sys, time; sys.path.insert(0, %r)\n"
+          "from multiverse_amd import parallel\n"
+          "assert parallel.call_with_deadline(lambda: 7, 5.0, 'quick') == 7\n"
+          "try:\n"
+          "  parallel.call_with_deadline(lambda: 1 / 0, 5.0, 'raises')\n"
+          "  raise SystemExit(9)\n"
+          "except ZeroDivisionError:\n"
+          "  pass\n"
+          "parallel.call_with_deadline(lambda: time.sleep(30), 0.3, 'stuck ncclCommInitRank')\n"
+          "raise SystemExit(8)\n" % root)
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=60)
+  assert r.returncode == 3, (r.returncode, r.stderr)
+  assert b"FATAL: stuck ncclCommInitRank did not return within 0 s" in r.stderr
+  assert b"MV_COMM_INIT_TIMEOUT_S" in r.stderr
