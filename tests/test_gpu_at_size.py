@@ -122,9 +122,21 @@ def test_configs1_batch64_recurrent_gain_3_every_row_vs_oracle(built_lib):
 
 
 def test_configs3_batch128_beam20_rows_vs_batch1_oracle(built_lib):
+  """bench.py's weights (the reference's initialisers): 8 rows incl. the first and last."""
+  _configs3_rows(built_lib, dict(), [0, 1, 37, 63, 64, 101, 126, 127])
+
+
+def test_configs3_batch128_beam20_gain3_32_rows_vs_batch1_oracle(built_lib):
+  """The same launch at recurrent gain 3 / bias 0.1 (logits O(1e-2 .. 1): the candidate scores
+  of a step are no longer ties of the initialiser's 1e-5 logits) on every fourth row: 32 rows
+  x 20 beams x 12 steps against the batch-1 oracle."""
+  _configs3_rows(built_lib, dict(recurrent_gain=3.0, bias_scale=0.1), list(range(0, 128, 4)))
+
+
+def _configs3_rows(built_lib, param_kw, rows):
   N, B = 128, 20
   cfg = synth.default_config(batch_size=N, use_grids=(1, 0), beam_size=B)
-  params = synth.make_params(cfg, seed=synth.SEED_BASE + 2)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 2, **param_kw)
   feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 2)
   eng = built_lib.Engine(cfg, device=0)
   eng.set_params(params)
@@ -143,8 +155,8 @@ def test_configs3_batch128_beam20_rows_vs_batch1_oracle(built_lib):
     assert (arrs[k] == arrs2[k]).all(), k
   assert np.isfinite(arrs["logits"]).all() and np.isfinite(arrs["logprobs"]).all()
   cfg1 = synth.default_config(batch_size=1, use_grids=(1, 0), beam_size=B)
-  rows = [0, 1, 37, 63, 64, 101, 126, 127]    # row 127's beams are state rows 2540..2559
-  for n in rows:
+  torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+  for n in rows:                              # (row 127's beams are state rows 2540..2559)
     f1 = dict(feed)
     f1["obs_scene"] = feed["obs_scene"][n:n + 1]
     f1["grid_obs_labels"] = [a[n:n + 1] for a in feed["grid_obs_labels"]]
