@@ -15,7 +15,7 @@ the same minADE_20 / minFDE_20 / grid NLL.
   2. the weights go to disk through multiverse_amd/tf_checkpoint.py (V2 bundle) and BOTH sides
      load that same file;
   3. on 64 held-out trajectories: greedy ids row by row (tie rule of tests/test_gpu_at_size.py),
-     logits / offsets <= 1e-4; on 32 of them: diverse beam-20 ids / logits / log-probs against
+     logits / offsets <= 1e-4 of their range (trained offsets are pixels, up to 1e3); on 32: diverse beam-20 ids / logits / log-probs against
      the batch-1 oracle (tie rule of tests/beam_compare.py);
   4. minADE_20 / minFDE_20 and NLL(T = 1..3) of the beam outputs against three synthetic
      futures per trajectory: engine vs oracle within 1 %;
@@ -114,7 +114,10 @@ def test_greedy_decode_on_trained_weights_every_row_vs_oracle(built_lib, ckpt):
     eng.set_compute_mode(mode)
     cls, reg = eng.forward_greedy(feed)
     eng.close()
-    check_greedy_rows(cfg, cls, reg, ocls, oreg, cfg.pred_len, "trained weights N=64 " + mode)
+    # trained offsets are PIXELS (up to ~1e3, one fp32 ulp there is 6e-5): the 1e-4 bars are
+    # taken relative to the output range
+    check_greedy_rows(cfg, cls, reg, ocls, oreg, cfg.pred_len, "trained weights N=64 " + mode,
+                      relative=True)
 
 
 def _futures(feed, n, rng):
@@ -156,7 +159,8 @@ def test_beam20_decode_and_multifuture_metrics_on_trained_weights(built_lib, ckp
     one = {k: v[n:n + 1] for k, v in arrs.items()}
     print("trained weights, beam-20 row %d:" % n, end=" ")
     compare_beams(one, oreg[0], obeam[0], obeam[1], obeam[2],
-                  np.stack(trace["beam_step_topvals"], axis=-1), trace["beam_trace"])
+                  np.stack(trace["beam_step_topvals"], axis=-1), trace["beam_trace"],
+                  relative=True)
     o_logits.append(obeam[0][0]); o_ids.append(obeam[1][0]); o_lp.append(obeam[2][0])
     o_reg.append(oreg[0][0])
     tv = np.stack(trace["beam_step_topvals"], axis=-1)[0].astype(np.float64)   # [B, T]
