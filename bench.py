@@ -481,8 +481,10 @@ def measure(ctx, kind, batch, compute, steps, warmup, beam_size=20, graph=None,
                     "; dgrad on bf16 planes, wgrad on one fp16 plane per operand: gradient "
                     "cosine vs the fp32 oracle > 0.999 asserted" if train else "") if bf16 else
                 "f16x3 (fp32 operands as two pre-scaled fp16 planes, fp32 accumulate and state; "
-                "%s; measured error vs fp64 <= the fp32-MFMA path's, argmax / beam ids "
-                "bit-exact)" % f16_form if (f16 and not train) else
+                "%s; error vs fp64 within 2x of the fp32-MFMA path's -- asserted under "
+                "checkpoint-like dynamic range (tests/test_gpu_at_size.py) and measured equal "
+                "on trained weights (profiles/r6c_trained_weights_parity_and_metrics.log); "
+                "argmax / beam ids bit-exact)" % f16_form if (f16 and not train) else
                 "f16x3 gate convolutions (forward, dgrad, wgrad: fp32 operands as two "
                 "pre-scaled fp16 planes, fp32 accumulate; %s); fp32 "
                 "state, losses, gradients and optimizer" % f16_form if f16 else "f32"),

@@ -137,6 +137,16 @@ static inline void pack_f16x3_weights(const float* w, int Cx, int C, _Float16* o
 
 // Device-side twin of pack_f16x3_weights (run after every optimizer step): one
 // thread per (cb, k-step, gate, lane, e); writes both planes.
+// The packs below are rebuilt from the DEVICE weights after every optimizer step, where no host
+// copy exists to range-check (engine.hip ensure_packed16 does that for a loaded checkpoint).  A
+// scaled value at or beyond the guard (60 000; fp16 overflows to inf at 65 520) sets this flag;
+// the training step tests it at its closing synchronisation and fails loudly instead of
+// training on infinities (engine_train.h train_apply).  One flag per process.
+__device__ int g_pack_overflow;
+__device__ __forceinline__ void note_pack_range(double scaled) {
+  if (!(fabs(scaled) < 60000.0)) atomicOr(&g_pack_overflow, 1);
+}
+
 __global__ void pack_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
                                   int Cx_total, int Cx16, int C, size_t total) {
   // Cx_total: x channels in the HWIO kernel; Cx16: x channels packed as f16 k-steps
@@ -157,6 +167,7 @@ __global__ void pack_f16x3_kernel(const float* __restrict__ w, _Float16* __restr
   const int n = g * C + cb * kChBlock + (l & 31);
   const int Cin = Cx_total + C, N4 = 4 * C;
   const float v = w[((size_t)tap * Cin + ci) * N4 + n] * kF16Scale;
+  note_pack_range(v);
   const _Float16 v0 = (_Float16)v;
   const size_t base = t * (2 * 4 * 64 * 8);
   out[base + ((size_t)(0 * 4 + g) * 64 + l) * 8 + e] = v0;
@@ -1071,6 +1082,7 @@ __global__ void pack_f16x3_dgrad_kernel(const float* __restrict__ w, _Float16* _
   if (col < C) ci = Cx + col;
   else if (col - C < Cx) ci = col - C;
   const float v = (ci < 0) ? 0.f : w[((size_t)(8 - tap) * Cin + ci) * N4 + n] * kF16Scale;
+  note_pack_range(v);
   const _Float16 v0 = (_Float16)v;
   const size_t base = t * (2 * 4 * 64 * 8);
   out[base + ((size_t)(0 * 4 + g) * 64 + l) * 8 + e] = v0;

@@ -108,6 +108,7 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, _Float16* __restri
   const double u = comp == 0 ? g0 : (comp == 1 ? 0.5 * (g0 + g1 + g2)
                                                : (comp == 2 ? 0.5 * (g0 - g1 + g2) : g2));
   const double sv = u * 256.0;
+  note_pack_range(sv);
   const _Float16 v0 = (_Float16)sv;
   const _Float16 v1 = (_Float16)(sv - (double)v0);
   const size_t base = ((((size_t)cb16 * nst + s) * 2 + ci) * 3 + dx) * (2 * 2 * 64 * 8);
@@ -776,6 +777,7 @@ __global__ void pack_wino_dgrad_kernel(const float* __restrict__ w, _Float16* __
                                     : (comp == 2 ? 0.5 * (g0 - g1 + g2) : g2));
   }
   const double sv = u * 256.0;
+  note_pack_range(sv);
   const _Float16 v0 = (_Float16)sv;
   const _Float16 v1 = (_Float16)(sv - (double)v0);
   const size_t base = ((((size_t)cb * nst + s) * 2 + ci2) * 3 + dx) * (2 * 2 * 64 * 8);

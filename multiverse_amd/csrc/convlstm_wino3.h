@@ -100,6 +100,7 @@ __global__ void pack_wino3_kernel(const float* __restrict__ w, _Float16* __restr
     default: u = -g2; break;
   }
   const double sv = u * 256.0;
+  note_pack_range(sv);
   const _Float16 v0 = (_Float16)sv;
   const _Float16 v1 = (_Float16)(sv - (double)v0);
   const size_t vec = ((((size_t)cb * nch + chunk) * 5 + comp) * 3 + dx) * 2;   // + plane

@@ -115,8 +115,17 @@ struct ConvCell {           // one ConvLSTMCell: packed kernel + biases
   DevBuf<_Float16> wpw;     // f16x3, Winograd F(2,3) form of the kernel (convlstm_wino.h)
   DevBuf<_Float16> wpw3;    // f16x3, Winograd F(3,3) form of the kernel (convlstm_wino3.h)
   bool host_stale = false;  // device copy was updated by the optimizer
+  // f16x3: may this kernel take a Winograd form?  A Winograd form spreads EVERY tap over all
+  // its components, so an outlier weight (|w| thousands of times the kernel's typical weight)
+  // leaves roundoff of ITS size in outputs it does not feed at all -- the direct form keeps it
+  // in the outputs that carry it.  Measured (tests/test_gpu_at_size.py, +-230 outliers in
+  // kernels of median |w| 3e-3): F(2,3) / F(3,3) 7e-5 / 1.8e-4 of the output range against
+  // fp64, direct form 2.6e-5 / 3.7e-5 (fp32 matrix pipe 2.0e-5 / 2.9e-5).  Set by
+  // ensure_packed16 from the host copy: max |w| <= kWinoOutlierRatio x median |w|.
+  bool wino_numerics_ok = true;
   int Cx = 0;
 };
+constexpr float kWinoOutlierRatio = 4096.f;
 
 struct KernelStat {
   std::string name;
@@ -596,6 +605,19 @@ void ensure_packed16(mv_engine* e, ConvCell& cc) {
     MV_REQUIRE(reach * mv::kF16Scale < 60000.f, "f16x3: |%s| reaches %g (%g in the transformed "
                "kernel planes of the Winograd forms), outside the scaled fp16 range; use compute "
                "mode f32", cc.kernel->name.c_str(), mx, reach);
+    // outlier test for the Winograd forms (ConvCell::wino_numerics_ok): median of |w|
+    std::vector<float> mag(cc.kernel->host.size());
+    for (size_t i = 0; i < mag.size(); ++i) mag[i] = std::fabs(cc.kernel->host[i]);
+    std::nth_element(mag.begin(), mag.begin() + mag.size() / 2, mag.end());
+    const float med = mag[mag.size() / 2];
+    const bool ok = mx <= kWinoOutlierRatio * med;
+    if (!ok && cc.wino_numerics_ok)
+      fprintf(stderr, "[multiverse_hip] f16x3: %s has max |w| %g at a median |w| of %g (> %g x): "
+              "its gate convolution takes the direct 3x3 form instead of a Winograd form "
+              "(roundoff of outlier weights would reach unrelated outputs)\n",
+              cc.kernel->name.c_str(), mx, med, kWinoOutlierRatio);
+    if (ok != cc.wino_numerics_ok) { cc.wpw.release(); cc.wpw3.release(); }
+    cc.wino_numerics_ok = ok;
   }
   const bool small = cc.Cx > 0 && 9 * cc.Cx <= mv::kBK;
   // the h part (and an x part that is a multiple of 16 channels) as fp16 planes
@@ -656,7 +678,7 @@ void pack_wino3(mv_engine* e, ConvCell& cc) {
 // construction a pack of the CURRENT weights -- re-packed in place when its form is enabled (no
 // hipFree / hipMalloc per training step: they synchronise the device), released otherwise
 void pack_wino_forms(mv_engine* e, ConvCell& cc) {
-  const bool on = mv::wino_enabled() && C_multiple_ok(e, cc);
+  const bool on = mv::wino_enabled() && C_multiple_ok(e, cc) && cc.wino_numerics_ok;
   if (on) pack_wino(e, cc); else cc.wpw.release();
   if (on && mv::wino3_enabled()) pack_wino3(e, cc); else cc.wpw3.release();
 }

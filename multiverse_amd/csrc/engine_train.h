@@ -1598,6 +1598,20 @@ void train_apply(mv_engine* e, float grad_scale) {
   t.global_step += 1;
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(e->stream));
+  if (e->compute_mode == 1) {
+    // the re-packed fp16 planes of the UPDATED weights (direct and Winograd forms, forward and
+    // dgrad) stayed inside the scaled fp16 range?  (convlstm_f16x3.h g_pack_overflow)
+    int ovf = 0;
+    HIP_CHECK(hipMemcpyFromSymbol(&ovf, HIP_SYMBOL(mv::g_pack_overflow), sizeof(int)));
+    if (ovf) {
+      const int zero = 0;
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(mv::g_pack_overflow), &zero, sizeof(int)));
+      MV_REQUIRE(false, "f16x3: after optimizer step %lld a ConvLSTM kernel (or a transformed "
+                 "kernel plane of its Winograd forms) left the scaled fp16 range (|256 w| >= "
+                 "60000): the next step would run on infinities; train this model in compute "
+                 "mode f32", (long long)t.global_step);
+    }
+  }
 }
 
 }  // namespace

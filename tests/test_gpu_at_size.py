@@ -133,13 +133,22 @@ def test_configs3_batch128_beam20_rows_vs_batch1_oracle(built_lib):
 
 
 def test_configs3_batch128_beam20_gain3_32_rows_vs_batch1_oracle(built_lib):
-  """The same launch at recurrent gain 3 / bias 0.1 (logits O(1e-2 .. 1): the candidate scores
-  of a step are no longer ties of the initialiser's 1e-5 logits) on every fourth row: 32 rows
-  x 20 beams x 12 steps against the batch-1 oracle."""
-  _configs3_rows(built_lib, dict(recurrent_gain=3.0, bias_scale=0.1), list(range(0, 128, 4)))
+  """The same launch at recurrent gain 3 / bias 0.1 (logits O(1e-2 .. 1)) on every fourth row:
+  32 rows x 20 beams x 12 steps against the batch-1 oracle.  Every beam's ids must match an
+  oracle beam exactly; logits rows may differ only where the ORACLE's own selected-candidate
+  scores are tied to 2e-5 (verified position by position).  Such ties are not rare with these
+  random saturating weights -- several of the 20 beams of a row carry near-identical states --
+  so the per-row cap is 50 % here, runs of tied beams count as ties (beam_compare.py
+  chained_ties; profiles/r6g_beam_gain3_row40_diag.log shows one such row: a dozen selected
+  scores of step 1 within 1e-5, the fp32 engine, the f16x3 engine, the fp32 and the fp64 oracle
+  each order them their own way while all 20 id sequences agree) and the count is printed per
+  row; on TRAINED weights (tests/test_gpu_trained_parity.py) the strict comparison finds no
+  differing row at all in 32 rows."""
+  _configs3_rows(built_lib, dict(recurrent_gain=3.0, bias_scale=0.1), list(range(0, 128, 4)),
+                 max_tied_frac=0.5, chained_ties=True)
 
 
-def _configs3_rows(built_lib, param_kw, rows):
+def _configs3_rows(built_lib, param_kw, rows, max_tied_frac=0.25, chained_ties=False):
   N, B = 128, 20
   cfg = synth.default_config(batch_size=N, use_grids=(1, 0), beam_size=B)
   params = synth.make_params(cfg, seed=synth.SEED_BASE + 2, **param_kw)
@@ -162,6 +171,7 @@ def _configs3_rows(built_lib, param_kw, rows):
   assert np.isfinite(arrs["logits"]).all() and np.isfinite(arrs["logprobs"]).all()
   cfg1 = synth.default_config(batch_size=1, use_grids=(1, 0), beam_size=B)
   torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+  tied = 0
   for n in rows:                              # (row 127's beams are state rows 2540..2559)
     f1 = dict(feed)
     f1["obs_scene"] = feed["obs_scene"][n:n + 1]
@@ -171,8 +181,11 @@ def _configs3_rows(built_lib, param_kw, rows):
     _, oreg, obeam = oracle.forward(params, cfg1, f1, trace=trace)
     one = {k: v[n:n + 1] for k, v in arrs.items()}
     print("configs[3] row %d:" % n, end=" ")
-    compare_beams(one, oreg[0], obeam[0], obeam[1], obeam[2],
-                  np.stack(trace["beam_step_topvals"], axis=-1), trace["beam_trace"])
+    tied += compare_beams(one, oreg[0], obeam[0], obeam[1], obeam[2],
+                          np.stack(trace["beam_step_topvals"], axis=-1), trace["beam_trace"],
+                          max_tied_frac=max_tied_frac, chained_ties=chained_ties)
+  print("configs[3]: %d of %d (n,b,t) logits rows on oracle-tied steps over %d rows"
+        % (tied, len(rows) * B * cfg.pred_len, len(rows)))
 
 
 def _rel(a, b):
@@ -255,8 +268,18 @@ def test_f16x3_numerics_under_checkpoint_like_dynamic_range(built_lib):
     eng = built_lib.Engine(cfg, device=0)
     eng.set_params(params)
     eng.set_compute_mode(mode)
+    eng.set_profiling(True)
+    eng.reset_kernel_stats()
     outs[mode] = eng.forward_greedy(feed)
+    st = eng.kernel_stats()["convlstm_step"]
     eng.close()
+    if mode == "f16x3":
+      # kernels with such outliers (max |w| > 4096 x median |w|) must NOT take a Winograd form
+      # (engine.hip ConvCell::wino_numerics_ok): three fp16 MFMAs issued per fp32 product = the
+      # direct 3x3 form.  (In the Winograd forms this case measured 7e-5 / 1.8e-4 of the range.)
+      per = st["flops_mfma"] / st["flops"]
+      print("f16x3 gate kernels of this model: %.2f fp16 MFMAs per fp32 product" % per)
+      assert per > 2.9
   o64 = oracle.forward(params, cfg, feed, dtype=torch.float64)
   o32 = oracle.forward(params, cfg, feed)
   s, N, Tp = 1, cfg.batch_size, cfg.pred_len
@@ -288,8 +311,8 @@ def test_f16x3_numerics_under_checkpoint_like_dynamic_range(built_lib):
         "fp32 MFMA cls %.2e reg %.2e flips %d | fp32 CPU oracle cls %.2e reg %.2e"
         % (res["f16x3"] + res["f32"] + (e_cpu, e_cpu_r)))
   # The network itself amplifies fp32 roundoff here (the fp32 CPU oracle is ~5e-5 from
-  # fp64), so the bar is relative: the split arithmetic must stay in the fp32 CLASS --
-  # within 8x of the worse of the two fp32 implementations, plus an absolute floor of
-  # 2e-6 of the range for the fp16-subnormal tails of the scaled planes.
-  assert res["f16x3"][0] <= 8 * max(res["f32"][0], e_cpu) + 2e-6
-  assert res["f16x3"][1] <= 8 * max(res["f32"][1], e_cpu_r) + 2e-6
+  # fp64).  The split arithmetic must stay in the fp32 CLASS: within 2x of the engine's own
+  # fp32 matrix-pipe path (+ an absolute floor of 2e-6 of the range for the fp16-subnormal
+  # tails of the scaled planes), and inside north_star's 1e-4 against fp64.
+  assert res["f16x3"][0] <= 2 * res["f32"][0] + 2e-6 and res["f16x3"][0] < 1e-4
+  assert res["f16x3"][1] <= 2 * res["f32"][1] + 2e-6 and res["f16x3"][1] < 1e-4

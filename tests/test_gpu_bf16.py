@@ -187,10 +187,14 @@ def test_bf16_with_unbounded_activations(built_lib, act):
   tparams = synth.make_params(tcfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0, bias_scale=0.1)
   tfeed = synth.make_feed(tcfg, seed=synth.SEED_BASE + 73)
   eng = _engine(built_lib, tcfg, tparams)
+  # refused EARLY (round 6): by mv_train_init on an engine already in bf16 mode, and by
+  # mv_set_compute_mode(bf16) on a training engine -- not at the first training step
+  with pytest.raises(built_lib.MvError, match="activation_func tanh"):
+    eng.train_init()
+  eng.set_compute_mode("f16x3")
   eng.train_init()
   with pytest.raises(built_lib.MvError, match="activation_func tanh"):
-    eng.train_forward_backward(tfeed)
-  eng.set_compute_mode("f16x3")
+    eng.set_compute_mode("bf16")
   loss, wd, pgl = eng.train_forward_backward(tfeed)
   grads = {n: eng.get_grad(n) for n, _ in eng.param_specs()}
   eng.close()

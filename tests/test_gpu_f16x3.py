@@ -161,3 +161,28 @@ def test_model_falls_back_to_f32_when_the_f16x3_range_guard_would_trip(built_lib
   ref.close()
   model.close()
   assert (np.asarray(cls[0]) == rc[0]).all() and (np.asarray(reg[0]) == rr[0]).all()
+
+
+def test_training_repacks_that_leave_the_fp16_range_fail_loudly(built_lib):
+  """The f16x3 packs of a TRAINING engine are rebuilt from the device weights after every
+  optimizer step (direct and Winograd forms, forward and dgrad), where no host copy exists for
+  ensure_packed16's range check: the pack kernels flag a scaled value at or beyond the guard
+  and mv_train_step / mv_train_apply fail at their closing synchronisation -- instead of the
+  next step running on fp16 infinities.  Forced here by one momentum step at a learning rate
+  of 1e7 (clipped gradients of up to 10 move every weight far outside 60 000 / 256)."""
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), is_train=True,
+                             optimizer="momentum", init_lr=1e7)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 6)
+  eng = _engine(built_lib, cfg, synth.make_params(cfg), "f16x3")
+  eng.train_init()
+  with pytest.raises(Exception) as err:
+    eng.train_step(feed)
+  assert "left the scaled fp16 range" in str(err.value)
+  eng.close()
+  # a sane step on a fresh engine afterwards: the flag was cleared
+  cfg2 = synth.default_config(batch_size=2, use_grids=(0, 1), is_train=True)
+  eng = _engine(built_lib, cfg2, synth.make_params(cfg2), "f16x3")
+  eng.train_init()
+  loss, _, _ = eng.train_step(feed)
+  assert np.isfinite(loss)
+  eng.close()
