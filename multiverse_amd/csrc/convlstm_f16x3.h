@@ -138,7 +138,7 @@ static inline void pack_f16x3_weights(const float* w, int Cx, int C, _Float16* o
 // Device-side twin of pack_f16x3_weights (run after every optimizer step): one
 // thread per (cb, k-step, gate, lane, e); writes both planes.
 // The packs below are rebuilt from the DEVICE weights after every optimizer step, where no host
-// copy exists to range-check (engine.hip ensure_packed16 does that for a loaded checkpoint).  A
+// copy exists to range-check (engine_setup.h ensure_packed16 does that for a loaded checkpoint).  A
 // scaled value at or beyond the guard (60 000; fp16 overflows to inf at 65 520) sets this flag;
 // the training step tests it at its closing synchronisation and fails loudly instead of
 // training on infinities (engine_train.h train_apply).  One flag per process.

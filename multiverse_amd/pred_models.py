@@ -171,7 +171,7 @@ def build_feed_dict(cfg, batch, is_train=False):
 
 
 def f16x3_out_of_range(params, limit=60000.0 / 256.0):
-  """The bound engine.hip ensure_packed16 enforces, on the host copy: max |w| of every
+  """The bound engine_setup.h ensure_packed16 enforces, on the host copy: max |w| of every
   3 x 3 gate kernel and of its Winograd-transformed rows ((g0 +- g1 + g2) / 2, (g0 + 2 g1 +
   4 g2) / 6 and its mirror, column by column) must stay below 60 000 / 256.  Returns None, or
   (name, max |w|, reach) of the first kernel that does not."""
@@ -219,7 +219,7 @@ class Model(object):
       self.compute_mode = "f32"
     if any(use and h * w < 32 for (h, w), use in zip(config.scene_grids, config.use_grids)):
       # the fp16-pipe kernels' epilogue lets a 32-cell wave tile span at most two images
-      # (engine.hip run_conv_group_f16x3 refuses smaller grids); such toy grids run on the
+      # (engine_forward.h run_conv_group_f16x3 refuses smaller grids); such toy grids run on the
       # fp32 matrix pipe, whose kernel wraps over any number of images
       if self.compute_mode != "f32":
         import logging
@@ -259,7 +259,7 @@ class Model(object):
       bad = f16x3_out_of_range(params)
       if bad is not None:
         # the f16x3 planes hold 256 w (and, in the Winograd packs, 256 x the transformed
-        # kernel rows) in fp16: engine.hip ensure_packed16 refuses a model that leaves that
+        # kernel rows) in fp16: engine_setup.h ensure_packed16 refuses a model that leaves that
         # range.  Such a model decodes on the fp32 matrix pipe instead (same results
         # contract, 1/5 of the rate) -- the toy-grid pattern above.
         import logging

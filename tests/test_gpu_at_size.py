@@ -275,7 +275,7 @@ def test_f16x3_numerics_under_checkpoint_like_dynamic_range(built_lib):
     eng.close()
     if mode == "f16x3":
       # kernels with such outliers (max |w| > 4096 x median |w|) must NOT take a Winograd form
-      # (engine.hip ConvCell::wino_numerics_ok): three fp16 MFMAs issued per fp32 product = the
+      # (engine_state.h ConvCell::wino_numerics_ok): three fp16 MFMAs issued per fp32 product = the
       # direct 3x3 form.  (In the Winograd forms this case measured 7e-5 / 1.8e-4 of the range.)
       per = st["flops_mfma"] / st["flops"]
       print("f16x3 gate kernels of this model: %.2f fp16 MFMAs per fp32 product" % per)
