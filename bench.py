@@ -756,6 +756,21 @@ def main():
                  cpu_base=not args.no_cpu_baseline, cpu_batch=args.cpu_batch)
   out = head
 
+  # A sub-workload that needs the in-library RCCL communicator (training) runs its bootstrap
+  # under a deadline (multiverse_amd/parallel.py).  If that expires the rank ends -- but the
+  # headline above is already measured and needs no collective beyond torch's barrier: rank 0
+  # emits the line as it stands (with the reason), the other ranks give it a moment to do so.
+  from multiverse_amd import parallel as _par
+
+  def _emit_partial(what):
+    if ctx.rank == 0:
+      out["aborted"] = "%s did not return; sub-workloads after this point are missing" % what
+      real_stdout.write(json.dumps(out) + "\n")
+      real_stdout.flush()
+    else:
+      time.sleep(5.0)
+  _par.deadline_hook = _emit_partial
+
   subs = []
   with_subs = (not args.no_sub and kind == "greedy" and args.batch is None and
                args.compute == "f16x3")

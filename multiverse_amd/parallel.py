@@ -153,11 +153,18 @@ def init_engine_comm(engine):
   return True
 
 
+# Called (with the description of what hung) just before a deadline ends the process: bench.py
+# puts the emission of what it has measured so far here, so that a stalled in-library RCCL
+# bootstrap in a SUB-workload cannot take the already measured headline line down with it.
+deadline_hook = None
+
+
 def call_with_deadline(fn, seconds, what):
   """Run a blocking native call (ctypes releases the GIL) under a deadline.  A call that
   does not come back cannot be cancelled, so on expiry this writes what hung, and why that
-  usually happens, to stderr and ends the PROCESS with status 3 -- a launcher then tears the
-  other ranks down instead of the job hanging until its wall-clock limit."""
+  usually happens, to stderr, runs `deadline_hook`, and ends the PROCESS with status 3 -- a
+  launcher then tears the other ranks down instead of the job hanging until its wall-clock
+  limit."""
   import sys
   import threading
   box = {}
@@ -177,6 +184,11 @@ def call_with_deadline(fn, seconds, what):
         "IPC); NCCL_DEBUG=INFO shows where RCCL's bootstrap stands.  Ending this rank "
         "(MV_COMM_INIT_TIMEOUT_S changes the deadline).\n" % (what, seconds))
     sys.stderr.flush()
+    if deadline_hook is not None:
+      try:
+        deadline_hook(what)
+      except BaseException:   # pylint: disable=broad-except
+        pass
     os._exit(3)
   if "e" in box:
     raise box["e"]

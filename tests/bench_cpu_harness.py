@@ -82,6 +82,13 @@ def main():
     assert float(t[0]) == dist.get_world_size()
     record["allreduce_calls"] += 1
   parallel.allreduce_engine_grads = fake_allreduce
+  if os.environ.get("MV_HARNESS_STUCK_COMM") == "1":
+    # the in-library RCCL bootstrap of the training sub-workload never returns
+    def stuck_comm(engine):
+      parallel.call_with_deadline(lambda: time.sleep(120), 1.0,
+                                  "mv_allreduce_init (ncclCommInitRank) [harness: stuck]")
+      return True
+    parallel.init_engine_comm = stuck_comm
   import bench
   try:
     bench.main()

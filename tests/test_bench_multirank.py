@@ -67,3 +67,25 @@ def test_bench_gpus_8_training_step_control_flow(tmp_path):
   for r in recs:
     assert r["allreduce_calls"] == 1 + steps + 1
   assert line["ms_per_step"] >= 0.9 * 2.0 * n
+
+
+@pytest.mark.timeout(900)
+def test_stalled_rccl_bootstrap_in_a_sub_workload_keeps_the_headline_line(tmp_path):
+  """The default run measures the headline first and the sub-workloads after it.  If the
+  in-library RCCL bootstrap of the training sub-workload never returns (here: a stand-in that
+  sleeps), its deadline ends the ranks -- and rank 0 still emits ONE line carrying the measured
+  headline and the reason, instead of the job dying without output or hanging."""
+  env = dict(os.environ, MV_BENCH_BACKEND="gloo", MV_HARNESS_DIR=str(tmp_path),
+             OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1", MV_HARNESS_STUCK_COMM="1")
+  for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, HARNESS, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                      "--no-cpu-baseline", "--no-fp32-ref", "--only-sub", "train_n32"],
+                     env=env, capture_output=True, timeout=600)
+  assert r.returncode != 0                       # the job failed, loudly ...
+  assert b"FATAL: mv_allreduce_init" in r.stderr
+  lines = [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
+  assert len(lines) == 1, r.stdout.decode()[-2000:]   # ... with the headline on the record
+  line = json.loads(lines[0])
+  assert line["n_gpus"] == 2 and line["value"] > 0 and "did not return" in line["aborted"]
+  assert "train_n32" not in line

@@ -199,9 +199,12 @@ def test_comm_init_deadline_ends_the_process_loudly():
           "  raise SystemExit(9)\n"
           "except ZeroDivisionError:\n"
           "  pass\n"
+          "parallel.deadline_hook = lambda what: print('HOOK: ' + what, flush=True)\n"
           "parallel.call_with_deadline(lambda: time.sleep(30), 0.3, 'stuck ncclCommInitRank')\n"
           "raise SystemExit(8)\n" % root)
   r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=60)
   assert r.returncode == 3, (r.returncode, r.stderr)
+  # the hook ran before the process ended (bench.py emits its measured headline there)
+  assert b"HOOK: stuck ncclCommInitRank" in r.stdout
   assert b"FATAL: stuck ncclCommInitRank did not return within 0 s" in r.stderr
   assert b"MV_COMM_INIT_TIMEOUT_S" in r.stderr
