@@ -86,11 +86,11 @@ typedef struct mv_config {
    * 0 = tanh (published), 1 = relu, 2 = lrelu (tf.nn.leaky_relu, alpha 0.2).  relu / lrelu
    * outputs are unbounded: in compute mode 1 their x operand planes carry a per-tensor
    * power-of-two scale taken from max |x| (DESIGN.md section 3c "x exponent"), so every
-   * compute mode DECODES them.  TRAINING such a model in compute mode 2 (bf16) is refused
-   * -- by mv_train_init on an engine already in mode 2, by mv_set_compute_mode(h, 2) on a
-   * training engine -- because one 8-bit-mantissa plane of an unbounded embedding costs the
-   * regression decoder's kernel gradient too much (cosine 0.96 vs the fp32 oracle): train
-   * them in mode 1. */
+   * compute mode decodes AND trains them.  In compute mode 2 (bf16) the x k-steps of such a
+   * model run as an f16x3 split of the x part alone (fp16 planes under that exponent, three
+   * fp16 MFMAs per product) while the h k-steps stay one bf16 plane: one bf16 plane of a
+   * pixel-offset embedding of hundreds had cost the regression decoder's kernel gradient its
+   * direction (cosine 0.96 vs the fp32 oracle; now 0.99995, the tanh models' figure). */
   int32_t activation;
 } mv_config;
 

@@ -417,19 +417,32 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   // load of 32 consecutive cells is two contiguous 512-byte runs instead of 32
   // separate cache lines.
   const int KGx = Cx >> 4, KGh = C >> 4;
+  // bf16 mode with unbounded activations (x_exp set, NPL == 1): the x stages come in THREE
+  // passes over the same (channel group, stencil row) sequence -- x hi plane x w hi, x lo x w hi,
+  // x hi x w lo (the f16x3 split of the x part alone, on the fp16 MFMA; the pack holds the x
+  // rows three times accordingly, pack_bf16_*) -- while the h stages stay one bf16 plane
+  const int xpasses = (EPI == kEpiLstm && NPL == 1 && p.x_exp) ? 3 : 1;
+  const int nxr = nxst / xpasses;                        // x stages of one pass
+  auto xq = [&](int st) {                                // st < nxst -> stage inside its pass
+    int q = st;
+    if (q >= nxr) q -= nxr;
+    if (q >= nxr) q -= nxr;
+    return q;
+  };
   auto stage_isx = [&](int st) { return st < nxst; };
+  auto stage_xlo = [&](int st) { return xpasses == 3 && st >= nxr && st < 2 * nxr; };
   auto stage_rowoff = [&](int st) {       // (stencil row - 1) * W + first cell of the lane
     const bool is_x = st < nxst;
-    const int q = is_x ? st : st - nxst;
+    const int q = is_x ? xq(st) : st - nxst;
     const int j = q - (q / 3) * 3;
     return (is_x ? xcell : hcell) + (j - 1) * W;
   };
   auto stage_cg = [&](int st) {
-    const int q = (st < nxst) ? st : st - nxst;
+    const int q = (st < nxst) ? xq(st) : st - nxst;
     return q / 3;
   };
   auto stage_rowok = [&](int st) {
-    const int q = (st < nxst) ? st : st - nxst;
+    const int q = (st < nxst) ? xq(st) : st - nxst;
     const int j = q - (q / 3) * 3;
     return ((okymask >> j) & 1) != 0;
   };
@@ -449,7 +462,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       uniform_ptr(const_cast<_Float16*>(h16 - kPlanePad)), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t hrs1 = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(const_cast<_Float16*>(h16 + hps - kPlanePad)), 0, 0x7fffffff, 0x00020000);
-#define MV_LOAD_A(ISX, ROWOFF, CG, ROWOK, KK, A0, A1)                                  \
+#define MV_LOAD_A(ISX, XLO, ROWOFF, CG, ROWOK, KK, A0, A1)                             \
   do {                                                                                  \
     const bool ok_ = (ROWOK) & ((KK) == 0 ? okx0 : ((KK) == 1 ? okx1 : okx2));          \
     const int mm_ = (ROWOFF) + ((KK) - 1);                                              \
@@ -458,7 +471,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
                (mm_ & 31) * 8 + kPlanePad) * 2                                          \
             : 0;                                                                        \
     A0 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(               \
-                                       (ISX) ? xrs0 : hrs0, off_, 0, 0));               \
+                                       (ISX) ? ((XLO) ? xrs1 : xrs0) : hrs0, off_, 0, 0)); \
     if (NPL == 2)                                                                       \
       A1 = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(             \
                                          (ISX) ? xrs1 : hrs1, off_, 0, 0));             \
@@ -496,7 +509,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     const int nsg = (st_hi - st_lo) / R;
     {
     stage_dma(st_lo, lds);
-    bool c_isx = stage_isx(st_lo);
+    bool c_isx = stage_isx(st_lo), c_xlo = stage_xlo(st_lo);
     int c_rowoff = stage_rowoff(st_lo), c_cg = stage_cg(st_lo);
     bool c_rowok = stage_rowok(st_lo);
     // A operands.  The three k-steps of a stencil row read the SAME 32 x 16 tile of the lane's
@@ -519,7 +532,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       return __builtin_bit_cast(f16x8, r);
     };
     f16x8 cc0, cc1;                        // SHIFT: centre fragments of the current stage
-    MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, SHIFT ? 1 : 0, cc0, cc1);
+    MV_LOAD_A(c_isx, c_xlo, c_rowoff, c_cg, c_rowok, SHIFT ? 1 : 0, cc0, cc1);
     if constexpr (NPL == 1) cc1 = cc0;
     __syncthreads();                       // carries the vmcnt(0) of the pending LDS-DMA
     for (int sg = 0; sg < nsg; ++sg) {
@@ -529,12 +542,12 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       for (int u = 0; u < R; ++u) {
       const int st = st_lo + sg * R + u;
       const int stn = st + 1 < st_hi ? st + 1 : st;
-      const bool n_isx = stage_isx(stn);
+      const bool n_isx = stage_isx(stn), n_xlo = stage_xlo(stn);
       const int n_rowoff = stage_rowoff(stn), n_cg = stage_cg(stn);
       const bool n_rowok = stage_rowok(stn);
       f16x8 cn0, cn1;                      // SHIFT: centre fragments of the next stage
       if constexpr (SHIFT) {
-        MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 1, cn0, cn1);   // (re-read at the very end)
+        MV_LOAD_A(n_isx, n_xlo, n_rowoff, n_cg, n_rowok, 1, cn0, cn1);   // (re-read at the very end)
         if constexpr (NPL == 1) cn1 = cn0;
       }
 #pragma unroll
@@ -550,8 +563,8 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
           }
         } else {
           fa0 = cc0; fa1 = cc1;            // loaded one k-step ago
-          if (kk < 2) MV_LOAD_A(c_isx, c_rowoff, c_cg, c_rowok, kk + 1, cc0, cc1);
-          else MV_LOAD_A(n_isx, n_rowoff, n_cg, n_rowok, 0, cc0, cc1);
+          if (kk < 2) MV_LOAD_A(c_isx, c_xlo, c_rowoff, c_cg, c_rowok, kk + 1, cc0, cc1);
+          else MV_LOAD_A(n_isx, n_xlo, n_rowoff, n_cg, n_rowok, 0, cc0, cc1);
         }
         // the DMA of the next stage goes out behind the first k-step's operands (vmcnt
         // retires in order); its target buffer was last read before the previous barrier
@@ -577,18 +590,27 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
           f16x8 b0[NG];
 #pragma unroll
           for (int g = 0; g < NG; ++g) b0[g] = buf[(kq * NG + g) * 64 + lane];
+          if (EPI == kEpiLstm && p.x_exp && c_isx) {     // fp16 x plane x fp16 x rows (uniform)
 #pragma unroll
-          for (int g = 0; g < NG; ++g)
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, fa0), __builtin_bit_cast(bf16x8, b0[g]), acc[g], 0,
-                0, 0);
+            for (int g = 0; g < NG; ++g)
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, fa0), __builtin_bit_cast(bf16x8, b0[g]), acc[g], 0,
+                  0, 0);
+          }
         }
       }
       if constexpr (SHIFT) { cc0 = cn0; cc1 = cn1; }
-      c_isx = n_isx; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
-      if constexpr (EPI == kEpiLstm && NPL == 2) {
-        if (p.x_exp && st == nxst - 1) {       // x planes at 2^e: bring the sums to 2^16
-          const float f = __int_as_float((127 + 8 - p.x_exp[0]) << 23);
+      c_isx = n_isx; c_xlo = n_xlo; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
+      if constexpr (EPI == kEpiLstm) {
+        if (p.x_exp && st == nxst - 1) {
+          // x planes at 2^e: bring the sums to 2^16 (f16x3: the h products follow at 2^8 * 2^8)
+          // or, bf16 mode, back to 1 (fp16 x plane at 2^e x fp16 x rows at 2^8; the h products
+          // follow unscaled)
+          const float f = __int_as_float((127 + (NPL == 2 ? 8 : -8) - p.x_exp[0]) << 23);
 #pragma unroll
           for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -873,16 +895,22 @@ void convlstm_step_bf16_kernel(const ConvLstm16Group g) {
 // bf16 pack of the gate kernel: [cb][k-step][gate][lane][8], the f16x3 pack's order
 // with one unscaled bf16 plane.  Host and device twins (the device one runs after
 // every optimizer step).
-static inline size_t bf16_wpack_elems(int Cx, int C) {
-  return (size_t)(C / kChBlock) * (size_t)(f16x3_xksteps(Cx) + 9 * (C / 16)) * 4 * 64 * 8;
+// xf16 (unbounded-activation models, ConvLstm16Args::x_exp): the x k-steps appear THREE times
+// -- fp16 of 256 w, the same again, fp16 of the residual 256 w - hi -- for the kernel's three x
+// passes (x hi x w hi, x lo x w hi, x hi x w lo); the h rows stay one bf16 plane
+static inline size_t bf16_wpack_elems(int Cx, int C, bool xf16 = false) {
+  return (size_t)(C / kChBlock) * (size_t)((xf16 ? 3 : 1) * f16x3_xksteps(Cx) + 9 * (C / 16)) *
+         4 * 64 * 8;
 }
-static inline void pack_bf16_weights(const float* w, int Cx, int C, _Float16* out) {
+static inline void pack_bf16_weights(const float* w, int Cx, int C, _Float16* out,
+                                     bool xf16 = false) {
   const int Cin = Cx + C, N4 = 4 * C;
-  const int nxk = f16x3_xksteps(Cx), nk = nxk + 9 * (C / 16);
+  const int nx1 = f16x3_xksteps(Cx), nxk = (xf16 ? 3 : 1) * nx1, nk = nxk + 9 * (C / 16);
   for (int cb = 0; cb < C / kChBlock; ++cb)
     for (int s = 0; s < nk; ++s) {
       const bool is_x = s < nxk;
-      const int q = is_x ? s : s - nxk;
+      const int pass = is_x ? s / (nx1 > 0 ? nx1 : 1) : 0;
+      const int q = is_x ? s - pass * nx1 : s - nxk;
       const int cg = q / 9, tap = q % 9;
       for (int g = 0; g < 4; ++g)
         for (int l = 0; l < 64; ++l)
@@ -890,29 +918,40 @@ static inline void pack_bf16_weights(const float* w, int Cx, int C, _Float16* ou
             const int k = 8 * (l >> 5) + e;
             const int ci = (is_x ? 0 : Cx) + cg * 16 + k;
             const int n = g * C + cb * kChBlock + (l & 31);
+            const float wv = w[((size_t)tap * Cin + ci) * N4 + n];
+            const _Float16 w0 = (_Float16)(wv * kF16Scale);
             out[(((size_t)cb * nk + s) * 4 + g) * 512 + (size_t)l * 8 + e] =
-                bf16_as_half(w[((size_t)tap * Cin + ci) * N4 + n]);
+                !(xf16 && is_x) ? bf16_as_half(wv)
+                                : (pass < 2 ? w0 : (_Float16)(wv * kF16Scale - (float)w0));
           }
     }
 }
 __global__ void pack_bf16_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
-                                 int Cx_total, int Cx16, int C, size_t total) {
+                                 int Cx_total, int Cx16, int C, size_t total, int xf16) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int e = idx & 7;
   const int l = (idx >> 3) & 63;
   const int g = (idx >> 9) & 3;
   const size_t t = idx >> 11;                    // cb * nk + s
-  const int nxk = 9 * (Cx16 / 16), nk = nxk + 9 * (C / 16);
+  const int nx1 = 9 * (Cx16 / 16), nxk = (xf16 ? 3 : 1) * nx1, nk = nxk + 9 * (C / 16);
   const int s = t % nk, cb = t / nk;
   const bool is_x = s < nxk;
-  const int q = is_x ? s : s - nxk;
+  const int pass = is_x ? s / (nx1 > 0 ? nx1 : 1) : 0;
+  const int q = is_x ? s - pass * nx1 : s - nxk;
   const int cg = q / 9, tap = q - cg * 9;
   const int k = 8 * (l >> 5) + e;
   const int ci = (is_x ? 0 : Cx_total) + cg * 16 + k;
   const int n = g * C + cb * kChBlock + (l & 31);
   const int Cin = Cx_total + C, N4 = 4 * C;
-  out[idx] = bf16_as_half(w[((size_t)tap * Cin + ci) * N4 + n]);
+  const float wv = w[((size_t)tap * Cin + ci) * N4 + n];
+  if (xf16 && is_x) {
+    note_pack_range(wv * kF16Scale);
+    const _Float16 w0 = (_Float16)(wv * kF16Scale);
+    out[idx] = pass < 2 ? w0 : (_Float16)(wv * kF16Scale - (float)w0);
+  } else {
+    out[idx] = bf16_as_half(wv);
+  }
 }
 
 static inline void launch_convlstm_bf16_steps(const ConvLstm16Args* probs, int n,

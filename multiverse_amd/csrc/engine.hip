@@ -330,9 +330,6 @@ int mv_train_init(mv_handle h, const mv_train_config* tc) {
                  "soft_kernel_size %d (3 or 5)", tc->soft_kernel_size);
     MV_REQUIRE(h->cfg.beam_size == 1, "training needs a greedy (beam_size 1) engine "
                "(reference pred_models.py:261)");
-    MV_REQUIRE(!(h->compute_mode == 2 && h->cfg.activation != 0),
-               "training in compute mode 2 (bf16) needs activation_func tanh: relu / lrelu "
-               "models train in mode 1 (f16x3); see mv_config.activation");
     if (!h->train) {
       h->train = new mv_train_holder();
       train_alloc(h);
@@ -687,9 +684,6 @@ int mv_set_compute_mode(mv_handle h, int32_t mode) {
   return guarded(h, [&] {
     MV_REQUIRE(mode >= 0 && mode <= 2, "compute mode %d (0 = fp32 MFMA, 1 = f16x3, 2 = bf16)",
                mode);
-    MV_REQUIRE(!(mode == 2 && h->train && h->cfg.activation != 0),
-               "compute mode 2 (bf16) on a TRAINING engine needs activation_func tanh: relu / "
-               "lrelu models train in mode 1 (f16x3); see mv_config.activation");
     MV_REQUIRE(mode == 0 || h->cfg.convlstm_kernel == 3,
                "compute mode %d needs convlstm_kernel 3 (%d given: the matrix-pipe gate kernels "
                "are 3 x 3 stencils; mode 0 runs the generic fp32 loops)", mode,

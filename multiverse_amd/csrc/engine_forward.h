@@ -91,9 +91,11 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     q.wp16 = bf16 ? cc->wpb.p : cc->wp16.p;
     q.wx32 = bf16 ? cc->wx32u.p : cc->wx32.p;
     const size_t cells = (size_t)a.rows * a.H * a.W;
-    q.n_xk = a.x_small ? 0 : mv::f16x3_xksteps(a.Cx);
+    // bf16 mode, unbounded activations: three x passes (convlstm_f16x3.h xpasses)
+    const int xpass = (bf16 && e->dyn_x() && !a.x_small) ? 3 : 1;
+    q.n_xk = a.x_small ? 0 : xpass * mv::f16x3_xksteps(a.Cx);
     q.n_hk = a.zero_state ? 0 : 9 * (a.C / 16);
-    q.w_ksteps = mv::f16x3_xksteps(a.Cx) + 9 * (a.C / 16);
+    q.w_ksteps = xpass * mv::f16x3_xksteps(a.Cx) + 9 * (a.C / 16);
     if (a.x_small) q.w_ksteps = 9 * (a.C / 16);
     if (bf16)       // an LDS stage of the bf16 kernel holds MV_BF16_UNITS row units of 3 k-steps
       MV_REQUIRE((q.n_xk / 3) % MV_BF16_UNITS == 0 && (q.n_hk / 3) % MV_BF16_UNITS == 0,

@@ -413,7 +413,8 @@ void ensure_packed_bf16(mv_engine* e, ConvCell& cc) {
   }
   const bool small = cc.Cx > 0 && 9 * cc.Cx <= mv::kBK;
   const int Cx16 = small ? 0 : cc.Cx;
-  std::vector<_Float16> pb(mv::bf16_wpack_elems(Cx16, C));
+  const bool xf16 = e->cfg.activation != 0 && !small;     // engine_state.h dyn_x
+  std::vector<_Float16> pb(mv::bf16_wpack_elems(Cx16, C, xf16));
   if (small) {
     const int Cin = cc.Cx + C, N4 = 4 * C;
     std::vector<float> wh((size_t)9 * C * N4);
@@ -433,7 +434,18 @@ void ensure_packed_bf16(mv_engine* e, ConvCell& cc) {
     HIP_CHECK(hipMemcpy(cc.wx32u.p, wx.data(), wx.size() * sizeof(float),
                         hipMemcpyHostToDevice));
   } else {
-    mv::pack_bf16_weights(cc.kernel->host.data(), cc.Cx, C, pb.data());
+    if (xf16) {        // the x rows travel as fp16 of 256 w there: same range bound as f16x3
+      const int Cin = cc.Cx + C, N4 = 4 * C;
+      float mx = 0.f;
+      for (int t = 0; t < 9; ++t)
+        for (int ci = 0; ci < cc.Cx; ++ci)
+          for (int n = 0; n < N4; ++n)
+            mx = std::max(mx, std::fabs(cc.kernel->host[((size_t)t * Cin + ci) * N4 + n]));
+      MV_REQUIRE(mx * mv::kF16Scale < 60000.f, "bf16 mode, unbounded activations: the x rows of "
+                 "%s reach %g, outside the scaled fp16 range; use compute mode f32",
+                 cc.kernel->name.c_str(), mx);
+    }
+    mv::pack_bf16_weights(cc.kernel->host.data(), cc.Cx, C, pb.data(), xf16);
   }
   cc.wpb.alloc(pb.size());
   HIP_CHECK(hipMemcpy(cc.wpb.p, pb.data(), pb.size() * sizeof(_Float16),

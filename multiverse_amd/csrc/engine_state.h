@@ -182,12 +182,16 @@ struct mv_engine {
   // F(3,3) gate kernel: the pre-transformed operands of a group slot (convlstm_wino3.h
   // wino3_transform_kernel), x and h
   DevBuf<_Float16> pv3x[mv::kMaxGroup], pv3h[mv::kMaxGroup];
-  // relu / lrelu models in f16x3 mode: the x operands of the gate convolutions are unbounded,
-  // so their planes carry a per-tensor exponent (max |x| as float bits [64] | exponent [1])
-  // instead of the fixed 2^8; the producers do not emit planes for these buffers
+  // relu / lrelu models on the fp16 / bf16 pipe: the x operands of the gate convolutions are
+  // unbounded, so their planes carry a per-tensor exponent (max |x| as float bits [64] |
+  // exponent [1]) instead of the fixed 2^8; the producers do not emit planes for these buffers.
+  // In bf16 mode (round 6) the x k-steps of such models run on the LEADING fp16 plane of that
+  // split (11 significand bits under the exponent, fp16 weights for the x rows, fp16 MFMA)
+  // instead of one bf16 plane (8 bits): a pixel-offset embedding of hundreds rounded to bf16
+  // cost the regression decoder's kernel gradient its direction (cosine 0.96)
   DevBuf<int32_t> xexp[mv::kMaxGroup];
   std::set<const float*> xbufs;
-  bool dyn_x() const { return compute_mode == 1 && cfg.activation != 0; }
+  bool dyn_x() const { return compute_mode != 0 && cfg.activation != 0; }
   // planes that travel with an fp32 operand buffer: producers (conv epilogue, graph
   // attention, embeddings) emit them, the next conv launch consumes them
   struct PlaneBuf { _Float16* p; size_t n; bool valid; };

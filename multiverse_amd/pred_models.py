@@ -395,17 +395,6 @@ class Trainer(object):
     if not getattr(config, "is_train", False):
       raise _lib.MvError("Trainer needs a config with is_train=True")
     from multiverse_amd import parallel
-    if model.compute_mode == "bf16" and \
-        getattr(config, "activation_func", "tanh") != "tanh":
-      # the engine refuses to train relu / lrelu models in bf16 (engine_train.h
-      # train_fwd_bwd: regression-decoder kernel gradient at cosine 0.96); f16x3 holds the
-      # fp32 bars for them
-      import logging
-      logging.getLogger("multiverse_amd").warning(
-          "compute mode bf16 overridden to f16x3 for training: activation_func %s",
-          config.activation_func)
-      model.compute_mode = "f16x3"
-      model.engine.set_compute_mode("f16x3")
     model.engine.train_init(config, world=parallel.world_size())
     # data parallel over RCCL: the all-reduce runs inside the library
     self.lib_allreduce = parallel.init_engine_comm(model.engine)

@@ -148,11 +148,16 @@ def test_bf16_training_step_and_beam_run(built_lib):
 
 @pytest.mark.parametrize("act", ["relu", "lrelu"])
 def test_bf16_with_unbounded_activations(built_lib, act):
-  """--activation_func relu / lrelu in bf16 mode (advisor, round 4): the embeddings feeding the
-  gate convolutions are unbounded; bf16 keeps fp32's exponent range, so its single operand plane
-  needs no per-tensor scale (the f16x3 mode's x exponent, tests/test_gpu_edge.py) -- held here:
-  greedy forward (logits within the mode's 3e-2 of range, regression maps within 8e-2), a training step with finite
-  that is REFUSED in bf16 and, after switching the same engine to f16x3, meets the fp32 bars."""
+  """--activation_func relu / lrelu in bf16 mode.  The embeddings feeding the gate convolutions
+  are unbounded (the regression decoder embeds pixel offsets of hundreds without a bounding
+  tanh); ONE bf16 plane of such an operand cost 4 - 5e-2 of the regression maps' range and left
+  the regression decoder's kernel gradient at cosine 0.96 (rounds 4 - 5: training refused).
+  Round 6: the x k-steps of such models run as an f16x3 split of the x part alone -- fp16 planes
+  under the per-tensor exponent, three passes on the fp16 MFMA, fp32-class -- while the h
+  k-steps stay one bf16 plane (csrc/convlstm_f16x3.h xpasses).  Held here: the greedy forward
+  within the mode's ordinary 3e-2 of range for logits AND offsets, and a bf16 training step at
+  the bars of the tanh models (loss 1e-4 relative, every gradient cosine > 0.999; measured
+  0.99995 / 0.99997 -- the tanh models' 0.99997)."""
   cfg = synth.default_config(batch_size=2, use_grids=(1, 1), activation_func=act)
   params = synth.make_params(cfg, seed=synth.SEED_BASE + 21, recurrent_gain=2.0, bias_scale=0.1)
   feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 22)
@@ -175,33 +180,25 @@ def test_bf16_with_unbounded_activations(built_lib, act):
     print("bf16 %s scale %d: logits err %.2e of range, reg err %.2e of range, %d / %d ids equal"
           % (act, s, ec / rng_c, er / rng_r, int((gi == oi).sum()), gi.size))
     assert ec <= BF16_TOL * rng_c
-    # the regression decoder embeds pixel offsets of hundreds WITHOUT a bounding tanh: one bf16
-    # rounding of such an operand is worth more of the output range than with tanh models --
-    # measured 4 - 5e-2 of the range (tanh: <= 3e-2); the reduced-precision mode's bar for these
-    # models is 8e-2, stated here and in DESIGN.md section 3d
-    assert er <= 8e-2 * rng_r or not (gi == oi).all()
-  # training such a model in bf16 is refused (engine_train.h train_fwd_bwd: the bf16 forward
-  # of an unbounded pixel-offset embedding left the regression decoder's kernel gradient at
-  # cosine 0.96, whichever backward ran); the same engine trains in f16x3 at the fp32 bars
+    assert er <= BF16_TOL * rng_r or not (gi == oi).all()
   tcfg = synth.default_config(batch_size=2, use_grids=(1, 1), is_train=True, activation_func=act)
   tparams = synth.make_params(tcfg, seed=synth.SEED_BASE + 3, recurrent_gain=2.0, bias_scale=0.1)
   tfeed = synth.make_feed(tcfg, seed=synth.SEED_BASE + 73)
   eng = _engine(built_lib, tcfg, tparams)
-  # refused EARLY (round 6): by mv_train_init on an engine already in bf16 mode, and by
-  # mv_set_compute_mode(bf16) on a training engine -- not at the first training step
-  with pytest.raises(built_lib.MvError, match="activation_func tanh"):
-    eng.train_init()
-  eng.set_compute_mode("f16x3")
   eng.train_init()
-  with pytest.raises(built_lib.MvError, match="activation_func tanh"):
-    eng.set_compute_mode("bf16")
   loss, wd, pgl = eng.train_forward_backward(tfeed)
   grads = {n: eng.get_grad(n) for n, _ in eng.param_specs()}
+  # one optimizer step: the device re-pack of the x rows (three fp16 passes) and its range flag
+  eng.train_apply(1.0)
+  loss2, _, _ = eng.train_forward_backward(tfeed)
   eng.close()
   oloss, owd, opgl, og = oracle.loss_and_grads(tparams, tcfg, tfeed)
-  print("%s model refused in bf16; f16x3 train: loss %.6f oracle %.6f" % (act, loss, oloss))
-  assert abs(loss - oloss) < 1e-4 * max(1.0, abs(oloss))
+  print("%s model, bf16 training step: loss %.6f oracle %.6f" % (act, loss, oloss))
+  assert abs(loss - oloss) < 1e-4 * max(1.0, abs(oloss)) and np.isfinite(loss2)
+  worst = 2.0
   for n in sorted(grads):
     a, b = grads[n].reshape(-1).astype(np.float64), og[n].reshape(-1).astype(np.float64)
     cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
-    assert np.isfinite(a).all() and cos > 0.9999, (n, cos)
+    worst = min(worst, cos)
+    assert np.isfinite(a).all() and cos > 0.999, (n, cos)
+  print("  worst gradient cosine vs the fp32 oracle: %.5f" % worst)
