@@ -10,7 +10,10 @@
 #   bench     the default `python bench.py` line (headline + every sub-workload)
 #   headline  `python bench.py --no-sub` x 2 (same-box repeatability of the headline)
 #   pmcgreedy rocprofv3 trace + PMC of the greedy workload only
-#   profiles  rocprofv3 traces + PMC of greedy / beam / train (tools/profile_workload.sh)
+#   profiles  rocprofv3 traces + PMC of greedy / beam / train / bf16 training (tools/profile_workload.sh)
+#   smoke     __graft_entry__.smoke()
+#   drivercmd the driver's own command line: python bench.py --gpus 1 --steps 20 --warmup 5
+#   collect   gather the session's evidence as gpurun_out/<tag>/to_profiles/<tag>_* (copy into profiles/)
 #   libab:<name>  headline + beam with build/variants/libmv_<name>.so against the default library
 #   ab:<ENV=V>  headline + beam with the env setting against the default, same box
 #   trainab:<ENV=V>  training parity tests, then the training step (configs[2]) with the env
@@ -35,7 +38,7 @@ for stage in "$@"; do
   echo "=== stage $stage"
   case $stage in
     margins)
-      (time timeout 1500 python -m pytest tests/test_gpu_at_size.py tests/test_gpu_wino.py tests/test_gpu_reference_pin.py -m gpu -q -s) > $O/margins.log 2>&1
+      (time timeout 2400 python -m pytest tests/test_gpu_at_size.py tests/test_gpu_wino.py tests/test_gpu_reference_pin.py tests/test_gpu_trained_parity.py -m gpu -q -s) > $O/margins.log 2>&1
       echo "margins rc $?"; grep -E "passed|failed|error" $O/margins.log | tail -3 ;;
     suite)
       (time timeout 1500 python -m pytest tests -q -m gpu) > $O/gpu_tests.log 2>&1
@@ -66,7 +69,29 @@ PY
       bash tools/profile_workload.sh ${T}_greedy > $O/prof_greedy.log 2>&1
       bash tools/profile_workload.sh ${T}_beam --workload beam > $O/prof_beam.log 2>&1
       bash tools/profile_workload.sh ${T}_train --workload train > $O/prof_train.log 2>&1
-      for w in greedy beam train; do echo "== $w"; head -8 gpurun_out/prof_${T}_$w/kernel_trace_stats.md; done ;;
+      bash tools/profile_workload.sh ${T}_train_bf16 --workload train --batch 64 --compute bf16 --scene-conv-kernel 1 > $O/prof_train_bf16.log 2>&1
+      for w in greedy beam train train_bf16; do echo "== $w"; head -8 gpurun_out/prof_${T}_$w/kernel_trace_stats.md; done ;;
+    smoke)
+      (time timeout 600 python -c "import __graft_entry__ as g; g.smoke()") > $O/smoke.log 2>&1; echo "smoke rc $?"; tail -3 $O/smoke.log ;;
+    drivercmd)
+      (time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5) > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; echo "driver cmd rc $?"
+      line $O/bench_driver_cmd.json ;;
+    collect)
+      # copy the session's evidence into profiles/<tag>_* (run LAST; profiles/ travels back only
+      # through gpurun_out/, so the copies land in gpurun_out/<tag>/to_profiles/)
+      P=$O/to_profiles; mkdir -p $P
+      for w in greedy beam train train_bf16; do
+        d=gpurun_out/prof_${T}_$w; [ -d $d ] || continue
+        cp $d/kernel_trace_stats.md $P/${T}_${w}_kernel_trace_stats.md
+        cp $d/bench_under_rocprof.json $P/${T}_${w}_bench_under_rocprof.json
+        for f in $d/pmc_*.json; do [ -f $f ] && cp $f $P/${T}_${w}_$(basename $f); done
+      done
+      [ -f $O/bench_default.json ] && cp $O/bench_default.json $P/${T}_bench_default.json
+      [ -f $O/bench_driver_cmd.json ] && cp $O/bench_driver_cmd.json $P/${T}_bench_driver_cmd.json
+      [ -f $O/gpu_tests.log ] && tail -5 $O/gpu_tests.log > $P/${T}_gpu_suite_tail.txt
+      [ -f $O/smoke.log ] && cp $O/smoke.log $P/${T}_smoke.log
+      [ -f $O/margins.log ] && grep -E "rows, max|flips|adversarial|error vs fp64|beam parity|passed|histogram|minADE|minFDE|NLL|worst|trained|configs\[3\]:" $O/margins.log > $P/${T}_parity_margins.log
+      ls $P | wc -l ;;
     trainab:*)
       kv=${stage#trainab:}; k=${kv%%=*}
       (time timeout 900 python -m pytest tests/test_gpu_train.py "tests/test_gpu_at_size.py::test_configs2_batch32_train_step_vs_oracle" -m gpu -q -x) > $O/train_tests.log 2>&1
