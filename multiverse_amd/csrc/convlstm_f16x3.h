@@ -298,7 +298,7 @@ constexpr int kLdsVec16 = 2 * kStageVec > kWaves16 * 256 ? 2 * kStageVec : kWave
 // 1 = bf16 (ONE bf16 plane of v itself, one v_mfma_f32_32x32x16_bf16 per product, fp32
 // accumulate: the reduced-precision mode of BASELINE.json configs[4]; plane buffers and
 // packs hold bf16 bit patterns in the same 16-bit containers, same tile layout).
-template <int EPI, int NG, int NPL = 2, bool SHIFT = false>
+template <int EPI, int NG, int NPL = 2, bool SHIFT = false, bool XF16 = false>
 __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int cb, int mt,
                                                     int kslice, int n_kslice,
                                                     f16x8* lds /* [2][kKpb * NPL * 4 * 64] */) {
@@ -421,7 +421,11 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
   // passes over the same (channel group, stencil row) sequence -- x hi plane x w hi, x lo x w hi,
   // x hi x w lo (the f16x3 split of the x part alone, on the fp16 MFMA; the pack holds the x
   // rows three times accordingly, pack_bf16_*) -- while the h stages stay one bf16 plane
-  const int xpasses = (EPI == kEpiLstm && NPL == 1 && p.x_exp) ? 3 : 1;
+  // (XF16 is a TEMPLATE parameter: compiled into the ordinary bf16 kernel the extra stage state
+  // pushed it from 117 registers into 1 900 spills -- 16x slower; found by the bench, not by the
+  // tests)
+  static_assert(!XF16 || (EPI == kEpiLstm && NPL == 1), "x passes: bf16 forward only");
+  constexpr int xpasses = XF16 ? 3 : 1;
   const int nxr = nxst / xpasses;                        // x stages of one pass
   auto xq = [&](int st) {                                // st < nxst -> stage inside its pass
     int q = st;
@@ -430,7 +434,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
     return q;
   };
   auto stage_isx = [&](int st) { return st < nxst; };
-  auto stage_xlo = [&](int st) { return xpasses == 3 && st >= nxr && st < 2 * nxr; };
+  auto stage_xlo = [&](int st) { return XF16 && st >= nxr && st < 2 * nxr; };
   auto stage_rowoff = [&](int st) {       // (stencil row - 1) * W + first cell of the lane
     const bool is_x = st < nxst;
     const int q = is_x ? xq(st) : st - nxst;
@@ -590,7 +594,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
           f16x8 b0[NG];
 #pragma unroll
           for (int g = 0; g < NG; ++g) b0[g] = buf[(kq * NG + g) * 64 + lane];
-          if (EPI == kEpiLstm && p.x_exp && c_isx) {     // fp16 x plane x fp16 x rows (uniform)
+          if (XF16 && c_isx) {                     // fp16 x plane x fp16 x rows (uniform)
 #pragma unroll
             for (int g = 0; g < NG; ++g)
               acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, b0[g], acc[g], 0, 0, 0);
@@ -605,7 +609,7 @@ __device__ __forceinline__ void convlstm16_lds_body(const ConvLstm16Args& p, int
       }
       if constexpr (SHIFT) { cc0 = cn0; cc1 = cn1; }
       c_isx = n_isx; c_xlo = n_xlo; c_rowoff = n_rowoff; c_cg = n_cg; c_rowok = n_rowok;
-      if constexpr (EPI == kEpiLstm) {
+      if constexpr (EPI == kEpiLstm && (NPL == 2 || XF16)) {
         if (p.x_exp && st == nxst - 1) {
           // x planes at 2^e: bring the sums to 2^16 (f16x3: the h products follow at 2^8 * 2^8)
           // or, bf16 mode, back to 1 (fp16 x plane at 2^e x fp16 x rows at 2^8; the h products
@@ -873,8 +877,9 @@ void convlstm_step_f16x3_lds_kernel(const ConvLstm16Group g) {
 }
 
 // The same step with ONE bf16 plane per operand (compute mode 2, BASELINE configs[4]).
-template <bool SHIFT>
-__global__ __launch_bounds__(kThreads16, MV_CONV_MINWAVES)
+// XF16: unbounded-activation models, three fp16 passes over the x k-steps (body: xpasses).
+template <bool SHIFT, bool XF16 = false>
+__global__ __launch_bounds__(kThreads16, XF16 ? 2 : MV_CONV_MINWAVES)
 void convlstm_step_bf16_kernel(const ConvLstm16Group g) {
   __shared__ f16x8 lds[MV_BF16_UNITS * kStageVec];   // 2 buffers x (units x 3 k-steps) x 4 KB
   int block = blockIdx.x;
@@ -885,10 +890,10 @@ void convlstm_step_bf16_kernel(const ConvLstm16Group g) {
   if (pi > 0) block -= g.block_end[pi - 1];
   int cb, mt;
   switch (pi) {
-    case 0: if (step_block_map(g.p[0].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT>(g.p[0], cb, mt, 0, 1, lds); break;
-    case 1: if (step_block_map(g.p[1].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT>(g.p[1], cb, mt, 0, 1, lds); break;
-    case 2: if (step_block_map(g.p[2].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT>(g.p[2], cb, mt, 0, 1, lds); break;
-    default: if (step_block_map(g.p[3].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT>(g.p[3], cb, mt, 0, 1, lds); break;
+    case 0: if (step_block_map(g.p[0].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT, XF16>(g.p[0], cb, mt, 0, 1, lds); break;
+    case 1: if (step_block_map(g.p[1].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT, XF16>(g.p[1], cb, mt, 0, 1, lds); break;
+    case 2: if (step_block_map(g.p[2].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT, XF16>(g.p[2], cb, mt, 0, 1, lds); break;
+    default: if (step_block_map(g.p[3].f, block, g.map_mode, cb, mt)) convlstm16_lds_body<kEpiLstm, 4, 1, SHIFT, XF16>(g.p[3], cb, mt, 0, 1, lds); break;
   }
 }
 
@@ -1227,10 +1232,20 @@ static inline void launch_convlstm_bf16_steps(const ConvLstm16Args* probs, int n
     g.block_end[i] = (int32_t)total;
   }
   for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
-  if (conv_group_shift(probs, n))
+  // unbounded-activation models (a problem carries an x exponent): the three-pass x kernel
+  bool xf16 = false;
+  for (int i = 0; i < n; ++i) xf16 = xf16 || probs[i].x_exp != nullptr;
+  const bool shift = conv_group_shift(probs, n);
+  if (xf16) {
+    if (shift)
+      hipLaunchKernelGGL((convlstm_step_bf16_kernel<true, true>), dim3(total), dim3(kThreads16), 0, stream, g);
+    else
+      hipLaunchKernelGGL((convlstm_step_bf16_kernel<false, true>), dim3(total), dim3(kThreads16), 0, stream, g);
+  } else if (shift) {
     hipLaunchKernelGGL(convlstm_step_bf16_kernel<true>, dim3(total), dim3(kThreads16), 0, stream, g);
-  else
+  } else {
     hipLaunchKernelGGL(convlstm_step_bf16_kernel<false>, dim3(total), dim3(kThreads16), 0, stream, g);
+  }
 }
 
 static inline void launch_convlstm16_steps(const ConvLstm16Args* probs, int n,

@@ -163,6 +163,40 @@ def test_full_size_properties_batch64(built_lib):
     assert (r4[s] == reg[s][lo:lo + 4]).all()
 
 
+def test_full_size_properties_batch256(built_lib):
+  """north_star's "batch 256" (the `greedy_b256` line of bench.py), both scales, f16x3 and f32:
+  (a) determinism; (b) batch independence at THAT size -- rows 64 .. 127 of the batch equal, bit
+  for bit, the same 64 trajectories run as a batch of 64 (whose every row tests/
+  test_gpu_at_size.py holds to the oracle): the 256-row launch tiles, maps to XCDs and groups
+  its problems differently, the arithmetic per row must not notice."""
+  cfg = synth.default_config(batch_size=256, use_grids=(1, 1))
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 2, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 8)
+  lo = 64
+  sub = dict(feed)
+  sub["obs_scene"] = feed["obs_scene"][lo:lo + 64]
+  sub["grid_obs_labels"] = [a[lo:lo + 64] for a in feed["grid_obs_labels"]]
+  sub["grid_obs_regress"] = [a[lo:lo + 64] for a in feed["grid_obs_regress"]]
+  cfg64 = synth.default_config(batch_size=64, use_grids=(1, 1))
+  for mode in ("f16x3", "f32"):
+    eng = built_lib.Engine(cfg, device=0)
+    eng.set_params(params)
+    eng.set_compute_mode(mode)
+    cls, reg = eng.forward_greedy(feed)
+    cls2, reg2 = eng.forward_greedy(feed)
+    eng.close()
+    eng64 = built_lib.Engine(cfg64, device=0)
+    eng64.set_params(params)
+    eng64.set_compute_mode(mode)
+    c64, r64 = eng64.forward_greedy(sub)
+    eng64.close()
+    for s in (0, 1):
+      assert np.isfinite(cls[s]).all() and np.isfinite(reg[s]).all()
+      assert (cls[s] == cls2[s]).all() and (reg[s] == reg2[s]).all()
+      assert (c64[s] == cls[s][lo:lo + 64]).all(), (mode, s)
+      assert (r64[s] == reg[s][lo:lo + 64]).all(), (mode, s)
+
+
 def test_compact_inputs_are_bit_identical(built_lib):
   """SURVEY 8f N3 (device-side batch assembly): labels + one (x, y) per step +
   uint8 masks, expanded in HBM, against the dense upload of the same batch --

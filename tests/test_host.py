@@ -451,3 +451,33 @@ def test_bench_algorithmic_counts_match_the_survey():
   fe, _ = bench.algorithmic_counts(synth.default_config(batch_size=1, use_grids=(1, 1)),
                                    executed=True, sparse_x=True)
   assert fe < fb          # zero-state first steps and the sparse x k-steps are not counted
+
+
+def test_no_kernel_spills_to_scratch(tmp_path):
+  """Every kernel of the library must fit its register budget: a stage loop that spills runs an
+  order of magnitude slower and NO parity test notices (round 6: a run-time switch added to the
+  bf16 gate kernel pushed it from 117 registers into 1 900 spills -- 16x slower, found by the
+  bench).  hipcc's own resource report, on the exact sources and flags of build()."""
+  import re
+  import subprocess
+  import __graft_entry__ as g
+  src = os.path.join(g.CSRC, "engine.hip")
+  cmd = [g.HIPCC] + [f for f in g.HIP_FLAGS if f not in ("-shared", "-fPIC")] + [
+      "--cuda-device-only", "-S", src, "-o", str(tmp_path / "engine.s"),
+      "-Rpass-analysis=kernel-resource-usage"]
+  r = subprocess.run(cmd, capture_output=True, timeout=1200)
+  assert r.returncode == 0, r.stderr.decode()[-2000:]
+  cur, rows = None, {}
+  for line in r.stderr.decode().splitlines():
+    m = re.search(r"Function Name: (\S+)", line)
+    if m:
+      cur = m.group(1)
+      rows[cur] = {}
+    for key in ("ScratchSize [bytes/lane]", "VGPRs Spill", "SGPRs Spill"):
+      m = re.search(re.escape(key) + r": (\d+)", line)
+      if m and cur:
+        rows[cur][key] = int(m.group(1))
+  assert len(rows) > 100, "resource report not parsed (%d kernels)" % len(rows)
+  bad = {k: v for k, v in rows.items()
+         if v.get("ScratchSize [bytes/lane]", 0) or v.get("VGPRs Spill", 0)}
+  assert not bad, "kernels spilling to scratch: %s" % bad
