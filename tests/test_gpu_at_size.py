@@ -188,6 +188,47 @@ def _configs3_rows(built_lib, param_kw, rows, max_tied_frac=0.25, chained_ties=F
         % (tied, len(rows) * B * cfg.pred_len, len(rows)))
 
 
+def test_configs3_every_row_of_batch128_equals_its_batch1_run_bitwise(built_lib):
+  """The reference decodes multi-future samples ONE at a time (batch 1, beam 20,
+  code/multifuture_inference.py:458-523); the benchmarked launch decodes 128 at once.  All 128
+  rows of the batch-128 decode -- ids, per-beam logits, log-probabilities, offsets -- must equal,
+  bit for bit, the batch-1 decode of the same trajectory by the same library (whose rows the
+  tests above hold to the batch-1 ORACLE): tiling, XCD maps, the shared first step and the
+  graph-attention dedupe by parent must not leak one trajectory's position into its numbers.
+  At recurrent gain 3 (real logits), f16x3."""
+  N, B = 128, 20
+  cfg = synth.default_config(batch_size=N, use_grids=(1, 0), beam_size=B)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 2, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 2)
+  eng = built_lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode("f16x3")
+  arrs, s = eng.forward_beam(feed)
+  eng.close()
+  cfg1 = synth.default_config(batch_size=1, use_grids=(1, 0), beam_size=B)
+  eng1 = built_lib.Engine(cfg1, device=0)
+  eng1.set_params(params)
+  eng1.set_compute_mode("f16x3")
+  bad = []
+  for n in range(N):
+    f1 = dict(feed)
+    # the scene table compacted to the frames this trajectory uses (a batch-1 engine takes at
+    # most T_o frames), as the reference's batcher does (code/pred_utils.py:672-704)
+    uniq, inv = np.unique(feed["obs_scene"][n], return_inverse=True)
+    f1["scene_feat"] = np.ascontiguousarray(feed["scene_feat"][uniq])
+    f1["obs_scene"] = np.ascontiguousarray(inv.reshape(1, -1).astype("int32"))
+    f1["grid_obs_labels"] = [a[n:n + 1] for a in feed["grid_obs_labels"]]
+    f1["grid_obs_regress"] = [a[n:n + 1] for a in feed["grid_obs_regress"]]
+    one, s1 = eng1.forward_beam(f1)
+    assert s1 == s
+    for k in ("ids", "logits", "logprobs", "grid_reg", "best_beam"):
+      if not (np.asarray(one[k])[0] == np.asarray(arrs[k])[n]).all():
+        bad.append((n, k))
+  eng1.close()
+  print("batch 128 x beam 20 vs 128 batch-1 decodes: %d (row, tensor) pairs differ" % len(bad))
+  assert not bad, bad[:10]
+
+
 def _rel(a, b):
   a = np.asarray(a, dtype=np.float64)
   b = np.asarray(b, dtype=np.float64)
