@@ -21,7 +21,7 @@ def compare_beams(arrs, oreg, ologits, oids, olp, topv, otrace, relative=False,
   max(1, max |oracle offset|) (trained offsets are pixels, up to 1e3).  max_tied_frac: cap on
   the fraction of (n, b, t) logits rows that may sit on such verified ties.  chained_ties: for
   models whose candidate scores cluster (saturating random weights: a dozen of the 20 selected
-  scores of a step within 1e-5 of each other -- tools/diag/beam_row_diag.py prints them) the
+  scores of a step within 1e-5 of each other -- tests/diag/beam_row_diag.py prints them) the
   ORDER of a whole run of beams is decided by float32 ulps, and a logits row (gathered by beam
   index, see above) can move although ITS OWN neighbours are not the tied pair; a differing row
   is then accepted when ANY adjacent pair of the step (or of the step before) is tied.  The

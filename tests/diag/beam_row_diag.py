@@ -1,7 +1,7 @@
 # coding=utf-8
 """Diagnostic (GPU box): one row of the configs[3] launch (N = 128, beam 20) at recurrent gain 3
 against the batch-1 oracle -- where do the logits rows differ, and what do the oracle's candidate
-scores look like there?  usage: python tools/diag/beam_row_diag.py <row> [gain]"""
+scores look like there?  usage: python tests/diag/beam_row_diag.py <row> [gain]"""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

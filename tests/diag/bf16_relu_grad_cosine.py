@@ -2,7 +2,7 @@
 """Diagnostic (GPU box): gradient cosines of a bf16-mode training step against the fp32 oracle
 for --activation_func relu / lrelu / tanh models (the x k-steps of unbounded-activation models
 run on an fp16 plane under a per-tensor exponent in bf16 mode).
-usage: python tools/diag/bf16_relu_grad_cosine.py"""
+usage: python tests/diag/bf16_relu_grad_cosine.py"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
