@@ -389,7 +389,9 @@ int  mv_op_convlstm_step(int device, const float* x, const float* c,
 /* The same step on the fp16 matrix pipe at fp32 accuracy (f16x3 operand planes):
  * variant 1 = direct 3x3 form, 2 = Winograd F(2,3) over image rows (W must divide 32),
  * 3 = Winograd F(3,3) over image rows (any W -- widths that do not divide 32 take the halo
- * tiling, operands below 2 GiB --, H >= 3; csrc/convlstm_wino3.h).
+ * tiling, operands below 2 GiB --, H >= 3; csrc/convlstm_wino3.h), 4 = REDUCED precision: one
+ * bf16 plane per operand on the same row-triple tile (compute mode 2's gate kernel; h16_out is
+ * then that one plane decoded).
  * h16_out (optional) [M,H,W,C]: the h' OPERAND PLANES the kernel emitted for the next
  * step, decoded back to fp32 ((hi + lo) / 256), so that a test sees the plane layout. */
 int  mv_op_convlstm_step16(int device, int32_t variant, const float* x, const float* c,

@@ -259,7 +259,14 @@ static inline void launch_wino3_transforms(const Wn3TransformItem* items, int n,
 // rest (their fragments are the neighbours of lanes 1 and 30) but store nothing -- 1 / 16 of the
 // matrix work for any W (the literal 36 x 18 / 18 x 9 grids of BASELINE.json, --scene_h /
 // --scene_w other than 36 x 64).
-template <int WAVES, int NRB, bool HALO>
+// BF16D (round 6): the same tile, block map, halo tiling and epilogue around a DIRECT 3x3 main
+// loop on ONE bf16 plane per operand (compute mode 2): three accumulator sets (the output rows
+// 3t .. 3t + 2) instead of five components, raw operand rows instead of pre-transformed ones,
+// one MFMA per product.  Against the 32-cell tile of convlstm_f16x3.h's bf16 body each weight
+// fragment read from LDS feeds THREE MFMAs (the three output rows) instead of one, and a stage
+// = a whole chunk: 54 MFMAs per wave and barrier on 18 KB of weights -- 0.5 KB moved per MFMA
+// instead of 1.2.
+template <int WAVES, int NRB, bool HALO, bool BF16D = false>
 __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, int cb, int mt,
                                                     f16x8* lds) {
   using G = Wn3<NRB>;
@@ -313,10 +320,11 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     }
   }
 
-  // acc[0..4]: the Winograd components
-  f32x16 acc[5][NRB];
+  // acc[0..4]: the Winograd components (BF16D: acc[0..2] = the three output rows)
+  constexpr int kAcc = BF16D ? 3 : 5;
+  f32x16 acc[kAcc][NRB];
 #pragma unroll
-  for (int c = 0; c < 5; ++c)
+  for (int c = 0; c < kAcc; ++c)
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -325,7 +333,8 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   // LDS: [stage buffer 0 | stage buffer 1 (two components each; the epilogue reuses them as the
   // waves' h' tiles) | per wave: c tile 96 x CH floats | per wave: two tables of 96 cell
   // offsets (state source rows, output rows)]
-  constexpr int kStageVec = 2 * 3 * 2 * NRB * 64;            // 16-byte vectors per stage
+  constexpr int kStageVec = BF16D ? 3 * 3 * NRB * 64         // a chunk: 9 taps, one plane
+                                  : 2 * 3 * 2 * NRB * 64;    // 16-byte vectors per stage
   constexpr uint32_t kStageBytes = kStageVec * 16;
   static_assert(2 * kStageVec * 16 >= WAVES * G::kTileFloats * 4, "h' tiles fit the stage buffers");
   float* const ctile = reinterpret_cast<float*>(lds + 2 * kStageVec) + wave * G::kTileFloats;
@@ -386,7 +395,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) {
         const float tw = p.w_hwio[((size_t)tap * Cin + chn) * N4 + n0 + rb * 8];
-        wv[rb] = kok ? tw * 65536.0f : 0.f;
+        wv[rb] = kok ? tw * (BF16D ? 1.0f : 65536.0f) : 0.f;     // bf16 mode: unscaled sums
       }
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
@@ -397,7 +406,9 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
         const float v = ok ? tv : 0.f;
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
-          if (e == 1) {
+          if constexpr (BF16D) {
+            acc[e][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[rb], v, acc[e][rb], 0, 0, 0);
+          } else if (e == 1) {
             acc[1][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[rb], 0.5f * v, acc[1][rb], 0, 0, 0);
             acc[2][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[rb], -0.5f * v, acc[2][rb], 0, 0, 0);
           } else {
@@ -418,6 +429,96 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   const int nxc = p.n_xc;
   const int ck_lo = a.sx_corr ? nxc : 0;                          // sparse x: table terms instead
   const int ck_hi = a.zero_state ? nxc : nxc + (C >> 4);
+  if constexpr (BF16D) {
+    // ---- direct 3 x 3 on ONE bf16 plane per operand.  A stage = a whole chunk of 16 input
+    // channels: 9 taps x NRB row blocks of weights (18 KB), double-buffered by LDS-DMA; the
+    // lane's five operand rows y0 - 1 .. y0 + 3 of the chunk (16 bytes each, from the ordinary
+    // tiled planes, the beam's parent indirection in the row offsets) are requested a chunk
+    // ahead.  Per stencil column dx: the five rows moved a lane (DPP) once, then for every
+    // kernel row dy one weight fragment per row block feeds THREE MFMAs (output rows 3t + e
+    // read operand row e + dy).
+    if (ck_hi > ck_lo) {
+      constexpr int kChunkVecD = 3 * 3 * NRB * 64;
+      constexpr int kPiecesD = 3 * 3 * NRB;                  // 1 KB pieces of a stage
+      const f16x8* wblk = reinterpret_cast<const f16x8*>(p.wpw) +
+                          ((size_t)cb * (nxc + (C >> 4)) + ck_lo) * kChunkVecD;
+      const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(const_cast<f16x8*>(wblk)), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(const_cast<_Float16*>(q.x16 ? q.x16 - kPlanePad : q.h16 - kPlanePad)), 0,
+          0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(const_cast<_Float16*>(q.h16 ? q.h16 - kPlanePad : q.x16 - kPlanePad)), 0,
+          0x7fffffff, 0x00020000);
+      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+      const uint32_t lane16 = (uint32_t)lane * 16u;
+      auto stage_dma = [&](int st, f16x8* dstbuf) {
+#pragma unroll
+        for (int i = 0; i < (kPiecesD + WAVES - 1) / WAVES; ++i) {
+          const int piece = i * WAVES + wave_u;
+          if (piece < kPiecesD)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                wrs, (__attribute__((address_space(3))) void*)(dstbuf + piece * 64), 16, lane16,
+                (uint32_t)st * (uint32_t)(kChunkVecD * 16) + (uint32_t)piece * 1024u, 0,
+                MV_DMA_AUX);
+        }
+      };
+      struct Rows { f16x8 d[5]; };
+      // chunk ck of the sequence (x chunks first); a request past the end repeats the last one
+      auto rload = [&](int ck, Rows& rw) {
+        const int cc = ck < ck_hi ? ck : ck_hi - 1;
+        const bool is_x = cc < nxc;
+        const uint32_t so = (uint32_t)(is_x ? cc : cc - nxc) * 1024u;   // channel group: 512 halves
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          // an out-of-image row keeps offset 0 = the zero pad in front of the plane (the channel
+          // group must not move it into the plane)
+          const uint32_t ro = is_x ? roffx[i] : roffh[i];
+          rw.d[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  is_x ? xrs : hrs, (int)(ro ? ro + so : 0u), 0, 0));
+        }
+      };
+      // (two row sets alternating without the copy below measured 3 % SLOWER: 0.368 vs 0.352 ms
+      // per launch, same box -- hipcc's schedule of the unrolled pair is worse)
+      Rows cur, nxt;
+      rload(ck_lo, cur);
+      nxt = cur;
+      stage_dma(0, lds);
+      __syncthreads();
+      for (int ck = ck_lo; ck < ck_hi; ++ck) {
+        const int st = ck - ck_lo;
+        f16x8* const buf = lds + ((st & 1) ? kStageVec : 0);
+        f16x8* const nbuf = lds + ((st & 1) ? 0 : kStageVec);
+        if (ck + 1 < ck_hi) {
+          stage_dma(st + 1, nbuf);       // its buffer was last read before the barrier
+          rload(ck + 1, nxt);
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          f16x8 sft[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            sft[i] = dx == 1 ? cur.d[i]
+                             : wn_lane_shift(cur.d[i], dx == 0, dx == 0 ? okx0 : okx2);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            f16x8 w[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) w[rb] = buf[((dy * 3 + dx) * NRB + rb) * 64 + lane];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+              for (int e = 0; e < 3; ++e)
+                acc[e][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, w[rb]), __builtin_bit_cast(bf16x8, sft[e + dy]),
+                    acc[e][rb], 0, 0, 0);
+          }
+        }
+        cur = nxt;
+        __syncthreads();                 // DMA + rows of the next chunk have landed
+      }
+    }
+  } else
   if (ck_hi > ck_lo) {
     static_assert(NRB == 2, "stage copy: 24 pieces of 64 vectors");
     const int G_total = (ck_hi - ck_lo) * 5;
@@ -581,7 +682,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
     const uint32_t hyx = a.sx_cellyx[a.sx_hot[(size_t)hr * a.sx_hot_stride]];
     hot_y = (int)(hyx >> 16); hot_x = (int)(hyx & 0xffffu);
   }
-  const float un = kF16Unscale;
+  const float un = BF16D ? 1.0f : kF16Unscale;
   const bool planes = q.h16_out != nullptr;
   u32x2 ph[3][NRB], pl[3][NRB];               // h' as plane halves (hi, lo), [e][rb]
 #pragma unroll
@@ -636,12 +737,16 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int reg = g * 4 + j;
-          const float m0 = acc[0][rb][reg], m1 = acc[1][rb][reg], m2 = acc[2][rb][reg],
-                      m3 = acc[3][rb][reg], m4 = acc[4][rb][reg];
           float yv;
-          if (e == 0) yv = (m0 + m1) + (m2 + m3);
-          else if (e == 1) yv = (m1 - m2) + 2.0f * m3;
-          else yv = (m1 + m2) + (4.0f * m3 + m4);
+          if constexpr (BF16D) {
+            yv = acc[e][rb][reg];
+          } else {
+            const float m0 = acc[0][rb][reg], m1 = acc[1][rb][reg], m2 = acc[2][rb][reg],
+                        m3 = acc[3][rb][reg], m4 = acc[kAcc - 1][rb][reg];
+            if (e == 0) yv = (m0 + m1) + (m2 + m3);
+            else if (e == 1) yv = (m1 - m2) + 2.0f * m3;
+            else yv = (m1 + m2) + (4.0f * m3 + m4);
+          }
           pre[g] = __builtin_fmaf(yv, un, add[g][j]);   // un = 2^-16: the product is exact
         }
         const float si = sigm_(pre[0]), tj = tanh_(pre[1]), sf = sigm_(pre[2] + a.forget_bias),
@@ -670,10 +775,15 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
         f16x4 p0, p1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float sc = hn4[j] * kF16Scale;
-          const _Float16 h0 = (_Float16)sc;
-          p0[j] = h0;
-          p1[j] = (_Float16)(sc - (float)h0);
+          if constexpr (BF16D) {         // ONE unscaled bf16 plane
+            p0[j] = bf16_as_half(hn4[j]);
+            p1[j] = p0[j];
+          } else {
+            const float sc = hn4[j] * kF16Scale;
+            const _Float16 h0 = (_Float16)sc;
+            p0[j] = h0;
+            p1[j] = (_Float16)(sc - (float)h0);
+          }
         }
         ph[e][rb] = __builtin_bit_cast(u32x2, p0);
         pl[e][rb] = __builtin_bit_cast(u32x2, p1);
@@ -718,7 +828,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
       const size_t o01 = (size_t)(mc01 >> 5) * KG * 512 + grp + (size_t)((int)(mc01 & 31u) * 8);
       const size_t o2 = (size_t)(mc2 >> 5) * KG * 512 + grp + (size_t)((int)(mc2 & 31u) * 8);
 #pragma unroll
-      for (int pn = 0; pn < 2; ++pn) {
+      for (int pn = 0; pn < (BF16D ? 1 : 2); ++pn) {
         const u32x2 A = pn ? pl[0][rb] : ph[0][rb], B = pn ? pl[1][rb] : ph[1][rb];
         const u32x2 D = pn ? pl[2][rb] : ph[2][rb];
         const u32x2 s0 = __builtin_amdgcn_permlane32_swap(A[0], B[0], false, false);
@@ -738,7 +848,7 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
   }
 }
 
-template <int WAVES, int NRB, bool HALO>
+template <int WAVES, int NRB, bool HALO, bool BF16D = false>
 __global__ __launch_bounds__(WAVES * 64, 2)
 void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
   extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
@@ -773,10 +883,10 @@ void convlstm_step_wino3_kernel(const ConvLstmWinoGroup g) {
   int cb, mt;
   constexpr int CH = Wn3<NRB>::kCh;
   switch (pi) {
-    case 0: cbmap(g.p[0].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO>(g.p[0], cb, mt, lds); break;
-    case 1: cbmap(g.p[1].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO>(g.p[1], cb, mt, lds); break;
-    case 2: cbmap(g.p[2].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO>(g.p[2], cb, mt, lds); break;
-    default: cbmap(g.p[3].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO>(g.p[3], cb, mt, lds); break;
+    case 0: cbmap(g.p[0].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO, BF16D>(g.p[0], cb, mt, lds); break;
+    case 1: cbmap(g.p[1].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO, BF16D>(g.p[1], cb, mt, lds); break;
+    case 2: cbmap(g.p[2].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO, BF16D>(g.p[2], cb, mt, lds); break;
+    default: cbmap(g.p[3].b.f.C / CH, cb, mt); convlstm_wino3_body<WAVES, NRB, HALO, BF16D>(g.p[3], cb, mt, lds); break;
   }
 }
 
@@ -864,6 +974,77 @@ static inline void launch_convlstm_wino3_steps(const ConvLstmWinoArgs* probs, in
   else
     hipLaunchKernelGGL((convlstm_step_wino3_kernel<kW3Waves, kW3Nrb, false>), dim3(total),
                        dim3(kW3Waves * 64), wino3_lds_bytes(), stream, g);
+}
+
+// ------------------------------------------------------------------ bf16 mode on this tile
+// (compute mode 2; body: BF16D).  Pack: [cb][chunk][dy 3][dx 3][rb][lane 64][8] bf16 of the
+// kernel itself -- a chunk IS the LDS image of its stage; element e of lane l: A-operand row
+// l & 31 = gate (row >> 3), channel cb * 8 nrb + rb * 8 + (row & 7); k = 8 (l >> 5) + e.
+static inline size_t bf16t_wpack_elems(int Cx16, int C, int nrb) {   // in halves
+  return (size_t)(C / (8 * nrb)) * (size_t)(Cx16 / 16 + C / 16) * 9 * nrb * 64 * 8;
+}
+__global__ void pack_bf16t_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
+                                  int Cx_total, int Cx16, int C, int nrb, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx & 7;
+  const int l = (idx >> 3) & 63;
+  size_t t = idx >> 9;
+  const int rb = (int)(t % nrb); t /= nrb;
+  const int tap = (int)(t % 9); t /= 9;                 // dy * 3 + dx
+  const int nxc = Cx16 / 16, nch = nxc + C / 16;
+  const int chunk = (int)(t % nch), cb = (int)(t / nch);
+  const bool is_x = chunk < nxc;
+  const int cg = is_x ? chunk : chunk - nxc;
+  const int k = 8 * (l >> 5) + e;
+  const int cin = (is_x ? 0 : Cx_total) + cg * 16 + k;
+  const int row = l & 31;
+  const int n = (row >> 3) * C + cb * 8 * nrb + rb * 8 + (row & 7);
+  const int Cin = Cx_total + C, N4 = 4 * C;
+  out[idx] = bf16_as_half(w[((size_t)tap * Cin + cin) * N4 + n]);
+}
+static inline size_t bf16t_lds_bytes() {
+  return (size_t)2 * (3 * 3 * kW3Nrb * 64 * 16) + (size_t)kW3Waves * Wn3<kW3Nrb>::kTileFloats * 4 +
+         (size_t)kW3Waves * 192 * 4;
+}
+// MV_BF16T=0 keeps the 32-cell bf16 body of convlstm_f16x3.h (A/B runs).
+static inline bool bf16t_enabled() {
+  static const bool off = getenv("MV_BF16T") && atoi(getenv("MV_BF16T")) == 0;
+  return !off;
+}
+static inline bool bf16t_geometry_ok(const ConvLstmArgs& a, const ConvLstm16Args& q) {
+  return a.W > 0 && a.C % Wn3<kW3Nrb>::kCh == 0 && (a.Cx % 16 == 0 || a.x_small) && a.H >= 3 &&
+         q.x_exp == nullptr;
+}
+template <bool HALO>
+static inline void bf16t_launch_one(const ConvLstmWinoGroup& g, unsigned total, hipStream_t stream) {
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(convlstm_step_wino3_kernel<kW3Waves, kW3Nrb, HALO, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf16t_lds_bytes());
+    return true;
+  }();
+  (void)attr;
+  hipLaunchKernelGGL((convlstm_step_wino3_kernel<kW3Waves, kW3Nrb, HALO, true>), dim3(total),
+                     dim3(kW3Waves * 64), bf16t_lds_bytes(), stream, g);
+}
+static inline void launch_convlstm_bf16t_steps(const ConvLstmWinoArgs* probs, int n,
+                                               hipStream_t stream) {
+  ConvLstmWinoGroup g{};
+  g.n = n;
+  static const int map_mode = getenv("MV_WINO_MAP") ? atoi(getenv("MV_WINO_MAP")) : 2;
+  g.map_mode = map_mode;
+  bool halo = false;
+  for (int i = 0; i < n; ++i) halo = halo || wino3_needs_halo(probs[i].b.f);
+  unsigned total = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = probs[i];
+    total += convlstm_wino3_blocks(probs[i].b.f, halo, map_mode);
+    g.block_end[i] = (int32_t)total;
+  }
+  for (int i = n; i < kMaxGroup; ++i) g.block_end[i] = (int32_t)total;
+  if (halo) bf16t_launch_one<true>(g, total, stream);
+  else bf16t_launch_one<false>(g, total, stream);
 }
 
 }  // namespace mv

@@ -175,7 +175,7 @@ int mv_set_param(mv_handle h, const char* tf_name, const float* data,
       for (ConvCell* cc : {&S.enc_cls, &S.enc_reg, &S.dec_cls, &S.dec_reg})
         if (cc->kernel == p) {
           cc->wpack.release(); cc->wp16.release(); cc->wx32.release();
-          cc->wpb.release(); cc->wx32u.release(); cc->wpw.release(); cc->wpw3.release();
+          cc->wpb.release(); cc->wpbt.release(); cc->wx32u.release(); cc->wpw.release(); cc->wpw3.release();
           cc->host_stale = false;
         }
     }

@@ -251,8 +251,22 @@ void run_conv_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     }
     factor = den > 0 ? num / den : (wino3 ? 5.0 / 3.0 : 2.0);
   }
+  // bf16 mode: the row-triple tile (convlstm_wino3.h BF16D) when every problem fits it
+  bool bf16t = bf16 && mv::bf16t_enabled();
+  for (size_t i = 0; i < p16.size() && bf16t; ++i) {
+    ConvCell* cc = cell_of_pack(e, probs[i].wpack);
+    if (!mv::bf16t_geometry_ok(p16[i].f, p16[i]) || !cc->wpbt.p) bf16t = false;
+  }
+  if (bf16t)
+    for (size_t i = 0; i < p16.size(); ++i) {
+      pw[i].b = p16[i];
+      pw[i].wpw = cell_of_pack(e, probs[i].wpack)->wpbt.p;
+      pw[i].v3x = pw[i].v3h = nullptr;
+    }
   launch(e, "convlstm_step", flops, bytes, [&] {
-    if (e->compute_mode == 2)
+    if (bf16t)
+      mv::launch_convlstm_bf16t_steps(pw.data(), (int)pw.size(), e->stream);
+    else if (e->compute_mode == 2)
       mv::launch_convlstm_bf16_steps(p16.data(), (int)p16.size(), e->stream);
     else if (wino3)
       mv::launch_convlstm_wino3_steps(pw.data(), (int)pw.size(), e->stream);

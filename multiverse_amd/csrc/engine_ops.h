@@ -52,6 +52,16 @@ __global__ void decode_planes_kernel(const _Float16* __restrict__ p0,
   const size_t o = mv::plane_index((long long)m, ch, C);
   out[i] = ((float)p0[o] + (float)p1[o]) * (1.0f / 256.0f);
 }
+// ONE bf16 plane of an [M][C] tensor in the tiled operand layout -> fp32 [M][C]
+__global__ void decode_plane_bf16_kernel(const _Float16* __restrict__ p0, float* __restrict__ out,
+                                         size_t M, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * (size_t)C) return;
+  const size_t m = i / C;
+  const int ch = (int)(i - m * C);
+  const uint16_t b = __builtin_bit_cast(uint16_t, p0[mv::plane_index((long long)m, ch, C)]);
+  out[i] = __uint_as_float((uint32_t)b << 16);
+}
 }  // namespace
 
 int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const float* c,
@@ -59,7 +69,9 @@ int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const flo
                           int32_t M, int32_t H, int32_t W, int32_t Cx, int32_t C,
                           float* c_out, float* h_out, float* h16_out) {
   return guarded(nullptr, [&] {
-    MV_REQUIRE(variant >= 1 && variant <= 3, "variant %d: 1 = direct f16x3, 2 = Winograd F(2,3), 3 = Winograd F(3,3)", variant);
+    MV_REQUIRE(variant >= 1 && variant <= 4, "variant %d: 1 = direct f16x3, 2 = Winograd F(2,3), "
+               "3 = Winograd F(3,3), 4 = bf16 on the row-triple tile", variant);
+    const bool bf = variant == 4;
     MV_REQUIRE(C % mv::kChBlock == 0 && C % mv::kBK == 0, "C %d must be a multiple of 32", C);
     MV_REQUIRE(mv::f16x3_cx_supported(Cx), "Cx %d unsupported (multiple of 16, or <= 3)", Cx);
     MV_REQUIRE(H * W >= 32, "grids of at least 32 cells");
@@ -89,7 +101,10 @@ int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const flo
       buf.alloc(2 * pst + mv::kPlanePad);
       HIP_CHECK(hipMemsetAsync(buf.p, 0, (2 * pst + mv::kPlanePad) * sizeof(_Float16), ctx.stream));
       _Float16* p0 = buf.p + mv::kPlanePad;
-      if (src)
+      if (src && bf)        // ONE unscaled bf16 plane (compute mode 2)
+        hipLaunchKernelGGL(mv::split_plane_bf16_kernel, dim3(mv::split_planes_blocks(cells, Cc)),
+                           dim3(256), 0, ctx.stream, src, p0, (int)cells, Cc);
+      else if (src)
         hipLaunchKernelGGL(mv::split_planes_kernel, dim3(mv::split_planes_blocks(cells, Cc)),
                            dim3(256), 0, ctx.stream, src, p0, p0 + pst, (int)cells, Cc);
       *stride = pst;
@@ -131,6 +146,16 @@ int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const flo
       ctx.up(wp, p16.data(), p16.size());
       q.wp16 = wp.p;
       mv::launch_convlstm16_steps(&q, 1, ctx.stream);
+    } else if (variant == 4) {
+      MV_REQUIRE(mv::bf16t_geometry_ok(a, q), "bf16 row-triple tile: H %d >= 3", H);
+      const size_t halves = mv::bf16t_wpack_elems(Cx16, C, mv::kW3Nrb);
+      wp.alloc(halves);
+      hipLaunchKernelGGL(mv::pack_bf16t_kernel, dim3(cdiv(halves, 256)), dim3(256), 0,
+                         ctx.stream, dk.p, wp.p, Cx, Cx16, C, mv::kW3Nrb, halves);
+      mv::ConvLstmWinoArgs wq{};
+      q.x_plane_stride = q.h_plane_stride = q.h16_out_stride = 0;     // single planes
+      wq.b = q; wq.wpw = wp.p; wq.w_hwio = dk.p; wq.n_xc = Cx16 / 16;
+      mv::launch_convlstm_bf16t_steps(&wq, 1, ctx.stream);
     } else if (variant == 3) {
       MV_REQUIRE(mv::wino3_geometry_ok(a, q), "Winograd F(3,3) form: H %d >= 3", H);
       MV_REQUIRE(mv::wino3_halo_addressable(a), "Winograd F(3,3) form, halo tiling (W %d does "
@@ -172,6 +197,10 @@ int mv_op_convlstm_step16(int device, int32_t variant, const float* x, const flo
     HIP_CHECK(hipGetLastError());
     if (h16_out) {
       dplanes.alloc(cells * C);
+      if (bf)
+        hipLaunchKernelGGL(decode_plane_bf16_kernel, dim3(cdiv(cells * C, 256)), dim3(256), 0,
+                           ctx.stream, q.h16_out, dplanes.p, cells, C);
+      else
       hipLaunchKernelGGL(decode_planes_kernel, dim3(cdiv(cells * C, 256)), dim3(256), 0,
                          ctx.stream, q.h16_out, q.h16_out + ost, dplanes.p, cells, C);
       HIP_CHECK(hipGetLastError());

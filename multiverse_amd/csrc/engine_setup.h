@@ -400,6 +400,23 @@ void ensure_packed_wino(mv_engine* e, ConvCell& cc) {
   pack_wino_forms(e, cc);
 }
 
+// bf16 mode on the row-triple tile (convlstm_wino3.h BF16D): the pack of the CURRENT device
+// weights, or none (tanh models only -- unbounded activations keep the three-pass x path of the
+// 32-cell body; MV_BF16T=0: A/B runs)
+void pack_bf16t(mv_engine* e, ConvCell& cc) {
+  const int C = e->cfg.hidden_size;
+  const bool small = cc.Cx > 0 && 9 * cc.Cx <= mv::kBK;
+  const int Cx16 = small ? 0 : cc.Cx;
+  if (!(mv::bf16t_enabled() && C_multiple_ok(e, cc) && e->cfg.activation == 0)) {
+    cc.wpbt.release();
+    return;
+  }
+  const size_t halves = mv::bf16t_wpack_elems(Cx16, C, mv::kW3Nrb);
+  cc.wpbt.alloc(halves);
+  hipLaunchKernelGGL(mv::pack_bf16t_kernel, dim3(cdiv(halves, 256)), dim3(256), 0, e->stream,
+                     cc.kernel->dev.p, cc.wpbt.p, cc.Cx, Cx16, C, mv::kW3Nrb, halves);
+}
+
 // bf16 packs (one unscaled plane; the 2-channel regression-encoder input keeps its fp32
 // chunk), from the CURRENT weights.
 void ensure_packed_bf16(mv_engine* e, ConvCell& cc) {
@@ -450,6 +467,7 @@ void ensure_packed_bf16(mv_engine* e, ConvCell& cc) {
   cc.wpb.alloc(pb.size());
   HIP_CHECK(hipMemcpy(cc.wpb.p, pb.data(), pb.size() * sizeof(_Float16),
                       hipMemcpyHostToDevice));
+  pack_bf16t(e, cc);
 }
 
 // scene channels the graph attention sees: all of them, except in the greedy decoder of the

@@ -81,6 +81,7 @@ struct ConvCell {           // one ConvLSTMCell: packed kernel + biases
   DevBuf<float> wx32u;      // bf16, Cx <= 3: the fp32 x chunk, unscaled
   DevBuf<_Float16> wpw;     // f16x3, Winograd F(2,3) form of the kernel (convlstm_wino.h)
   DevBuf<_Float16> wpw3;    // f16x3, Winograd F(3,3) form of the kernel (convlstm_wino3.h)
+  DevBuf<_Float16> wpbt;    // bf16 mode on the row-triple tile (convlstm_wino3.h BF16D)
   bool host_stale = false;  // device copy was updated by the optimizer
   // f16x3: may this kernel take a Winograd form?  A Winograd form spreads EVERY tap over all
   // its components, so an outlier weight (|w| thousands of times the kernel's typical weight)

@@ -370,7 +370,7 @@ void run_pack(mv_engine* e, TrainChain& ch) {
       hipLaunchKernelGGL(mv::pack_f16x3_kernel, dim3(cdiv(threads, 256)), dim3(256), 0,
                          e->stream, cc.kernel->dev.p, cc.wp16.p, Cx, Cx16, C, threads);
       pack_wino_forms(e, cc);     // releases both Winograd packs, re-packs what is enabled
-      cc.wpb.release(); cc.wx32u.release();
+      cc.wpb.release(); cc.wpbt.release(); cc.wx32u.release();
     } else {                    // bf16 forward (the backward's packs: below)
       const bool xf16 = e->cfg.activation != 0 && Cx16 > 0;
       const size_t halves = mv::bf16_wpack_elems(Cx16, C, xf16);
@@ -378,6 +378,7 @@ void run_pack(mv_engine* e, TrainChain& ch) {
       hipLaunchKernelGGL(mv::pack_bf16_kernel, dim3(cdiv(halves, 256)), dim3(256), 0,
                          e->stream, cc.kernel->dev.p, cc.wpb.p, Cx, Cx16, C, halves,
                          xf16 ? 1 : 0);
+      pack_bf16t(e, cc);
       cc.wp16.release(); cc.wx32.release(); cc.wpw.release(); cc.wpw3.release();
     }
     if (e->compute_mode == 2 && bf16_bwd_enabled(e)) {
@@ -411,7 +412,7 @@ void run_pack(mv_engine* e, TrainChain& ch) {
     }
   } else {
     cc.wp16.release(); cc.wx32.release();   // rebuilt lazily if the mode is switched on
-    cc.wpb.release(); cc.wx32u.release(); cc.wpw.release(); cc.wpw3.release();
+    cc.wpb.release(); cc.wpbt.release(); cc.wx32u.release(); cc.wpw.release(); cc.wpw3.release();
   }
 }
 

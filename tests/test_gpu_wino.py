@@ -203,3 +203,39 @@ def test_wino3_halo_transpose_detecting(built_lib):
         assert err.max() < 1e-6, "tap (%d,%d) source (%d,%d)\n%s" % (ky, kx, sy, sx,
                                                                     _where(err, "c'"))
         assert np.abs(hg - ho).max() < 1e-6
+
+
+def _bf16_round(a):
+  """round-to-nearest-even to bf16, as the planes hold the operands in compute mode 2"""
+  u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+  u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+  return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+@pytest.mark.parametrize("M,H,W,Cx,zero", SHAPES + HALO_SHAPES)
+def test_bf16_row_triple_tile_vs_oracle_on_bf16_operands(built_lib, M, H, W, Cx, zero):
+  """Compute mode 2's gate kernel on the row-triple tile (csrc/convlstm_wino3.h BF16D, op variant
+  4): ONE bf16 plane per operand, fp32 accumulate.  Held to the oracle evaluated ON THE ROUNDED
+  OPERANDS (h and the 16-channel x groups and the kernel rows they meet rounded to bf16; the
+  2-channel fp32 chunk and its kernel rows exact), so that what is left is summation order:
+  the same 2e-5 as the f16x3 forms.  Every tiling case of the F(3,3) kernel incl. the halo."""
+  x, c, h, kernel, biases, _, _ = _case(M, H, W, Cx, zero, M * 1000 + H * 10 + Cx + 5)
+  kr = kernel.copy()
+  if Cx > 3:
+    kr = _bf16_round(kernel)
+    xr = _bf16_round(x)
+  else:
+    kr[:, :, Cx:, :] = _bf16_round(kernel[:, :, Cx:, :])
+    xr = x
+  C = kernel.shape[3] // 4
+  c0 = np.zeros((M, H, W, C), "f4") if zero else c
+  h0 = np.zeros((M, H, W, C), "f4") if zero else _bf16_round(h)
+  co, ho = oracle.convlstm_step_np(xr, c0, h0, kr, biases)
+  cg, hg, h16 = built_lib.op_convlstm_step16(x, c, h, kernel, biases, variant=4)
+  ec, eh = np.abs(cg - co), np.abs(hg - ho)
+  print("bf16 row-triple tile M=%d %dx%d Cx=%d zero=%s: max|dc| %.3g max|dh| %.3g, plane vs h' %.3g"
+        % (M, H, W, Cx, zero, ec.max(), eh.max(), np.abs(h16 - _bf16_round(hg)).max()))
+  assert ec.max() < 2e-5, _where(ec, "c'")
+  assert eh.max() < 2e-5, _where(eh, "h'")
+  # the emitted plane IS h' rounded to bf16
+  assert np.abs(h16 - _bf16_round(hg)).max() == 0, _where(np.abs(h16 - _bf16_round(hg)), "plane")
