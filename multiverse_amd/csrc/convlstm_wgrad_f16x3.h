@@ -183,6 +183,184 @@ void transpose_split_narrow_kernel(const float* __restrict__ in, _Float16* __res
   }
 }
 
+// ---------------------------------------------------------------- the row-triple form (round 6)
+// dW in Winograd F(3,3) form over image-row triples -- the forward's algebra (convlstm_wino3.h)
+// with the roles of kernel rows and output rows exchanged: per stencil column dx and triple t,
+//     dg_k = sum_i G(3t + i) d_{i+k}            (d0..d4 = input rows 3t-1 .. 3t+3, k = 0..2)
+// is the correlation the forward computes with the gate-gradient rows as its "kernel", so
+//     U0 = G0 / 2   U1 = -(G0 + G1 + G2) / 2   U2 = (-G0 + G1 - G2) / 6   U3 = (G0 + 2 G1 + 4 G2) / 6
+//     U4 = -G2      V0..V4 = the forward's input components of d
+//     M_c = sum over triple-cells of V_c U_c     (the GEMMs: 15 "taps" = 5 components x 3 dx)
+//     dg_0 = M0 + M1 + M2 + M3    dg_1 = M1 - M2 + 2 M3    dg_2 = M1 + M2 + 4 M3 + M4
+// and the sums over cells commute with the output combination: the GEMMs run on a third of the
+// cells with 15 taps instead of 9 -- 5/9 of the MFMAs -- and the three-row combination is applied
+// once, to the summed partials (wgrad_wino3_reduce_kernel).  The operands are transformed in fp32
+// BEFORE the split into planes (no extra rounding in the planes); both transposes below write
+// the GEMM kernels' cell-blocked layout per component.  |V| <= 6 |d|, |U| <= 1.5 |G|: the
+// exponents of the direct form keep every plane finite.
+//
+// G operand: in fp32 [Mtot][Cc] -> out [5][2][Mrow3/32][Cc][32]; triple-cell m3 = (q, x), q = image
+// * H/3 + triple, reads the raw cells (3q + i) W + x.  Bias partials: sum of the three rows =
+// -2 U1.  Block = 64 triple-cells x 32 channels; grid (Mrow3/64, Cc/32).
+__global__ __launch_bounds__(256)
+void wino3_transpose_g_kernel(const float* __restrict__ in, _Float16* __restrict__ out,
+                              long long Mtot3, int Cc, long long Mrow3, int W,
+                              const int32_t* __restrict__ exp_ptr, float* __restrict__ colsum_out,
+                              long long comp_stride) {
+  __shared__ float tile[5][64][33];
+  const int e = exp_ptr[0];
+  const float sc2e = __int_as_float((127 + e) << 23);
+  const long long m0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 32;
+  const int tid = threadIdx.x;
+  const int lc = (tid & 7) * 4, lj = tid >> 3;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int j = pass * 32 + lj;
+    const long long m3 = m0 + j;
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0;
+    if (m3 < Mtot3) {
+      const long long q = m3 / W;
+      const int x = (int)(m3 - q * W);
+      const float* src = in + (size_t)(3 * q * W + x) * Cc + c0 + lc;
+      g0 = *reinterpret_cast<const f32x4*>(src);
+      g1 = *reinterpret_cast<const f32x4*>(src + (size_t)W * Cc);
+      g2 = *reinterpret_cast<const f32x4*>(src + (size_t)2 * W * Cc);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      tile[0][j][lc + k] = 0.5f * g0[k];
+      tile[1][j][lc + k] = -0.5f * ((g0[k] + g1[k]) + g2[k]);
+      tile[2][j][lc + k] = ((g1[k] - g0[k]) - g2[k]) * (1.0f / 6.0f);
+      tile[3][j][lc + k] = ((g0[k] + 2.0f * g1[k]) + 4.0f * g2[k]) * (1.0f / 6.0f);
+      tile[4][j][lc + k] = -g2[k];
+    }
+  }
+  __syncthreads();
+  if (colsum_out && tid < 32) {          // per-block column sums of G (bias gradient partials)
+    float sum = 0.f;
+#pragma unroll 8
+    for (int jj = 0; jj < 64; ++jj) sum += tile[1][jj][tid];
+    colsum_out[(size_t)blockIdx.x * Cc + c0 + tid] = -2.0f * sum;
+  }
+  const int ch = tid >> 3, grp = tid & 7;
+  const size_t o = wg16_plane_index(m0 + grp * 8, c0 + ch, Cc);
+#pragma unroll
+  for (int comp = 0; comp < 5; ++comp) {
+    f16x8 p0, p1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float sv = tile[comp][grp * 8 + q][ch] * sc2e;
+      const _Float16 h0 = (_Float16)sv;
+      p0[q] = h0;
+      p1[q] = (_Float16)(sv - (float)h0);
+    }
+    _Float16* const oc = out + (size_t)comp * (size_t)comp_stride + o;
+    *reinterpret_cast<f16x8*>(oc) = p0;
+    *reinterpret_cast<f16x8*>(oc + (size_t)Cc * Mrow3) = p1;
+  }
+}
+
+// A operand (h, or the x rows' input): in fp32 [Mtot][Cc] -> the three column-shifted copies
+// out{0,1,2} [5][2][Mrow3/32][Cc][32] of the components V0..V4; rows outside the image are zero
+// (H = image rows, a multiple of 3), a shifted cell outside its image row is zero.  Any Cc (the
+// pixel-offset inputs have 2 channels): block = 64 triple-cells (+ one neighbour each side) x 32
+// channels; grid (Mrow3/64, ceil(Cc/32)).
+__global__ __launch_bounds__(256)
+void wino3_transpose_a3_kernel(const float* __restrict__ in, _Float16* __restrict__ out0,
+                               _Float16* __restrict__ out1, _Float16* __restrict__ out2,
+                               long long Mtot3, int Cc, long long Mrow3, int H, int W,
+                               const int32_t* __restrict__ exp_ptr, int exp_const,
+                               long long comp_stride) {
+  __shared__ float tile[5][66][33];                // tile[c][j] = triple-cell m0 - 1 + j
+  const int e = exp_ptr ? exp_ptr[0] : exp_const;
+  const float sc2e = __int_as_float((127 + e) << 23);
+  const long long m0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 32;
+  const int tid = threadIdx.x;
+  const int lc = (tid & 7) * 4, lj = tid >> 3;
+  const int H3 = H / 3;
+  const bool vec4 = (Cc & 3) == 0;
+#pragma unroll
+  for (int pass = 0; pass < 3; ++pass) {
+    const int j = pass * 32 + lj;
+    if (j < 66) {
+      const long long m3 = m0 - 1 + j;
+      f32x4 d[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m3 >= 0 && m3 < Mtot3 && c0 + lc < Cc) {
+        const long long q = m3 / W;
+        const int x = (int)(m3 - q * W);
+        const int t3 = (int)(q % H3) * 3;          // first image row of the triple
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const int y = t3 - 1 + i;
+          if (y >= 0 && y < H) {
+            const float* src = in + (size_t)((3 * q - 1 + i) * W + x) * Cc + c0 + lc;
+            if (vec4) d[i] = *reinterpret_cast<const f32x4*>(src);
+            else
+              for (int k = 0; k < 4; ++k)
+                if (c0 + lc + k < Cc) d[i][k] = src[k];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v3 = d[3][k] - d[1][k];
+        const float d32 = d[3][k] - d[2][k];
+        tile[0][j][lc + k] = 2.0f * (d[0][k] - d[2][k]) + v3;
+        tile[1][j][lc + k] = d32 - 2.0f * d[1][k];
+        tile[2][j][lc + k] = 2.0f * (d[1][k] - d[2][k]) + d32;
+        tile[3][j][lc + k] = v3;
+        tile[4][j][lc + k] = 2.0f * v3 + (d[2][k] - d[4][k]);
+      }
+    }
+  }
+  __syncthreads();
+  const int ch = tid >> 3, grp = tid & 7;
+  if (c0 + ch >= Cc) return;
+  const size_t o = wg16_plane_index(m0 + grp * 8, c0 + ch, Cc);
+#pragma unroll
+  for (int comp = 0; comp < 5; ++comp) {
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd) {
+      _Float16* const out = (dd == 0 ? out0 : (dd == 1 ? out1 : out2)) + (size_t)comp * (size_t)comp_stride;
+      const int dx = dd - 1;
+      f16x8 p0, p1;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const long long m = m0 + grp * 8 + q;
+        const int x = (int)(m % W);
+        const bool ok = (m < Mtot3) & (x + dx >= 0) & (x + dx < W);
+        const float sv = ok ? tile[comp][grp * 8 + q + 1 + dx][ch] * sc2e : 0.f;
+        const _Float16 h0 = (_Float16)sv;
+        p0[q] = h0;
+        p1[q] = (_Float16)(sv - (float)h0);
+      }
+      *reinterpret_cast<f16x8*>(out + o) = p0;
+      *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow3 + o) = p1;
+    }
+  }
+}
+
+// Sum of the splits' partials [nsplit][15][per] in split order (bitwise reproducible) and the
+// output combination of the row-triple form -> dW [9][per] (tap = (dy + 1) * 3 + (dx + 1)).
+__global__ __launch_bounds__(256)
+void wgrad_wino3_reduce_kernel(const float* __restrict__ partial, int nsplit, size_t per,
+                               float* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 3 * per) return;
+  const size_t dxi = idx / per, el = idx - dxi * per;
+  float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < nsplit; ++sp)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) m[c] += partial[((size_t)sp * 15 + c * 3 + dxi) * per + el];
+  out[(0 * 3 + dxi) * per + el] = ((m[0] + m[1]) + m[2]) + m[3];
+  out[(1 * 3 + dxi) * per + el] = (m[1] - m[2]) + 2.0f * m[3];
+  out[(2 * 3 + dxi) * per + el] = ((m[1] + m[2]) + 4.0f * m[3]) + m[4];
+}
+
 // max |in| as float bits (non-negative floats order like ints); *out zeroed before
 __global__ __launch_bounds__(256)
 void absmax_bits_kernel(const float* __restrict__ in, size_t n, int32_t* __restrict__ out) {
@@ -197,9 +375,10 @@ void absmax_bits_kernel(const float* __restrict__ in, size_t n, int32_t* __restr
   if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
 }
 
-// exponent of the chain-wide G scale: e = 13 - ilogb(max over the chain's steps)
+// exponent of the chain-wide G scale: e = top - ilogb(max over the chain's steps); top = 13
+// leaves the planes below 2^14 (10 for an operand the row-triple form multiplies by up to 6)
 __global__ void chain_exp_kernel(const int32_t* __restrict__ gmax, int nsteps, int step_stride,
-                                 int32_t* __restrict__ exp_out) {
+                                 int32_t* __restrict__ exp_out, int top = 13) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int mb = 0;
   for (int s = 0; s < nsteps; ++s)
@@ -207,7 +386,7 @@ __global__ void chain_exp_kernel(const int32_t* __restrict__ gmax, int nsteps, i
   const float mx = __int_as_float(mb);
   int e = 0;
   if (mx > 0.f) {
-    e = 13 - ilogbf(mx);
+    e = top - ilogbf(mx);
     e = e < -100 ? -100 : (e > 100 ? 100 : e);
   }
   exp_out[0] = e;
@@ -226,7 +405,13 @@ struct Wgrad16Args {
   int32_t ksteps_per_split;  // even
   int32_t nsplit;            // multiple of 8 (split -> XCD), or the wide kernel's own count
   int32_t map_mode;          // wide kernel: tiles -> XCDs (0 by group, 1 by split, 2 mixed)
+  // Winograd F(3,3) form over image-row triples (see "the row-triple form" below): ntaps = 15,
+  // tap = component * 3 + (dx + 1), no row shift; cells are triple-cells (H = triples per image),
+  // the operands hold five components each, *_comp_stride halves apart.  0 / 9 = the direct form.
+  int32_t ntaps;
+  int64_t a_comp_stride, g_comp_stride;
 };
+__host__ __device__ __forceinline__ int wg16_ntaps(const Wgrad16Args& a) { return a.ntaps == 15 ? 15 : 9; }
 
 constexpr int kWg16Pitch = 40;                         // halves per LDS row (32 cells + pad)
 constexpr int kWg16Tile = 2 * 128 * kWg16Pitch;        // halves per operand tile (2 planes)
@@ -256,7 +441,12 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
   const int H = a.H, W = a.W, C = a.C, N4 = 4 * C, Ca = a.Ca;
   const int wk = W / 16;                               // k-steps per image row
   const int nnb = N4 / 128;
-  const int nrb = XROWS ? (9 * Ca + 127) / 128 : 9 * (C / 128);   // row blocks
+  const int NT = wg16_ntaps(a);
+  const bool wn = NT == 15;
+  // x rows of the row-triple form: a tile's rows are (dx, channel) pairs of ONE component (the G
+  // tile is that component's), nrbc tiles per component
+  const int nrbc = (3 * Ca + 127) / 128;
+  const int nrb = XROWS ? (wn ? 5 * nrbc : (9 * Ca + 127) / 128) : NT * (C / 128);   // row blocks
   const int tiles_per_split = nrb * nnb;
   const int xcd = blockIdx.x & 7;                      // split -> XCD (see convlstm_wgrad.h)
   int j = blockIdx.x >> 3;
@@ -272,7 +462,10 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
   // h rows: rb = tap * (C/128) + cib
   const int tap_u = XROWS ? 0 : rb / (C / 128);
   const int ci0_u = XROWS ? 0 : (rb - tap_u * (C / 128)) * 128;
-  const int dy_u = tap_u / 3 - 1;
+  const int dy_u = wn ? 0 : tap_u / 3 - 1;
+  const int comp_u = wn ? (XROWS ? rb / nrbc : tap_u / 3) : 0;     // the workgroup's component
+  const int rbi = (XROWS && wn) ? rb - comp_u * nrbc : rb;
+  const size_t aco = (size_t)comp_u * (size_t)a.a_comp_stride, gco = (size_t)comp_u * (size_t)a.g_comp_stride;
   const long long Mrow = a.Mrow;
 
   const int ks0 = split * a.ksteps_per_split;
@@ -296,17 +489,17 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int plane = q >> 1, row = (q & 1) * 64 + (tid >> 2);
-    gp[q] = a.gt + (size_t)plane * N4 * Mrow + (size_t)(n0 + row) * 32 + vec * 8;
+    gp[q] = a.gt + gco + (size_t)plane * N4 * Mrow + (size_t)(n0 + row) * 32 + vec * 8;
     if (XROWS) {
-      const int R = rb * 128 + row;
-      const bool live = R < 9 * Ca;
-      const int tap = live ? R / Ca : 4;
+      const int R = rbi * 128 + row;
+      const bool live = R < (wn ? 3 : 9) * Ca;
+      const int tap = live ? R / Ca : (wn ? 1 : 4);
       const int ci = live ? R - tap * Ca : 0;
-      dyq[q] = live ? tap / 3 - 1 : (1 << 20);
-      ap[q] = a.at[tap - (tap / 3) * 3] + (size_t)plane * Ca * Mrow + (size_t)ci * 32;
+      dyq[q] = live ? (wn ? 0 : tap / 3 - 1) : (1 << 20);
+      ap[q] = a.at[tap - (tap / 3) * 3] + aco + (size_t)plane * Ca * Mrow + (size_t)ci * 32;
     } else {
       dyq[q] = dy_u;
-      ap[q] = a.at[tap_u - (tap_u / 3) * 3] + (size_t)plane * Ca * Mrow + (size_t)(ci0_u + row) * 32;
+      ap[q] = a.at[tap_u - (tap_u / 3) * 3] + aco + (size_t)plane * Ca * Mrow + (size_t)(ci0_u + row) * 32;
     }
   }
 
@@ -434,7 +627,7 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
   // D: col j = lane&31 (n), row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const float scale = ldexpf(1.0f, -(a.a_exp[0] + a.g_exp[0]));
   const int Cin = a.Cx + C;
-  float* ps = a.partial + (size_t)split * 9 * Cin * N4;
+  float* ps = a.partial + (size_t)split * NT * Cin * N4;
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -445,9 +638,10 @@ void convlstm_wgrad_f16x3_kernel(const Wgrad16Args a) {
         const int r = wi * 64 + x * 32 + i;
         const int n = n0 + wj * 64 + y * 32 + (lane & 31);
         if (XROWS) {
-          const int R = rb * 128 + r;
-          if (R < 9 * Ca) {
-            const int tap = R / Ca, ci = R - tap * Ca;
+          const int R = rbi * 128 + r;
+          if (R < (wn ? 3 : 9) * Ca) {
+            const int tq = R / Ca, ci = R - tq * Ca;
+            const int tap = comp_u * 3 + tq;           // direct form: comp_u == 0
             ps[((size_t)tap * Cin + ci) * N4 + n] = acc[x][y][reg] * scale;
           }
         } else {
@@ -504,37 +698,43 @@ void convlstm_wgrad_f16x3_wide_kernel(const Wgrad16Args a) {
   const int wk = W / 16;
   const int ncib = C / kWgwA, nnb = N4 / kWgwG;
   const int xcd = blockIdx.x & 7;
+  const int NT = wg16_ntaps(a);
+  const bool wn = NT == 15;
+  const int nrbc = (3 * Ca + kWgwA - 1) / kWgwA;     // x rows, row-triple form: tiles per component
   int j = blockIdx.x >> 3;
-  int tap = 4, split, cib = 0, nb, rb = 0;
+  int tap = wn ? 1 : 4, split, cib = 0, nb, rb = 0;
   if (XROWS) {
-    const int nrb = (9 * Ca + kWgwA - 1) / kWgwA;
+    const int nrb = wn ? 5 * nrbc : (9 * Ca + kWgwA - 1) / kWgwA;
     j = blockIdx.x;
     nb = j % nnb; j /= nnb;
     rb = j % nrb;
     split = j / nrb;
+    if (wn) { tap = (rb / nrbc) * 3 + 1; rb -= (rb / nrbc) * nrbc; }   // tap / 3 = the component
   } else if (a.map_mode == 1) {             // split -> XCD: every operand byte through ONE L2
-    const int tps = 9 * ncib * nnb;
+    const int tps = NT * ncib * nnb;
     split = xcd + 8 * (j / tps);
     j %= tps;
-    tap = j % 9; j /= 9;
+    tap = j % NT; j /= NT;
     cib = j % ncib; nb = j / ncib;
   } else if (a.map_mode == 2) {      // (channel block, split mod 4) -> XCD; ncib == 2
-    const int tps = 9 * nnb;
+    const int tps = NT * nnb;
     cib = xcd & 1;
     split = (xcd >> 1) + 4 * (j / tps);
     j %= tps;
-    tap = j % 9; nb = j / 9;
+    tap = j % NT; nb = j / NT;
   } else {                           // (channel block, column block) -> XCD
     const int gpx = (ncib * nnb) >> 3;
     const int group = xcd + 8 * (j % gpx);
     j /= gpx;
-    tap = j % 9;
-    split = j / 9;
+    tap = j % NT;
+    split = j / NT;
     cib = group % ncib; nb = group / ncib;
   }
   const int ci0 = cib * kWgwA;
   const int n0 = nb * kWgwG;
-  const int dy = tap / 3 - 1;
+  const int dy = wn ? 0 : tap / 3 - 1;
+  const int comp = wn ? tap / 3 : 0;
+  const size_t aco = (size_t)comp * (size_t)a.a_comp_stride, gco = (size_t)comp * (size_t)a.g_comp_stride;
   const long long Mrow = a.Mrow;
 
   const int ks0 = split * a.ksteps_per_split;
@@ -558,17 +758,17 @@ void convlstm_wgrad_f16x3_wide_kernel(const Wgrad16Args a) {
   for (int k = 0; k < 2; ++k) {
     if (XROWS) {
       const int R = rb * kWgwA + k * 64 + trow;
-      const bool live = R < 9 * Ca;
-      const int tp = live ? R / Ca : 4;
+      const bool live = R < (wn ? 3 : 9) * Ca;
+      const int tp = live ? R / Ca : (wn ? 1 : 4);
       const int ci = live ? R - tp * Ca : 0;
-      dyq[k] = live ? tp / 3 - 1 : (1 << 20);
-      abase[k] = a.at[tp - (tp / 3) * 3] + (size_t)ci * 32;
+      dyq[k] = live ? (wn ? 0 : tp / 3 - 1) : (1 << 20);
+      abase[k] = a.at[tp - (tp / 3) * 3] + aco + (size_t)ci * 32;
     } else {
       dyq[k] = dy;
-      abase[k] = a.at[tap - (tap / 3) * 3] + (size_t)(ci0 + k * 64 + trow) * 32;
+      abase[k] = a.at[tap - (tap / 3) * 3] + aco + (size_t)(ci0 + k * 64 + trow) * 32;
     }
   }
-  const _Float16* const gbase = a.gt + (size_t)(n0 + trow) * 32 + vec * 8;
+  const _Float16* const gbase = a.gt + gco + (size_t)(n0 + trow) * 32 + vec * 8;
   const size_t apl = (size_t)Ca * Mrow, gpl = (size_t)N4 * Mrow;    // plane strides
   const int wslot = (trow * 4 + (vec ^ wgw_swz(trow))) * 8;         // halves; + 64 rows: + 2048
   static_assert(wgw_swz(64) == 0 && wgw_swz(5 + 64) == wgw_swz(5), "row + 64 keeps its swizzle");
@@ -678,7 +878,7 @@ void convlstm_wgrad_f16x3_wide_kernel(const Wgrad16Args a) {
   // D: col j = lane&31 (n), row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const float scale = ldexpf(1.0f, -(a.a_exp[0] + a.g_exp[0]));
   const int Cin = a.Cx + C;
-  float* ps = a.partial + (size_t)split * 9 * Cin * N4;
+  float* ps = a.partial + (size_t)split * NT * Cin * N4;
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -690,8 +890,9 @@ void convlstm_wgrad_f16x3_wide_kernel(const Wgrad16Args a) {
         const int n = n0 + wj * 128 + y * 32 + (lane & 31);
         if (XROWS) {
           const int R = rb * kWgwA + r;
-          if (R < 9 * Ca) {
-            const int tp = R / Ca, ci = R - tp * Ca;
+          if (R < (wn ? 3 : 9) * Ca) {
+            const int tq = R / Ca, ci = R - tq * Ca;
+            const int tp = comp * 3 + tq;              // direct form: comp == 0
             ps[((size_t)tp * Cin + ci) * N4 + n] = acc[x][y][reg] * scale;
           }
         } else {
@@ -727,10 +928,13 @@ static inline int wgrad16_wide_splits(long long Mtot, int planned, int map_mode)
   return planned >= 7 ? 7 : planned;
 }
 static inline unsigned wgrad16_wide_blocks(const Wgrad16Args& a, bool xrows = false) {
+  const bool wn = a.ntaps == 15;
   if (xrows)
-    return (unsigned)a.nsplit * (unsigned)((9 * a.Ca + kWgwA - 1) / kWgwA) *
+    return (unsigned)a.nsplit *
+           (unsigned)(wn ? 5 * ((3 * a.Ca + kWgwA - 1) / kWgwA) : (9 * a.Ca + kWgwA - 1) / kWgwA) *
            (unsigned)(4 * a.C / kWgwG);
-  return (unsigned)a.nsplit * 9u * (unsigned)(a.C / kWgwA) * (unsigned)(4 * a.C / kWgwG);
+  return (unsigned)a.nsplit * (unsigned)wg16_ntaps(a) * (unsigned)(a.C / kWgwA) *
+         (unsigned)(4 * a.C / kWgwG);
 }
 // The x rows on the wide tile measured the same as on the 128 x 128 tile (2.59 vs 2.56 ms per
 // training step, profiles/r5wg_wgrad_wide_tile_ab.md: 20 fat workgroups per split fill the chip
@@ -744,6 +948,11 @@ constexpr size_t kWg16LdsBytes = (size_t)2 * 2 * kWg16Tile * sizeof(_Float16);  
 constexpr size_t kWg16LdsBytes1 = (size_t)2 * 2 * wg16_tile<1>() * sizeof(_Float16);   // NP = 1: 40 KB
 
 static inline bool wgrad16_ok(int W, int C) { return (W % 16) == 0 && (C % 128) == 0; }
+// the row-triple form: whole triples only; MV_WGRAD_WINO=0 keeps the direct form
+static inline bool wgrad16_wino3_ok(int H) {
+  static const bool on = !(getenv("MV_WGRAD_WINO") && atoi(getenv("MV_WGRAD_WINO")) == 0);
+  return on && H >= 3 && H % 3 == 0;
+}
 
 static inline void wgrad16_plan(Wgrad16Args& a, long long Mtot, int nsplit) {
   a.ksteps_total = (int32_t)(Mtot / 16);
@@ -754,7 +963,9 @@ static inline void wgrad16_plan(Wgrad16Args& a, long long Mtot, int nsplit) {
 }
 
 static inline unsigned wgrad16_blocks(const Wgrad16Args& a, bool xrows) {
-  const unsigned nrb = xrows ? (unsigned)((9 * a.Ca + 127) / 128) : 9u * (unsigned)(a.C / 128);
+  const bool wn = a.ntaps == 15;
+  const unsigned nrb = xrows ? (unsigned)(wn ? 5 * ((3 * a.Ca + 127) / 128) : (9 * a.Ca + 127) / 128)
+                             : (unsigned)wg16_ntaps(a) * (unsigned)(a.C / 128);
   return (unsigned)a.nsplit * nrb * (unsigned)(4 * a.C / 128);
 }
 

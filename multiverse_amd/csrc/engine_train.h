@@ -160,7 +160,8 @@ void train_alloc(mv_engine* e) {
       mv::WgradArgs wa{};
       wa.R = (int)(T * N); wa.H = S.H; wa.W = S.W; wa.Cx = cell->Cx; wa.C = (int)C;
       mv::wgrad_plan(wa, 3072);
-      max_partial = std::max(max_partial, mv::wgrad_partial_elems(wa));
+      // (the row-triple form of the f16x3 wgrad keeps 15 partial taps per split instead of 9)
+      max_partial = std::max(max_partial, (mv::wgrad_partial_elems(wa) * 15 + 8) / 9);
     };
     chain(R.enc[0], &S.enc_cls, To, true);
     chain(R.dec[0], &S.dec_cls, Tp, true);
@@ -1049,6 +1050,8 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
   }
   const size_t ncols = (size_t)9 * (ch.Cx + C) * 4 * C;
   const bool f16 = e->compute_mode != 0 && mv::wgrad16_ok(W, C);
+  bool wino_form = false;                  // f16x3: the row-triple form (15 partial taps)
+  size_t bias_blocks = (size_t)(((long long)cells + 63) / 64);
   if (f16) {
     // both operands as cell-contiguous fp16 plane pairs, then the f16x3 GEMMs
     // (convlstm_wgrad_f16x3.h): h rows, x rows; bias partials fall out of the G pass
@@ -1060,11 +1063,17 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
     const bool one = e->compute_mode == 2 && bf16_bwd_enabled(e);
     const int npl = one ? 1 : 2;
     MV_REQUIRE((size_t)Mrow <= t.mrow_max, "internal: wgrad plane scratch");
-    t.gt16.alloc((size_t)2 * 4 * C * t.mrow_max);
+    // Winograd F(3,3) over row triples (convlstm_wgrad_f16x3.h, "the row-triple form"): 5/9 of
+    // the MFMAs on operands of 5/3 the size; both planes only (fp32-class mode)
+    const bool wino = !one && e->compute_mode == 1 && mv::wgrad16_wino3_ok(H);
+    const long long Mtot3 = Mtot / 3, Mrow3 = (Mtot3 + 63) / 64 * 64;
+    const size_t mrow3_max = (t.mrow_max / 3 + 63) / 64 * 64 + 64;
+    const size_t pl_cells = wino ? 5 * mrow3_max : t.mrow_max;   // plane pairs x cells per channel
+    t.gt16.alloc((size_t)2 * 4 * C * pl_cells);
     t.bias_part.alloc(t.mrow_max / 64 * 4 * C);
-    for (int d = 0; d < 3; ++d) t.at16[d].alloc((size_t)2 * C * t.mrow_max);
+    for (int d = 0; d < 3; ++d) t.at16[d].alloc((size_t)2 * C * pl_cells);
     if (Cx)
-      for (int d = 0; d < 3; ++d) t.xt16[d].alloc((size_t)2 * std::max(64, Cx) * t.mrow_max);
+      for (int d = 0; d < 3; ++d) t.xt16[d].alloc((size_t)2 * std::max(64, Cx) * pl_cells);
     // x rows: any width up to 64 (narrow transpose), or whole 64-channel column groups
     // (--emb_size 128: the transpose of the h operand, one grid row per group)
     MV_REQUIRE(Cx <= 64 || Cx % 64 == 0, "internal: f16x3 wgrad x operand of %d channels", Cx);
@@ -1078,6 +1087,32 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
       t.wgrad16_attr = true;
     }
 
+    if (wino)
+      launch(e, "wgrad_transpose", 0,
+             cells * (4.0 * C * (4.0 + 4.0 * 5 / 3) + (C + Cx) * (4.0 + 3.0 * 4.0 * 5 / 3)), [&] {
+        hipLaunchKernelGGL(mv::chain_exp_kernel, dim3(1), dim3(64), 0, e->stream,
+                           t.gmax.p + (size_t)gslot * 64, Tsteps, 64, t.chain_exp.p);
+        hipLaunchKernelGGL(mv::wino3_transpose_g_kernel, dim3((unsigned)(Mrow3 / 64), 4 * C / 32),
+                           dim3(256), 0, e->stream, ch.gates.p, t.gt16.p, Mtot3, 4 * C, Mrow3, W,
+                           t.chain_exp.p, t.bias_part.p, (long long)2 * 4 * C * Mrow3);
+        hipLaunchKernelGGL(mv::wino3_transpose_a3_kernel, dim3((unsigned)(Mrow3 / 64), C / 32),
+                           dim3(256), 0, e->stream, hin, t.at16[0].p, t.at16[1].p, t.at16[2].p,
+                           Mtot3, C, Mrow3, H, W, (const int32_t*)nullptr, 8,
+                           (long long)2 * C * Mrow3);
+        if (Cx) {   // x operand: exponent from max |x| of the chain
+          HIP_CHECK(hipMemsetAsync(t.chain_exp.p + 64, 0, 64 * sizeof(int32_t), e->stream));
+          hipLaunchKernelGGL(mv::absmax_bits_kernel, dim3(256), dim3(256), 0, e->stream,
+                             ch.xs.p, (size_t)Mtot * Cx, t.chain_exp.p + 64);
+          // |V| <= 6 max|x|: three more bits of headroom than the direct form's 2^13
+          hipLaunchKernelGGL(mv::chain_exp_kernel, dim3(1), dim3(64), 0, e->stream,
+                             t.chain_exp.p + 64, 1, 64, t.chain_exp.p + 2, 10);
+          hipLaunchKernelGGL(mv::wino3_transpose_a3_kernel,
+                             dim3((unsigned)(Mrow3 / 64), (unsigned)((Cx + 31) / 32)), dim3(256), 0,
+                             e->stream, ch.xs.p, t.xt16[0].p, t.xt16[1].p, t.xt16[2].p, Mtot3, Cx,
+                             Mrow3, H, W, t.chain_exp.p + 2, 0, (long long)2 * Cx * Mrow3);
+        }
+      });
+    else
     launch(e, "wgrad_transpose", 0, cells * (4.0 * C + (C + Cx) * 3.0) * (4.0 + 2.0 * npl), [&] {
       hipLaunchKernelGGL(mv::chain_exp_kernel, dim3(1), dim3(64), 0, e->stream,
                          t.gmax.p + (size_t)gslot * 64, Tsteps, 64, t.chain_exp.p);
@@ -1122,14 +1157,21 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
     q.gt = t.gt16.p; q.partial = t.partial.p; q.g_exp = t.chain_exp.p;
     q.a_exp = t.chain_exp.p + 1;
     q.Mrow = Mrow; q.H = H; q.W = W; q.Cx = Cx; q.C = C; q.Ca = C;
+    if (wino) {
+      q.ntaps = 15; q.Mrow = Mrow3; q.H = H / 3;
+      q.a_comp_stride = (int64_t)2 * C * Mrow3; q.g_comp_stride = (int64_t)2 * 4 * C * Mrow3;
+    }
+    const long long Mgemm = wino ? Mtot3 : Mtot;          // cells of the GEMMs' reduction
+    wino_form = wino;
+    if (wino) bias_blocks = (size_t)(Mrow3 / 64);
     // the wide tile (convlstm_wgrad_f16x3.h) balances on 7 / 14 splits; the x rows and the
     // reduction follow its count
     const bool wide = mv::wgrad16_wide_ok(W, C);
     if (wide) {
       q.map_mode = mv::wgrad16_wide_map_mode(C);
-      wa.nsplit = mv::wgrad16_wide_splits(Mtot, wa.nsplit, q.map_mode);
+      wa.nsplit = mv::wgrad16_wide_splits(Mgemm, wa.nsplit, q.map_mode);
     }
-    mv::wgrad16_plan(q, Mtot, wa.nsplit);
+    mv::wgrad16_plan(q, Mgemm, wa.nsplit);
     launch(e, "convlstm_wgrad", 2.0 * cells * 9 * C * 4.0 * C, cells * 5.0 * C * 4.0, [&] {
       if (wide && one)
         hipLaunchKernelGGL(mv::convlstm_wgrad_f16x3_wide_kernel<1>,
@@ -1145,11 +1187,12 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
       hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_kernel<false, 3>),
                          dim3(mv::wgrad16_blocks(q, false)), dim3(256), mv::kWg16LdsBytes,
                          e->stream, q);
-    }, -1.0, one ? 1.0 : 3.0);
+    }, -1.0, one ? 1.0 : (wino ? 5.0 / 3.0 : 3.0));
     if (Cx > 0) {
       mv::Wgrad16Args qx = q;
       for (int d = 0; d < 3; ++d) qx.at[d] = t.xt16[d].p;
       qx.Ca = Cx; qx.a_exp = t.chain_exp.p + 2;
+      if (wino) qx.a_comp_stride = (int64_t)2 * Cx * Mrow3;
       launch(e, "convlstm_wgrad_x", 2.0 * cells * 9 * Cx * 4.0 * C,
              cells * (Cx + 4.0 * C) * 4.0, [&] {
         if (wide && mv::wgrad16_wide_x_enabled() && one)
@@ -1166,7 +1209,7 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
         hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_kernel<true, 3>),
                            dim3(mv::wgrad16_blocks(qx, true)), dim3(256), mv::kWg16LdsBytes,
                            e->stream, qx);
-      }, -1.0, one ? 1.0 : 3.0);
+      }, -1.0, one ? 1.0 : (wino ? 5.0 / 3.0 : 3.0));
     }
   } else {
   launch(e, "convlstm_wgrad", 2.0 * cells * 9 * (ch.Cx + C) * 4.0 * C,
@@ -1174,7 +1217,12 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
     mv::launch_convlstm_wgrad(wa, e->stream);
   }, -1.0, 1.0);
   }
-  launch(e, "wgrad_reduce", 0, 4.0 * ncols * (wa.nsplit + 1), [&] {
+  launch(e, "wgrad_reduce", 0, 4.0 * ncols * ((wino_form ? 15.0 / 9 : 1.0) * wa.nsplit + 1), [&] {
+    if (wino_form)
+      hipLaunchKernelGGL(mv::wgrad_wino3_reduce_kernel, dim3(cdiv(ncols / 3, 256)), dim3(256), 0,
+                         e->stream, t.partial.p, wa.nsplit, ncols / 9,
+                         grad_of(e, ch.cell->kernel));
+    else
     hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv(ncols, 256)), dim3(256), 0,
                        e->stream, t.partial.p, grad_of(e, ch.cell->kernel),
                        (size_t)wa.nsplit, ncols, (size_t)wa.nsplit);
@@ -1182,7 +1230,7 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
   // biases: column sums of G
   launch(e, "bias_colsum", 0, cells * 4.0 * C * 4.0, [&] {
     if (f16)
-      run_colsum(e, t.bias_part.p, (size_t)(((long long)cells + 63) / 64), (size_t)4 * C,
+      run_colsum(e, t.bias_part.p, bias_blocks, (size_t)4 * C,
                  grad_of(e, ch.cell->biases), t.partial.p);
     else
       run_colsum(e, ch.gates.p, (size_t)cells, (size_t)4 * C, grad_of(e, ch.cell->biases),
