@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256)
 void wino3_transpose_g_kernel(const float* __restrict__ in, _Float16* __restrict__ out,
                               long long Mtot3, int Cc, long long Mrow3, int W,
                               const int32_t* __restrict__ exp_ptr, float* __restrict__ colsum_out,
-                              long long comp_stride) {
+                              long long comp_stride, int nplanes) {
   __shared__ float tile[5][64][33];
   const int e = exp_ptr[0];
   const float sc2e = __int_as_float((127 + e) << 23);
@@ -257,7 +257,7 @@ void wino3_transpose_g_kernel(const float* __restrict__ in, _Float16* __restrict
     }
     _Float16* const oc = out + (size_t)comp * (size_t)comp_stride + o;
     *reinterpret_cast<f16x8*>(oc) = p0;
-    *reinterpret_cast<f16x8*>(oc + (size_t)Cc * Mrow3) = p1;
+    if (nplanes == 2) *reinterpret_cast<f16x8*>(oc + (size_t)Cc * Mrow3) = p1;
   }
 }
 
@@ -271,7 +271,7 @@ void wino3_transpose_a3_kernel(const float* __restrict__ in, _Float16* __restric
                                _Float16* __restrict__ out1, _Float16* __restrict__ out2,
                                long long Mtot3, int Cc, long long Mrow3, int H, int W,
                                const int32_t* __restrict__ exp_ptr, int exp_const,
-                               long long comp_stride) {
+                               long long comp_stride, int nplanes) {
   __shared__ float tile[5][66][33];                // tile[c][j] = triple-cell m0 - 1 + j
   const int e = exp_ptr ? exp_ptr[0] : exp_const;
   const float sc2e = __int_as_float((127 + e) << 23);
@@ -339,7 +339,7 @@ void wino3_transpose_a3_kernel(const float* __restrict__ in, _Float16* __restric
         p1[q] = (_Float16)(sv - (float)h0);
       }
       *reinterpret_cast<f16x8*>(out + o) = p0;
-      *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow3 + o) = p1;
+      if (nplanes == 2) *reinterpret_cast<f16x8*>(out + (size_t)Cc * Mrow3 + o) = p1;
     }
   }
 }
@@ -949,9 +949,11 @@ constexpr size_t kWg16LdsBytes1 = (size_t)2 * 2 * wg16_tile<1>() * sizeof(_Float
 
 static inline bool wgrad16_ok(int W, int C) { return (W % 16) == 0 && (C % 128) == 0; }
 // the row-triple form: whole triples only; MV_WGRAD_WINO=0 keeps the direct form
-static inline bool wgrad16_wino3_ok(int H) {
+// (one_plane: the reduced-precision mode's single fp16 plane per operand, MV_WGRAD_WINO_BF16=0)
+static inline bool wgrad16_wino3_ok(int H, bool one_plane) {
   static const bool on = !(getenv("MV_WGRAD_WINO") && atoi(getenv("MV_WGRAD_WINO")) == 0);
-  return on && H >= 3 && H % 3 == 0;
+  static const bool on1 = !(getenv("MV_WGRAD_WINO_BF16") && atoi(getenv("MV_WGRAD_WINO_BF16")) == 0);
+  return on && (on1 || !one_plane) && H >= 3 && H % 3 == 0;
 }
 
 static inline void wgrad16_plan(Wgrad16Args& a, long long Mtot, int nsplit) {

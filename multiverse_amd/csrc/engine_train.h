@@ -1065,7 +1065,7 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
     MV_REQUIRE((size_t)Mrow <= t.mrow_max, "internal: wgrad plane scratch");
     // Winograd F(3,3) over row triples (convlstm_wgrad_f16x3.h, "the row-triple form"): 5/9 of
     // the MFMAs on operands of 5/3 the size; both planes only (fp32-class mode)
-    const bool wino = !one && e->compute_mode == 1 && mv::wgrad16_wino3_ok(H);
+    const bool wino = mv::wgrad16_wino3_ok(H, one);
     const long long Mtot3 = Mtot / 3, Mrow3 = (Mtot3 + 63) / 64 * 64;
     const size_t mrow3_max = (t.mrow_max / 3 + 63) / 64 * 64 + 64;
     const size_t pl_cells = wino ? 5 * mrow3_max : t.mrow_max;   // plane pairs x cells per channel
@@ -1094,11 +1094,11 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
                            t.gmax.p + (size_t)gslot * 64, Tsteps, 64, t.chain_exp.p);
         hipLaunchKernelGGL(mv::wino3_transpose_g_kernel, dim3((unsigned)(Mrow3 / 64), 4 * C / 32),
                            dim3(256), 0, e->stream, ch.gates.p, t.gt16.p, Mtot3, 4 * C, Mrow3, W,
-                           t.chain_exp.p, t.bias_part.p, (long long)2 * 4 * C * Mrow3);
+                           t.chain_exp.p, t.bias_part.p, (long long)2 * 4 * C * Mrow3, npl);
         hipLaunchKernelGGL(mv::wino3_transpose_a3_kernel, dim3((unsigned)(Mrow3 / 64), C / 32),
                            dim3(256), 0, e->stream, hin, t.at16[0].p, t.at16[1].p, t.at16[2].p,
                            Mtot3, C, Mrow3, H, W, (const int32_t*)nullptr, 8,
-                           (long long)2 * C * Mrow3);
+                           (long long)2 * C * Mrow3, npl);
         if (Cx) {   // x operand: exponent from max |x| of the chain
           HIP_CHECK(hipMemsetAsync(t.chain_exp.p + 64, 0, 64 * sizeof(int32_t), e->stream));
           hipLaunchKernelGGL(mv::absmax_bits_kernel, dim3(256), dim3(256), 0, e->stream,
@@ -1109,7 +1109,7 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
           hipLaunchKernelGGL(mv::wino3_transpose_a3_kernel,
                              dim3((unsigned)(Mrow3 / 64), (unsigned)((Cx + 31) / 32)), dim3(256), 0,
                              e->stream, ch.xs.p, t.xt16[0].p, t.xt16[1].p, t.xt16[2].p, Mtot3, Cx,
-                             Mrow3, H, W, t.chain_exp.p + 2, 0, (long long)2 * Cx * Mrow3);
+                             Mrow3, H, W, t.chain_exp.p + 2, 0, (long long)2 * Cx * Mrow3, npl);
         }
       });
     else
@@ -1187,7 +1187,7 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
       hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_kernel<false, 3>),
                          dim3(mv::wgrad16_blocks(q, false)), dim3(256), mv::kWg16LdsBytes,
                          e->stream, q);
-    }, -1.0, one ? 1.0 : (wino ? 5.0 / 3.0 : 3.0));
+    }, -1.0, (one ? 1.0 : 3.0) * (wino ? 5.0 / 9.0 : 1.0));
     if (Cx > 0) {
       mv::Wgrad16Args qx = q;
       for (int d = 0; d < 3; ++d) qx.at[d] = t.xt16[d].p;
@@ -1209,7 +1209,7 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
         hipLaunchKernelGGL((mv::convlstm_wgrad_f16x3_kernel<true, 3>),
                            dim3(mv::wgrad16_blocks(qx, true)), dim3(256), mv::kWg16LdsBytes,
                            e->stream, qx);
-      }, -1.0, one ? 1.0 : (wino ? 5.0 / 3.0 : 3.0));
+      }, -1.0, (one ? 1.0 : 3.0) * (wino ? 5.0 / 9.0 : 1.0));
     }
   } else {
   launch(e, "convlstm_wgrad", 2.0 * cells * 9 * (ch.Cx + C) * 4.0 * C,
