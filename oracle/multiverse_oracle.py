@@ -389,6 +389,7 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None,
   sm = tile(scene_mean)  # tile_to_beam (:831-834)
   prev_lp = torch.zeros(N, B, dtype=dt)
   all_ids, all_parents, all_logits, all_prev, all_topvals = [], [], [], [], []
+  all_cutgaps, all_rankgaps = [], []
   all_states = []     # emit_output of raw_rnn: the cell output, in the step's own row order
   # raw_rnn: loop_fn(0) -> [cell -> loop_fn(time)] for time = 1..T_pred
   for time in range(0, T_pred + 1):
@@ -399,11 +400,20 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None,
       logits = conv2d_same(h, outW).reshape(N, B, K)        # :550-555
       lp = log_softmax_tf(logits)                           # :557
       lp = prev_lp.unsqueeze(-1) + lp                       # :560
+      if trace is not None:      # test aid: smallest gap among a parent's three best candidates
+        top3 = -np.sort(-lp.numpy().astype("float64"), axis=-1)[..., :3]
+        all_rankgaps.append((top3[..., :-1] - top3[..., 1:]).reshape(N, -1).min(axis=-1)
+                            if cfg.diverse_beam else np.full((N,), np.inf))
       if cfg.diverse_beam:
         lp = add_div_penalty(lp, cfg.diverse_gamma)         # :561-567
       flat = lp.reshape(N, B * K) if time > 1 else lp[:, 0]  # :569-573
       new_lp, idx = topk_stable(flat, B)                    # :578-579
       all_topvals.append(new_lp.numpy().copy())
+      if trace is not None and flat.shape[-1] > B:          # test aid: score gap AT the cut
+        nxt = topk_stable(flat, B + 1)[0].numpy()
+        all_cutgaps.append((nxt[:, B - 1] - nxt[:, B]).astype("float64"))
+      elif trace is not None:
+        all_cutgaps.append(np.full((N,), np.inf))
       if not time > cfg.fix_num_timestep:                   # :581-584
         new_lp = torch.zeros(N, B, dtype=dt)
       ids = (idx % K).astype("int32")                       # :588
@@ -446,6 +456,10 @@ def beam_decoder(P, cfg, s, first_input, state, T_pred, scene_mean, trace=None,
     trace["beam_step_parents"] = all_parents
     trace["beam_step_prev_lp"] = all_prev
     trace["beam_step_topvals"] = all_topvals  # selected scores before zeroing
+    trace["beam_step_cut_gap"] = all_cutgaps  # B-th minus (B+1)-th candidate score, per step
+    # diverse beam: the penalty is log(gamma) x RANK within a parent (:1197-1223), so two
+    # candidates of one parent a float32 ulp apart trade a whole log(gamma) between them
+    trace["beam_step_rank_gap"] = all_rankgaps
     trace["beam_trace"] = out_trace           # beam index of each path per step
     trace["beam_step_logits"] = [l.numpy() for l in all_logits]
   if save_states:

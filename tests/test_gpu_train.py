@@ -329,3 +329,67 @@ def test_graph_forward_after_train_init_replays_current_tables(built_lib, mode):
   s = 1
   assert np.array_equal(cls_g[s], cls_e[s]) and np.array_equal(reg_g[s], reg_e[s])
   assert not np.array_equal(cls0[s], cls_e[s])   # the step did change the outputs
+
+
+_DIRECT_WGRAD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from multiverse_amd import _lib, synth
+out = {}
+for mode in ("f16x3", "bf16"):
+  cfg = synth.default_config(batch_size=2, use_grids=(1, 1), is_train=True)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 4, recurrent_gain=2.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 54)
+  eng = _lib.Engine(cfg, device=0)
+  eng.set_params(params)
+  eng.set_compute_mode(mode)
+  eng.set_profiling(True)
+  eng.train_init()
+  eng.train_forward_backward(feed)
+  for n, _ in eng.param_specs():
+    out[mode + "|" + n] = eng.get_grad(n)
+  eng.close()
+np.savez(%(out)r, **out)
+"""
+
+
+def test_row_triple_wgrad_against_the_direct_form(built_lib, tmp_path):
+  """The weight gradient of the gate kernels in Winograd F(3,3) form over row triples (the
+  default: csrc/convlstm_wgrad_f16x3.h, 15 taps on a third of the cells) against the SAME engine
+  with MV_WGRAD_WINO=0 (direct form, read once per process -> a subprocess), both scales, x rows
+  and h rows apart: fp32-class agreement in f16x3 (both forms carry ~5e-6 of max |g| against the
+  fp32 pipe, test_f16x3_gradients_match_f32_mode), and in the bf16 mode -- one fp16 plane per
+  operand -- agreement far inside that mode's own distance from the oracle (cosine bar 0.999)."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = str(tmp_path / "direct_wgrad.npz")
+  subprocess.check_call([sys.executable, "-c", _DIRECT_WGRAD % dict(root=root, out=out)],
+                        env=dict(os.environ, MV_WGRAD_WINO="0"))
+  direct = np.load(out)
+  for mode, tol in (("f16x3", 2e-5), ("bf16", 5e-3)):
+    cfg = synth.default_config(batch_size=2, use_grids=(1, 1), is_train=True)
+    params = synth.make_params(cfg, seed=synth.SEED_BASE + 4, recurrent_gain=2.0, bias_scale=0.1)
+    feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 54)
+    eng = built_lib.Engine(cfg, device=0)
+    eng.set_params(params)
+    eng.set_compute_mode(mode)
+    eng.train_init()
+    eng.train_forward_backward(feed)
+    C = cfg.enc_hidden_size
+    worst, differs = 0.0, False
+    for n, _ in eng.param_specs():
+      a, b = direct[mode + "|" + n], eng.get_grad(n)
+      if not (n.endswith("/kernel") and a.ndim == 4 and a.shape[3] == 4 * C):
+        continue
+      Cx = a.shape[2] - C
+      for what, u, v in (("x rows", a[:, :, :Cx], b[:, :, :Cx]), ("h rows", a[:, :, Cx:], b[:, :, Cx:])):
+        err = float(np.abs(u - v).max() / max(np.abs(u).max(), 1e-30))
+        differs |= bool((u != v).any())
+        worst = max(worst, err)
+        assert np.isfinite(v).all() and err < tol, (mode, n, what, err)
+    eng.close()
+    print("  %-5s row-triple vs direct wgrad: worst %.2e of max|g|" % (mode, worst))
+    assert differs, "the two forms gave the same bits: the switch did nothing"
