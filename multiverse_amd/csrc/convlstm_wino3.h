@@ -479,7 +479,10 @@ __device__ __forceinline__ void convlstm_wino3_body(const ConvLstmWinoArgs& p, i
         }
       };
       // (two row sets alternating without the copy below measured 3 % SLOWER: 0.368 vs 0.352 ms
-      // per launch, same box -- hipcc's schedule of the unrolled pair is worse)
+      // per launch, same box -- hipcc's schedule of the unrolled pair is worse; requesting the
+      // weight fragments of tap s + 1 before the MFMAs of tap s, pinned with sched_barrier:
+      // 0.3436 / 0.3471 against 0.3441 / 0.3435 ms -- nothing: the second wave of the SIMD
+      // already covers the fragment reads, profiles/r6q_*)
       Rows cur, nxt;
       rload(ck_lo, cur);
       nxt = cur;
