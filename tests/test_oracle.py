@@ -208,3 +208,41 @@ def test_gnn_against_scikit_learn_and_scipy():
     want[m] = (h[m].reshape(K, C) + a @ h[m].reshape(K, C)).reshape(H, W, C)
   got = oracle.gnn_np(h, sm, dtype=torch.float64)
   assert np.abs(got - want).max() < 1e-12
+
+
+def test_beam_comparison_rules_on_the_oracle_against_itself():
+  """tests/beam_compare.py (the checker of every beam-search parity test) on the oracle's own
+  outputs: identical outputs pass with nothing tolerated; a swapped-in hypothesis is refused
+  unless the oracle's trace shows a keep / drop cut or a within-parent rank pair tied to float32
+  resolution at some step of that row ("beam_step_cut_gap", "beam_step_rank_gap": the diversity
+  penalty is log(gamma) x rank within a parent, code/pred_models.py:1197-1223)."""
+  import pytest
+  from beam_compare import compare_beams
+  cfg = synth.default_config(batch_size=2, use_grids=(0, 1), beam_size=5)
+  cfg.diverse_beam = True
+  params = synth.make_params(cfg, seed=5, recurrent_gain=3.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=5)
+  trace = {}
+  cls, reg, beam = oracle.forward(params, cfg, feed, trace=trace)
+  T = cfg.pred_len
+  cut = np.stack(trace["beam_step_cut_gap"], axis=-1)
+  rank = np.stack(trace["beam_step_rank_gap"], axis=-1)
+  assert cut.shape == (2, T) and rank.shape == (2, T)
+  assert (cut >= 0).all() and (rank >= 0).all() and np.isfinite(rank).all()
+  topv = np.stack(trace["beam_step_topvals"], axis=-1)
+  arrs = {"ids": beam[1].copy(), "logits": beam[0].copy(), "logprobs": beam[2].copy(),
+          "best_beam": beam[0][:, 0].copy(), "grid_reg": reg[1].copy()}
+  args = (reg[1], beam[0], beam[1], beam[2], topv, trace["beam_trace"])
+  assert compare_beams(arrs, *args, cut_gap=np.minimum(cut, rank)) == 0
+  assert compare_beams.unmatched == 0
+  # a hypothesis the oracle does not hold, in the last beam of row 1
+  bad = {k: v.copy() for k, v in arrs.items()}
+  bad["ids"][1, -1, T - 1] = (bad["ids"][1, -1, T - 1] + 1) % beam[0].shape[-1]
+  with pytest.raises(AssertionError):
+    compare_beams(bad, *args)
+  with pytest.raises(AssertionError):       # gaps of this model are far from a float32 tie
+    compare_beams(bad, *args, cut_gap=np.minimum(cut, rank))
+  tied = np.minimum(cut, rank).copy()
+  tied[1, 3] = 1e-6                         # ... unless the trace says the row has one
+  compare_beams(bad, *args, cut_gap=tied)
+  assert compare_beams.unmatched == 1
