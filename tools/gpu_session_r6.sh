@@ -90,7 +90,7 @@ PY
       [ -f $O/bench_driver_cmd.json ] && cp $O/bench_driver_cmd.json $P/${T}_bench_driver_cmd.json
       [ -f $O/gpu_tests.log ] && tail -5 $O/gpu_tests.log > $P/${T}_gpu_suite_tail.txt
       [ -f $O/smoke.log ] && cp $O/smoke.log $P/${T}_smoke.log
-      [ -f $O/margins.log ] && grep -E "rows, max|flips|adversarial|error vs fp64|beam parity|passed|histogram|minADE|minFDE|NLL|worst|trained|configs\[3\]:" $O/margins.log > $P/${T}_parity_margins.log
+      [ -f $O/margins.log ] && grep -E "rows, max|flips|adversarial|error vs fp64|beam parity|passed|histogram|minADE|minFDE|NLL|worst|trained|rows whose|without an oracle|row-triple vs|configs\[3\]:" $O/margins.log > $P/${T}_parity_margins.log
       ls $P | wc -l ;;
     trainab:*)
       kv=${stage#trainab:}; k=${kv%%=*}
