@@ -346,14 +346,17 @@ void wino3_transpose_a3_kernel(const float* __restrict__ in, _Float16* __restric
 
 // Sum of the splits' partials [nsplit][15][per] in split order (bitwise reproducible) and the
 // output combination of the row-triple form -> dW [9][per] (tap = (dy + 1) * 3 + (dx + 1)).
+// per = (Cx + C) x N4; the x rows (input channel < Cx) were written by nsplit_x <= nsplit splits
+// (their GEMM balances on its own split count, see wgrad16_x_splits).
 __global__ __launch_bounds__(256)
-void wgrad_wino3_reduce_kernel(const float* __restrict__ partial, int nsplit, size_t per,
-                               float* __restrict__ out) {
+void wgrad_wino3_reduce_kernel(const float* __restrict__ partial, int nsplit, int nsplit_x,
+                               size_t x_elems, size_t per, float* __restrict__ out) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= 3 * per) return;
   const size_t dxi = idx / per, el = idx - dxi * per;
+  const int ns = el < x_elems ? nsplit_x : nsplit;
   float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int sp = 0; sp < nsplit; ++sp)
+  for (int sp = 0; sp < ns; ++sp)
 #pragma unroll
     for (int c = 0; c < 5; ++c) m[c] += partial[((size_t)sp * 15 + c * 3 + dxi) * per + el];
   out[(0 * 3 + dxi) * per + el] = ((m[0] + m[1]) + m[2]) + m[3];
@@ -962,6 +965,18 @@ static inline void wgrad16_plan(Wgrad16Args& a, long long Mtot, int nsplit) {
   per = (per + 1) & ~1;
   a.ksteps_per_split = per;
   a.nsplit = nsplit;
+}
+
+// Split count of the x rows in the row-triple form.  Their 128 x 128 tiles number 40 or 80 per
+// split (5 components x 1 or 2 row tiles x 8 column blocks) on 512 workgroup slots: 12 splits =
+// 480 / 960 workgroups fill one / two rounds to 94 % (the h rows' 21: 1.64 / 3.28 rounds).
+// Measured: 1.94 against 2.17 - 2.28 ms per training step (profiles/r6t, MV_WGRAD_WIDE_SPLITS
+// sweep).  MV_WGRAD_X_SPLITS overrides; never more than the h rows' count (the partial buffer).
+static inline int wgrad16_x_splits(long long Mgemm, int nsplit_h) {
+  int v = 12;
+  if (const char* ev = getenv("MV_WGRAD_X_SPLITS")) v = atoi(ev);
+  if (v < 1 || v > nsplit_h || Mgemm / 16 < (long long)v * 32) return nsplit_h;
+  return v;
 }
 
 static inline unsigned wgrad16_blocks(const Wgrad16Args& a, bool xrows) {

@@ -1051,6 +1051,7 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
   const size_t ncols = (size_t)9 * (ch.Cx + C) * 4 * C;
   const bool f16 = e->compute_mode != 0 && mv::wgrad16_ok(W, C);
   bool wino_form = false;                  // f16x3: the row-triple form (15 partial taps)
+  int nsplit_x = 0;                        // ... and the split count of its x rows
   size_t bias_blocks = (size_t)(((long long)cells + 63) / 64);
   if (f16) {
     // both operands as cell-contiguous fp16 plane pairs, then the f16x3 GEMMs
@@ -1192,7 +1193,11 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
       mv::Wgrad16Args qx = q;
       for (int d = 0; d < 3; ++d) qx.at[d] = t.xt16[d].p;
       qx.Ca = Cx; qx.a_exp = t.chain_exp.p + 2;
-      if (wino) qx.a_comp_stride = (int64_t)2 * Cx * Mrow3;
+      if (wino) {
+        qx.a_comp_stride = (int64_t)2 * Cx * Mrow3;
+        nsplit_x = mv::wgrad16_x_splits(Mgemm, wa.nsplit);
+        mv::wgrad16_plan(qx, Mgemm, nsplit_x);
+      }
       launch(e, "convlstm_wgrad_x", 2.0 * cells * 9 * Cx * 4.0 * C,
              cells * (Cx + 4.0 * C) * 4.0, [&] {
         if (wide && mv::wgrad16_wide_x_enabled() && one)
@@ -1220,8 +1225,8 @@ void run_wgrad(mv_engine* e, TrainChain& ch, const float* hin, int Tsteps, int H
   launch(e, "wgrad_reduce", 0, 4.0 * ncols * ((wino_form ? 15.0 / 9 : 1.0) * wa.nsplit + 1), [&] {
     if (wino_form)
       hipLaunchKernelGGL(mv::wgrad_wino3_reduce_kernel, dim3(cdiv(ncols / 3, 256)), dim3(256), 0,
-                         e->stream, t.partial.p, wa.nsplit, ncols / 9,
-                         grad_of(e, ch.cell->kernel));
+                         e->stream, t.partial.p, wa.nsplit, nsplit_x > 0 ? nsplit_x : wa.nsplit,
+                         (size_t)ch.Cx * 4 * C, ncols / 9, grad_of(e, ch.cell->kernel));
     else
     hipLaunchKernelGGL(mv::colsum_kernel, dim3(1, cdiv(ncols, 256)), dim3(256), 0,
                        e->stream, t.partial.p, grad_of(e, ch.cell->kernel),
