@@ -87,6 +87,7 @@ struct TrainState {
   // f16x3 dgrad: planes of the gate gradients of the current step per group slot,
   // max |G| bits and scale exponents per (launch slot, step)
   DevBuf<_Float16> g16[mv::kMaxGroup];
+  bool g16_fused[mv::kMaxGroup] = {};   // bf16 backward: lstm_gate_bwd wrote the plane itself
   DevBuf<float> dpart0[mv::kMaxGroup], dpart1[mv::kMaxGroup];   // dgrad split-K partials
   DevBuf<int32_t> gmax, gexp;
   // f16x3 wgrad: cell-contiguous operand planes of one chain at a time
@@ -769,12 +770,31 @@ void train_losses(mv_engine* e) {
 }
 
 // ------------------------------------------------------------ backward
+// group_slot >= 0 (compute mode 2 with the bf16 backward): the step's G also leaves as the bf16
+// operand plane of the dgrad problem that will take that slot of the group (t.g16[slot]), and
+// run_dgrad_group_f16x3 skips its split pass.  MV_BF16_FUSED_SPLIT=0: the separate pass.
 void run_gate_bwd(mv_engine* e, float* gates, const float* c_prev, const float* c_new,
                   const float* dh, float* dc, size_t cells, int C,
-                  int32_t* gmax_bits = nullptr) {
+                  int32_t* gmax_bits = nullptr, int group_slot = -1) {
   const size_t total = cells * C;
-  launch(e, "lstm_gate_bwd", 30.0 * total, 4.0 * total * 13, [&] {
-    if (C % 4 == 0)
+  static const bool fuse_on = !(getenv("MV_BF16_FUSED_SPLIT") && atoi(getenv("MV_BF16_FUSED_SPLIT")) == 0);
+  _Float16* plane = nullptr;
+  if (fuse_on && group_slot >= 0 && group_slot < mv::kMaxGroup && C % 32 == 0 &&
+      e->compute_mode == 2 && bf16_bwd_enabled(e)) {
+    TrainState& t = TS(e);
+    const size_t n = cells * 4 * (size_t)C;
+    if (t.g16[group_slot].n >= 2 * (n + mv::kPlaneSlack + mv::kPlanePad)) {
+      plane = t.g16[group_slot].p + mv::kPlanePad;
+      t.g16_fused[group_slot] = true;
+    }
+  }
+  launch(e, "lstm_gate_bwd", 30.0 * total, 4.0 * total * (plane ? 15 : 13), [&] {
+    if (plane)
+      hipLaunchKernelGGL(mv::lstm_gate_bwd4_plane_kernel,
+                         dim3((unsigned)(((cells + 31) / 32) * (size_t)(C / 32))), dim3(256), 0,
+                         e->stream, gates, c_prev, c_new, dh, dc, (long long)cells, C, plane,
+                         gmax_bits);
+    else if (C % 4 == 0)
       hipLaunchKernelGGL(mv::lstm_gate_bwd4_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0,
                          e->stream, gates, c_prev, c_new, dh, dc, total / 4, C, gmax_bits);
     else
@@ -811,6 +831,9 @@ void run_dgrad_group_f16x3(mv_engine* e, const std::vector<ConvLstmArgs>& probs,
     const size_t gcells = (size_t)a.rows * a.H * a.W;
     MV_REQUIRE(t.g16[i].n >= 2 * pst, "internal: G plane scratch");
     _Float16* p0 = t.g16[i].p + mv::kPlanePad;
+    const bool fused = bf && t.g16_fused[i];       // the plane came out of lstm_gate_bwd
+    t.g16_fused[i] = false;
+    if (!fused)
     launch(e, "split_planes", 0, (bf ? 6.0 : 8.0) * n, [&] {
       if (bf)
         hipLaunchKernelGGL(mv::split_plane_bf16_kernel, dim3(mv::split_planes_blocks(gcells, a.C)),
@@ -1292,7 +1315,8 @@ void train_backward(mv_engine* e) {
         float* G = R.dec[b].gates.p + (size_t)ts * 4 * NKC;
         const int gs = (2 * s + b) * 64 + ts;
         run_gate_bwd(e, G, R.cs[b].p + slot * NKC, R.cs[b].p + (slot + 1) * NKC,
-                     dh_a[s][b], R.dc[b].p, NK, C, f16 ? t.gmax.p + (size_t)gs * 64 : nullptr);
+                     dh_a[s][b], R.dc[b].p, NK, C, f16 ? t.gmax.p + (size_t)gs * 64 : nullptr,
+                     (int)probs.size());
         chains.push_back(&R.dec[b]);
         slots.push_back(gs);
         ConvLstmArgs a;
@@ -1386,7 +1410,8 @@ void train_backward(mv_engine* e) {
         const bool need_dh = ts > 0, need_dx = (b == 0);
         run_gate_bwd(e, G, R.cs[b].p + ts * NKC, R.cs[b].p + (ts + 1) * NKC, dh_a[s][b],
                      R.dc[b].p, NK, C,
-                     f16 ? t.gmax.p + (size_t)gs * 64 : nullptr);
+                     f16 ? t.gmax.p + (size_t)gs * 64 : nullptr,
+                     (need_dh || need_dx) ? (int)probs.size() : -1);
         if (!need_dh && !need_dx) continue;
         chains.push_back(&R.enc[b]);
         slots.push_back(gs);

@@ -11,6 +11,7 @@
 #include <math.h>
 
 #include "kernels_misc.h"
+#include "convlstm_f16x3.h"
 
 namespace mv {
 
@@ -112,6 +113,93 @@ void lstm_gate_bwd4_kernel(float* __restrict__ gates, const float* __restrict__ 
       mx = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
       if (mx > 0.f && mx < INFINITY)
         atomicMax(gmax_bits + (blockIdx.x & 63), __float_as_int(mx));
+    }
+  }
+}
+
+// The same for compute mode 2 with the bf16 backward: G leaves as fp32 (the wgrad's operand) AND
+// as ONE bf16 plane in the dgrad's tiled operand layout (plane_layout.h) -- the bits
+// split_plane_bf16_kernel would produce from the fp32 G in a pass of its own (2.7 ms per training
+// step at 64 / GPU).  The plane wants 32 consecutive cells of an 8-channel group contiguous (512
+// bytes), the state tensors 4C consecutive floats of a cell: a workgroup takes 32 cells x 32
+// channels (8 threads x 16 bytes = 128-byte runs per cell and tensor), computes as above, and
+// passes the bf16 values through LDS so that they leave as whole 512-byte runs.  C % 32 == 0.
+__global__ __launch_bounds__(256)
+void lstm_gate_bwd4_plane_kernel(float* __restrict__ gates, const float* __restrict__ c_prev,
+                                 const float* __restrict__ c_new, const float* __restrict__ dh,
+                                 float* __restrict__ dc_io, long long cells, int C,
+                                 _Float16* __restrict__ plane,
+                                 int32_t* __restrict__ gmax_bits) {
+  typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+  float mx = 0.f;
+  __shared__ __attribute__((aligned(16))) _Float16 tile[4][4][32][8];   // [gate][group of 8][cell][8]
+  const int ncb = C >> 5;
+  const long long blk = blockIdx.x;
+  const long long m0 = (blk / ncb) * 32;
+  const int cbase = (int)(blk % ncb) * 32;
+  const int tid = threadIdx.x;
+  const int cl = tid >> 3, c4 = (tid & 7) * 4;
+  const long long m = m0 + cl;
+  if (m < cells) {
+    const int ch = cbase + c4;
+    float* gp = gates + (size_t)m * 4 * (size_t)C + ch;
+    const size_t idx = (size_t)m * (size_t)C + ch;
+    const f32x4_t si = *reinterpret_cast<const f32x4_t*>(gp),
+                  tj = *reinterpret_cast<const f32x4_t*>(gp + C),
+                  sf = *reinterpret_cast<const f32x4_t*>(gp + 2 * C),
+                  so = *reinterpret_cast<const f32x4_t*>(gp + 3 * C);
+    const f32x4_t cn = *reinterpret_cast<const f32x4_t*>(c_new + idx);
+    const f32x4_t dhv = *reinterpret_cast<const f32x4_t*>(dh + idx);
+    const f32x4_t dci = *reinterpret_cast<const f32x4_t*>(dc_io + idx);
+    f32x4_t cp = {0.f, 0.f, 0.f, 0.f};
+    if (c_prev) cp = *reinterpret_cast<const f32x4_t*>(c_prev + idx);
+    f32x4_t gi, gj, gf, go, dco;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float tc = tanhf(cn[j]);
+      const float dcv = dci[j] + dhv[j] * so[j] * (1.f - tc * tc);
+      gi[j] = dcv * tj[j] * (si[j] * (1.f - si[j]));
+      gj[j] = dcv * si[j] * (1.f - tj[j] * tj[j]);
+      gf[j] = dcv * cp[j] * (sf[j] * (1.f - sf[j]));
+      go[j] = dhv[j] * tc * (so[j] * (1.f - so[j]));
+      dco[j] = dcv * sf[j];
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(gi[j]), fabsf(gj[j])), fmaxf(fabsf(gf[j]), fabsf(go[j]))));
+    }
+    *reinterpret_cast<f32x4_t*>(gp) = gi;
+    *reinterpret_cast<f32x4_t*>(gp + C) = gj;
+    *reinterpret_cast<f32x4_t*>(gp + 2 * C) = gf;
+    *reinterpret_cast<f32x4_t*>(gp + 3 * C) = go;
+    *reinterpret_cast<f32x4_t*>(dc_io + idx) = dco;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4_t v = g == 0 ? gi : (g == 1 ? gj : (g == 2 ? gf : go));
+      f16x4_t b;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = bf16_as_half(v[j]);
+      *reinterpret_cast<f16x4_t*>(&tile[g][c4 >> 3][cl][c4 & 7]) = b;
+    }
+  }
+  __shared__ float wm[4];
+  if (gmax_bits) {   // max |G| of the step (the wgrad's chain exponent): one atomic per workgroup
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((tid & 63) == 0) wm[tid >> 6] = mx;
+  }
+  __syncthreads();
+  if (gmax_bits && tid == 0) {
+    mx = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (mx > 0.f && mx < INFINITY)
+      atomicMax(gmax_bits + (blockIdx.x & 63), __float_as_int(mx));
+  }
+  // 16 runs (gate, group of 8) of 32 cells x 16 bytes; thread -> (run = tid >> 4, two cells)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = it * 256 + tid;                 // 512 items = 16 runs x 32 cells
+    const int run = item >> 5, cell = item & 31;
+    const int g = run >> 2, grp = run & 3;
+    if (m0 + cell < cells) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(&tile[g][grp][cell][0]);
+      *reinterpret_cast<f16x8*>(plane + plane_index(m0 + cell, g * C + cbase + grp * 8, 4 * C)) = v;
     }
   }
 }
