@@ -202,3 +202,57 @@ def test_bf16_with_unbounded_activations(built_lib, act):
     worst = min(worst, cos)
     assert np.isfinite(a).all() and cos > 0.999, (n, cos)
   print("  worst gradient cosine vs the fp32 oracle: %.5f" % worst)
+
+
+_SEPARATE_SPLIT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from multiverse_amd import _lib, synth
+cfg = synth.default_config(batch_size=3, use_grids=(1, 1), is_train=True)
+params = synth.make_params(cfg, seed=synth.SEED_BASE + 4, recurrent_gain=2.0, bias_scale=0.1)
+feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 54)
+eng = _lib.Engine(cfg, device=0)
+eng.set_params(params)
+eng.set_compute_mode("bf16")
+eng.set_profiling(True)
+eng.train_init()
+eng.train_forward_backward(feed)
+out = {n.replace("/", "|"): eng.get_grad(n) for n, _ in eng.param_specs()}
+out["__split_planes_launches"] = np.array([eng.kernel_stats()["split_planes"]["launches"]])
+np.savez(%(out)r, **out)
+eng.close()
+"""
+
+
+def test_gate_backward_writes_the_dgrad_plane_bitwise_like_the_split_pass(built_lib, tmp_path):
+  """Compute mode 2: `lstm_gate_bwd4_plane_kernel` emits the step's gate gradient as the dgrad's
+  bf16 operand plane (32 x 32 tile, LDS-staged) next to the fp32 tensor; with
+  MV_BF16_FUSED_SPLIT=0 (read once per process -> a subprocess) `split_plane_bf16_kernel` makes
+  the plane in a pass of its own.  Same bits in the plane -> every gradient tensor of a training
+  step bitwise equal, both scales, batch 3 (a partial last 32-cell tile at scale 1)."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = str(tmp_path / "separate.npz")
+  subprocess.check_call([sys.executable, "-c", _SEPARATE_SPLIT % dict(root=root, out=out)],
+                        env=dict(os.environ, MV_BF16_FUSED_SPLIT="0"))
+  sep = np.load(out)
+  cfg = synth.default_config(batch_size=3, use_grids=(1, 1), is_train=True)
+  params = synth.make_params(cfg, seed=synth.SEED_BASE + 4, recurrent_gain=2.0, bias_scale=0.1)
+  feed = synth.make_feed(cfg, seed=synth.SEED_BASE + 54)
+  eng = _engine(built_lib, cfg, params)
+  eng.set_profiling(True)
+  eng.train_init()
+  eng.train_forward_backward(feed)
+  stats = eng.kernel_stats()
+  nonzero = False
+  for n, _ in eng.param_specs():
+    g = eng.get_grad(n)
+    assert (g == sep[n.replace("/", "|")]).all(), n
+    nonzero |= bool(np.abs(g).max() > 0)
+  eng.close()
+  assert nonzero
+  # the pass is gone from the backward (the forward's operand splits keep the name)
+  assert stats.get("split_planes", {"launches": 0})["launches"] < int(sep["__split_planes_launches"][0])
